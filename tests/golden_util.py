@@ -1,0 +1,59 @@
+"""Helpers to read tests/golden/*.npz (written by tests/golden/make_golden.py)."""
+import json
+import os
+
+import numpy as np
+import torch
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = ["u2_2k_k16_c32", "ragged_b2_refl_c8", "surface_cap_c4", "dups_tiny_b3_c4", "u4_3k_refl_c8", "u2_16k_c32"]
+SMALL_CASES = CASES[:5]
+
+
+def manifest():
+    return json.load(open(os.path.join(GOLDEN_DIR, "manifest.json")))
+
+
+def load(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    g = {k: z[k] for k in z.files}
+    C, k, wseed, nb = [int(v) for v in g["meta"]]
+    inp = {
+        "pos": torch.from_numpy(g["in.pos"]), "batch": torch.from_numpy(g["in.batch"]).long(),
+        "reflectance": torch.from_numpy(g["in.reflectance"]), "sf": torch.from_numpy(g["in.sf"]),
+        "local_shift": torch.from_numpy(g["in.local_shift"]), "ptr": torch.from_numpy(g["in.ptr"]).long(),
+    }
+    return g, inp, dict(C=C, k=k, wseed=wseed, B=nb)
+
+
+def check(g, name, t, rtol=0.0, atol=0.0, what=""):
+    """Compare tensor ``t`` with golden entry ``name`` (full tensor, or checksum + sampled rows)."""
+    a = t.detach().cpu().numpy()
+    exact = (rtol == 0.0 and atol == 0.0)
+    if name in g:
+        ref = g[name]
+        assert tuple(a.shape) == tuple(ref.shape), f"{what}{name}: shape {a.shape} != {ref.shape}"
+        if exact:
+            assert np.array_equal(a.astype(ref.dtype), ref), f"{what}{name}: not bit-equal"
+        else:
+            err = np.abs(a.astype(np.float64) - ref.astype(np.float64))
+            lim = atol + rtol * np.abs(ref.astype(np.float64))
+            assert (err <= lim).all(), f"{what}{name}: max err {err.max():.3e} (limit {lim.flat[err.argmax()]:.3e})"
+        return
+    shape = tuple(int(v) for v in g[name + "__shape"])
+    assert tuple(a.shape) == shape, f"{what}{name}: shape {a.shape} != {shape}"
+    rows = g[name + "__rows"].astype(np.int64)
+    ref = g[name + "__sample"]
+    s = g[name + "__sum"]
+    if exact:
+        assert np.array_equal(a[rows].astype(ref.dtype), ref), f"{what}{name}: sampled rows differ"
+        a64 = a.astype(np.int64)
+        assert int(a64.sum()) == int(s[0]), f"{what}{name}: checksum"
+        w = np.arange(a.size).reshape(a.shape) % 8191 + 1
+        assert int((a64 * w).sum()) == int(s[1]), f"{what}{name}: weighted checksum"
+    else:
+        err = np.abs(a[rows].astype(np.float64) - ref.astype(np.float64))
+        lim = atol + rtol * np.abs(ref.astype(np.float64))
+        assert (err <= lim).all(), f"{what}{name}: sampled rows max err {err.max():.3e}"
+        tot = a.astype(np.float64).sum()
+        assert abs(tot - s[0]) <= atol * a.size + rtol * s[1] + 1e-6, f"{what}{name}: sum {tot} vs {s[0]}"

@@ -1,0 +1,53 @@
+"""Pin the CPU oracle (oracle/net.py) to vectors produced by the reference's own model code
+(tests/golden/make_golden.py, run in the authoring container)."""
+import hashlib
+import os
+
+import pytest
+import torch
+
+from oracle import net as onet
+from oracle import synth, weights
+from tests import golden_util as G
+
+
+def test_manifest_hashes():
+    man = G.manifest()
+    for name in G.CASES:
+        path = os.path.join(G.GOLDEN_DIR, man[name]["file"])
+        assert hashlib.sha256(open(path, "rb").read()).hexdigest() == man[name]["sha256"]
+
+
+def test_key_table_is_257_keys():
+    tab = weights.key_table(1, 32)
+    assert len(tab) == 257
+    sd = weights.synth_state_dict(1, 32, seed=0)
+    assert sum(v.numel() for k, v in sd.items() if v.dtype == torch.float32 and "running" not in k) == 18158852
+
+
+def test_survey_known_answers():
+    """sampler alone on U(2.0, 2048, seed 123)."""
+    v = synth.uniform_voxel(2.0, 2048, 123)
+    from oracle import ops
+    b = torch.zeros(2048, dtype=torch.long)
+    idx = ops.consecutive_cluster(ops.voxel_grid(v["pos"], 0.04, b))[1]
+    assert idx.numel() == 2034 and int(idx.sum()) == 2083618 and idx[:4].tolist() == [245, 1133, 855, 63]
+
+
+@pytest.mark.parametrize("name", G.CASES)
+def test_oracle_matches_reference_vectors(name):
+    g, inp, meta = G.load(name)
+    sd = weights.synth_state_dict(1, meta["C"], seed=meta["wseed"])
+    cap = {}
+    logits = onet.forward(sd, inp["pos"], inp["batch"], inp["reflectance"], inp["sf"], k=meta["k"], capture=cap)
+    for l in (1, 2, 3):
+        G.check(g, f"idx{l}", cap[f"sa{l}_module.idx"])
+        G.check(g, f"edge{l}.q", cap[f"sa{l}_module.edge_q"])
+        G.check(g, f"edge{l}.c", cap[f"sa{l}_module.edge_c"])
+    G.check(g, "stem", cap["stem"], rtol=1e-5, atol=1e-6)
+    for n in ("sa1_module.conv", "sa1_module.out", "sa2_module.conv", "sa2_module.out", "sa3_module.conv",
+              "sa3_module.out", "sa4_module.out", "fp4_module.out", "fp3_module.out", "fp2_module.out",
+              "fp1_module.out"):
+        G.check(g, n, cap[n], rtol=2e-4, atol=2e-4)
+    G.check(g, "logits", logits, rtol=1e-4, atol=4e-4)
+    G.check(g, "probs", torch.sigmoid(logits), atol=1e-4)
