@@ -1,0 +1,162 @@
+/*
+ * p2w.h - C ABI of libp2w_gfx950.so: the MI355X (gfx950) kernels behind the
+ * PointsToWood inference forward.
+ *
+ * Boundary rules:
+ *   - extern "C", plain pointers + sizes, no C++/torch types, no exceptions;
+ *   - every entry point is re-entrant, keeps no global mutable state, never
+ *     allocates and never synchronises: the caller owns all device buffers
+ *     (worst-case sized) and passes the HIP stream to launch on;
+ *   - every entry point returns an int32 status: 0 = OK, > 0 = hipError_t from
+ *     the launch, < 0 = a P2W_E* argument error; p2w_strerror() names it;
+ *   - all index arrays are int32, all features fp32 row-major, positions are
+ *     float4 records "xyzr" = (x, y, z, reflectance), 16-byte aligned;
+ *   - ragged batches are CSR: ptr[B+1] (int32, DEVICE memory) over the
+ *     concatenated voxels; element counts that are only known on the device
+ *     are read from ptr[B] by the kernels, the host passes an upper bound.
+ *
+ * Each function names the reference call site it replaces (paths relative to
+ * the reference repo, harryjfowen/PointsToWood @ 2025-09-12).  The third-party
+ * operators themselves (torch-cluster / torch-scatter / torch-geometric) are not
+ * vendored by the reference; their semantics are fixed by oracle/ops.py.
+ */
+#ifndef P2W_H
+#define P2W_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* p2w_stream_t; /* hipStream_t */
+
+#define P2W_OK 0
+#define P2W_EINVAL (-1)    /* bad scalar argument (k, sizes, strides)        */
+#define P2W_ENULL (-2)     /* required pointer is NULL                        */
+#define P2W_EALIGN (-3)    /* pointer / stride not 16-byte aligned            */
+#define P2W_EWORKSPACE (-4)/* workspace too small                             */
+#define P2W_EUNSUPPORTED (-5)
+
+#define P2W_MAX_K 64       /* neighbours per query (wave64: one lane per slot) */
+
+int32_t p2w_version(void);
+const char* p2w_strerror(int32_t code);
+
+/* ---- geometry ---------------------------------------------------------- */
+
+/* xyzr[i] = (pos[i*pos_stride + 0..2], refl[i]); batch[i] = voxel of point i (from ptr).
+ * Feeds SAModule.forward's cat(pos[:, :3], reflectance) - pointstowood/src/model.py:109. */
+int32_t p2w_pack_xyzr(const float* pos, int32_t pos_stride, const float* refl, const int32_t* ptr, int32_t B,
+                      int32_t n, float* xyzr, int32_t* batch, p2w_stream_t stream);
+
+/* Grid sub-sampling of one level: SAModule.voxelsample (model.py:103-106) =
+ * PyG voxel_grid -> torch-cluster grid_cluster + PyG consecutive_cluster.
+ * In : xyzr[n_bound] (records >= ptr[B] ignored), ptr[B+1], cell size `res`.
+ * Out: idx_out[<= n_bound] (index into xyzr of the representative = LARGEST point index of each
+ *      occupied cell, ascending cell id i.e. voxel-major), ptr_out[B+1] (CSR of the sampled level;
+ *      ptr_out[B] = M), batch_out[M].
+ * ws : p2w_voxel_sample_ws_bytes(n_bound) bytes of scratch. */
+size_t p2w_voxel_sample_ws_bytes(int32_t n_bound);
+int32_t p2w_voxel_sample(const float* xyzr, const int32_t* ptr, int32_t B, int32_t n_bound, float res,
+                         int32_t* idx_out, int32_t* ptr_out, int32_t* batch_out, void* ws, size_t ws_bytes,
+                         p2w_stream_t stream);
+
+/* The two halves of p2w_voxel_sample as separate operators (the reference calls them separately,
+ * model.py:104-105): cell ids exactly as PyG voxel_grid(pos, size, batch) returns them (int64), and
+ * consecutive_cluster(cell) -> (inv[n] = rank of each point's cell, perm[count] = largest point index
+ * per cell, ascending cell id).  inv_out may be NULL.  ws: p2w_voxel_sample_ws_bytes(n). */
+int32_t p2w_voxel_grid(const float* xyzr, const int32_t* ptr, int32_t B, int32_t n, float res, int64_t* cell_out,
+                       void* ws, size_t ws_bytes, p2w_stream_t stream);
+int32_t p2w_consecutive_cluster(const int64_t* cell, int32_t n, int32_t* inv_out, int32_t* perm_out,
+                                int32_t* count_out, void* ws, size_t ws_bytes, p2w_stream_t stream);
+
+/* Next level's records: out[i] = ((p / sf_b) * sf_b, refl) of src[idx[i]] - the in-place scale /
+ * un-scale round trip of model.py:122,124 followed by the slices of :126. */
+int32_t p2w_level_gather(const float* xyzr_src, const int32_t* idx, const int32_t* batch_dst, const int32_t* ptr_dst,
+                         int32_t B, int32_t m_bound, const float* sf, float* xyzr_dst, p2w_stream_t stream);
+
+/* Ball query: torch-cluster radius(x, y, r, batch_x, batch_y, max_num_neighbors) - model.py:118.
+ * Queries are x[qidx[q]] (qidx NULL = identity).  For query q of voxel b the first `cap` candidates
+ * c in ptr_x[b]..ptr_x[b+1] (ascending) with d2 < (float)(r*r) (r is a double, as torch-cluster's host code takes it) are written to
+ * nbr[q*cap + 0..deg[q]-1]; remaining slots are -1. */
+int32_t p2w_ball_query(const float* xyzr_x, const int32_t* ptr_x, const float* xyzr_q, const int32_t* qidx,
+                       const int32_t* ptr_q, int32_t B, int32_t m_bound, double r, int32_t cap, int32_t* nbr,
+                       int32_t* deg, p2w_stream_t stream);
+
+/* Exact brute-force kNN: torch-cluster knn(x, y, k, batch_x, batch_y) - model.py:120 and inside
+ * PyG knn_interpolate (model.py:149).  Ascending (d2, index); deg[q] = min(k, #candidates). */
+int32_t p2w_knn(const float* xyzr_x, const int32_t* ptr_x, const float* xyzr_q, const int32_t* qidx,
+                const int32_t* ptr_q, int32_t B, int32_t m_bound, int32_t k, int32_t* nbr, int32_t* deg,
+                p2w_stream_t stream);
+
+/* ---- features ---------------------------------------------------------- */
+
+/* stem_mlp: out[n,C] = relu(W[C,3] * xyz + b) - model.py:208,228. */
+int32_t p2w_stem(const float* xyzr, int32_t n, const float* w, const float* b, int32_t C, float* out,
+                 p2w_stream_t stream);
+
+/* Epilogue description for p2w_gemm: v = acc + bias; relu0; v = v*sc0+sh0; relu1; v = v*sc1+sh1; relu2;
+ * v += residual; relu_final.  NULL scale pointers skip their stage. */
+typedef struct p2w_epilogue {
+    const float* bias;   /* [N] or NULL */
+    const float* sc0;    /* [N] */
+    const float* sh0;    /* [N] */
+    const float* sc1;    /* [N] */
+    const float* sh1;    /* [N] */
+    const float* residual; /* [M, ldr] or NULL */
+    int32_t ldr;
+    int32_t relu0, relu1, relu2, relu_final;
+} p2w_epilogue;
+
+/* Packed weight: Wp[N_pad][K_pad] fp32, row n = output channel, k contiguous, zero padded
+ * (K_pad = round_up(K, 32), N_pad = round_up(N, 128)); see p2w_packed_dims. */
+void p2w_packed_dims(int32_t N, int32_t K, int32_t* N_pad, int32_t* K_pad);
+
+/* out[M,N] = epilogue(A[M,K] * W^T): Linear / 1x1 Conv1d + folded BatchNorm / depthwise affines +
+ * ReLU + residual - model.py:75-85 (InvertedResidualBlock), :198-202 (MLP), :241-242 (head).
+ * fp32 MFMA (v_mfma_f32_32x32x2_f32), exact fp32 products, fp32 accumulate. */
+int32_t p2w_gemm(const float* A, int32_t lda, const float* Wp, int32_t M, int32_t N, int32_t K,
+                 const p2w_epilogue* epi, float* out, int32_t ldo, p2w_stream_t stream);
+
+/* Fused PointNetConv (pointnet.py:86-132) for one SA level:
+ *   per target i and neighbour slot s (j = nbr[i,s]):
+ *     rel  = xyz_s[j] - xyz_s[idx[i]]            on sf-scaled coordinates (model.py:122)
+ *     dmax = max_s ||rel||                        (scatter_max, pointnet.py:122)
+ *     h1   = relu(P[j] + (rel/(dmax+1e-8)) * W1r + refl_j * W1f)       layer 1, hoisted:
+ *            P = x_src * W1x^T + b1 is computed once per source point by p2w_gemm
+ *     h2   = relu(h1 * W2^T + b2) * bn_s + bn_t                       layer 2 + BN (model.py:198-202)
+ *   out[i] = max over valid slots of h2 (rows without neighbours = 0). */
+int32_t p2w_sa_conv(const float* P, int32_t ldp, const float* xyzr_src, const int32_t* idx, const int32_t* batch_dst,
+                    const float* sf, const int32_t* nbr, const int32_t* deg, int32_t kw, int32_t M,
+                    const float* w1r4 /* [4][C1_pad] */, const float* W2p, int32_t C1, int32_t C2,
+                    const float* b2, const float* bn_s, const float* bn_t, float* out, int32_t ldo,
+                    p2w_stream_t stream);
+
+/* knn_interpolate (k<=2) + concat with the skip features - model.py:149-151:
+ *   out[q, 0:Fc] = (sum_s w_s * xc[nbr[q,s]]) / (sum_s w_s),  w_s = 1/max(d2, 1e-16)
+ *   out[q, Fc:Fc+Fs] = skip[q].  Rows padded to ldo are zero-filled. */
+int32_t p2w_interp_concat(const float* xc, int32_t Fc, const float* xyzr_c, const float* xyzr_f, const int32_t* nbr,
+                          const int32_t* deg, int32_t kw, const float* skip, int32_t Fs, int32_t m, float* out,
+                          int32_t ldo, p2w_stream_t stream);
+
+/* [x | xyz] concat feeding GlobalSAModule.NN - model.py:135. */
+int32_t p2w_concat_xyz(const float* x, int32_t F, const float* xyzr, int32_t m, float* out, int32_t ldo,
+                       p2w_stream_t stream);
+
+/* global_max_pool - model.py:136: out[b,:] = max over rows ptr[b]..ptr[b+1] (empty = 0). */
+int32_t p2w_segment_max(const float* x, int32_t ldx, int32_t F, const int32_t* ptr, int32_t B, float* out,
+                        p2w_stream_t stream);
+
+/* conv2 with one output channel - model.py:243: out[i] = dot(x[i,:], w) + b. */
+int32_t p2w_rowdot(const float* x, int32_t ldx, int32_t F, const float* w, float b, int32_t m, float* out,
+                   p2w_stream_t stream);
+
+/* FPModule 4 (model.py:236): the coarse level has ONE point per voxel: nbr[q] = batch[q], deg = 1. */
+int32_t p2w_fill_batch_nbr(const int32_t* batch, int32_t m, int32_t* nbr, int32_t* deg, p2w_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* P2W_H */

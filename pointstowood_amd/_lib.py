@@ -1,0 +1,92 @@
+"""ctypes binding of libp2w_gfx950.so (C ABI: include/p2w.h).
+
+The library is the product path: there is no CPU or eager-PyTorch fallback, so a
+missing library is a hard error naming the build command.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libp2w_gfx950.so")
+
+_vp, _i32, _f32, _sz = C.c_void_p, C.c_int32, C.c_float, C.c_size_t
+
+
+class Epilogue(C.Structure):
+    _fields_ = [("bias", _vp), ("sc0", _vp), ("sh0", _vp), ("sc1", _vp), ("sh1", _vp), ("residual", _vp),
+                ("ldr", _i32), ("relu0", _i32), ("relu1", _i32), ("relu2", _i32), ("relu_final", _i32)]
+
+
+# name -> (restype, argtypes); must list every symbol declared in include/p2w.h
+SIGNATURES = {
+    "p2w_version": (_i32, []),
+    "p2w_strerror": (C.c_char_p, [_i32]),
+    "p2w_pack_xyzr": (_i32, [_vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
+    "p2w_voxel_sample_ws_bytes": (_sz, [_i32]),
+    "p2w_voxel_sample": (_i32, [_vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "p2w_voxel_grid": (_i32, [_vp, _vp, _i32, _i32, _f32, _vp, _vp, _sz, _vp]),
+    "p2w_consecutive_cluster": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "p2w_level_gather": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
+    "p2w_ball_query": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, C.c_double, _i32, _vp, _vp, _vp]),
+    "p2w_knn": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "p2w_stem": (_i32, [_vp, _i32, _vp, _vp, _i32, _vp, _vp]),
+    "p2w_packed_dims": (None, [_i32, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
+    "p2w_gemm": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, C.POINTER(Epilogue), _vp, _i32, _vp]),
+    "p2w_sa_conv": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp,
+                           _vp, _i32, _vp]),
+    "p2w_interp_concat": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _i32, _vp]),
+    "p2w_concat_xyz": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _vp]),
+    "p2w_segment_max": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _vp]),
+    "p2w_rowdot": (_i32, [_vp, _i32, _i32, _vp, _f32, _i32, _vp, _vp]),
+    "p2w_fill_batch_nbr": (_i32, [_vp, _i32, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raise loudly when the library is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension is the only compute path "
+                "(no CPU fallback). Build it with `python -m pointstowood_amd.build`.")
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)  # AttributeError = symbol missing from the build
+            fn.restype, fn.argtypes = res, args
+        _lib = h
+    return _lib
+
+
+def check(code: int, what: str = "") -> None:
+    if code != 0:
+        msg = lib().p2w_strerror(code).decode()
+        raise RuntimeError(f"{what or 'p2w'} failed: {msg} (code {code})")
+
+
+def ptr(t):
+    """Raw device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("pointstowood_amd operators need tensors on an MI355X (cuda) device; "
+                               "there is no CPU fallback")
+
+
+def packed_dims(n: int, k: int):
+    a, b = _i32(), _i32()
+    lib().p2w_packed_dims(n, k, C.byref(a), C.byref(b))
+    return a.value, b.value

@@ -1,0 +1,67 @@
+"""Build libp2w_gfx950.so in-tree with hipcc (cross-compiles without a GPU).
+
+    python -m pointstowood_amd.build [--force]
+
+Flags that matter: ``--offload-arch=gfx950`` (MI355X only, no other targets),
+``-ffp-contract=off`` (the geometry kernels need individually rounded fp32 ops for
+bit-exact neighbour sets; kernels that want an FMA call fmaf explicitly).
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+LIB = os.path.join(HERE, "libp2w_gfx950.so")
+SOURCES = ["p2w_geom.hip", "p2w_feat.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-I", INCLUDE]
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(INCLUDE, "p2w.h"), __file__]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not _stale():
+        return LIB
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    hipcc = _hipcc()
+
+    def cc(src):
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr}")
+        return obj
+
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        objs = list(ex.map(cc, SOURCES))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB + ".tmp", *objs]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stderr}")
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,488 @@
+// Geometry kernels: record packing, grid sub-sampling, level gather, ball query, exact kNN.
+// gfx950 only (wave64, LDS-staged candidate tiles, wave-level ballot/popcount selection).
+#include "p2w_common.h"
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+// ------------------------------------------------------------------------------------------------
+// pack: xyzr + batch ids
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_xyzr_kernel(const float* __restrict__ pos, int pos_stride,
+                                                        const float* __restrict__ refl, const int* __restrict__ ptr,
+                                                        int B, int n, float4* __restrict__ xyzr, int* __restrict__ batch) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float* p = pos + (size_t)i * pos_stride;
+    xyzr[i] = make_float4(p[0], p[1], p[2], refl ? refl[i] : 0.0f);
+    batch[i] = p2w_find_segment(ptr, B, i);
+}
+
+extern "C" int32_t p2w_pack_xyzr(const float* pos, int32_t pos_stride, const float* refl, const int32_t* ptr, int32_t B,
+                                 int32_t n, float* xyzr, int32_t* batch, p2w_stream_t stream) {
+    if (n == 0) return P2W_OK;
+    P2W_CHECK_PTR(pos); P2W_CHECK_PTR(ptr); P2W_CHECK_PTR(xyzr); P2W_CHECK_PTR(batch);
+    P2W_CHECK_ALIGN16(xyzr);
+    if (n < 0 || B <= 0 || pos_stride < 3) return P2W_EINVAL;
+    pack_xyzr_kernel<<<p2w_cdiv(n, 256), 256, 0, p2w_s(stream)>>>(pos, pos_stride, refl, ptr, B, n,
+                                                                   reinterpret_cast<float4*>(xyzr), batch);
+    return P2W_LAUNCH_STATUS();
+}
+
+// ------------------------------------------------------------------------------------------------
+// voxel sample = voxel_grid + consecutive_cluster
+// ------------------------------------------------------------------------------------------------
+// float <-> order-preserving uint (for atomic min/max)
+__device__ __forceinline__ unsigned f2ord(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned o) {
+    const unsigned u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+    return __uint_as_float(u);
+}
+
+struct VsHeader {          // lives at the start of the workspace
+    unsigned lo[3], hi[3]; // order-encoded min / max of x, y, z over the whole batch
+    int pad[2];
+};
+
+__global__ void vs_init_kernel(VsHeader* h) {
+    if (threadIdx.x < 3) { h->lo[threadIdx.x] = 0xffffffffu; h->hi[threadIdx.x] = 0u; }
+}
+
+__global__ __launch_bounds__(256) void vs_minmax_kernel(const float4* __restrict__ xyzr, const int* __restrict__ ptr, int B,
+                                                        VsHeader* h) {
+    const int n = ptr[B];
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const float4 p = xyzr[i];
+        lo[0] = fminf(lo[0], p.x); hi[0] = fmaxf(hi[0], p.x);
+        lo[1] = fminf(lo[1], p.y); hi[1] = fmaxf(hi[1], p.y);
+        lo[2] = fminf(lo[2], p.z); hi[2] = fmaxf(hi[2], p.z);
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            lo[d] = fminf(lo[d], __shfl_xor(lo[d], off));
+            hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], off));
+        }
+    }
+    if ((threadIdx.x & 63) == 0 && n > 0) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            atomicMin(&h->lo[d], f2ord(lo[d]));
+            atomicMax(&h->hi[d], f2ord(hi[d]));
+        }
+    }
+}
+
+// key_i = sum_d trunc((P_id - lo_d) / S_d) * stride_d over d = x, y, z, batch   (oracle/ops.py voxel_grid)
+__global__ __launch_bounds__(256) void vs_keys_kernel(const float4* __restrict__ xyzr, const int* __restrict__ ptr, int B,
+                                                      int n_bound, float res, const VsHeader* __restrict__ h,
+                                                      unsigned long long* __restrict__ keys, int* __restrict__ vals) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_bound) return;
+    const int n = ptr[B];
+    if (vals) vals[i] = i;
+    if (i >= n) { keys[i] = ~0ull; return; }
+    // batch column: min of the batch ids that occur
+    int b_lo = 0;
+    while (b_lo < B - 1 && ptr[b_lo + 1] == ptr[b_lo]) ++b_lo;
+    const float lo0 = ord2f(h->lo[0]), lo1 = ord2f(h->lo[1]), lo2 = ord2f(h->lo[2]);
+    const long long c0 = (long long)((ord2f(h->hi[0]) - lo0) / res) + 1;
+    const long long c1 = (long long)((ord2f(h->hi[1]) - lo1) / res) + 1;
+    const long long c2 = (long long)((ord2f(h->hi[2]) - lo2) / res) + 1;
+    const float4 p = xyzr[i];
+    const int b = p2w_find_segment(ptr, B, i);
+    const long long k0 = (long long)((p.x - lo0) / res);
+    const long long k1 = (long long)((p.y - lo1) / res);
+    const long long k2 = (long long)((p.z - lo2) / res);
+    const long long kb = (long long)(((float)b - (float)b_lo) / 1.0f);
+    const long long key = k0 + k1 * c0 + k2 * (c0 * c1) + kb * (c0 * c1 * c2);
+    keys[i] = (unsigned long long)key;
+}
+
+__global__ __launch_bounds__(256) void vs_iota_kernel(int n, int* __restrict__ vals) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) vals[i] = i;
+}
+
+// n_dev: device count of valid (non-padding) keys, or nullptr when all n_bound keys are valid
+__global__ __launch_bounds__(256) void vs_flags_kernel(const unsigned long long* __restrict__ keys, const int* __restrict__ n_dev,
+                                                       int n_bound, int* __restrict__ flags) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_bound) return;
+    const int n = n_dev ? *n_dev : n_bound;
+    flags[i] = (i < n && (i == n - 1 || keys[i] != keys[i + 1])) ? 1 : 0;  // last of each run = largest point index
+}
+
+// perm (one representative per run, ascending key), optional inv (rank of every point's key), optional CSR of the result
+__global__ __launch_bounds__(256) void vs_scatter_kernel(const int* __restrict__ flags, const int* __restrict__ scan,
+                                                         const int* __restrict__ vals, const int* __restrict__ ptr, int B,
+                                                         const int* __restrict__ n_dev, int n_bound, int* __restrict__ idx_out,
+                                                         int* __restrict__ ptr_out, int* __restrict__ batch_out,
+                                                         int* __restrict__ inv_out, int* __restrict__ count_out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int n = n_dev ? *n_dev : n_bound;
+    const int total = (n == 0) ? 0 : scan[n - 1] + flags[n - 1];
+    if (i == 0 && count_out) *count_out = total;
+    if (ptr_out && i <= B) {  // sorted position p belongs to voxel b iff ptr[b] <= p < ptr[b+1] (keys are voxel-major)
+        const int p = ptr[i];
+        ptr_out[i] = (p < n) ? scan[p] : total;
+    }
+    if (i >= n || i >= n_bound) return;
+    if (inv_out) inv_out[vals[i]] = scan[i];
+    if (flags[i]) {
+        const int o = scan[i];
+        idx_out[o] = vals[i];
+        if (batch_out) batch_out[o] = p2w_find_segment(ptr, B, i);
+    }
+}
+
+struct VsLayout { size_t hdr, keys_in, keys_out, vals_in, vals_out, flags, scan, temp, temp_bytes, total; };
+
+static hipError_t vs_layout(int n_bound, VsLayout* L) {
+    auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
+    size_t sort_bytes = 0, scan_bytes = 0;
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, sort_bytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr,
+                                             (int*)nullptr, (int*)nullptr, (size_t)n_bound, 0, 64, (hipStream_t)0);
+    if (e != hipSuccess) return e;
+    e = rocprim::exclusive_scan(nullptr, scan_bytes, (int*)nullptr, (int*)nullptr, 0, (size_t)n_bound, rocprim::plus<int>(),
+                                (hipStream_t)0);
+    if (e != hipSuccess) return e;
+    size_t off = 0;
+    L->hdr = off; off += up(sizeof(VsHeader));
+    L->keys_in = off; off += up(sizeof(unsigned long long) * n_bound);
+    L->keys_out = off; off += up(sizeof(unsigned long long) * (n_bound + 1));
+    L->vals_in = off; off += up(sizeof(int) * n_bound);
+    L->vals_out = off; off += up(sizeof(int) * n_bound);
+    L->flags = off; off += up(sizeof(int) * n_bound);
+    L->scan = off; off += up(sizeof(int) * n_bound);
+    L->temp = off; L->temp_bytes = up(sort_bytes > scan_bytes ? sort_bytes : scan_bytes); off += L->temp_bytes;
+    L->total = off;
+    return hipSuccess;
+}
+
+extern "C" size_t p2w_voxel_sample_ws_bytes(int32_t n_bound) {
+    if (n_bound <= 0) return 256;
+    VsLayout L;
+    if (vs_layout(n_bound, &L) != hipSuccess) return 0;
+    return L.total;
+}
+
+// min/max + keys into keys_out[n_bound] (padding keys = ~0)
+static int32_t vs_compute_keys(const float4* x4, const int* ptr, int B, int n_bound, float res, VsHeader* hdr,
+                               unsigned long long* keys, int* vals, hipStream_t s) {
+    const int nblk = p2w_cdiv(n_bound, 256);
+    vs_init_kernel<<<1, 64, 0, s>>>(hdr);
+    vs_minmax_kernel<<<nblk < 1024 ? nblk : 1024, 256, 0, s>>>(x4, ptr, B, hdr);
+    vs_keys_kernel<<<nblk, 256, 0, s>>>(x4, ptr, B, n_bound, res, hdr, keys, vals);
+    return P2W_LAUNCH_STATUS();
+}
+
+// sort (key, point) pairs, flag the last element of each run, compact
+static int32_t vs_cluster(char* w, const VsLayout& L, const unsigned long long* keys_in, const int* ptr, int B,
+                          const int* n_dev, int n_bound, int* idx_out, int* ptr_out, int* batch_out, int* inv_out,
+                          int* count_out, hipStream_t s) {
+    auto* keys_out = reinterpret_cast<unsigned long long*>(w + L.keys_out);
+    int* vals_in = reinterpret_cast<int*>(w + L.vals_in);
+    int* vals_out = reinterpret_cast<int*>(w + L.vals_out);
+    int* flags = reinterpret_cast<int*>(w + L.flags);
+    int* scan = reinterpret_cast<int*>(w + L.scan);
+    const int nblk = p2w_cdiv(n_bound, 256);
+    size_t tb = L.temp_bytes;
+    hipError_t e = rocprim::radix_sort_pairs(w + L.temp, tb, keys_in, keys_out, vals_in, vals_out, (size_t)n_bound, 0, 64, s);
+    if (e != hipSuccess) return (int32_t)e;
+    vs_flags_kernel<<<nblk, 256, 0, s>>>(keys_out, n_dev, n_bound, flags);
+    tb = L.temp_bytes;
+    e = rocprim::exclusive_scan(w + L.temp, tb, flags, scan, 0, (size_t)n_bound, rocprim::plus<int>(), s);
+    if (e != hipSuccess) return (int32_t)e;
+    const int nblk2 = p2w_cdiv((n_bound > B + 1 ? n_bound : B + 1), 256);
+    vs_scatter_kernel<<<nblk2, 256, 0, s>>>(flags, scan, vals_out, ptr, B, n_dev, n_bound, idx_out, ptr_out, batch_out,
+                                            inv_out, count_out);
+    return P2W_LAUNCH_STATUS();
+}
+
+extern "C" int32_t p2w_voxel_sample(const float* xyzr, const int32_t* ptr, int32_t B, int32_t n_bound, float res,
+                                    int32_t* idx_out, int32_t* ptr_out, int32_t* batch_out, void* ws, size_t ws_bytes,
+                                    p2w_stream_t stream) {
+    P2W_CHECK_PTR(ptr); P2W_CHECK_PTR(ptr_out);
+    if (B <= 0 || n_bound < 0 || !(res > 0.0f)) return P2W_EINVAL;
+    hipStream_t s = p2w_s(stream);
+    if (n_bound == 0) return (int32_t)hipMemsetAsync(ptr_out, 0, sizeof(int) * (B + 1), s);
+    P2W_CHECK_PTR(xyzr); P2W_CHECK_PTR(idx_out); P2W_CHECK_PTR(batch_out); P2W_CHECK_PTR(ws);
+    P2W_CHECK_ALIGN16(xyzr); P2W_CHECK_ALIGN16(ws);
+    VsLayout L;
+    hipError_t e = vs_layout(n_bound, &L);
+    if (e != hipSuccess) return (int32_t)e;
+    if (ws_bytes < L.total) return P2W_EWORKSPACE;
+    char* w = static_cast<char*>(ws);
+    auto* keys_in = reinterpret_cast<unsigned long long*>(w + L.keys_in);
+    int32_t st = vs_compute_keys(reinterpret_cast<const float4*>(xyzr), ptr, B, n_bound, res,
+                                 reinterpret_cast<VsHeader*>(w + L.hdr), keys_in, reinterpret_cast<int*>(w + L.vals_in), s);
+    if (st != P2W_OK) return st;
+    return vs_cluster(w, L, keys_in, ptr, B, ptr + B, n_bound, idx_out, ptr_out, batch_out, nullptr, nullptr, s);
+}
+
+extern "C" int32_t p2w_voxel_grid(const float* xyzr, const int32_t* ptr, int32_t B, int32_t n, float res, int64_t* cell_out,
+                                  void* ws, size_t ws_bytes, p2w_stream_t stream) {
+    if (n == 0) return P2W_OK;
+    P2W_CHECK_PTR(xyzr); P2W_CHECK_PTR(ptr); P2W_CHECK_PTR(cell_out); P2W_CHECK_PTR(ws);
+    P2W_CHECK_ALIGN16(xyzr); P2W_CHECK_ALIGN16(ws);
+    if (B <= 0 || n < 0 || !(res > 0.0f)) return P2W_EINVAL;
+    if (ws_bytes < 256) return P2W_EWORKSPACE;
+    return vs_compute_keys(reinterpret_cast<const float4*>(xyzr), ptr, B, n, res, static_cast<VsHeader*>(ws),
+                           reinterpret_cast<unsigned long long*>(cell_out), nullptr, p2w_s(stream));
+}
+
+extern "C" int32_t p2w_consecutive_cluster(const int64_t* cell, int32_t n, int32_t* inv_out, int32_t* perm_out,
+                                           int32_t* count_out, void* ws, size_t ws_bytes, p2w_stream_t stream) {
+    P2W_CHECK_PTR(count_out);
+    hipStream_t s = p2w_s(stream);
+    if (n == 0) return (int32_t)hipMemsetAsync(count_out, 0, sizeof(int), s);
+    P2W_CHECK_PTR(cell); P2W_CHECK_PTR(perm_out); P2W_CHECK_PTR(ws); P2W_CHECK_ALIGN16(ws);
+    if (n < 0) return P2W_EINVAL;
+    VsLayout L;
+    hipError_t e = vs_layout(n, &L);
+    if (e != hipSuccess) return (int32_t)e;
+    if (ws_bytes < L.total) return P2W_EWORKSPACE;
+    char* w = static_cast<char*>(ws);
+    vs_iota_kernel<<<p2w_cdiv(n, 256), 256, 0, s>>>(n, reinterpret_cast<int*>(w + L.vals_in));
+    // non-negative int64 cell ids order like their unsigned bit patterns
+    return vs_cluster(w, L, reinterpret_cast<const unsigned long long*>(cell), nullptr, 0, nullptr, n, perm_out, nullptr,
+                      nullptr, inv_out, count_out, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// level gather with the (p / sf) * sf round trip
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void level_gather_kernel(const float4* __restrict__ src, const int* __restrict__ idx,
+                                                           const int* __restrict__ batch_dst, const int* __restrict__ ptr_dst,
+                                                           int B, const float* __restrict__ sf, float4* __restrict__ dst) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= ptr_dst[B]) return;
+    const float4 p = src[idx[i]];
+    const float s = sf[batch_dst[i]];
+    dst[i] = make_float4((p.x / s) * s, (p.y / s) * s, (p.z / s) * s, p.w);
+}
+
+extern "C" int32_t p2w_level_gather(const float* xyzr_src, const int32_t* idx, const int32_t* batch_dst, const int32_t* ptr_dst,
+                                    int32_t B, int32_t m_bound, const float* sf, float* xyzr_dst, p2w_stream_t stream) {
+    if (m_bound == 0) return P2W_OK;
+    P2W_CHECK_PTR(xyzr_src); P2W_CHECK_PTR(idx); P2W_CHECK_PTR(batch_dst); P2W_CHECK_PTR(ptr_dst); P2W_CHECK_PTR(sf);
+    P2W_CHECK_PTR(xyzr_dst); P2W_CHECK_ALIGN16(xyzr_src); P2W_CHECK_ALIGN16(xyzr_dst);
+    if (m_bound < 0 || B <= 0) return P2W_EINVAL;
+    level_gather_kernel<<<p2w_cdiv(m_bound, 256), 256, 0, p2w_s(stream)>>>(
+        reinterpret_cast<const float4*>(xyzr_src), idx, batch_dst, ptr_dst, B, sf, reinterpret_cast<float4*>(xyzr_dst));
+    return P2W_LAUNCH_STATUS();
+}
+
+// ------------------------------------------------------------------------------------------------
+// brute-force neighbour search
+//
+// Work decomposition: a workgroup (4 waves) owns a tile of QT = 4*QPW queries of ONE voxel; it streams
+// that voxel's candidates HBM -> LDS in coalesced 16-byte records (TILE per stage); each wave keeps
+// QPW queries' selection state in registers and visits 64 candidates per step (one per lane), so a
+// candidate record is read from LDS once per QPW queries.  Query coordinates and thresholds are
+// wave-uniform (SGPRs); admission is a ballot, so the common "nothing admitted" case costs
+// 8 VALU + 1 compare + 1 scalar branch per 64 pairs and nothing diverges.
+// ------------------------------------------------------------------------------------------------
+constexpr int S_QPW = 16;            // queries per wave
+constexpr int S_QT = 4 * S_QPW;      // queries per workgroup
+constexpr int S_TILE = 1024;         // candidates per LDS stage (16 KiB)
+
+// blockIdx -> (voxel b, first query q0, end q1).  Tiles never straddle voxels.
+__device__ __forceinline__ bool search_tile(const int* __restrict__ ptr_q, int B, int tile, int* b_out, int* q0, int* q1) {
+    int acc = 0;
+    for (int b = 0; b < B; ++b) {
+        const int s = ptr_q[b], e = ptr_q[b + 1];
+        const int t = (e - s + S_QT - 1) / S_QT;
+        if (tile < acc + t) {
+            *b_out = b;
+            *q0 = s + (tile - acc) * S_QT;
+            *q1 = min(*q0 + S_QT, e);
+            return true;
+        }
+        acc += t;
+    }
+    return false;
+}
+
+__device__ __forceinline__ float rfl(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
+__device__ __forceinline__ float rdlane(float v, int l) { return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), l)); }
+
+__global__ __launch_bounds__(256) void knn_kernel(const float4* __restrict__ x, const int* __restrict__ ptr_x,
+                                                  const float4* __restrict__ xq, const int* __restrict__ qidx,
+                                                  const int* __restrict__ ptr_q, int B, int k, int* __restrict__ nbr,
+                                                  int* __restrict__ deg) {
+    __shared__ float4 cand[S_TILE];
+    __shared__ float4 qs[S_QT];
+    int b, q0, q1;
+    if (!search_tile(ptr_q, B, blockIdx.x, &b, &q0, &q1)) return;
+    const int c0 = ptr_x[b], c1 = ptr_x[b + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < S_QT) {
+        const int q = q0 + tid;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q < q1) v = xq[qidx ? qidx[q] : q];
+        qs[tid] = v;
+    }
+    // selection state: lane l of best_*[j] holds the l-th nearest so far of query j (lanes >= k: +inf)
+    float best_d[S_QPW];
+    int best_i[S_QPW];
+    float thr[S_QPW];  // wave-uniform: current k-th smallest distance (+inf until k admitted; -inf = query slot unused)
+#pragma unroll
+    for (int j = 0; j < S_QPW; ++j) {
+        best_d[j] = INFINITY; best_i[j] = -1;
+        thr[j] = (q0 + wave * S_QPW + j < q1) ? INFINITY : -INFINITY;
+    }
+    for (int base = c0; base < c1; base += S_TILE) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < S_TILE / 256; ++r) {
+            const int c = base + tid + 256 * r;
+            cand[tid + 256 * r] = (c < c1) ? x[c] : make_float4(INFINITY, INFINITY, INFINITY, 0.f);
+        }
+        __syncthreads();
+        const int nch = (min(S_TILE, c1 - base) + 63) >> 6;
+        for (int ch = 0; ch < nch; ++ch) {
+            const float4 c = cand[ch * 64 + lane];
+            const int cbase = base + ch * 64;
+#pragma unroll
+            for (int j = 0; j < S_QPW; ++j) {
+                const float4 q = qs[wave * S_QPW + j];
+                const float d = p2w_d2(rfl(q.x), rfl(q.y), rfl(q.z), c.x, c.y, c.z);
+                unsigned long long m = __ballot(d < thr[j]);
+                while (m) {  // wave-uniform; candidates admitted in ascending index => ties keep the lower index first
+                    const int src = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const float dn = rdlane(d, src);
+                    if (!(dn < thr[j])) continue;
+                    const int pos = __popcll(__ballot(best_d[j] <= dn));
+                    const float up_d = __shfl_up(best_d[j], 1);
+                    const int up_i = __shfl_up(best_i[j], 1);
+                    if (lane == pos) { best_d[j] = dn; best_i[j] = cbase + src; }
+                    else if (lane > pos && lane < k) { best_d[j] = up_d; best_i[j] = up_i; }
+                    thr[j] = rdlane(best_d[j], k - 1);
+                }
+            }
+        }
+    }
+    const int cnt = min(k, c1 - c0);
+#pragma unroll
+    for (int j = 0; j < S_QPW; ++j) {
+        const int q = q0 + wave * S_QPW + j;
+        if (q < q1) {
+            if (lane < k) nbr[(size_t)q * k + lane] = (lane < cnt) ? best_i[j] : -1;
+            if (lane == 0) deg[q] = cnt;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void ball_kernel(const float4* __restrict__ x, const int* __restrict__ ptr_x,
+                                                   const float4* __restrict__ xq, const int* __restrict__ qidx,
+                                                   const int* __restrict__ ptr_q, int B, float r2, int cap,
+                                                   int* __restrict__ nbr, int* __restrict__ deg) {
+    __shared__ float4 cand[S_TILE];
+    __shared__ float4 qs[S_QT];
+    int b, q0, q1;
+    if (!search_tile(ptr_q, B, blockIdx.x, &b, &q0, &q1)) return;
+    const int c0 = ptr_x[b], c1 = ptr_x[b + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < S_QT) {
+        const int q = q0 + tid;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q < q1) v = xq[qidx ? qidx[q] : q];
+        qs[tid] = v;
+    }
+    int cnt[S_QPW];  // wave-uniform: neighbours kept so far (cap = full / unused slot)
+#pragma unroll
+    for (int j = 0; j < S_QPW; ++j) cnt[j] = (q0 + wave * S_QPW + j < q1) ? 0 : cap;
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int base = c0; base < c1; base += S_TILE) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < S_TILE / 256; ++r) {
+            const int c = base + tid + 256 * r;
+            cand[tid + 256 * r] = (c < c1) ? x[c] : make_float4(INFINITY, INFINITY, INFINITY, 0.f);
+        }
+        __syncthreads();
+        const int nch = (min(S_TILE, c1 - base) + 63) >> 6;
+        for (int ch = 0; ch < nch; ++ch) {
+            const float4 c = cand[ch * 64 + lane];
+            const int cidx = base + ch * 64 + lane;
+#pragma unroll
+            for (int j = 0; j < S_QPW; ++j) {
+                const float4 q = qs[wave * S_QPW + j];
+                const float d = p2w_d2(rfl(q.x), rfl(q.y), rfl(q.z), c.x, c.y, c.z);
+                const bool hit = d < r2;
+                const unsigned long long m = __ballot(hit);
+                if (m != 0ull && cnt[j] < cap) {  // first `cap` hits in ascending candidate index
+                    const int rank = cnt[j] + __popcll(m & lt_mask);
+                    if (hit && rank < cap) nbr[(size_t)(q0 + wave * S_QPW + j) * cap + rank] = cidx;
+                    cnt[j] = min(cap, cnt[j] + __popcll(m));
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < S_QPW; ++j) {
+        const int q = q0 + wave * S_QPW + j;
+        if (q < q1) {
+            if (lane >= cnt[j] && lane < cap) nbr[(size_t)q * cap + lane] = -1;
+            if (lane == 0) deg[q] = cnt[j];
+        }
+    }
+}
+
+static int32_t search_args(const float* xyzr_x, const int32_t* ptr_x, const float* xyzr_q, const int32_t* ptr_q, int32_t B,
+                           int32_t m_bound, int32_t k, const int32_t* nbr, const int32_t* deg) {
+    P2W_CHECK_PTR(xyzr_x); P2W_CHECK_PTR(ptr_x); P2W_CHECK_PTR(xyzr_q); P2W_CHECK_PTR(ptr_q); P2W_CHECK_PTR(nbr);
+    P2W_CHECK_PTR(deg); P2W_CHECK_ALIGN16(xyzr_x); P2W_CHECK_ALIGN16(xyzr_q);
+    if (B <= 0 || m_bound < 0 || k <= 0 || k > P2W_MAX_K) return P2W_EINVAL;
+    return P2W_OK;
+}
+
+extern "C" int32_t p2w_knn(const float* xyzr_x, const int32_t* ptr_x, const float* xyzr_q, const int32_t* qidx,
+                           const int32_t* ptr_q, int32_t B, int32_t m_bound, int32_t k, int32_t* nbr, int32_t* deg,
+                           p2w_stream_t stream) {
+    if (m_bound == 0) return P2W_OK;
+    const int32_t st = search_args(xyzr_x, ptr_x, xyzr_q, ptr_q, B, m_bound, k, nbr, deg);
+    if (st != P2W_OK) return st;
+    const int grid = p2w_cdiv(m_bound, S_QT) + B;  // upper bound on sum_b ceil(m_b / QT)
+    knn_kernel<<<grid, 256, 0, p2w_s(stream)>>>(reinterpret_cast<const float4*>(xyzr_x), ptr_x,
+                                                reinterpret_cast<const float4*>(xyzr_q), qidx, ptr_q, B, k, nbr, deg);
+    return P2W_LAUNCH_STATUS();
+}
+
+extern "C" int32_t p2w_ball_query(const float* xyzr_x, const int32_t* ptr_x, const float* xyzr_q, const int32_t* qidx,
+                                  const int32_t* ptr_q, int32_t B, int32_t m_bound, double r, int32_t cap, int32_t* nbr,
+                                  int32_t* deg, p2w_stream_t stream) {
+    if (m_bound == 0) return P2W_OK;
+    const int32_t st = search_args(xyzr_x, ptr_x, xyzr_q, ptr_q, B, m_bound, cap, nbr, deg);
+    if (st != P2W_OK) return st;
+    const float r2 = (float)(r * r);
+    if (!(r > 0.0)) return P2W_EINVAL;
+    const int grid = p2w_cdiv(m_bound, S_QT) + B;
+    ball_kernel<<<grid, 256, 0, p2w_s(stream)>>>(reinterpret_cast<const float4*>(xyzr_x), ptr_x,
+                                                 reinterpret_cast<const float4*>(xyzr_q), qidx, ptr_q, B, r2, cap, nbr, deg);
+    return P2W_LAUNCH_STATUS();
+}
+
+__global__ __launch_bounds__(256) void fill_batch_nbr_kernel(const int* __restrict__ batch, int m, int* __restrict__ nbr,
+                                                             int* __restrict__ deg) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    nbr[i] = batch[i];
+    deg[i] = 1;
+}
+
+extern "C" int32_t p2w_fill_batch_nbr(const int32_t* batch, int32_t m, int32_t* nbr, int32_t* deg, p2w_stream_t stream) {
+    if (m == 0) return P2W_OK;
+    P2W_CHECK_PTR(batch); P2W_CHECK_PTR(nbr); P2W_CHECK_PTR(deg);
+    if (m < 0) return P2W_EINVAL;
+    fill_batch_nbr_kernel<<<p2w_cdiv(m, 256), 256, 0, p2w_s(stream)>>>(batch, m, nbr, deg);
+    return P2W_LAUNCH_STATUS();
+}

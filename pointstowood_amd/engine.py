@@ -1,0 +1,318 @@
+"""Host-side orchestration of the MI355X forward.
+
+Replaces the body of ``Net.forward`` (reference ``pointstowood/src/model.py:226-245``) and
+the modules it calls with two phases on one HIP stream:
+
+* **geometry** - depends on positions only: record packing, the three grid sub-samplings
+  (``SAModule.voxelsample``), ball query / kNN per SA level, the ``(p/sf)*sf`` level
+  positions and the three k=2 searches of the feature-propagation levels.  Level sizes
+  are data dependent and stay on the device; kernels are launched over upper bounds.
+* **features** - after ONE small device-to-host copy of the three level sizes: stem,
+  per level a hoisted layer-1 GEMM + the fused PointNetConv kernel + the 4-GEMM residual
+  block, the global level, four interpolate+MLP levels and the head.
+
+BatchNorm (eval) and the depthwise 1x1 convolutions are per-channel affines; they are
+folded into the neighbouring GEMM's weights or epilogue when the checkpoint is packed
+(``PackedWeights``), so a residual block is 4 GEMM launches instead of ~20 kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import torch
+
+from . import _lib
+from ._lib import Epilogue, check, lib, ptr
+
+BN_EPS = 1e-5
+SA_RES = (0.04, 0.08, 0.16)  # model.py:210-212
+
+
+# --------------------------------------------------------------------------- weights
+@dataclass
+class Linear:
+    """One packed GEMM: W [N_pad, K_pad] (k contiguous, zero padded) + epilogue vectors."""
+    w: torch.Tensor
+    N: int
+    K: int
+    bias: torch.Tensor | None = None
+    sc0: torch.Tensor | None = None
+    sh0: torch.Tensor | None = None
+    sc1: torch.Tensor | None = None
+    sh1: torch.Tensor | None = None
+    relu0: int = 0
+    relu1: int = 0
+    relu2: int = 0
+    relu_final: int = 0
+
+
+def _bn_affine(sd, p):
+    s = sd[p + ".weight"].double() / torch.sqrt(sd[p + ".running_var"].double() + BN_EPS)
+    t = sd[p + ".bias"].double() - sd[p + ".running_mean"].double() * s
+    return s, t
+
+
+class PackedWeights:
+    """Device-resident, kernel-ready form of the reference's 257-key state dict."""
+
+    def __init__(self, sd, C_: int, num_classes: int, device):
+        self.C, self.num_classes, self.device = C_, num_classes, device
+        if C_ % 4 != 0:
+            raise ValueError("C must be a multiple of 4 (16-byte feature rows)")
+        sd = {k: v.detach().cpu() for k, v in sd.items()}
+        f32 = lambda t: t.to(torch.float32).contiguous().to(device)
+        self._f32 = f32
+
+        def pack(W, **kw):
+            W = W.double()
+            N, K = W.shape
+            Np, Kp = _lib.packed_dims(N, K)
+            Wp = torch.zeros((Np, Kp), dtype=torch.float64)
+            Wp[:N, :K] = W
+            vec = {k: (f32(v) if isinstance(v, torch.Tensor) else v) for k, v in kw.items()}
+            return Linear(w=f32(Wp), N=N, K=K, **vec)
+
+        self.stem_w = f32(sd["stem_mlp.0.0.weight"])
+        self.stem_b = f32(sd["stem_mlp.0.0.bias"])
+        self.sa = []
+        f_in = C_
+        for l in (1, 2, 3):
+            p = f"sa{l}_module"
+            W1, b1 = sd[p + ".conv.local_nn.0.0.weight"], sd[p + ".conv.local_nn.0.0.bias"]
+            C1 = W1.shape[0]
+            W2, b2 = sd[p + ".conv.local_nn.1.0.weight"], sd[p + ".conv.local_nn.1.0.bias"]
+            C2 = W2.shape[0]
+            s2, t2 = _bn_affine(sd, p + ".conv.local_nn.1.2")
+            _, C1p = _lib.packed_dims(C2, C1)
+            w1r4 = torch.zeros((4, C1p), dtype=torch.float32)
+            w1r4[:, :C1] = W1[:, f_in:f_in + 4].t()
+            lvl = {
+                "F_in": f_in, "C1": C1, "C2": C2,
+                "hoist": pack(W1[:, :f_in], bias=b1),               # P = x_src W1x^T + b1
+                "w1r4": f32(w1r4),
+                "W2": pack(W2), "b2": f32(b2), "bn_s": f32(s2), "bn_t": f32(t2),
+            }
+            # InvertedResidualBlock (model.py:46-85) as 4 GEMMs
+            r, F, E = p + ".residual_block", C2, 4 * C2
+            se, te = _bn_affine(sd, r + ".expand.1")
+            dws, dwt = self._dw_affine(sd, r + ".conv.0")
+            lvl["g1"] = pack(sd[r + ".expand.0.weight"][:, :, 0].double() * se[:, None],
+                             bias=se * sd[r + ".expand.0.bias"].double() + te, relu0=1, sc0=dws, sh0=dwt, relu1=1)
+            sp, tp = _bn_affine(sd, r + ".conv.0.pointwise_bn")
+            s1, t1 = _bn_affine(sd, r + ".conv.1")
+            dws2, dwt2 = self._dw_affine(sd, r + ".conv.3")
+            lvl["g2"] = pack(sd[r + ".conv.0.pointwise_conv.weight"][:, :, 0].double() * sp[:, None],
+                             bias=sp * sd[r + ".conv.0.pointwise_conv.bias"].double() + tp, relu0=1,
+                             sc0=s1, sh0=t1, relu1=1, sc1=dws2, sh1=dwt2, relu2=1)
+            sp2, tp2 = _bn_affine(sd, r + ".conv.3.pointwise_bn")
+            lvl["g3"] = pack(sd[r + ".conv.3.pointwise_conv.weight"][:, :, 0].double() * sp2[:, None],
+                             bias=sp2 * sd[r + ".conv.3.pointwise_conv.bias"].double() + tp2, relu0=1)
+            s4, t4 = _bn_affine(sd, r + ".conv.4")          # BN before the projection: fold into its input side
+            spj, tpj = _bn_affine(sd, r + ".project.1")     # BN after it: fold into its output side
+            Wp = sd[r + ".project.0.weight"][:, :, 0].double()
+            lvl["g4"] = pack(spj[:, None] * Wp * s4[None, :],
+                             bias=spj * (Wp @ t4 + sd[r + ".project.0.bias"].double()) + tpj, relu_final=1)
+            self.sa.append(lvl)
+            f_in = C2
+        self.sa4 = self._mlp2(sd, "sa4_module.NN", pack)
+        self.fp = {l: self._mlp2(sd, f"fp{l}_module.NN", pack) for l in (4, 3, 2, 1)}
+        sn, tn = _bn_affine(sd, "norm")
+        self.head1 = pack(sd["conv1.weight"][:, :, 0].double() * sn[:, None],
+                          bias=sn * sd["conv1.bias"].double() + tn, relu0=1)
+        self.head2_w = f32(sd["conv2.weight"][:, :, 0])
+        self.head2_b = sd["conv2.bias"].to(torch.float32)
+        self.head2 = pack(sd["conv2.weight"][:, :, 0], bias=sd["conv2.bias"]) if num_classes != 1 else None
+
+    @staticmethod
+    def _dw_affine(sd, p):
+        """depthwise k=1 conv (per-channel w*x+b) followed by its BatchNorm = one affine."""
+        s, t = _bn_affine(sd, p + ".depthwise_bn")
+        w = sd[p + ".depthwise_conv.weight"][:, 0, 0].double()
+        b = sd[p + ".depthwise_conv.bias"].double()
+        return w * s, b * s + t
+
+    @staticmethod
+    def _mlp2(sd, p, pack):
+        """MLP([a,b,c]) (model.py:198-202): Lin+ReLU, then Lin+ReLU+BN."""
+        s, t = _bn_affine(sd, p + ".1.2")
+        return (pack(sd[p + ".0.0.weight"], bias=sd[p + ".0.0.bias"], relu0=1),
+                pack(sd[p + ".1.0.weight"], bias=sd[p + ".1.0.bias"], relu0=1, sc0=s, sh0=t))
+
+
+# --------------------------------------------------------------------------- geometry
+@dataclass
+class Level:
+    xyzr: torch.Tensor           # [n_bound, 4] records of this level
+    ptr: torch.Tensor            # [B+1] int32 CSR (device)
+    batch: torch.Tensor          # [n_bound] int32
+    idx: torch.Tensor | None = None   # [n_bound] index into the previous level
+    nbr: torch.Tensor | None = None   # [n_bound, k] neighbours in the previous level
+    deg: torch.Tensor | None = None
+    n: int = -1                  # exact size once known on the host
+
+
+@dataclass
+class Geometry:
+    B: int
+    N: int
+    k: int
+    sf: torch.Tensor
+    levels: list = field(default_factory=list)   # 0..3
+    fp_nbr: dict = field(default_factory=dict)   # l -> (nbr [n,2], deg) of fine level l-1... see Engine.geometry
+
+
+class Engine:
+    def __init__(self, weights: PackedWeights, k: int = 32):
+        self.w = weights
+        self.k = int(k)
+        if not 1 <= self.k <= 32:
+            raise ValueError("k must be in 1..32 (one 32-row MFMA tile per target)")
+        self.events = None  # set to a list to record (name, start, end) events per launch
+        self.stem_out = None
+        self._ws = None
+
+    # -- small helpers ------------------------------------------------------------------------
+    def _call(self, name, fn, *args):
+        ev = self.events
+        if ev is not None:
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+        check(fn(*args, _lib.stream()), name)
+        if ev is not None:
+            e.record()
+            ev.append((name, s, e))
+
+    def _gemm(self, name, A, lda, M, lin: Linear, out, ldo, residual=None, ldr=0):
+        ep = Epilogue(ptr(lin.bias), ptr(lin.sc0), ptr(lin.sh0), ptr(lin.sc1), ptr(lin.sh1), ptr(residual), ldr,
+                      lin.relu0, lin.relu1, lin.relu2, lin.relu_final)
+        self._call(name, lib().p2w_gemm, ptr(A), lda, ptr(lin.w), M, lin.N, lin.K, C.byref(ep), ptr(out), ldo)
+
+    def _workspace(self, n, device):
+        need = int(lib().p2w_voxel_sample_ws_bytes(n))
+        if need == 0:
+            raise RuntimeError("p2w_voxel_sample_ws_bytes failed (no usable HIP device?)")
+        if self._ws is None or self._ws.numel() < need or self._ws.device != device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=device)
+        return self._ws
+
+    # -- phase 1 ------------------------------------------------------------------------------
+    def geometry(self, pos, reflectance, ptr0, sf) -> Geometry:
+        L = lib()
+        dev = pos.device
+        N, B, k = pos.shape[0], sf.numel(), self.k
+        i32 = dict(dtype=torch.int32, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        geo = Geometry(B=B, N=N, k=k, sf=sf)
+        xyzr0, batch0 = torch.empty((N, 4), **f32), torch.empty(N, **i32)
+        self._call("pack_xyzr", L.p2w_pack_xyzr, ptr(pos), pos.stride(0), ptr(reflectance), ptr(ptr0), B, N,
+                   ptr(xyzr0), ptr(batch0))
+        geo.levels.append(Level(xyzr=xyzr0, ptr=ptr0, batch=batch0, n=N))
+        ws = self._workspace(N, dev)
+        for l, res in enumerate(SA_RES):
+            src = geo.levels[l]
+            lv = Level(xyzr=torch.empty((N, 4), **f32), ptr=torch.empty(B + 1, **i32), batch=torch.empty(N, **i32),
+                       idx=torch.empty(N, **i32), nbr=torch.empty((N, k), **i32), deg=torch.empty(N, **i32))
+            self._call("voxel_sample", L.p2w_voxel_sample, ptr(src.xyzr), ptr(src.ptr), B, N, res, ptr(lv.idx),
+                       ptr(lv.ptr), ptr(lv.batch), ptr(ws), ws.numel())
+            if l == 0:   # model.py:117-118: the 0.04 level uses radius(r = 2*resolution)
+                self._call("ball_query", L.p2w_ball_query, ptr(src.xyzr), ptr(src.ptr), ptr(src.xyzr), ptr(lv.idx),
+                           ptr(lv.ptr), B, N, res * 2, k, ptr(lv.nbr), ptr(lv.deg))
+            else:        # model.py:120
+                self._call("knn", L.p2w_knn, ptr(src.xyzr), ptr(src.ptr), ptr(src.xyzr), ptr(lv.idx), ptr(lv.ptr), B, N,
+                           k, ptr(lv.nbr), ptr(lv.deg))
+            self._call("level_gather", L.p2w_level_gather, ptr(src.xyzr), ptr(lv.idx), ptr(lv.batch), ptr(lv.ptr), B, N,
+                       ptr(sf), ptr(lv.xyzr))
+            geo.levels.append(lv)
+        # k=2 searches of knn_interpolate (model.py:149): fine level f queries coarse level f+1
+        for f in (2, 1, 0):
+            fine, coarse = geo.levels[f], geo.levels[f + 1]
+            nbr, deg = torch.empty((N, 2), **i32), torch.empty(N, **i32)
+            self._call("knn2", L.p2w_knn, ptr(coarse.xyzr), ptr(coarse.ptr), ptr(fine.xyzr), None, ptr(fine.ptr), B, N, 2,
+                       ptr(nbr), ptr(deg))
+            geo.fp_nbr[f] = (nbr, deg)
+        # the only host sync of the forward: three level sizes
+        counts = torch.stack([geo.levels[l].ptr[B] for l in (1, 2, 3)]).cpu()
+        for l in (1, 2, 3):
+            geo.levels[l].n = int(counts[l - 1])
+        return geo
+
+    # -- phase 2 ------------------------------------------------------------------------------
+    def features(self, geo: Geometry, keep: dict | None = None):
+        L, w = lib(), self.w
+        dev = geo.sf.device
+        Cw = w.C
+        new = lambda r, c: torch.empty((r, c), dtype=torch.float32, device=dev)
+        lv = geo.levels
+        N = geo.N
+        x = [new(N, Cw)]
+        self._call("stem", L.p2w_stem, ptr(lv[0].xyzr), N, ptr(w.stem_w), ptr(w.stem_b), Cw, ptr(x[0]))
+        self.stem_out = x[0]
+        if keep is not None:
+            keep["stem"] = x[0]
+        for l in (1, 2, 3):
+            p, src, dst = w.sa[l - 1], lv[l - 1], lv[l]
+            M, C1, C2, E = dst.n, p["C1"], p["C2"], 4 * p["C2"]
+            P = new(src.n, C1)
+            self._gemm("gemm_hoist", x[l - 1], p["F_in"], src.n, p["hoist"], P, C1)
+            conv = new(M, C2)
+            self._call("sa_conv", L.p2w_sa_conv, ptr(P), C1, ptr(src.xyzr), ptr(dst.idx), ptr(dst.batch), ptr(geo.sf),
+                       ptr(dst.nbr), ptr(dst.deg), geo.k, M, ptr(p["w1r4"]), ptr(p["W2"].w), C1, C2, ptr(p["b2"]),
+                       ptr(p["bn_s"]), ptr(p["bn_t"]), ptr(conv), C2)
+            e1, e2 = new(M, E), new(M, E)
+            self._gemm("gemm_res", conv, C2, M, p["g1"], e1, E)
+            self._gemm("gemm_res", e1, E, M, p["g2"], e2, E)
+            self._gemm("gemm_res", e2, E, M, p["g3"], e1, E)
+            out = new(M, C2)
+            self._gemm("gemm_res", e1, E, M, p["g4"], out, C2, residual=conv, ldr=C2)
+            x.append(out)
+            if keep is not None:
+                keep[f"sa{l}_module.conv"], keep[f"sa{l}_module.out"] = conv, out
+        # GlobalSAModule (model.py:134-140)
+        F3, M3, B = 16 * Cw, lv[3].n, geo.B
+        cat = new(M3, F3 + 4)
+        self._call("concat_xyz", L.p2w_concat_xyz, ptr(x[3]), F3, ptr(lv[3].xyzr), M3, ptr(cat), F3 + 4)
+        h1, h2 = new(M3, F3), new(M3, F3)
+        self._gemm("gemm_mlp", cat, F3 + 4, M3, w.sa4[0], h1, F3)
+        self._gemm("gemm_mlp", h1, F3, M3, w.sa4[1], h2, F3)
+        g = new(B, F3)
+        self._call("segment_max", L.p2w_segment_max, ptr(h2), F3, F3, ptr(lv[3].ptr), B, ptr(g))
+        if keep is not None:
+            keep["sa4_module.out"] = g
+        # FPModule 4..1 (model.py:148-153)
+        nbr4 = torch.empty(M3, dtype=torch.int32, device=dev)
+        deg4 = torch.empty(M3, dtype=torch.int32, device=dev)
+        self._call("fill_batch_nbr", L.p2w_fill_batch_nbr, ptr(lv[3].batch), M3, ptr(nbr4), ptr(deg4))
+        zeros_c = torch.zeros((B, 4), dtype=torch.float32, device=dev)
+        y, y_xyzr = g, zeros_c
+        for fl in (4, 3, 2, 1):
+            fine = lv[fl - 1]
+            m, Fc, Fs = fine.n, y.shape[1], x[fl - 1].shape[1]
+            nbr, deg, kw = (nbr4, deg4, 1) if fl == 4 else (*geo.fp_nbr[fl - 1], 2)
+            cat = new(m, Fc + Fs)
+            self._call("interp_concat", L.p2w_interp_concat, ptr(y), Fc, ptr(y_xyzr), ptr(fine.xyzr), ptr(nbr), ptr(deg),
+                       kw, ptr(x[fl - 1]), Fs, m, ptr(cat), Fc + Fs)
+            l0, l1 = w.fp[fl]
+            a, b = new(m, l0.N), new(m, l1.N)
+            self._gemm("gemm_mlp", cat, Fc + Fs, m, l0, a, l0.N)
+            self._gemm("gemm_mlp", a, l0.N, m, l1, b, l1.N)
+            y, y_xyzr = b, fine.xyzr
+            if keep is not None:
+                keep[f"fp{fl}_module.out"] = b
+        # head (model.py:241-243)
+        hd = new(N, F3)
+        self._gemm("gemm_mlp", y, F3, N, w.head1, hd, F3)
+        if w.num_classes == 1:
+            logits = torch.empty(N, dtype=torch.float32, device=dev)
+            self._call("rowdot", L.p2w_rowdot, ptr(hd), F3, F3, ptr(w.head2_w), float(w.head2_b[0]), N, ptr(logits))
+        else:
+            o = new(N, w.num_classes)
+            self._gemm("gemm_mlp", hd, F3, N, w.head2, o, w.num_classes)
+            logits = o.t()
+        return torch.squeeze(logits)
+
+    def forward(self, pos, reflectance, ptr0, sf, keep=None):
+        geo = self.geometry(pos, reflectance, ptr0, sf)
+        if keep is not None:
+            keep["geometry"] = geo
+        return self.features(geo, keep)

@@ -1,0 +1,156 @@
+"""``Net`` - drop-in for the reference's ``src.model.Net`` on MI355X.
+
+Same constructor (``Net(num_classes, C=32)``), same 257-key ``state_dict`` (names, order,
+shapes - so ``global.pth`` loads unchanged through ``load_state_dict(..., strict=False)``,
+reference ``pointstowood/src/predicter.py:97-105``), same ``forward(data) -> [sum N] fp32
+logits`` over a duck-typed batch with ``pos``, ``batch``, ``reflectance``, ``sf``
+(``pointstowood/src/model.py:226-245``).  The module tree is generated from a key table
+instead of hand-written layer classes because no PyTorch layer is ever executed: the
+forward runs ``pointstowood_amd.engine.Engine`` over weights folded and packed for the
+HIP kernels.  Inference only (eval semantics; no autograd graph is built).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import _lib
+from .engine import Engine, PackedWeights
+
+
+def _bn(prefix, c):
+    return [(f"{prefix}.weight", (c,), "ones"), (f"{prefix}.bias", (c,), "zeros"),
+            (f"{prefix}.running_mean", (c,), "buf0"), (f"{prefix}.running_var", (c,), "buf1"),
+            (f"{prefix}.num_batches_tracked", (), "bufn")]
+
+
+def _lin(prefix, o, i, conv=False):
+    return [(f"{prefix}.weight", (o, i, 1) if conv else (o, i), "conv" if conv else "lin"),
+            (f"{prefix}.bias", (o,), "zeros")]
+
+
+def _mlp(prefix, ch):
+    keys = []
+    for i in range(1, len(ch)):
+        keys += _lin(f"{prefix}.{i-1}.0", ch[i], ch[i - 1])
+        if i != 1:
+            keys += _bn(f"{prefix}.{i-1}.2", ch[i])
+    return keys
+
+
+def _dsc(prefix, c):
+    return ([(f"{prefix}.depthwise_conv.weight", (c, 1, 1), "conv"), (f"{prefix}.depthwise_conv.bias", (c,), "zeros")]
+            + _bn(f"{prefix}.depthwise_bn", c) + _lin(f"{prefix}.pointwise_conv", c, c, conv=True)
+            + _bn(f"{prefix}.pointwise_bn", c))
+
+
+def checkpoint_layout(num_classes: int = 1, C: int = 32):
+    """(key, shape, kind) for every entry of the reference ``Net.state_dict()``, in its order."""
+    keys = _mlp("stem_mlp", [3, C])
+    f_in = C
+    for l, f in ((1, 4 * C), (2, 8 * C), (3, 16 * C)):
+        p = f"sa{l}_module"
+        keys += _mlp(p + ".conv.local_nn", [f_in + 4, {1: 2, 2: 6, 3: 12}[l] * C, f])
+        e = 4 * f
+        r = p + ".residual_block"
+        keys += _lin(r + ".expand.0", e, f, conv=True) + _bn(r + ".expand.1", e)
+        keys += _dsc(r + ".conv.0", e) + _bn(r + ".conv.1", e) + _dsc(r + ".conv.3", e) + _bn(r + ".conv.4", e)
+        keys += _lin(r + ".project.0", f, e, conv=True) + _bn(r + ".project.1", f)
+        y = p + ".reflectanceyesno"
+        keys += _lin(y + ".fc1", 32, 1) + _lin(y + ".fc2", 32, 32) + _lin(y + ".fc3", 1, 32)
+        f_in = f
+    keys += _mlp("sa4_module.NN", [16 * C + 3, 16 * C, 16 * C])
+    for l, ch in ((4, [32, 24, 16]), (3, [24, 20, 16]), (2, [20, 16, 16]), (1, [17, 16, 16])):
+        keys += _mlp(f"fp{l}_module.NN", [c * C for c in ch])
+    keys += _lin("conv1", 16 * C, 16 * C, conv=True) + _lin("conv2", num_classes, 16 * C, conv=True)
+    keys += _bn("norm", 16 * C)
+    return keys
+
+
+class _Node(torch.nn.Module):
+    """Anonymous container: only carries parameters/buffers under the reference's names."""
+
+
+class Net(torch.nn.Module):
+    def __init__(self, num_classes: int, C: int = 32, k: int = 32):
+        super().__init__()
+        self.num_classes, self.C, self.k = int(num_classes), int(C), int(k)
+        for key, shape, kind in checkpoint_layout(self.num_classes, self.C):
+            *path, leaf = key.split(".")
+            node = self
+            for part in path:
+                if part not in node._modules:
+                    node.add_module(part, _Node())
+                node = node._modules[part]
+            if kind.startswith("buf"):
+                t = (torch.zeros(shape) if kind == "buf0" else torch.ones(shape) if kind == "buf1"
+                     else torch.zeros((), dtype=torch.long))
+                node.register_buffer(leaf, t)
+            else:
+                node.register_parameter(leaf, torch.nn.Parameter(self._init(shape, kind), requires_grad=False))
+        self._packed = None
+        self._engine = None
+        self.eval()
+
+    @staticmethod
+    def _init(shape, kind):
+        """Same distributions as the reference's ``initialize_weights`` (model.py:9-16)."""
+        if kind == "ones":
+            return torch.ones(shape)
+        if kind == "zeros":
+            return torch.zeros(shape)
+        t = torch.empty(shape)
+        fan_in = int(shape[1] * (shape[2] if len(shape) == 3 else 1))
+        if kind == "lin":   # xavier uniform
+            bound = math.sqrt(6.0 / (fan_in + shape[0]))
+        else:               # Conv1d: kaiming uniform, fan_in, relu
+            bound = math.sqrt(2.0) * math.sqrt(3.0 / fan_in)
+        return t.uniform_(-bound, bound)
+
+    # -- weight packing -------------------------------------------------------------------------
+    def _apply(self, fn, *a, **kw):
+        self._packed = None
+        return super()._apply(fn, *a, **kw)
+
+    def load_state_dict(self, *a, **kw):
+        self._packed = None
+        return super().load_state_dict(*a, **kw)
+
+    def repack(self):
+        """Call after mutating parameters in place."""
+        self._packed = None
+
+    def _ensure_packed(self, device):
+        if self._packed is None or self._packed.device != device:
+            self._packed = PackedWeights(self.state_dict(), self.C, self.num_classes, device)
+            self._engine = Engine(self._packed, k=self.k)
+        if self._engine.k != self.k:
+            self._engine = Engine(self._packed, k=self.k)
+        return self._engine
+
+    # -- forward --------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, data, keep: dict | None = None):
+        if self.training:
+            raise RuntimeError("pointstowood_amd.Net is inference-only: call .eval()")
+        pos, batch, refl, sf = data.pos, data.batch, data.reflectance, data.sf
+        _lib.require_cuda(pos, batch, refl, sf)
+        _lib.lib()
+        dev = pos.device
+        B = int(sf.numel())
+        pos = pos.to(torch.float32)
+        if pos.stride(1) != 1:
+            pos = pos.contiguous()
+        refl = refl.to(torch.float32).contiguous()
+        sf = sf.to(torch.float32).reshape(-1).contiguous()
+        p = getattr(data, "ptr", None)
+        if p is not None and p.numel() == B + 1:
+            ptr0 = p.to(device=dev, dtype=torch.int32).contiguous()
+        else:  # sorted batch vector -> CSR, on the device, no sync
+            ptr0 = torch.searchsorted(batch.to(torch.int64).contiguous(),
+                                      torch.arange(B + 1, device=dev, dtype=torch.int64)).to(torch.int32)
+        eng = self._ensure_packed(dev)
+        logits = eng.forward(pos, refl, ptr0, sf, keep=keep)
+        data.x = eng.stem_out  # the reference stores the stem features on the batch (model.py:228)
+        return logits

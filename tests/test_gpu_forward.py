@@ -1,0 +1,118 @@
+"""End-to-end and per-level parity of the HIP forward (pointstowood_amd.Net on cuda:0) against
+(a) the golden vectors produced by the reference's own model code and (b) the CPU oracle run live.
+
+Tolerances: indices bit-exact; level features 2e-4 (abs+rel, fp32 accumulation-order noise through
+up to 25 layers, K <= 2048); logits 4e-4 absolute, which bounds the wood probability error by 1e-4
+(|d sigmoid| <= 0.25 |d logit|) - the north-star's parity bar; probabilities checked at 1e-4 too."""
+import pytest
+import torch
+
+from oracle import net as onet
+from oracle import synth, weights
+from tests import golden_util as G
+
+pytestmark = pytest.mark.gpu
+
+
+class _D:
+    pass
+
+
+def _run(inp, C, k, wseed, keep=None):
+    from pointstowood_amd import Net
+    net = Net(num_classes=1, C=C, k=k)
+    net.load_state_dict(weights.synth_state_dict(1, C, seed=wseed), strict=True)
+    net = net.cuda().eval()
+    d = _D()
+    d.pos, d.batch = inp["pos"].cuda(), inp["batch"].cuda()
+    d.reflectance, d.sf = inp["reflectance"].cuda(), inp["sf"].cuda()
+    out = net(d, keep=keep)
+    torch.cuda.synchronize()
+    return out, d
+
+
+def _edges(lv, k):
+    from pointstowood_amd.ops import _edges
+    return _edges(lv.nbr[: lv.n], lv.deg[: lv.n])
+
+
+@pytest.mark.parametrize("name", G.CASES)
+def test_forward_matches_reference_vectors(name):
+    g, inp, meta = G.load(name)
+    keep = {}
+    logits, d = _run(inp, meta["C"], meta["k"], meta["wseed"], keep)
+    geo = keep["geometry"]
+    for l in (1, 2, 3):
+        lv = geo.levels[l]
+        G.check(g, f"idx{l}", lv.idx[: lv.n].long(), what="geometry ")
+        e = _edges(lv, meta["k"])
+        G.check(g, f"edge{l}.q", e[0], what="geometry ")
+        G.check(g, f"edge{l}.c", e[1], what="geometry ")
+    G.check(g, "stem", keep["stem"], rtol=1e-5, atol=1e-6)
+    assert d.x is keep["stem"]
+    for n in ("sa1_module.conv", "sa1_module.out", "sa2_module.conv", "sa2_module.out", "sa3_module.conv",
+              "sa3_module.out", "sa4_module.out", "fp4_module.out", "fp3_module.out", "fp2_module.out",
+              "fp1_module.out"):
+        G.check(g, n, keep[n], rtol=2e-4, atol=2e-4, what="features ")
+    G.check(g, "logits", logits, rtol=0.0, atol=4e-4)
+    G.check(g, "probs", torch.sigmoid(logits), atol=1e-4)
+
+
+def test_forward_matches_live_oracle_mixed_batch():
+    vox = [synth.uniform_voxel(2.0, 5000, 41, True), synth.surface_voxel(2.0, 2500, 42, True),
+           synth.uniform_voxel(4.0, 300, 43, False), synth.uniform_voxel(2.0, 16384, 44, True)]
+    inp = synth.collate(vox)
+    C, k, wseed = 8, 32, 3
+    sd = weights.synth_state_dict(1, C, seed=wseed)
+    cap = {}
+    ref = onet.forward(sd, inp["pos"], inp["batch"], inp["reflectance"], inp["sf"], k=k, capture=cap)
+    keep = {}
+    got, _ = _run(inp, C, k, wseed, keep)
+    geo = keep["geometry"]
+    for l in (1, 2, 3):
+        lv = geo.levels[l]
+        assert torch.equal(lv.idx[: lv.n].long().cpu(), cap[f"sa{l}_module.idx"])
+        e = _edges(lv, k).cpu()
+        assert torch.equal(e[0], cap[f"sa{l}_module.edge_q"]) and torch.equal(e[1], cap[f"sa{l}_module.edge_c"])
+    assert (got.cpu() - ref).abs().max() <= 4e-4
+    assert (torch.sigmoid(got.cpu()) - torch.sigmoid(ref)).abs().max() <= 1e-4
+
+
+def test_forward_is_deterministic_and_batch_order_is_voxel_major():
+    g, inp, meta = G.load("ragged_b2_refl_c8")
+    a, _ = _run(inp, meta["C"], meta["k"], meta["wseed"])
+    b, _ = _run(inp, meta["C"], meta["k"], meta["wseed"])
+    assert torch.equal(a, b)
+
+
+def test_config2_full_size_properties():
+    """BASELINE config 2 (B=8 x 16384, k=32, xyz only) at full size: structural invariants that do not need the
+    oracle at this size + parity of voxel 0's logits... (the grid origin is batch-global, so single-voxel logits are
+    not an invariant; instead check per-level structure and finiteness)."""
+    vox = [synth.uniform_voxel(2.0, 16384, 123 + i, False) for i in range(8)]
+    inp = synth.collate(vox)
+    keep = {}
+    logits, _ = _run(inp, 32, 32, 0, keep)
+    assert logits.shape == (8 * 16384,) and bool(torch.isfinite(logits).all())
+    geo = keep["geometry"]
+    prev_n = 8 * 16384
+    for l in (1, 2, 3):
+        lv = geo.levels[l]
+        assert 0 < lv.n <= prev_n
+        ptr = lv.ptr.cpu()
+        assert int(ptr[0]) == 0 and int(ptr[-1]) == lv.n and bool((ptr[1:] >= ptr[:-1]).all())
+        b = lv.batch[: lv.n].cpu()
+        assert bool((b[1:] >= b[:-1]).all())                       # voxel-major
+        idx = lv.idx[: lv.n].long().cpu()
+        assert idx.unique().numel() == lv.n                        # one representative per cell
+        src_batch = geo.levels[l - 1].batch[: prev_n].cpu()
+        assert torch.equal(src_batch[idx].long(), b.long())        # representatives stay in their voxel
+        nbr, deg = lv.nbr[: lv.n].cpu().long(), lv.deg[: lv.n].cpu()
+        assert int(deg.min()) >= 1 and int(deg.max()) <= 32
+        first = nbr[:, 0]
+        assert torch.equal(src_batch[first].long(), b.long())      # neighbours from the same voxel
+        if l > 1:  # kNN: the query's own source point is its nearest neighbour (distance 0)
+            assert torch.equal(first, idx)
+        prev_n = lv.n
+    # known level sizes of voxel 0 alone are ~15366/10156/2185; in a batch they shift by << 1 %
+    assert abs(geo.levels[1].n / 8 - 15366) < 200 and abs(geo.levels[2].n / 8 - 10156) < 200

@@ -1,0 +1,129 @@
+"""Operator-level parity on the GPU: every HIP operator (through the C ABI) against oracle/ops.py
+on seeded inputs.  Index results must be bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops as O
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def H():
+    from pointstowood_amd import ops
+    return ops
+
+
+def _batch(sizes, side=2.0, seed=0, surface=False):
+    vox = [(synth.surface_voxel if surface else synth.uniform_voxel)(side, n, seed + i, True) for i, n in enumerate(sizes)]
+    return synth.collate(vox)
+
+
+@pytest.mark.parametrize("sizes,res", [([2048], 0.04), ([3000, 17, 900], 0.08), ([16384, 512], 0.16), ([1], 0.04)])
+def test_voxel_grid_and_cluster_exact(H, sizes, res):
+    b = _batch(sizes, seed=3)
+    cell_ref = O.voxel_grid(b["pos"], res, b["batch"])
+    inv_ref, perm_ref = O.consecutive_cluster(cell_ref)
+    cell = H.voxel_grid(b["pos"].cuda(), res, b["batch"].cuda())
+    assert torch.equal(cell.cpu(), cell_ref)
+    inv, perm = H.consecutive_cluster(cell)
+    assert torch.equal(perm.cpu(), perm_ref)
+    assert torch.equal(inv.cpu(), inv_ref)
+
+
+@pytest.mark.parametrize("sizes,cap,surface", [([2048], 32, False), ([3000], 32, True), ([1500, 40, 700], 16, True)])
+def test_radius_exact(H, sizes, cap, surface):
+    b = _batch(sizes, seed=5, surface=surface)
+    idx = O.consecutive_cluster(O.voxel_grid(b["pos"], 0.04, b["batch"]))[1]
+    ref = O.radius(b["pos"], b["pos"][idx], 0.08, b["batch"], b["batch"][idx], max_num_neighbors=cap)
+    got = H.radius(b["pos"].cuda(), b["pos"][idx].cuda(), 0.08, b["batch"].cuda(), b["batch"][idx].cuda(),
+                   max_num_neighbors=cap)
+    assert torch.equal(got.cpu(), ref)
+
+
+@pytest.mark.parametrize("sizes,k", [([2048], 32), ([2048], 16), ([700, 20, 3000], 32), ([5000], 2), ([9], 32), ([300], 64)])
+def test_knn_exact(H, sizes, k):
+    b = _batch(sizes, seed=7)
+    idx = O.consecutive_cluster(O.voxel_grid(b["pos"], 0.08, b["batch"]))[1]
+    ref = O.knn(b["pos"], b["pos"][idx], k, b["batch"], b["batch"][idx])
+    got = H.knn(b["pos"].cuda(), b["pos"][idx].cuda(), k, b["batch"].cuda(), b["batch"][idx].cuda())
+    assert torch.equal(got.cpu(), ref)
+
+
+def test_knn_ties_prefer_lower_index(H):
+    g = torch.Generator().manual_seed(1)
+    base = torch.rand(400, 3, generator=g)
+    x = torch.cat([base, base, base[:100]], 0)           # every distance occurs 2-3 times
+    x = x[torch.randperm(x.shape[0], generator=g)]
+    y = x[::7].clone()
+    ref = O.knn(x, y, 32)
+    got = H.knn(x.cuda(), y.cuda(), 32)
+    assert torch.equal(got.cpu(), ref)
+    # lattice: many exactly equal distances between distinct points
+    lat = torch.stack(torch.meshgrid(*[torch.arange(9.0)] * 3, indexing="ij"), -1).reshape(-1, 3) * 0.125
+    lat = lat[torch.randperm(lat.shape[0], generator=g)]
+    assert torch.equal(H.knn(lat.cuda(), lat[:200].cuda(), 32).cpu(), O.knn(lat, lat[:200], 32))
+    assert torch.equal(H.radius(lat.cuda(), lat[:200].cuda(), 0.25, max_num_neighbors=32).cpu(),
+                       O.radius(lat, lat[:200], 0.25, max_num_neighbors=32))
+
+
+def test_knn_interpolate_and_pool(H):
+    b = _batch([3000, 50, 1200], seed=9)
+    idx = O.consecutive_cluster(O.voxel_grid(b["pos"], 0.16, b["batch"]))[1]
+    g = torch.Generator().manual_seed(2)
+    feat = torch.randn(idx.numel(), 24, generator=g)
+    ref = O.knn_interpolate(feat, b["pos"][idx], b["pos"], b["batch"][idx], b["batch"], k=2)
+    got = H.knn_interpolate(feat.cuda(), b["pos"][idx].cuda(), b["pos"].cuda(), b["batch"][idx].cuda(), b["batch"].cuda(), k=2)
+    assert (got.cpu() - ref).abs().max() <= 1e-5 * ref.abs().max()
+    x = torch.randn(b["pos"].shape[0], 40, generator=g)
+    assert torch.equal(H.global_max_pool(x.cuda(), b["batch"].cuda()).cpu(), O.global_max_pool(x, b["batch"]))
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 4, 4), (129, 8, 36), (1000, 192, 128), (4097, 512, 2048), (300, 640, 768), (77, 100, 516)])
+def test_gemm_epilogue(M, N, K):
+    """fp32 MFMA GEMM + fused epilogue vs fp64.  Tolerance: fp32 accumulation of K products."""
+    import ctypes as C
+    from pointstowood_amd import _lib
+    from pointstowood_amd._lib import Epilogue, check, lib, ptr, stream
+    g = torch.Generator().manual_seed(M + N + K)
+    lda = (K + 3) // 4 * 4
+    A = torch.randn(M, lda, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    vec = lambda: torch.randn(N, generator=g)
+    bias, s0, t0, s1, t1 = vec(), vec(), vec(), vec(), vec()
+    R = torch.randn(M, N, generator=g)
+    Np, Kp = _lib.packed_dims(N, K)
+    Wp = torch.zeros(Np, Kp)
+    Wp[:N, :K] = W
+    d = lambda t: t.cuda().contiguous()
+    dA, dW, db, ds0, dt0, ds1, dt1, dR = map(d, (A, Wp, bias, s0, t0, s1, t1, R))
+    out = torch.full((M, N), float("nan"), device="cuda")
+    ep = Epilogue(ptr(db), ptr(ds0), ptr(dt0), ptr(ds1), ptr(dt1), ptr(dR), N, 1, 1, 1, 1)
+    check(lib().p2w_gemm(ptr(dA), lda, ptr(dW), M, N, K, C.byref(ep), ptr(out), N, stream()))
+    v = A[:, :K].double() @ W.double().t() + bias.double()
+    v = torch.relu(v) * s0.double() + t0.double()
+    v = torch.relu(v) * s1.double() + t1.double()
+    v = torch.relu(torch.relu(v) + R.double())
+    err = (out.cpu().double() - v).abs().max().item()
+    assert err <= 2e-5 * max(1.0, v.abs().max().item()), err
+    # plain (no epilogue) into a wider output
+    out2 = torch.zeros((M, N + 4), device="cuda")
+    check(lib().p2w_gemm(ptr(dA), lda, ptr(dW), M, N, K, None, ptr(out2), N + 4, stream()))
+    v2 = A[:, :K].double() @ W.double().t()
+    assert (out2[:, :N].cpu().double() - v2).abs().max().item() <= 2e-5 * max(1.0, v2.abs().max().item())
+    assert float(out2[:, N:].abs().max()) == 0.0
+
+
+def test_c_abi_rejects_bad_arguments():
+    from pointstowood_amd._lib import lib, ptr, stream
+    x = torch.zeros(16, 4, device="cuda")
+    p = torch.tensor([0, 16], dtype=torch.int32, device="cuda")
+    n = torch.zeros(16, 100, dtype=torch.int32, device="cuda")
+    d = torch.zeros(16, dtype=torch.int32, device="cuda")
+    L = lib()
+    assert L.p2w_knn(ptr(x), ptr(p), ptr(x), None, ptr(p), 1, 16, 100, ptr(n), ptr(d), stream()) == -1   # k > 64
+    assert L.p2w_knn(None, ptr(p), ptr(x), None, ptr(p), 1, 16, 8, ptr(n), ptr(d), stream()) == -2       # NULL
+    assert L.p2w_knn(x.data_ptr() + 4, ptr(p), ptr(x), None, ptr(p), 1, 16, 8, ptr(n), ptr(d), stream()) == -3  # alignment
+    assert b"NULL" in L.p2w_strerror(-2)
