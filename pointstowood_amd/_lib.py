@@ -52,10 +52,14 @@ def lib():
     """Load (once) and return the ctypes handle; raise loudly when the library is not built."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise RuntimeError(
-                f"{LIB_PATH} is missing: the HIP extension is the only compute path "
-                "(no CPU fallback). Build it with `python -m pointstowood_amd.build`.")
+        from . import build as _build
+        if _build._stale():  # missing, or built from other sources than the ones in the tree
+            try:
+                _build.build()
+            except Exception as e:  # no hipcc, compile error, read-only tree ...
+                raise RuntimeError(
+                    f"{LIB_PATH} is missing or stale and could not be rebuilt ({e}). The HIP extension is the "
+                    "only compute path (no CPU fallback). Build it with `python -m pointstowood_amd.build`.") from e
         h = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(h, name)  # AttributeError = symbol missing from the build

@@ -28,12 +28,19 @@ def _hipcc() -> str:
     return "hipcc"
 
 
+def source_hash() -> str:
+    """sha256 over the kernel sources, the ABI header and the compile flags."""
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS[:-1]).encode())
+    for path in sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)) + [os.path.join(INCLUDE, "p2w.h")]:
+        h.update(open(path, "rb").read())
+    return h.hexdigest()
+
+
 def _stale() -> bool:
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(LIB + ".srchash"):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(INCLUDE, "p2w.h"), __file__]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return open(LIB + ".srchash").read().strip() != source_hash()
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -60,6 +67,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr}")
     os.replace(LIB + ".tmp", LIB)
+    with open(LIB + ".srchash", "w") as f:
+        f.write(source_hash())
     return LIB
 
 

@@ -60,8 +60,8 @@ def voxel_grid(pos, size, batch=None):
     nb = _num_batches(batch)
     x = _xyzr(pos)
     cell = torch.empty(n, dtype=torch.int64, device=pos.device)
-    ws = _ws(n, pos.device)
-    check(lib().p2w_voxel_grid(ptr(x), ptr(_csr(batch, nb)), nb, n, float(size), ptr(cell), ptr(ws), ws.numel(), stream()),
+    ws, csr = _ws(n, pos.device), _csr(batch, nb)
+    check(lib().p2w_voxel_grid(ptr(x), ptr(csr), nb, n, float(size), ptr(cell), ptr(ws), ws.numel(), stream()),
           "voxel_grid")
     return cell
 
@@ -127,8 +127,8 @@ def global_max_pool(x, batch, size=None):
     nb = _num_batches(batch) if size is None else int(size)
     x = x.to(torch.float32).contiguous()
     out = torch.empty((nb, x.shape[1]), dtype=torch.float32, device=x.device)
-    check(lib().p2w_segment_max(ptr(x), x.shape[1], x.shape[1], ptr(_csr(batch, nb)), nb, ptr(out), stream()),
-          "global_max_pool")
+    csr = _csr(batch, nb)
+    check(lib().p2w_segment_max(ptr(x), x.shape[1], x.shape[1], ptr(csr), nb, ptr(out), stream()), "global_max_pool")
     return out
 
 
@@ -147,6 +147,7 @@ def knn_interpolate(x, pos_x, pos_y, batch_x=None, batch_y=None, k=3, num_worker
     m, F = pos_y.shape[0], x.shape[1]
     out = torch.empty((m, F), dtype=torch.float32, device=x.device)
     xc = x.to(torch.float32).contiguous()
-    check(lib().p2w_interp_concat(ptr(xc), F, ptr(_xyzr(pos_x)), ptr(_xyzr(pos_y)), ptr(nbr), ptr(deg), int(k), None, 0, m,
+    rc, rf = _xyzr(pos_x), _xyzr(pos_y)   # keep both alive until the launch is enqueued
+    check(lib().p2w_interp_concat(ptr(xc), F, ptr(rc), ptr(rf), ptr(nbr), ptr(deg), int(k), None, 0, m,
                                   ptr(out), F, stream()), "knn_interpolate")
     return out
