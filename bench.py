@@ -83,7 +83,7 @@ def profile_step(net, data):
 def cpu_baseline():
     from oracle import net as onet
     from oracle import synth, weights
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))  # more threads only add contention on this path
     sd = weights.synth_state_dict(1, C, seed=0)
     v = synth.collate([synth.uniform_voxel(2.0, NPTS, 123, False)])
     run = lambda: onet.forward(sd, v["pos"], v["batch"], v["reflectance"], v["sf"], k=K_NBR)

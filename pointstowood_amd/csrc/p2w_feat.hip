@@ -410,24 +410,47 @@ extern "C" int32_t p2w_concat_xyz(const float* x, int32_t F, const float* xyzr, 
     return P2W_LAUNCH_STATUS();
 }
 
-// one workgroup per (voxel, 256-column slab): coalesced row sweeps, 4 row lanes x 64 column lanes... kept simple:
-// thread = one column, rows strided over gridDim.y blocks would need atomics; voxels are few and M3 small, so one
-// block per (voxel, 256 columns) walks the voxel's rows.
+// global max pool: (voxel, 64-column group, row split) blocks; 4 row lanes x 64 columns per block, LDS combine, then
+// one order-preserving-uint atomicMax per column into `out` (pre-set to 0 = below every float); a second tiny kernel
+// decodes in place.  Empty voxels decode to 0 like the reference's scatter.
+__device__ __forceinline__ unsigned sm_f2ord(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
 __global__ __launch_bounds__(256) void segment_max_kernel(const float* __restrict__ x, int ldx, int F, const int* __restrict__ ptr,
-                                                          float* __restrict__ out) {
-    const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= F) return;
+                                                          unsigned* __restrict__ out) {
+    __shared__ float red[4][64];
+    const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
     const int s = ptr[b], e = ptr[b + 1];
-    float v = (e > s) ? -INFINITY : 0.f;
-    for (int r = s; r < e; ++r) v = fmaxf(v, x[(size_t)r * ldx + c]);
-    out[(size_t)b * F + c] = v;
+    const int per = (e - s + gridDim.z - 1) / gridDim.z;
+    const int r0 = s + blockIdx.z * per, r1 = min(e, r0 + per);
+    float v = -INFINITY;
+    if (c < F)
+        for (int r = r0 + rl; r < r1; r += 4) v = fmaxf(v, x[(size_t)r * ldx + c]);
+    red[rl][threadIdx.x & 63] = v;
+    __syncthreads();
+    if (rl == 0 && c < F && r1 > r0) {
+        v = fmaxf(fmaxf(red[0][threadIdx.x], red[1][threadIdx.x]), fmaxf(red[2][threadIdx.x], red[3][threadIdx.x]));
+        atomicMax(&out[(size_t)b * F + c], sm_f2ord(v));
+    }
+}
+__global__ __launch_bounds__(256) void segment_max_decode_kernel(unsigned* __restrict__ out, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned o = out[i];
+    const unsigned u = (o == 0u) ? 0u : ((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+    out[i] = u;  // same bits reinterpreted as float by the caller
 }
 
 extern "C" int32_t p2w_segment_max(const float* x, int32_t ldx, int32_t F, const int32_t* ptr, int32_t B, float* out,
                                    p2w_stream_t stream) {
     P2W_CHECK_PTR(x); P2W_CHECK_PTR(ptr); P2W_CHECK_PTR(out);
     if (B <= 0 || F <= 0 || ldx < F) return P2W_EINVAL;
-    segment_max_kernel<<<dim3(p2w_cdiv(F, 256), B), 256, 0, p2w_s(stream)>>>(x, ldx, F, ptr, out);
+    hipStream_t s = p2w_s(stream);
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * F, s);
+    if (e != hipSuccess) return (int32_t)e;
+    segment_max_kernel<<<dim3(p2w_cdiv(F, 64), B, 16), 256, 0, s>>>(x, ldx, F, ptr, reinterpret_cast<unsigned*>(out));
+    segment_max_decode_kernel<<<p2w_cdiv((long)B * F, 256), 256, 0, s>>>(reinterpret_cast<unsigned*>(out), B * F);
     return P2W_LAUNCH_STATUS();
 }
 

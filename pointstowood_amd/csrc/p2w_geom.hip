@@ -53,28 +53,34 @@ __global__ void vs_init_kernel(VsHeader* h) {
 
 __global__ __launch_bounds__(256) void vs_minmax_kernel(const float4* __restrict__ xyzr, const int* __restrict__ ptr, int B,
                                                         VsHeader* h) {
+    __shared__ float red[4][6];
     const int n = ptr[B];
-    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    float v[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};  // lo xyz, hi xyz
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const float4 p = xyzr[i];
-        lo[0] = fminf(lo[0], p.x); hi[0] = fmaxf(hi[0], p.x);
-        lo[1] = fminf(lo[1], p.y); hi[1] = fmaxf(hi[1], p.y);
-        lo[2] = fminf(lo[2], p.z); hi[2] = fmaxf(hi[2], p.z);
+        v[0] = fminf(v[0], p.x); v[3] = fmaxf(v[3], p.x);
+        v[1] = fminf(v[1], p.y); v[4] = fmaxf(v[4], p.y);
+        v[2] = fminf(v[2], p.z); v[5] = fmaxf(v[5], p.z);
     }
 #pragma unroll
-    for (int d = 0; d < 3; ++d) {
+    for (int d = 0; d < 6; ++d) {
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
-            lo[d] = fminf(lo[d], __shfl_xor(lo[d], off));
-            hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], off));
+            const float o = __shfl_xor(v[d], off);
+            v[d] = d < 3 ? fminf(v[d], o) : fmaxf(v[d], o);
         }
     }
-    if ((threadIdx.x & 63) == 0 && n > 0) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            atomicMin(&h->lo[d], f2ord(lo[d]));
-            atomicMax(&h->hi[d], f2ord(hi[d]));
-        }
+        for (int d = 0; d < 6; ++d) red[wave][d] = v[d];
+    }
+    __syncthreads();
+    if (threadIdx.x < 6 && n > 0) {  // one atomic per block and component
+        const int d = threadIdx.x;
+        float r = red[0][d];
+        for (int w = 1; w < 4; ++w) r = d < 3 ? fminf(r, red[w][d]) : fmaxf(r, red[w][d]);
+        if (d < 3) atomicMin(&h->lo[d], f2ord(r)); else atomicMax(&h->hi[d - 3], f2ord(r));
     }
 }
 
@@ -177,7 +183,7 @@ static int32_t vs_compute_keys(const float4* x4, const int* ptr, int B, int n_bo
                                unsigned long long* keys, int* vals, hipStream_t s) {
     const int nblk = p2w_cdiv(n_bound, 256);
     vs_init_kernel<<<1, 64, 0, s>>>(hdr);
-    vs_minmax_kernel<<<nblk < 1024 ? nblk : 1024, 256, 0, s>>>(x4, ptr, B, hdr);
+    vs_minmax_kernel<<<nblk < 256 ? nblk : 256, 256, 0, s>>>(x4, ptr, B, hdr);
     vs_keys_kernel<<<nblk, 256, 0, s>>>(x4, ptr, B, n_bound, res, hdr, keys, vals);
     return P2W_LAUNCH_STATUS();
 }
@@ -289,7 +295,7 @@ extern "C" int32_t p2w_level_gather(const float* xyzr_src, const int32_t* idx, c
 // wave-uniform (SGPRs); admission is a ballot, so the common "nothing admitted" case costs
 // 8 VALU + 1 compare + 1 scalar branch per 64 pairs and nothing diverges.
 // ------------------------------------------------------------------------------------------------
-constexpr int S_QPW = 16;            // queries per wave
+constexpr int S_QPW = 8;             // queries per wave
 constexpr int S_QT = 4 * S_QPW;      // queries per workgroup
 constexpr int S_TILE = 1024;         // candidates per LDS stage (16 KiB)
 
@@ -310,70 +316,98 @@ __device__ __forceinline__ bool search_tile(const int* __restrict__ ptr_q, int B
     return false;
 }
 
-__device__ __forceinline__ float rfl(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
 __device__ __forceinline__ float rdlane(float v, int l) { return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), l)); }
+// value of lane-1 (lane 0 keeps its own): v_mov_b32_dpp wave_shr:1
+__device__ __forceinline__ float shr1(float v) {
+    return __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(v), __float_as_uint(v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ int shr1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }
+
+// wave-uniform query coordinates: the index is built from SGPR values only, so these are scalar loads
+struct UQuery { float x, y, z; bool valid; };
+__device__ __forceinline__ UQuery load_query(const float4* __restrict__ xq, const int* __restrict__ qidx, int q, int q1) {
+    UQuery u;
+    u.valid = q < q1;
+    const int src = u.valid ? (qidx ? qidx[q] : q) : 0;
+    const float4 v = xq[src];
+    u.x = v.x; u.y = v.y; u.z = v.z;
+    return u;
+}
+
+__device__ __forceinline__ void stage_candidates(float4* cand, const float4* __restrict__ x, int base, int c1, int tid) {
+#pragma unroll
+    for (int r = 0; r < S_TILE / 256; ++r) {
+        const int c = base + tid + 256 * r;
+        cand[tid + 256 * r] = (c < c1) ? x[c] : make_float4(INFINITY, INFINITY, INFINITY, 0.f);
+    }
+}
 
 __global__ __launch_bounds__(256) void knn_kernel(const float4* __restrict__ x, const int* __restrict__ ptr_x,
                                                   const float4* __restrict__ xq, const int* __restrict__ qidx,
                                                   const int* __restrict__ ptr_q, int B, int k, int* __restrict__ nbr,
                                                   int* __restrict__ deg) {
     __shared__ float4 cand[S_TILE];
-    __shared__ float4 qs[S_QT];
     int b, q0, q1;
     if (!search_tile(ptr_q, B, blockIdx.x, &b, &q0, &q1)) return;
     const int c0 = ptr_x[b], c1 = ptr_x[b + 1];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid < S_QT) {
-        const int q = q0 + tid;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (q < q1) v = xq[qidx ? qidx[q] : q];
-        qs[tid] = v;
-    }
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qw = q0 + wave * S_QPW;
+    UQuery uq[S_QPW];
     // selection state: lane l of best_*[j] holds the l-th nearest so far of query j (lanes >= k: +inf)
     float best_d[S_QPW];
     int best_i[S_QPW];
     float thr[S_QPW];  // wave-uniform: current k-th smallest distance (+inf until k admitted; -inf = query slot unused)
 #pragma unroll
     for (int j = 0; j < S_QPW; ++j) {
+        uq[j] = load_query(xq, qidx, qw + j, q1);
         best_d[j] = INFINITY; best_i[j] = -1;
-        thr[j] = (q0 + wave * S_QPW + j < q1) ? INFINITY : -INFINITY;
+        thr[j] = uq[j].valid ? INFINITY : -INFINITY;
     }
+    const bool in_k = lane < k;
     for (int base = c0; base < c1; base += S_TILE) {
         __syncthreads();
-#pragma unroll
-        for (int r = 0; r < S_TILE / 256; ++r) {
-            const int c = base + tid + 256 * r;
-            cand[tid + 256 * r] = (c < c1) ? x[c] : make_float4(INFINITY, INFINITY, INFINITY, 0.f);
-        }
+        stage_candidates(cand, x, base, c1, tid);
         __syncthreads();
-        const int nch = (min(S_TILE, c1 - base) + 63) >> 6;
-        for (int ch = 0; ch < nch; ++ch) {
-            const float4 c = cand[ch * 64 + lane];
-            const int cbase = base + ch * 64;
+        // groups of 4 chunks (256 candidates) are held in registers while the wave walks its queries, so the
+        // per-query state is in scalars inside the admission loop (padding records are +inf and never admitted)
+        const int ngr = (min(S_TILE, c1 - base) + 255) >> 8;
+        for (int gr = 0; gr < ngr; ++gr) {
+            float4 c[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) c[u] = cand[gr * 256 + u * 64 + lane];
 #pragma unroll
             for (int j = 0; j < S_QPW; ++j) {
-                const float4 q = qs[wave * S_QPW + j];
-                const float d = p2w_d2(rfl(q.x), rfl(q.y), rfl(q.z), c.x, c.y, c.z);
-                unsigned long long m = __ballot(d < thr[j]);
-                while (m) {  // wave-uniform; candidates admitted in ascending index => ties keep the lower index first
-                    const int src = __ffsll((long long)m) - 1;
-                    m &= m - 1;
-                    const float dn = rdlane(d, src);
-                    if (!(dn < thr[j])) continue;
-                    const int pos = __popcll(__ballot(best_d[j] <= dn));
-                    const float up_d = __shfl_up(best_d[j], 1);
-                    const int up_i = __shfl_up(best_i[j], 1);
-                    if (lane == pos) { best_d[j] = dn; best_i[j] = cbase + src; }
-                    else if (lane > pos && lane < k) { best_d[j] = up_d; best_i[j] = up_i; }
-                    thr[j] = rdlane(best_d[j], k - 1);
+                float bd = best_d[j], t = thr[j];
+                int bi = best_i[j];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int cbase = base + gr * 256 + u * 64;
+                    const float d = p2w_d2(uq[j].x, uq[j].y, uq[j].z, c[u].x, c[u].y, c[u].z);
+                    unsigned long long m = __ballot(d < t);
+                    while (m) {  // wave-uniform; candidates admitted in ascending index => ties keep the lower index first
+                        const int src = __ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        const float dn = rdlane(d, src);
+                        if (dn < t) {  // scalar branch: the threshold may have tightened inside this chunk
+                            const int pos = __popcll(__ballot(bd <= dn));
+                            const float up_d = shr1(bd);
+                            const int up_i = shr1(bi);
+                            const bool here = lane == pos, sh = (lane > pos) & in_k;
+                            bd = here ? dn : (sh ? up_d : bd);
+                            bi = here ? (cbase + src) : (sh ? up_i : bi);
+                            t = rdlane(bd, k - 1);
+                        }
+                    }
                 }
+                best_d[j] = bd; best_i[j] = bi; thr[j] = t;
             }
         }
     }
     const int cnt = min(k, c1 - c0);
 #pragma unroll
     for (int j = 0; j < S_QPW; ++j) {
-        const int q = q0 + wave * S_QPW + j;
+        const int q = qw + j;
         if (q < q1) {
             if (lane < k) nbr[(size_t)q * k + lane] = (lane < cnt) ? best_i[j] : -1;
             if (lane == 0) deg[q] = cnt;
@@ -386,28 +420,23 @@ __global__ __launch_bounds__(256) void ball_kernel(const float4* __restrict__ x,
                                                    const int* __restrict__ ptr_q, int B, float r2, int cap,
                                                    int* __restrict__ nbr, int* __restrict__ deg) {
     __shared__ float4 cand[S_TILE];
-    __shared__ float4 qs[S_QT];
     int b, q0, q1;
     if (!search_tile(ptr_q, B, blockIdx.x, &b, &q0, &q1)) return;
     const int c0 = ptr_x[b], c1 = ptr_x[b + 1];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid < S_QT) {
-        const int q = q0 + tid;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (q < q1) v = xq[qidx ? qidx[q] : q];
-        qs[tid] = v;
-    }
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qw = q0 + wave * S_QPW;
+    UQuery uq[S_QPW];
     int cnt[S_QPW];  // wave-uniform: neighbours kept so far (cap = full / unused slot)
 #pragma unroll
-    for (int j = 0; j < S_QPW; ++j) cnt[j] = (q0 + wave * S_QPW + j < q1) ? 0 : cap;
+    for (int j = 0; j < S_QPW; ++j) {
+        uq[j] = load_query(xq, qidx, qw + j, q1);
+        cnt[j] = uq[j].valid ? 0 : cap;
+    }
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     for (int base = c0; base < c1; base += S_TILE) {
         __syncthreads();
-#pragma unroll
-        for (int r = 0; r < S_TILE / 256; ++r) {
-            const int c = base + tid + 256 * r;
-            cand[tid + 256 * r] = (c < c1) ? x[c] : make_float4(INFINITY, INFINITY, INFINITY, 0.f);
-        }
+        stage_candidates(cand, x, base, c1, tid);
         __syncthreads();
         const int nch = (min(S_TILE, c1 - base) + 63) >> 6;
         for (int ch = 0; ch < nch; ++ch) {
@@ -415,13 +444,12 @@ __global__ __launch_bounds__(256) void ball_kernel(const float4* __restrict__ x,
             const int cidx = base + ch * 64 + lane;
 #pragma unroll
             for (int j = 0; j < S_QPW; ++j) {
-                const float4 q = qs[wave * S_QPW + j];
-                const float d = p2w_d2(rfl(q.x), rfl(q.y), rfl(q.z), c.x, c.y, c.z);
+                const float d = p2w_d2(uq[j].x, uq[j].y, uq[j].z, c.x, c.y, c.z);
                 const bool hit = d < r2;
                 const unsigned long long m = __ballot(hit);
                 if (m != 0ull && cnt[j] < cap) {  // first `cap` hits in ascending candidate index
                     const int rank = cnt[j] + __popcll(m & lt_mask);
-                    if (hit && rank < cap) nbr[(size_t)(q0 + wave * S_QPW + j) * cap + rank] = cidx;
+                    if (hit && rank < cap) nbr[(size_t)(qw + j) * cap + rank] = cidx;
                     cnt[j] = min(cap, cnt[j] + __popcll(m));
                 }
             }
@@ -429,7 +457,7 @@ __global__ __launch_bounds__(256) void ball_kernel(const float4* __restrict__ x,
     }
 #pragma unroll
     for (int j = 0; j < S_QPW; ++j) {
-        const int q = q0 + wave * S_QPW + j;
+        const int q = qw + j;
         if (q < q1) {
             if (lane >= cnt[j] && lane < cap) nbr[(size_t)q * cap + lane] = -1;
             if (lane == 0) deg[q] = cnt[j];
