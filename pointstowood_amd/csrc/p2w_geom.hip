@@ -342,6 +342,21 @@ __device__ __forceinline__ void stage_candidates(float4* cand, const float4* __r
     }
 }
 
+// Staging permutes the records of a tile (slot s holds candidate base + ((s * 389) & 1023)) so that every
+// 64-slot chunk samples the whole tile: levels >= 1 are stored in grid-cell order, and a scan in storage order
+// approaches each query monotonically, which makes almost every candidate a new admission.  The candidate's
+// index travels in the record's 4th component; admission is order-independent (lexicographic (d2, index)).
+__device__ __forceinline__ void stage_shuffled(float4* cand, const float4* __restrict__ x, int base, int c1, int tid) {
+#pragma unroll
+    for (int r = 0; r < S_TILE / 256; ++r) {
+        const int s = tid + 256 * r;
+        const int c = base + ((s * 389) & (S_TILE - 1));
+        float4 v = make_float4(INFINITY, INFINITY, INFINITY, __int_as_float(0x7fffffff));
+        if (c < c1) { v = x[c]; v.w = __int_as_float(c); }
+        cand[s] = v;
+    }
+}
+
 __global__ __launch_bounds__(256) void knn_kernel(const float4* __restrict__ x, const int* __restrict__ ptr_x,
                                                   const float4* __restrict__ xq, const int* __restrict__ qidx,
                                                   const int* __restrict__ ptr_q, int B, int k, int* __restrict__ nbr,
@@ -354,55 +369,69 @@ __global__ __launch_bounds__(256) void knn_kernel(const float4* __restrict__ x, 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qw = q0 + wave * S_QPW;
     UQuery uq[S_QPW];
-    // selection state: lane l of best_*[j] holds the l-th nearest so far of query j (lanes >= k: +inf)
-    float best_d[S_QPW];
-    int best_i[S_QPW];
-    float thr[S_QPW];  // wave-uniform: current k-th smallest distance (+inf until k admitted; -inf = query slot unused)
+    // selection state: lane l of (best_d, best_i)[j] = the l-th smallest (d2, index) so far of query j;
+    // empty slots and lanes >= k hold (+inf, INT_MAX); (thr, thi) = wave-uniform copy of slot k-1
+    float best_d[S_QPW], thr[S_QPW];
+    int best_i[S_QPW], thi[S_QPW];
 #pragma unroll
     for (int j = 0; j < S_QPW; ++j) {
         uq[j] = load_query(xq, qidx, qw + j, q1);
-        best_d[j] = INFINITY; best_i[j] = -1;
+        best_d[j] = INFINITY; best_i[j] = 0x7fffffff;
         thr[j] = uq[j].valid ? INFINITY : -INFINITY;
+        thi[j] = 0x7fffffff;
     }
     const bool in_k = lane < k;
-    for (int base = c0; base < c1; base += S_TILE) {
+    // tile visiting order: start where the block's first query most likely has its neighbours and move outwards
+    const int ntiles = (c1 - c0 + S_TILE - 1) / S_TILE;
+    int t0;
+    if (qidx) t0 = (qidx[q0] - c0) / S_TILE;                                    // the query is itself a candidate
+    else t0 = (int)(((long long)(q0 - ptr_q[b]) * ntiles) / max(1, ptr_q[b + 1] - ptr_q[b]));  // same storage order
+    t0 = min(max(t0, 0), max(ntiles - 1, 0));
+    for (int step = 0; step < 2 * ntiles - 1; ++step) {
+        const int off = (step + 1) >> 1;
+        const int tile = (step & 1) ? t0 + off : t0 - off;
+        if (tile < 0 || tile >= ntiles) continue;
+        const int base = c0 + tile * S_TILE;
         __syncthreads();
-        stage_candidates(cand, x, base, c1, tid);
+        stage_shuffled(cand, x, base, c1, tid);
         __syncthreads();
         // groups of 4 chunks (256 candidates) are held in registers while the wave walks its queries, so the
-        // per-query state is in scalars inside the admission loop (padding records are +inf and never admitted)
+        // per-query state is in scalars inside the admission loop
         const int ngr = (min(S_TILE, c1 - base) + 255) >> 8;
-        for (int gr = 0; gr < ngr; ++gr) {
+        for (int gr = 0; gr < S_TILE / 256; ++gr) {   // all groups: the shuffle spreads a partial tile over every group
             float4 c[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) c[u] = cand[gr * 256 + u * 64 + lane];
 #pragma unroll
             for (int j = 0; j < S_QPW; ++j) {
                 float bd = best_d[j], t = thr[j];
-                int bi = best_i[j];
+                int bi = best_i[j], ti = thi[j];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int cbase = base + gr * 256 + u * 64;
                     const float d = p2w_d2(uq[j].x, uq[j].y, uq[j].z, c[u].x, c[u].y, c[u].z);
-                    unsigned long long m = __ballot(d < t);
-                    while (m) {  // wave-uniform; candidates admitted in ascending index => ties keep the lower index first
+                    const int ci = __float_as_int(c[u].w);
+                    unsigned long long m = __ballot(d <= t);
+                    while (m) {  // wave-uniform loop over the candidates that may enter
                         const int src = __ffsll((long long)m) - 1;
                         m &= m - 1;
                         const float dn = rdlane(d, src);
-                        if (dn < t) {  // scalar branch: the threshold may have tightened inside this chunk
-                            const int pos = __popcll(__ballot(bd <= dn));
+                        const int in = __builtin_amdgcn_readlane(ci, src);
+                        if (dn < t || (dn == t && in < ti)) {  // scalar branch: (dn, in) < slot k-1
+                            const int pos = __popcll(__ballot(bd < dn || (bd == dn && bi < in)));
                             const float up_d = shr1(bd);
                             const int up_i = shr1(bi);
                             const bool here = lane == pos, sh = (lane > pos) & in_k;
                             bd = here ? dn : (sh ? up_d : bd);
-                            bi = here ? (cbase + src) : (sh ? up_i : bi);
+                            bi = here ? in : (sh ? up_i : bi);
                             t = rdlane(bd, k - 1);
+                            ti = __builtin_amdgcn_readlane(bi, k - 1);
                         }
                     }
                 }
-                best_d[j] = bd; best_i[j] = bi; thr[j] = t;
+                best_d[j] = bd; best_i[j] = bi; thr[j] = t; thi[j] = ti;
             }
         }
+        (void)ngr;
     }
     const int cnt = min(k, c1 - c0);
 #pragma unroll
