@@ -30,7 +30,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+# MI355X_MICROARCH.md dense MFMA peaks: v_mfma_f32_32x32x2_f32 and v_mfma_f32_32x32x16_f16
+PEAK_TFLOPS = {"fp32": 157.3, "f16x3": 2500.0}
 C, K_NBR, BATCH, NPTS = 32, 32, 8, 16384
 
 
@@ -103,6 +104,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "fp32"],
+                    help="f16x3: split-fp16 MFMA (3 fp16 MFMAs per product, fp32 accumulate); fp32: fp32 MFMA")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -126,10 +129,11 @@ def main():
     from oracle import weights
     from pointstowood_amd import Net
     from pointstowood_amd.dist import gather_logits
-    net = Net(num_classes=1, C=C, k=K_NBR)
+    net = Net(num_classes=1, C=C, k=K_NBR, precision=args.precision)
     net.load_state_dict(weights.synth_state_dict(1, C, seed=0), strict=True)
     net = net.to(device).eval()
     data = make_batch(rank, device)
+    peak = PEAK_TFLOPS[args.precision]
 
     def step():
         logits = net(data)
@@ -165,13 +169,15 @@ def main():
         line = {
             "metric": "classified points/sec", "value": pts / dt, "unit": "points/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: batch_size 8 x 16384-pt 2 m voxels, k=32, xyz-only, 1 batch per GPU per step",
                        "global_batch_voxels": world * BATCH, "points_per_step": world * BATCH * NPTS, "C": C,
                        "level_sizes": sizes, "parallelism": f"voxel-batch sharding x{world}, RCCL all-gather of logits"},
             "end_to_end_tflops_algorithmic": 2.0 * total_macs * args.steps / dt / 1e12,
-            "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": peak,
+                         "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                         "note": ("f16x3 issues 3 fp16 MFMAs per algorithmic product: ceiling for algorithmic FLOPs is peak/3"
+                                  if args.precision == "f16x3" else "exact fp32 MFMA"),
                          "launches_per_step": dom_launches, "kernel_ms_per_step": dom_ms,
                          "algorithmic_gflop_per_step": 2.0 * kmacs[dom] / 1e9},
             "kernel_ms_per_step": {kname: round(v[0], 4) for kname, v in sorted(per.items(), key=lambda kv: -kv[1][0])},

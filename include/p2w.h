@@ -134,6 +134,17 @@ int32_t p2w_sa_conv(const float* P, int32_t ldp, const float* xyzr_src, const in
                     const float* b2, const float* bn_s, const float* bn_t, float* out, int32_t ldo,
                     p2w_stream_t stream);
 
+/* Split-fp16 variants ("f16x3") of p2w_gemm / p2w_sa_conv: identical semantics and interface except for the
+ * weight operand.  Wh = [2][N_pad][K_pad] fp16, plane 0 = hi, plane 1 = lo of W * 2^e (e chosen at pack time so
+ * that lo stays a normal fp16), wscale = 2^-e.  Activations are split hi/lo on the fly; the contraction is
+ * a_lo*w_hi + a_hi*w_lo + a_hi*w_hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation (~22-bit operands). */
+int32_t p2w_gemm_f16x3(const float* A, int32_t lda, const void* Wh, float wscale, int32_t M, int32_t N, int32_t K,
+                       const p2w_epilogue* epi, float* out, int32_t ldo, p2w_stream_t stream);
+int32_t p2w_sa_conv_f16x3(const float* P, int32_t ldp, const float* xyzr_src, const int32_t* idx, const int32_t* batch_dst,
+                          const float* sf, const int32_t* nbr, const int32_t* deg, int32_t kw, int32_t M,
+                          const float* w1r4, const void* W2h, float wscale, int32_t C1, int32_t C2, const float* b2,
+                          const float* bn_s, const float* bn_t, float* out, int32_t ldo, p2w_stream_t stream);
+
 /* knn_interpolate (k<=2) + concat with the skip features - model.py:149-151:
  *   out[q, 0:Fc] = (sum_s w_s * xc[nbr[q,s]]) / (sum_s w_s),  w_s = 1/max(d2, 1e-16)
  *   out[q, Fc:Fc+Fs] = skip[q].  Rows padded to ldo are zero-filled. */

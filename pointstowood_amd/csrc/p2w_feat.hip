@@ -72,6 +72,37 @@ struct EpiArgs {
     int ldr, relu0, relu1, relu2, relu_final;
 };
 
+// v = acc * wscale + bias; relu0; v*sc0+sh0; relu1; v*sc1+sh1; relu2; + residual; relu_final   (p2w_epilogue in p2w.h)
+__device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[2][2], const EpiArgs& ep, float wscale, int row0, int col0,
+                                              int lane, int M, int N, float* __restrict__ out, int ldo) {
+    const int h = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = col0 + j * 32 + (lane & 31);
+        if (col >= N) continue;
+        const float bias = ep.bias ? ep.bias[col] : 0.f;
+        const float s0 = ep.sc0 ? ep.sc0[col] : 1.f, t0 = ep.sc0 ? ep.sh0[col] : 0.f;
+        const float s1 = ep.sc1 ? ep.sc1[col] : 1.f, t1 = ep.sc1 ? ep.sh1[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row >= M) continue;
+                float v = fmaf(acc[i][j][r], wscale, bias);
+                if (ep.relu0) v = fmaxf(v, 0.f);
+                if (ep.sc0) { v = fmaf(v, s0, t0); }
+                if (ep.relu1) v = fmaxf(v, 0.f);
+                if (ep.sc1) { v = fmaf(v, s1, t1); }
+                if (ep.relu2) v = fmaxf(v, 0.f);
+                if (ep.residual) v += ep.residual[(size_t)row * ep.ldr + col];
+                if (ep.relu_final) v = fmaxf(v, 0.f);
+                out[(size_t)row * ldo + col] = v;
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ void load_a_tile(const float* __restrict__ A, int lda, int M, int K, int m0, int k0, int lrow,
                                             int lkq, float4 (&ra)[4]) {
     const int k = k0 + 4 * lkq;
@@ -119,33 +150,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
         }
         mma_slab(As, Bs, wr, wc, lane, acc);
     }
-    // epilogue
-    const int h = lane >> 5;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = n0 + wc * 64 + j * 32 + (lane & 31);
-        if (col >= N) continue;
-        const float bias = ep.bias ? ep.bias[col] : 0.f;
-        const float s0 = ep.sc0 ? ep.sc0[col] : 1.f, t0 = ep.sc0 ? ep.sh0[col] : 0.f;
-        const float s1 = ep.sc1 ? ep.sc1[col] : 1.f, t1 = ep.sc1 ? ep.sh1[col] : 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (row >= M) continue;
-                float v = acc[i][j][r] + bias;
-                if (ep.relu0) v = fmaxf(v, 0.f);
-                if (ep.sc0) { v = fmaf(v, s0, t0); }
-                if (ep.relu1) v = fmaxf(v, 0.f);
-                if (ep.sc1) { v = fmaf(v, s1, t1); }
-                if (ep.relu2) v = fmaxf(v, 0.f);
-                if (ep.residual) v += ep.residual[(size_t)row * ep.ldr + col];
-                if (ep.relu_final) v = fmaxf(v, 0.f);
-                out[(size_t)row * ldo + col] = v;
-            }
-        }
-    }
+    gemm_epilogue(acc, ep, 1.0f, m0 + wr * 64, n0 + wc * 64, lane, M, N, out, ldo);
 }
 
 extern "C" int32_t p2w_gemm(const float* A, int32_t lda, const float* Wp, int32_t M, int32_t N, int32_t K,
@@ -173,25 +178,42 @@ extern "C" int32_t p2w_gemm(const float* A, int32_t lda, const float* Wp, int32_
 // so the max over neighbours is a max over the accumulator tile's rows (16 registers + one lane^32
 // exchange) and the [E, C] edge tensors of the reference never exist in HBM.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sa_conv_kernel(const float* __restrict__ P, int ldp, const float4* __restrict__ xyzr,
-                                                      const int* __restrict__ idx, const int* __restrict__ batch_dst,
-                                                      const float* __restrict__ sf, const int* __restrict__ nbr,
-                                                      const int* __restrict__ deg, int kw, int M,
-                                                      const float* __restrict__ w1r4, int C1, int C1pad,
-                                                      const float* __restrict__ W2p, int C2, int nMt, int nNt,
-                                                      const float* __restrict__ b2, const float* __restrict__ bn_s,
-                                                      const float* __restrict__ bn_t, float* __restrict__ out, int ldo) {
-    __shared__ __attribute__((aligned(16))) float As[G_BM * G_LD];
-    __shared__ __attribute__((aligned(16))) float Bs[G_BN * G_LD];
-    __shared__ int m_j[G_BM];
-    __shared__ float m_g[G_BM][4];  // normalised relative position (3) + reflectance of the source point
-    int mt, nt;
-    if (!tile_coords(nMt, nNt, &mt, &nt)) return;
-    const int t0 = mt * 4, n0 = nt * G_BN;  // 4 targets per row tile
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
-    const int lrow = tid >> 3, lkq = tid & 7;
+// layer-2 bias + ReLU + BN affine, then max over the target's valid neighbour slots (rows of the 32-row MFMA tile)
+__device__ __forceinline__ void sa_epilogue(const f32x16 (&acc)[2][2], float wscale, int t0, int n0, int wr, int wc, int lane,
+                                            int M, int kw, const int* __restrict__ deg, int C2, const float* __restrict__ b2,
+                                            const float* __restrict__ bn_s, const float* __restrict__ bn_t,
+                                            float* __restrict__ out, int ldo) {
+    const int h = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int tgt = t0 + wr * 2 + i;
+        if (tgt >= M) continue;
+        const int d = min(deg[tgt], kw);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wc * 64 + j * 32 + (lane & 31);
+            const bool cv = col < C2;
+            const float bias = cv ? b2[col] : 0.f, s = cv ? bn_s[col] : 0.f, t = cv ? bn_t[col] : 0.f;
+            float vmax = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int slot = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float v = fmaf(fmaxf(fmaf(acc[i][j][r], wscale, bias), 0.f), s, t);
+                if (slot < d) vmax = fmaxf(vmax, v);
+            }
+            vmax = fmaxf(vmax, __shfl_xor(vmax, 32));
+            if (d == 0) vmax = 0.f;
+            if (cv && h == 0) out[(size_t)tgt * ldo + col] = vmax;
+        }
+    }
+}
 
-    // ---- per-row geometry (pointnet.py:119-129): rows tid<128 = (target t0 + tid/32, slot tid%32)
+// per-row geometry of a 4-target row tile (pointnet.py:119-129): rows tid<128 = (target t0 + tid/32, slot tid%32);
+// writes the source index and (normalised relative position, source reflectance) of every row to LDS
+__device__ __forceinline__ void sa_row_geometry(int tid, int t0, int M, int kw, const float4* __restrict__ xyzr,
+                                                const int* __restrict__ idx, const int* __restrict__ batch_dst,
+                                                const float* __restrict__ sf, const int* __restrict__ nbr,
+                                                const int* __restrict__ deg, int* m_j, float (*m_g)[4]) {
     if (tid < G_BM) {
         const int tgt = t0 + (tid >> 5), slot = tid & 31;
         int j = 0;
@@ -217,6 +239,52 @@ __global__ __launch_bounds__(256) void sa_conv_kernel(const float* __restrict__ 
         m_j[tid] = j;
         m_g[tid][0] = rx / den; m_g[tid][1] = ry / den; m_g[tid][2] = rz / den; m_g[tid][3] = rf;
     }
+}
+
+// A producer of the fused kernel: h1[row][k..k+3] = relu(P[j][k] + g . W1r[:, k])
+__device__ __forceinline__ void sa_load_h1(const float* __restrict__ P, int ldp, const float* __restrict__ w1r4, int C1,
+                                           int C1pad, int k, const int (&rj)[4], const float4 (&rg)[4], float4 (&ra)[4]) {
+    if (k < C1) {
+        const float4 wx = *reinterpret_cast<const float4*>(&w1r4[0 * C1pad + k]);
+        const float4 wy = *reinterpret_cast<const float4*>(&w1r4[1 * C1pad + k]);
+        const float4 wz = *reinterpret_cast<const float4*>(&w1r4[2 * C1pad + k]);
+        const float4 wf = *reinterpret_cast<const float4*>(&w1r4[3 * C1pad + k]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float4 p = *reinterpret_cast<const float4*>(&P[(size_t)rj[i] * ldp + k]);
+            const float4 g = rg[i];
+            float4 v;
+            v.x = fmaxf(fmaf(g.w, wf.x, fmaf(g.z, wz.x, fmaf(g.y, wy.x, fmaf(g.x, wx.x, p.x)))), 0.f);
+            v.y = fmaxf(fmaf(g.w, wf.y, fmaf(g.z, wz.y, fmaf(g.y, wy.y, fmaf(g.x, wx.y, p.y)))), 0.f);
+            v.z = fmaxf(fmaf(g.w, wf.z, fmaf(g.z, wz.z, fmaf(g.y, wy.z, fmaf(g.x, wx.z, p.z)))), 0.f);
+            v.w = fmaxf(fmaf(g.w, wf.w, fmaf(g.z, wz.w, fmaf(g.y, wy.w, fmaf(g.x, wx.w, p.w)))), 0.f);
+            ra[i] = v;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+__global__ __launch_bounds__(256) void sa_conv_kernel(const float* __restrict__ P, int ldp, const float4* __restrict__ xyzr,
+                                                      const int* __restrict__ idx, const int* __restrict__ batch_dst,
+                                                      const float* __restrict__ sf, const int* __restrict__ nbr,
+                                                      const int* __restrict__ deg, int kw, int M,
+                                                      const float* __restrict__ w1r4, int C1, int C1pad,
+                                                      const float* __restrict__ W2p, int C2, int nMt, int nNt,
+                                                      const float* __restrict__ b2, const float* __restrict__ bn_s,
+                                                      const float* __restrict__ bn_t, float* __restrict__ out, int ldo) {
+    __shared__ __attribute__((aligned(16))) float As[G_BM * G_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[G_BN * G_LD];
+    __shared__ int m_j[G_BM];
+    __shared__ float m_g[G_BM][4];  // normalised relative position (3) + reflectance of the source point
+    int mt, nt;
+    if (!tile_coords(nMt, nNt, &mt, &nt)) return;
+    const int t0 = mt * 4, n0 = nt * G_BN;  // 4 targets per row tile
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+    const int lrow = tid >> 3, lkq = tid & 7;
+
+    sa_row_geometry(tid, t0, M, kw, xyzr, idx, batch_dst, sf, nbr, deg, m_j, m_g);
     __syncthreads();
     int rj[4];
     float4 rg[4];
@@ -234,33 +302,8 @@ __global__ __launch_bounds__(256) void sa_conv_kernel(const float* __restrict__ 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // A producer: h1[row][k] = relu(P[j][k] + g.x*W1r[0][k] + g.y*W1r[1][k] + g.z*W1r[2][k] + g.w*W1r[3][k])
-    auto load_h1 = [&](int k0, float4 (&ra)[4]) {
-        const int k = k0 + 4 * lkq;
-        if (k < C1) {
-            const float4 wx = *reinterpret_cast<const float4*>(&w1r4[0 * C1pad + k]);
-            const float4 wy = *reinterpret_cast<const float4*>(&w1r4[1 * C1pad + k]);
-            const float4 wz = *reinterpret_cast<const float4*>(&w1r4[2 * C1pad + k]);
-            const float4 wf = *reinterpret_cast<const float4*>(&w1r4[3 * C1pad + k]);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float4 p = *reinterpret_cast<const float4*>(&P[(size_t)rj[i] * ldp + k]);
-                const float4 g = rg[i];
-                float4 v;
-                v.x = fmaxf(fmaf(g.w, wf.x, fmaf(g.z, wz.x, fmaf(g.y, wy.x, fmaf(g.x, wx.x, p.x)))), 0.f);
-                v.y = fmaxf(fmaf(g.w, wf.y, fmaf(g.z, wz.y, fmaf(g.y, wy.y, fmaf(g.x, wx.y, p.y)))), 0.f);
-                v.z = fmaxf(fmaf(g.w, wf.z, fmaf(g.z, wz.z, fmaf(g.y, wy.z, fmaf(g.x, wx.z, p.z)))), 0.f);
-                v.w = fmaxf(fmaf(g.w, wf.w, fmaf(g.z, wz.w, fmaf(g.y, wy.w, fmaf(g.x, wx.w, p.w)))), 0.f);
-                ra[i] = v;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-
     float4 ra[4], rb[4];
-    load_h1(0, ra);
+    sa_load_h1(P, ldp, w1r4, C1, C1pad, 4 * lkq, rj, rg, ra);
     load_w_tile(W2p, C1pad, n0, 0, lrow, lkq, rb);
     for (int k0 = 0; k0 < C1pad; k0 += G_BK) {
         __syncthreads();
@@ -268,36 +311,13 @@ __global__ __launch_bounds__(256) void sa_conv_kernel(const float* __restrict__ 
         store_tile(Bs, lrow, lkq, rb);
         __syncthreads();
         if (k0 + G_BK < C1pad) {
-            load_h1(k0 + G_BK, ra);
+            sa_load_h1(P, ldp, w1r4, C1, C1pad, k0 + G_BK + 4 * lkq, rj, rg, ra);
             load_w_tile(W2p, C1pad, n0, k0 + G_BK, lrow, lkq, rb);
         }
         mma_slab(As, Bs, wr, wc, lane, acc);
     }
 
-    // epilogue: layer-2 bias + ReLU + BN affine, then max over the target's valid slots
-    const int h = lane >> 5;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int tgt = t0 + wr * 2 + i;
-        if (tgt >= M) continue;
-        const int d = min(deg[tgt], kw);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wc * 64 + j * 32 + (lane & 31);
-            const bool cv = col < C2;
-            const float bias = cv ? b2[col] : 0.f, s = cv ? bn_s[col] : 0.f, t = cv ? bn_t[col] : 0.f;
-            float vmax = -INFINITY;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int slot = (r & 3) + 8 * (r >> 2) + 4 * h;
-                const float v = fmaf(fmaxf(acc[i][j][r] + bias, 0.f), s, t);
-                if (slot < d) vmax = fmaxf(vmax, v);
-            }
-            vmax = fmaxf(vmax, __shfl_xor(vmax, 32));
-            if (d == 0) vmax = 0.f;
-            if (cv && h == 0) out[(size_t)tgt * ldo + col] = vmax;
-        }
-    }
+    sa_epilogue(acc, 1.0f, t0, n0, wr, wc, lane, M, kw, deg, C2, b2, bn_s, bn_t, out, ldo);
 }
 
 extern "C" int32_t p2w_sa_conv(const float* P, int32_t ldp, const float* xyzr_src, const int32_t* idx, const int32_t* batch_dst,
@@ -316,6 +336,212 @@ extern "C" int32_t p2w_sa_conv(const float* P, int32_t ldp, const float* xyzr_sr
     sa_conv_kernel<<<tile_grid(nMt, nNt), 256, 0, p2w_s(stream)>>>(
         P, ldp, reinterpret_cast<const float4*>(xyzr_src), idx, batch_dst, sf, nbr, deg, kw, M, w1r4, C1, C1pad, W2p, C2,
         nMt, nNt, b2, bn_s, bn_t, out, ldo);
+    return P2W_LAUNCH_STATUS();
+}
+
+// ------------------------------------------------------------------------------------------------
+// split-fp16 MFMA path ("f16x3"): a = a_hi + a_lo, w*2^e = w_hi + w_lo (fp16 pairs, ~22 mantissa bits);
+//   a*w ~= (a_lo*w_hi + a_hi*w_lo + a_hi*w_hi) * 2^-e      three v_mfma_f32_32x32x16_f16, fp32 accumulate
+// = fp32-class accuracy at 3/16 of the fp32-MFMA cycles.  Activations stay fp32 in HBM and are split while
+// they are staged into LDS; weights are split (and scaled by a power of two so that w_lo stays in the normal
+// fp16 range) once, when the checkpoint is packed: Wh[2][N_pad][K_pad] halfs, plane 0 = hi, plane 1 = lo.
+//   A operand of 32x32x16: lane l supplies A[row l&31][k = 8*(l>>5) + 0..7] (16 contiguous bytes), B alike.
+// LDS rows are 32 halfs + 8 pad = 80 bytes: 16-byte aligned fragments, conflict-free ds_read_b128.
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+constexpr int H_LD = 40;
+
+__device__ __forceinline__ void split_store(_Float16* __restrict__ Sh, _Float16* __restrict__ Sl, int lrow, int lkq,
+                                            const float4 (&r)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float v[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
+        h4 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            hi[e] = (_Float16)v[e];
+            lo[e] = (_Float16)(v[e] - (float)hi[e]);
+        }
+        *reinterpret_cast<h4*>(&Sh[(lrow + 32 * i) * H_LD + 4 * lkq]) = hi;
+        *reinterpret_cast<h4*>(&Sl[(lrow + 32 * i) * H_LD + 4 * lkq]) = lo;
+    }
+}
+
+// W tile: 128 rows x 32 halfs per plane; thread -> rows (tid>>2) + 64*i, 8 halfs at k = 8*(tid&3)
+__device__ __forceinline__ void load_w16_tile(const _Float16* __restrict__ Wh, size_t plane, int Kpad, int n0, int k0, int tid,
+                                              h8 (&rb)[2][2]) {
+    const int row = tid >> 2, kq = tid & 3;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const size_t o = (size_t)(n0 + row + 64 * i) * Kpad + k0 + 8 * kq;
+        rb[0][i] = *reinterpret_cast<const h8*>(&Wh[o]);
+        rb[1][i] = *reinterpret_cast<const h8*>(&Wh[plane + o]);
+    }
+}
+__device__ __forceinline__ void store_w16_tile(_Float16* __restrict__ Bh, _Float16* __restrict__ Bl, int tid,
+                                               const h8 (&rb)[2][2]) {
+    const int row = tid >> 2, kq = tid & 3;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        *reinterpret_cast<h8*>(&Bh[(row + 64 * i) * H_LD + 8 * kq]) = rb[0][i];
+        *reinterpret_cast<h8*>(&Bl[(row + 64 * i) * H_LD + 8 * kq]) = rb[1][i];
+    }
+}
+
+__device__ __forceinline__ void mma16_slab(const _Float16* __restrict__ Ah, const _Float16* __restrict__ Al,
+                                           const _Float16* __restrict__ Bh, const _Float16* __restrict__ Bl, int wr, int wc,
+                                           int lane, f32x16 (&acc)[2][2]) {
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int kk = 0; kk < G_BK; kk += 16) {
+        h8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            ah[i] = *reinterpret_cast<const h8*>(&Ah[(wr * 64 + 32 * i + r) * H_LD + kk + 8 * h]);
+            al[i] = *reinterpret_cast<const h8*>(&Al[(wr * 64 + 32 * i + r) * H_LD + kk + 8 * h]);
+            bh[i] = *reinterpret_cast<const h8*>(&Bh[(wc * 64 + 32 * i + r) * H_LD + kk + 8 * h]);
+            bl[i] = *reinterpret_cast<const h8*>(&Bl[(wc * 64 + 32 * i + r) * H_LD + kk + 8 * h]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+            }
+    }
+}
+
+__global__ __launch_bounds__(256) void gemm16_kernel(const float* __restrict__ A, int lda, const _Float16* __restrict__ Wh,
+                                                     size_t plane, float wscale, int M, int N, int K, int Kpad, int nMt,
+                                                     int nNt, EpiArgs ep, float* __restrict__ out, int ldo) {
+    __shared__ __attribute__((aligned(16))) _Float16 S[4 * G_BM * H_LD];  // Ah | Al | Bh | Bl
+    _Float16 *Ah = S, *Al = S + G_BM * H_LD, *Bh = S + 2 * G_BM * H_LD, *Bl = S + 3 * G_BM * H_LD;
+    int mt, nt;
+    if (!tile_coords(nMt, nNt, &mt, &nt)) return;
+    const int m0 = mt * G_BM, n0 = nt * G_BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+    const int lrow = tid >> 3, lkq = tid & 7;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float4 ra[4];
+    h8 rb[2][2];
+    load_a_tile(A, lda, M, K, m0, 0, lrow, lkq, ra);
+    load_w16_tile(Wh, plane, Kpad, n0, 0, tid, rb);
+    for (int k0 = 0; k0 < Kpad; k0 += G_BK) {
+        __syncthreads();
+        split_store(Ah, Al, lrow, lkq, ra);
+        store_w16_tile(Bh, Bl, tid, rb);
+        __syncthreads();
+        if (k0 + G_BK < Kpad) {
+            load_a_tile(A, lda, M, K, m0, k0 + G_BK, lrow, lkq, ra);
+            load_w16_tile(Wh, plane, Kpad, n0, k0 + G_BK, tid, rb);
+        }
+        mma16_slab(Ah, Al, Bh, Bl, wr, wc, lane, acc);
+    }
+    gemm_epilogue(acc, ep, wscale, m0 + wr * 64, n0 + wc * 64, lane, M, N, out, ldo);
+}
+
+extern "C" int32_t p2w_gemm_f16x3(const float* A, int32_t lda, const void* Wh, float wscale, int32_t M, int32_t N, int32_t K,
+                                  const p2w_epilogue* epi, float* out, int32_t ldo, p2w_stream_t stream) {
+    if (M == 0) return P2W_OK;
+    P2W_CHECK_PTR(A); P2W_CHECK_PTR(Wh); P2W_CHECK_PTR(out);
+    P2W_CHECK_ALIGN16(A); P2W_CHECK_ALIGN16(Wh);
+    if (M < 0 || N <= 0 || K <= 0 || lda < K || ldo < N || (lda & 3) != 0 || !(wscale > 0.f)) return P2W_EINVAL;
+    EpiArgs ep = {};
+    if (epi) {
+        if ((epi->sc0 && !epi->sh0) || (epi->sc1 && !epi->sh1)) return P2W_ENULL;
+        if (epi->residual && epi->ldr < N) return P2W_EINVAL;
+        ep = {epi->bias, epi->sc0, epi->sh0, epi->sc1, epi->sh1, epi->residual,
+              epi->ldr, epi->relu0, epi->relu1, epi->relu2, epi->relu_final};
+    }
+    int Npad, Kpad;
+    p2w_packed_dims(N, K, &Npad, &Kpad);
+    const int nMt = p2w_cdiv(M, G_BM), nNt = Npad / G_BN;
+    gemm16_kernel<<<tile_grid(nMt, nNt), 256, 0, p2w_s(stream)>>>(A, lda, static_cast<const _Float16*>(Wh),
+                                                                   (size_t)Npad * Kpad, wscale, M, N, K, Kpad, nMt, nNt, ep,
+                                                                   out, ldo);
+    return P2W_LAUNCH_STATUS();
+}
+
+__global__ __launch_bounds__(256) void sa_conv16_kernel(const float* __restrict__ P, int ldp, const float4* __restrict__ xyzr,
+                                                        const int* __restrict__ idx, const int* __restrict__ batch_dst,
+                                                        const float* __restrict__ sf, const int* __restrict__ nbr,
+                                                        const int* __restrict__ deg, int kw, int M,
+                                                        const float* __restrict__ w1r4, int C1, int C1pad,
+                                                        const _Float16* __restrict__ W2h, size_t plane, float wscale, int C2,
+                                                        int nMt, int nNt, const float* __restrict__ b2,
+                                                        const float* __restrict__ bn_s, const float* __restrict__ bn_t,
+                                                        float* __restrict__ out, int ldo) {
+    __shared__ __attribute__((aligned(16))) _Float16 S[4 * G_BM * H_LD];
+    _Float16 *Ah = S, *Al = S + G_BM * H_LD, *Bh = S + 2 * G_BM * H_LD, *Bl = S + 3 * G_BM * H_LD;
+    __shared__ int m_j[G_BM];
+    __shared__ float m_g[G_BM][4];
+    int mt, nt;
+    if (!tile_coords(nMt, nNt, &mt, &nt)) return;
+    const int t0 = mt * 4, n0 = nt * G_BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+    const int lrow = tid >> 3, lkq = tid & 7;
+    sa_row_geometry(tid, t0, M, kw, xyzr, idx, batch_dst, sf, nbr, deg, m_j, m_g);
+    __syncthreads();
+    int rj[4];
+    float4 rg[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        rj[i] = m_j[lrow + 32 * i];
+        rg[i] = *reinterpret_cast<const float4*>(&m_g[lrow + 32 * i][0]);
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float4 ra[4];
+    h8 rb[2][2];
+    sa_load_h1(P, ldp, w1r4, C1, C1pad, 4 * lkq, rj, rg, ra);
+    load_w16_tile(W2h, plane, C1pad, n0, 0, tid, rb);
+    for (int k0 = 0; k0 < C1pad; k0 += G_BK) {
+        __syncthreads();
+        split_store(Ah, Al, lrow, lkq, ra);
+        store_w16_tile(Bh, Bl, tid, rb);
+        __syncthreads();
+        if (k0 + G_BK < C1pad) {
+            sa_load_h1(P, ldp, w1r4, C1, C1pad, k0 + G_BK + 4 * lkq, rj, rg, ra);
+            load_w16_tile(W2h, plane, C1pad, n0, k0 + G_BK, tid, rb);
+        }
+        mma16_slab(Ah, Al, Bh, Bl, wr, wc, lane, acc);
+    }
+    sa_epilogue(acc, wscale, t0, n0, wr, wc, lane, M, kw, deg, C2, b2, bn_s, bn_t, out, ldo);
+}
+
+extern "C" int32_t p2w_sa_conv_f16x3(const float* P, int32_t ldp, const float* xyzr_src, const int32_t* idx,
+                                     const int32_t* batch_dst, const float* sf, const int32_t* nbr, const int32_t* deg,
+                                     int32_t kw, int32_t M, const float* w1r4, const void* W2h, float wscale, int32_t C1,
+                                     int32_t C2, const float* b2, const float* bn_s, const float* bn_t, float* out,
+                                     int32_t ldo, p2w_stream_t stream) {
+    if (M == 0) return P2W_OK;
+    P2W_CHECK_PTR(P); P2W_CHECK_PTR(xyzr_src); P2W_CHECK_PTR(idx); P2W_CHECK_PTR(batch_dst); P2W_CHECK_PTR(sf);
+    P2W_CHECK_PTR(nbr); P2W_CHECK_PTR(deg); P2W_CHECK_PTR(w1r4); P2W_CHECK_PTR(W2h); P2W_CHECK_PTR(b2);
+    P2W_CHECK_PTR(bn_s); P2W_CHECK_PTR(bn_t); P2W_CHECK_PTR(out);
+    P2W_CHECK_ALIGN16(P); P2W_CHECK_ALIGN16(xyzr_src); P2W_CHECK_ALIGN16(w1r4); P2W_CHECK_ALIGN16(W2h);
+    if (M < 0 || kw <= 0 || kw > 32 || C1 <= 0 || C2 <= 0 || (C1 & 3) || (ldp & 3) || ldp < C1 || ldo < C2 ||
+        !(wscale > 0.f))
+        return P2W_EINVAL;
+    int C2pad, C1pad;
+    p2w_packed_dims(C2, C1, &C2pad, &C1pad);
+    const int nMt = p2w_cdiv(M, 4), nNt = C2pad / G_BN;
+    sa_conv16_kernel<<<tile_grid(nMt, nNt), 256, 0, p2w_s(stream)>>>(
+        P, ldp, reinterpret_cast<const float4*>(xyzr_src), idx, batch_dst, sf, nbr, deg, kw, M, w1r4, C1, C1pad,
+        static_cast<const _Float16*>(W2h), (size_t)C2pad * C1pad, wscale, C2, nMt, nNt, b2, bn_s, bn_t, out, ldo);
     return P2W_LAUNCH_STATUS();
 }
 

@@ -18,6 +18,7 @@ folded into the neighbouring GEMM's weights or epilogue when the checkpoint is p
 from __future__ import annotations
 
 import ctypes as C
+import math
 from dataclasses import dataclass, field
 
 import torch
@@ -45,6 +46,8 @@ class Linear:
     relu1: int = 0
     relu2: int = 0
     relu_final: int = 0
+    w16: torch.Tensor | None = None   # [2, N_pad, K_pad] fp16: hi / lo planes of W * 2^e  (f16x3 path)
+    wscale: float = 1.0               # 2^-e
 
 
 def _bn_affine(sd, p):
@@ -71,7 +74,15 @@ class PackedWeights:
             Wp = torch.zeros((Np, Kp), dtype=torch.float64)
             Wp[:N, :K] = W
             vec = {k: (f32(v) if isinstance(v, torch.Tensor) else v) for k, v in kw.items()}
-            return Linear(w=f32(Wp), N=N, K=K, **vec)
+            # split-fp16 form: scale by a power of two so the largest weight sits near 2^10 (lo parts stay normal fp16)
+            amax = float(Wp.abs().max())
+            e = int(math.floor(math.log2(1024.0 / amax))) if amax > 0 else 0
+            e = max(-24, min(24, e))
+            Ws = Wp * (2.0 ** e)
+            hi = Ws.to(torch.float32).to(torch.float16)
+            lo = (Ws - hi.double()).to(torch.float32).to(torch.float16)
+            w16 = torch.stack([hi, lo]).contiguous().to(device)
+            return Linear(w=f32(Wp), N=N, K=K, w16=w16, wscale=2.0 ** (-e), **vec)
 
         self.stem_w = f32(sd["stem_mlp.0.0.weight"])
         self.stem_b = f32(sd["stem_mlp.0.0.bias"])
@@ -163,9 +174,12 @@ class Geometry:
 
 
 class Engine:
-    def __init__(self, weights: PackedWeights, k: int = 32):
+    def __init__(self, weights: PackedWeights, k: int = 32, precision: str = "f16x3"):
         self.w = weights
         self.k = int(k)
+        if precision not in ("f16x3", "fp32"):
+            raise ValueError("precision must be 'f16x3' (split-fp16 MFMA, fp32-class accuracy) or 'fp32' (fp32 MFMA)")
+        self.precision = precision
         if not 1 <= self.k <= 32:
             raise ValueError("k must be in 1..32 (one 32-row MFMA tile per target)")
         self.events = None  # set to a list to record (name, start, end) events per launch
@@ -186,7 +200,11 @@ class Engine:
     def _gemm(self, name, A, lda, M, lin: Linear, out, ldo, residual=None, ldr=0):
         ep = Epilogue(ptr(lin.bias), ptr(lin.sc0), ptr(lin.sh0), ptr(lin.sc1), ptr(lin.sh1), ptr(residual), ldr,
                       lin.relu0, lin.relu1, lin.relu2, lin.relu_final)
-        self._call(name, lib().p2w_gemm, ptr(A), lda, ptr(lin.w), M, lin.N, lin.K, C.byref(ep), ptr(out), ldo)
+        if self.precision == "f16x3":
+            self._call(name, lib().p2w_gemm_f16x3, ptr(A), lda, ptr(lin.w16), lin.wscale, M, lin.N, lin.K, C.byref(ep),
+                       ptr(out), ldo)
+        else:
+            self._call(name, lib().p2w_gemm, ptr(A), lda, ptr(lin.w), M, lin.N, lin.K, C.byref(ep), ptr(out), ldo)
 
     def _workspace(self, n, device):
         need = int(lib().p2w_voxel_sample_ws_bytes(n))
@@ -256,9 +274,14 @@ class Engine:
             P = new(src.n, C1)
             self._gemm("gemm_hoist", x[l - 1], p["F_in"], src.n, p["hoist"], P, C1)
             conv = new(M, C2)
-            self._call("sa_conv", L.p2w_sa_conv, ptr(P), C1, ptr(src.xyzr), ptr(dst.idx), ptr(dst.batch), ptr(geo.sf),
-                       ptr(dst.nbr), ptr(dst.deg), geo.k, M, ptr(p["w1r4"]), ptr(p["W2"].w), C1, C2, ptr(p["b2"]),
-                       ptr(p["bn_s"]), ptr(p["bn_t"]), ptr(conv), C2)
+            if self.precision == "f16x3":
+                self._call("sa_conv", L.p2w_sa_conv_f16x3, ptr(P), C1, ptr(src.xyzr), ptr(dst.idx), ptr(dst.batch),
+                           ptr(geo.sf), ptr(dst.nbr), ptr(dst.deg), geo.k, M, ptr(p["w1r4"]), ptr(p["W2"].w16),
+                           p["W2"].wscale, C1, C2, ptr(p["b2"]), ptr(p["bn_s"]), ptr(p["bn_t"]), ptr(conv), C2)
+            else:
+                self._call("sa_conv", L.p2w_sa_conv, ptr(P), C1, ptr(src.xyzr), ptr(dst.idx), ptr(dst.batch), ptr(geo.sf),
+                           ptr(dst.nbr), ptr(dst.deg), geo.k, M, ptr(p["w1r4"]), ptr(p["W2"].w), C1, C2, ptr(p["b2"]),
+                           ptr(p["bn_s"]), ptr(p["bn_t"]), ptr(conv), C2)
             e1, e2 = new(M, E), new(M, E)
             self._gemm("gemm_res", conv, C2, M, p["g1"], e1, E)
             self._gemm("gemm_res", e1, E, M, p["g2"], e2, E)

@@ -73,9 +73,10 @@ class _Node(torch.nn.Module):
 
 
 class Net(torch.nn.Module):
-    def __init__(self, num_classes: int, C: int = 32, k: int = 32):
+    def __init__(self, num_classes: int, C: int = 32, k: int = 32, precision: str = "f16x3"):
         super().__init__()
         self.num_classes, self.C, self.k = int(num_classes), int(C), int(k)
+        self.precision = precision  # "f16x3": split-fp16 MFMA with fp32 accumulate; "fp32": fp32 MFMA
         for key, shape, kind in checkpoint_layout(self.num_classes, self.C):
             *path, leaf = key.split(".")
             node = self
@@ -124,9 +125,9 @@ class Net(torch.nn.Module):
     def _ensure_packed(self, device):
         if self._packed is None or self._packed.device != device:
             self._packed = PackedWeights(self.state_dict(), self.C, self.num_classes, device)
-            self._engine = Engine(self._packed, k=self.k)
-        if self._engine.k != self.k:
-            self._engine = Engine(self._packed, k=self.k)
+            self._engine = Engine(self._packed, k=self.k, precision=self.precision)
+        if self._engine.k != self.k or self._engine.precision != self.precision:
+            self._engine = Engine(self._packed, k=self.k, precision=self.precision)
         return self._engine
 
     # -- forward --------------------------------------------------------------------------------

@@ -18,9 +18,9 @@ class _D:
     pass
 
 
-def _run(inp, C, k, wseed, keep=None):
+def _run(inp, C, k, wseed, keep=None, precision="f16x3"):
     from pointstowood_amd import Net
-    net = Net(num_classes=1, C=C, k=k)
+    net = Net(num_classes=1, C=C, k=k, precision=precision)
     net.load_state_dict(weights.synth_state_dict(1, C, seed=wseed), strict=True)
     net = net.cuda().eval()
     d = _D()
@@ -36,11 +36,12 @@ def _edges(lv, k):
     return _edges(lv.nbr[: lv.n], lv.deg[: lv.n])
 
 
+@pytest.mark.parametrize("precision", ["f16x3", "fp32"])
 @pytest.mark.parametrize("name", G.CASES)
-def test_forward_matches_reference_vectors(name):
+def test_forward_matches_reference_vectors(name, precision):
     g, inp, meta = G.load(name)
     keep = {}
-    logits, d = _run(inp, meta["C"], meta["k"], meta["wseed"], keep)
+    logits, d = _run(inp, meta["C"], meta["k"], meta["wseed"], keep, precision)
     geo = keep["geometry"]
     for l in (1, 2, 3):
         lv = geo.levels[l]
@@ -58,7 +59,8 @@ def test_forward_matches_reference_vectors(name):
     G.check(g, "probs", torch.sigmoid(logits), atol=1e-4)
 
 
-def test_forward_matches_live_oracle_mixed_batch():
+@pytest.mark.parametrize("precision", ["f16x3", "fp32"])
+def test_forward_matches_live_oracle_mixed_batch(precision):
     vox = [synth.uniform_voxel(2.0, 5000, 41, True), synth.surface_voxel(2.0, 2500, 42, True),
            synth.uniform_voxel(4.0, 300, 43, False), synth.uniform_voxel(2.0, 16384, 44, True)]
     inp = synth.collate(vox)
@@ -67,7 +69,7 @@ def test_forward_matches_live_oracle_mixed_batch():
     cap = {}
     ref = onet.forward(sd, inp["pos"], inp["batch"], inp["reflectance"], inp["sf"], k=k, capture=cap)
     keep = {}
-    got, _ = _run(inp, C, k, wseed, keep)
+    got, _ = _run(inp, C, k, wseed, keep, precision)
     geo = keep["geometry"]
     for l in (1, 2, 3):
         lv = geo.levels[l]

@@ -114,6 +114,16 @@ def test_gemm_epilogue(M, N, K):
     v2 = A[:, :K].double() @ W.double().t()
     assert (out2[:, :N].cpu().double() - v2).abs().max().item() <= 2e-5 * max(1.0, v2.abs().max().item())
     assert float(out2[:, N:].abs().max()) == 0.0
+    # split-fp16 path: same contract, weights as hi/lo fp16 planes of W * 2^e
+    e = int(np.floor(np.log2(1024.0 / float(Wp.abs().max()))))
+    Ws = Wp.double() * 2.0 ** e
+    hi = Ws.float().half()
+    lo = (Ws - hi.double()).float().half()
+    dW16 = torch.stack([hi, lo]).contiguous().cuda()
+    out3 = torch.full((M, N), float("nan"), device="cuda")
+    check(lib().p2w_gemm_f16x3(ptr(dA), lda, ptr(dW16), 2.0 ** -e, M, N, K, C.byref(ep), ptr(out3), N, stream()))
+    err3 = (out3.cpu().double() - v).abs().max().item()
+    assert err3 <= 4e-5 * max(1.0, v.abs().max().item()), err3
 
 
 def test_c_abi_rejects_bad_arguments():

@@ -15,7 +15,7 @@ from pointstowood_amd import Net  # noqa: E402
 phase = sys.argv[1] if len(sys.argv) > 1 else "forward"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 dev = torch.device("cuda", 0)
-net = Net(1, C=bench.C, k=bench.K_NBR)
+net = Net(1, C=bench.C, k=bench.K_NBR, precision=os.environ.get("P2W_PRECISION", "f16x3"))
 net.load_state_dict(weights.synth_state_dict(1, bench.C, seed=0))
 net = net.to(dev).eval()
 d = bench.make_batch(0, dev)
