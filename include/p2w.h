@@ -143,7 +143,23 @@ int32_t p2w_gemm_f16x3(const float* A, int32_t lda, const void* Wh, float wscale
 int32_t p2w_sa_conv_f16x3(const float* P, int32_t ldp, const float* xyzr_src, const int32_t* idx, const int32_t* batch_dst,
                           const float* sf, const int32_t* nbr, const int32_t* deg, int32_t kw, int32_t M,
                           const float* w1r4, const void* W2h, float wscale, int32_t C1, int32_t C2, const float* b2,
-                          const float* bn_s, const float* bn_t, float* out, int32_t ldo, p2w_stream_t stream);
+                          const float* bn_s, const float* bn_t, float* out, int32_t ldo, void* out_h2, int32_t ldh,
+                          p2w_stream_t stream);
+
+/* "H2" activations: a tensor [M, F] held as fp16 hi/lo planes, row-interleaved (row m = hi[0..ldh) | lo[0..ldh),
+ * ldh = round_up(F, 8), pad columns zero; value = hi + lo to ~22 bits).  Same bytes as fp32; a consumer GEMM stages
+ * it with plain 16-byte copies, so the fp32 -> hi/lo split happens once per element (in the producer's epilogue)
+ * instead of once per output-column tile.  p2w_gemm_h2 = p2w_gemm_f16x3 with an H2 A operand and fp32 and/or H2
+ * outputs (either pointer may be NULL).  The *_h2 variants of the small kernels write H2 (and fp32 where given). */
+int32_t p2w_gemm_h2(const void* A_h2, int32_t ldh_a, const void* Wh, float wscale, int32_t M, int32_t N, int32_t K,
+                    const p2w_epilogue* epi, float* out_f32, int32_t ldo, void* out_h2, int32_t ldh_o, p2w_stream_t stream);
+int32_t p2w_stem_h2(const float* xyzr, int32_t n, const float* w, const float* b, int32_t C, float* out, void* out_h2,
+                    int32_t ldh, p2w_stream_t stream);
+int32_t p2w_interp_concat_h2(const float* xc, int32_t Fc, const float* xyzr_c, const float* xyzr_f, const int32_t* nbr,
+                             const int32_t* deg, int32_t kw, const float* skip, int32_t Fs, int32_t m, void* out_h2,
+                             int32_t ldh, p2w_stream_t stream);
+int32_t p2w_concat_xyz_h2(const float* x, int32_t F, const float* xyzr, int32_t m, void* out_h2, int32_t ldh,
+                          p2w_stream_t stream);
 
 /* knn_interpolate (k<=2) + concat with the skip features - model.py:149-151:
  *   out[q, 0:Fc] = (sum_s w_s * xc[nbr[q,s]]) / (sum_s w_s),  w_s = 1/max(d2, 1e-16)

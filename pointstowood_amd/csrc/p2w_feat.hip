@@ -178,11 +178,22 @@ extern "C" int32_t p2w_gemm(const float* A, int32_t lda, const float* Wp, int32_
 // so the max over neighbours is a max over the accumulator tile's rows (16 registers + one lane^32
 // exchange) and the [E, C] edge tensors of the reference never exist in HBM.
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void sa_split(float v, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)v;
+    lo = (_Float16)(v - (float)hi);
+}
+__device__ __forceinline__ unsigned sa_pack(_Float16 a, _Float16 b) {
+    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+    h2v p = {a, b};
+    return __builtin_bit_cast(unsigned, p);
+}
+
 // layer-2 bias + ReLU + BN affine, then max over the target's valid neighbour slots (rows of the 32-row MFMA tile)
 __device__ __forceinline__ void sa_epilogue(const f32x16 (&acc)[2][2], float wscale, int t0, int n0, int wr, int wc, int lane,
                                             int M, int kw, const int* __restrict__ deg, int C2, const float* __restrict__ b2,
                                             const float* __restrict__ bn_s, const float* __restrict__ bn_t,
-                                            float* __restrict__ out, int ldo) {
+                                            float* __restrict__ out, int ldo, _Float16* __restrict__ out_h2 = nullptr,
+                                            int ldh = 0) {
     const int h = lane >> 5;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -203,7 +214,18 @@ __device__ __forceinline__ void sa_epilogue(const f32x16 (&acc)[2][2], float wsc
             }
             vmax = fmaxf(vmax, __shfl_xor(vmax, 32));
             if (d == 0) vmax = 0.f;
-            if (cv && h == 0) out[(size_t)tgt * ldo + col] = vmax;
+            if (cv && h == 0 && out) out[(size_t)tgt * ldo + col] = vmax;
+            if (out_h2) {  // lanes (2p, 2p+1) hold adjacent columns: the even lane stores both as one word per plane
+                const float nb = __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(vmax), 0xB1, 0xf, 0xf, false));
+                if (h == 0 && (lane & 1) == 0 && col < ldh) {
+                    _Float16 h0, l0, h1, l1;
+                    sa_split(vmax, h0, l0);
+                    sa_split(nb, h1, l1);
+                    _Float16* p = out_h2 + (size_t)tgt * (2 * ldh) + col;
+                    *reinterpret_cast<unsigned*>(p) = sa_pack(h0, h1);
+                    *reinterpret_cast<unsigned*>(p + ldh) = sa_pack(l0, l1);
+                }
+            }
         }
     }
 }
@@ -471,6 +493,169 @@ extern "C" int32_t p2w_gemm_f16x3(const float* A, int32_t lda, const void* Wh, f
     return P2W_LAUNCH_STATUS();
 }
 
+// ------------------------------------------------------------------------------------------------
+// "H2" activations: a tensor [M, F] stored as fp16 hi/lo planes, row-interleaved: row m = [hi(0..ldh) | lo(0..ldh)],
+// ldh = round_up(F, 8) halfs, pad columns zero.  Same bytes as fp32, but a consumer GEMM stages it with plain
+// 16-byte copies (no conversion), exactly like the packed weights.  Producers split once, in their epilogue.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void h2_split(float v, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)v;
+    lo = (_Float16)(v - (float)hi);
+}
+__device__ __forceinline__ unsigned h2_pack(_Float16 a, _Float16 b) {
+    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+    h2v p = {a, b};
+    return __builtin_bit_cast(unsigned, p);
+}
+// store 4 consecutive columns of one row (col % 4 == 0)
+__device__ __forceinline__ void h2_store4(_Float16* __restrict__ base, int ldh, size_t row, int col, const float (&v)[4]) {
+    _Float16 hi[4], lo[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) h2_split(v[e], hi[e], lo[e]);
+    _Float16* p = base + row * (size_t)(2 * ldh) + col;
+    *reinterpret_cast<uint2*>(p) = make_uint2(h2_pack(hi[0], hi[1]), h2_pack(hi[2], hi[3]));
+    *reinterpret_cast<uint2*>(p + ldh) = make_uint2(h2_pack(lo[0], lo[1]), h2_pack(lo[2], lo[3]));
+}
+
+// A tile from an H2 tensor: 128 rows x 32 halfs per plane; thread -> rows (tid>>2) + 64*i, 8 halfs at k = 8*(tid&3)
+__device__ __forceinline__ void load_a16_tile(const _Float16* __restrict__ A, int ldh, int M, int m0, int k0, int tid,
+                                              h8 (&ra)[2][2]) {
+    const int row = tid >> 2, k = k0 + 8 * (tid & 3);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = m0 + row + 64 * i;
+        h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        ra[0][i] = z; ra[1][i] = z;
+        if (r < M && k < ldh) {
+            const _Float16* p = A + (size_t)r * (2 * ldh) + k;
+            ra[0][i] = *reinterpret_cast<const h8*>(p);
+            ra[1][i] = *reinterpret_cast<const h8*>(p + ldh);
+        }
+    }
+}
+
+// epilogue value -> optional fp32 store + optional H2 store.  H2: lanes (2p, 2p+1) own adjacent columns of the same
+// rows; they swap one register of each (r, r+1) pair so that every lane stores two adjacent columns as one 32-bit
+// word per plane (even lane: row(r), odd lane: row(r+1)).
+struct OutArgs { float* f32; int ldo; _Float16* h2; int ldh; };
+
+__device__ __forceinline__ float epi_value(float a, float wscale, float bias, const EpiArgs& ep, float s0, float t0, float s1,
+                                           float t1, size_t row, int col, bool ok) {
+    float v = fmaf(a, wscale, bias);
+    if (ep.relu0) v = fmaxf(v, 0.f);
+    if (ep.sc0) { v = fmaf(v, s0, t0); }
+    if (ep.relu1) v = fmaxf(v, 0.f);
+    if (ep.sc1) { v = fmaf(v, s1, t1); }
+    if (ep.relu2) v = fmaxf(v, 0.f);
+    if (ep.residual && ok) v += ep.residual[row * ep.ldr + col];
+    if (ep.relu_final) v = fmaxf(v, 0.f);
+    return v;
+}
+
+__device__ __forceinline__ void gemm_epilogue2(const f32x16 (&acc)[2][2], const EpiArgs& ep, float wscale, int row0, int col0,
+                                               int lane, int M, int N, const OutArgs& o) {
+    const int h = lane >> 5, odd = lane & 1;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = col0 + j * 32 + (lane & 31);
+        const bool cv = col < N;
+        const float bias = (cv && ep.bias) ? ep.bias[col] : 0.f;
+        const float s0 = (cv && ep.sc0) ? ep.sc0[col] : 1.f, t0 = (cv && ep.sc0) ? ep.sh0[col] : 0.f;
+        const float s1 = (cv && ep.sc1) ? ep.sc1[col] : 1.f, t1 = (cv && ep.sc1) ? ep.sh1[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const int rowa = row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;  // row of register r; r+1 is rowa + 1
+                float va = epi_value(acc[i][j][r], wscale, bias, ep, s0, t0, s1, t1, (size_t)rowa, col, cv && rowa < M);
+                float vb = epi_value(acc[i][j][r + 1], wscale, bias, ep, s0, t0, s1, t1, (size_t)rowa + 1, col,
+                                     cv && rowa + 1 < M);
+                if (!cv) { va = 0.f; vb = 0.f; }  // pad columns of an H2 row must be zero
+                if (o.f32 && cv) {
+                    if (rowa < M) o.f32[(size_t)rowa * o.ldo + col] = va;
+                    if (rowa + 1 < M) o.f32[(size_t)(rowa + 1) * o.ldo + col] = vb;
+                }
+                if (o.h2) {
+                    const float send = odd ? va : vb;
+                    const float recv = __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(send), 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, false));
+                    const float c0v = odd ? recv : va, c1v = odd ? vb : recv;  // columns (col & ~1), (col | 1)
+                    const int roww = rowa + odd, colw = col & ~1;
+                    if (roww < M && colw < o.ldh) {
+                        _Float16 h0, l0, h1, l1;
+                        h2_split(c0v, h0, l0);
+                        h2_split(c1v, h1, l1);
+                        _Float16* p = o.h2 + (size_t)roww * (2 * o.ldh) + colw;
+                        *reinterpret_cast<unsigned*>(p) = h2_pack(h0, h1);
+                        *reinterpret_cast<unsigned*>(p + o.ldh) = h2_pack(l0, l1);
+                    }
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gemm_h2_kernel(const _Float16* __restrict__ A, int ldh_a, const _Float16* __restrict__ Wh,
+                                                      size_t plane, float wscale, int M, int N, int Kpad, int nMt, int nNt,
+                                                      EpiArgs ep, OutArgs o) {
+    __shared__ __attribute__((aligned(16))) _Float16 S[4 * G_BM * H_LD];  // Ah | Al | Bh | Bl
+    _Float16 *Ah = S, *Al = S + G_BM * H_LD, *Bh = S + 2 * G_BM * H_LD, *Bl = S + 3 * G_BM * H_LD;
+    int mt, nt;
+    if (!tile_coords(nMt, nNt, &mt, &nt)) return;
+    const int m0 = mt * G_BM, n0 = nt * G_BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    h8 ra[2][2], rb[2][2];
+    load_a16_tile(A, ldh_a, M, m0, 0, tid, ra);
+    load_w16_tile(Wh, plane, Kpad, n0, 0, tid, rb);
+    for (int k0 = 0; k0 < Kpad; k0 += G_BK) {
+        __syncthreads();
+        store_w16_tile(Ah, Al, tid, ra);
+        store_w16_tile(Bh, Bl, tid, rb);
+        __syncthreads();
+        if (k0 + G_BK < Kpad) {
+            load_a16_tile(A, ldh_a, M, m0, k0 + G_BK, tid, ra);
+            load_w16_tile(Wh, plane, Kpad, n0, k0 + G_BK, tid, rb);
+        }
+        mma16_slab(Ah, Al, Bh, Bl, wr, wc, lane, acc);
+    }
+    gemm_epilogue2(acc, ep, wscale, m0 + wr * 64, n0 + wc * 64, lane, M, N, o);
+}
+
+extern "C" int32_t p2w_gemm_h2(const void* A_h2, int32_t ldh_a, const void* Wh, float wscale, int32_t M, int32_t N, int32_t K,
+                               const p2w_epilogue* epi, float* out_f32, int32_t ldo, void* out_h2, int32_t ldh_o,
+                               p2w_stream_t stream) {
+    if (M == 0) return P2W_OK;
+    P2W_CHECK_PTR(A_h2); P2W_CHECK_PTR(Wh);
+    if (!out_f32 && !out_h2) return P2W_ENULL;
+    P2W_CHECK_ALIGN16(A_h2); P2W_CHECK_ALIGN16(Wh);
+    if (out_h2) P2W_CHECK_ALIGN16(out_h2);
+    if (M < 0 || N <= 0 || K <= 0 || ldh_a < K || (ldh_a & 7) || !(wscale > 0.f)) return P2W_EINVAL;
+    if (out_f32 && ldo < N) return P2W_EINVAL;
+    if (out_h2 && (ldh_o < N || (ldh_o & 7))) return P2W_EINVAL;
+    EpiArgs ep = {};
+    if (epi) {
+        if ((epi->sc0 && !epi->sh0) || (epi->sc1 && !epi->sh1)) return P2W_ENULL;
+        if (epi->residual && epi->ldr < N) return P2W_EINVAL;
+        ep = {epi->bias, epi->sc0, epi->sh0, epi->sc1, epi->sh1, epi->residual,
+              epi->ldr, epi->relu0, epi->relu1, epi->relu2, epi->relu_final};
+    }
+    int Npad, Kpad;
+    p2w_packed_dims(N, K, &Npad, &Kpad);
+    if (out_h2 && ldh_o > Npad) return P2W_EINVAL;
+    const int nMt = p2w_cdiv(M, G_BM), nNt = Npad / G_BN;
+    OutArgs o = {out_f32, ldo, static_cast<_Float16*>(out_h2), ldh_o};
+    gemm_h2_kernel<<<tile_grid(nMt, nNt), 256, 0, p2w_s(stream)>>>(static_cast<const _Float16*>(A_h2), ldh_a,
+                                                                    static_cast<const _Float16*>(Wh), (size_t)Npad * Kpad,
+                                                                    wscale, M, N, Kpad, nMt, nNt, ep, o);
+    return P2W_LAUNCH_STATUS();
+}
+
 __global__ __launch_bounds__(256) void sa_conv16_kernel(const float* __restrict__ P, int ldp, const float4* __restrict__ xyzr,
                                                         const int* __restrict__ idx, const int* __restrict__ batch_dst,
                                                         const float* __restrict__ sf, const int* __restrict__ nbr,
@@ -479,7 +664,8 @@ __global__ __launch_bounds__(256) void sa_conv16_kernel(const float* __restrict_
                                                         const _Float16* __restrict__ W2h, size_t plane, float wscale, int C2,
                                                         int nMt, int nNt, const float* __restrict__ b2,
                                                         const float* __restrict__ bn_s, const float* __restrict__ bn_t,
-                                                        float* __restrict__ out, int ldo) {
+                                                        float* __restrict__ out, int ldo, _Float16* __restrict__ out_h2,
+                                                        int ldh) {
     __shared__ __attribute__((aligned(16))) _Float16 S[4 * G_BM * H_LD];
     _Float16 *Ah = S, *Al = S + G_BM * H_LD, *Bh = S + 2 * G_BM * H_LD, *Bl = S + 3 * G_BM * H_LD;
     __shared__ int m_j[G_BM];
@@ -520,63 +706,86 @@ __global__ __launch_bounds__(256) void sa_conv16_kernel(const float* __restrict_
         }
         mma16_slab(Ah, Al, Bh, Bl, wr, wc, lane, acc);
     }
-    sa_epilogue(acc, wscale, t0, n0, wr, wc, lane, M, kw, deg, C2, b2, bn_s, bn_t, out, ldo);
+    sa_epilogue(acc, wscale, t0, n0, wr, wc, lane, M, kw, deg, C2, b2, bn_s, bn_t, out, ldo, out_h2, ldh);
 }
 
 extern "C" int32_t p2w_sa_conv_f16x3(const float* P, int32_t ldp, const float* xyzr_src, const int32_t* idx,
                                      const int32_t* batch_dst, const float* sf, const int32_t* nbr, const int32_t* deg,
                                      int32_t kw, int32_t M, const float* w1r4, const void* W2h, float wscale, int32_t C1,
                                      int32_t C2, const float* b2, const float* bn_s, const float* bn_t, float* out,
-                                     int32_t ldo, p2w_stream_t stream) {
+                                     int32_t ldo, void* out_h2, int32_t ldh, p2w_stream_t stream) {
     if (M == 0) return P2W_OK;
     P2W_CHECK_PTR(P); P2W_CHECK_PTR(xyzr_src); P2W_CHECK_PTR(idx); P2W_CHECK_PTR(batch_dst); P2W_CHECK_PTR(sf);
     P2W_CHECK_PTR(nbr); P2W_CHECK_PTR(deg); P2W_CHECK_PTR(w1r4); P2W_CHECK_PTR(W2h); P2W_CHECK_PTR(b2);
-    P2W_CHECK_PTR(bn_s); P2W_CHECK_PTR(bn_t); P2W_CHECK_PTR(out);
+    P2W_CHECK_PTR(bn_s); P2W_CHECK_PTR(bn_t);
+    if (!out && !out_h2) return P2W_ENULL;
     P2W_CHECK_ALIGN16(P); P2W_CHECK_ALIGN16(xyzr_src); P2W_CHECK_ALIGN16(w1r4); P2W_CHECK_ALIGN16(W2h);
-    if (M < 0 || kw <= 0 || kw > 32 || C1 <= 0 || C2 <= 0 || (C1 & 3) || (ldp & 3) || ldp < C1 || ldo < C2 ||
-        !(wscale > 0.f))
+    if (M < 0 || kw <= 0 || kw > 32 || C1 <= 0 || C2 <= 0 || (C1 & 3) || (ldp & 3) || ldp < C1 || (out && ldo < C2) ||
+        (out_h2 && (ldh < C2 || (ldh & 7))) || !(wscale > 0.f))
         return P2W_EINVAL;
     int C2pad, C1pad;
     p2w_packed_dims(C2, C1, &C2pad, &C1pad);
     const int nMt = p2w_cdiv(M, 4), nNt = C2pad / G_BN;
     sa_conv16_kernel<<<tile_grid(nMt, nNt), 256, 0, p2w_s(stream)>>>(
         P, ldp, reinterpret_cast<const float4*>(xyzr_src), idx, batch_dst, sf, nbr, deg, kw, M, w1r4, C1, C1pad,
-        static_cast<const _Float16*>(W2h), (size_t)C2pad * C1pad, wscale, C2, nMt, nNt, b2, bn_s, bn_t, out, ldo);
+        static_cast<const _Float16*>(W2h), (size_t)C2pad * C1pad, wscale, C2, nMt, nNt, b2, bn_s, bn_t, out, ldo,
+        static_cast<_Float16*>(out_h2), ldh);
     return P2W_LAUNCH_STATUS();
 }
 
 // ------------------------------------------------------------------------------------------------
 // small HBM-bound kernels
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void stem_kernel(const float4* __restrict__ xyzr, int n, const float* __restrict__ w,
-                                                   const float* __restrict__ b, int C, float* __restrict__ out) {
-    const long g = (long)blockIdx.x * 256 + threadIdx.x;  // one thread per (row, channel)
-    if (g >= (long)n * C) return;
-    const int row = (int)(g / C), c = (int)(g % C);
-    const float4 p = xyzr[row];
-    // F.linear order: ((b + x*w0) + y*w1) + z*w2 differs from a BLAS dot only in the last bits
-    const float v = fmaf(p.z, w[c * 3 + 2], fmaf(p.y, w[c * 3 + 1], fmaf(p.x, w[c * 3 + 0], b[c])));
-    out[g] = fmaxf(v, 0.f);
+// 4 consecutive output columns of one row -> fp32 row (pitch ldo) and/or H2 row (pitch ldh)
+__device__ __forceinline__ void store4(const OutArgs& o, size_t row, int c, const float (&v)[4]) {
+    if (o.f32 && c < o.ldo) *reinterpret_cast<float4*>(&o.f32[row * o.ldo + c]) = make_float4(v[0], v[1], v[2], v[3]);
+    if (o.h2 && c < o.ldh) h2_store4(o.h2, o.ldh, row, c, v);
 }
 
+__global__ __launch_bounds__(256) void stem_kernel(const float4* __restrict__ xyzr, int n, const float* __restrict__ w,
+                                                   const float* __restrict__ b, int C, int q4, OutArgs o) {
+    const long g = (long)blockIdx.x * 256 + threadIdx.x;  // one thread per (row, 4 channels incl. zero padding)
+    if (g >= (long)n * q4) return;
+    const int row = (int)(g / q4), c0 = (int)(g % q4) * 4;
+    const float4 p = xyzr[row];
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int c = c0 + e;
+        v[e] = (c < C) ? fmaxf(fmaf(p.z, w[c * 3 + 2], fmaf(p.y, w[c * 3 + 1], fmaf(p.x, w[c * 3 + 0], b[c]))), 0.f) : 0.f;
+    }
+    store4(o, (size_t)row, c0, v);
+}
+
+static int32_t stem_launch(const float* xyzr, int32_t n, const float* w, const float* b, int32_t C, float* out, void* out_h2,
+                           int32_t ldh, p2w_stream_t stream) {
+    if (n == 0) return P2W_OK;
+    P2W_CHECK_PTR(xyzr); P2W_CHECK_PTR(w); P2W_CHECK_PTR(b); P2W_CHECK_ALIGN16(xyzr);
+    if (!out && !out_h2) return P2W_ENULL;
+    if (n < 0 || C <= 0 || (C & 3) || (out_h2 && (ldh < C || (ldh & 7)))) return P2W_EINVAL;
+    OutArgs o = {out, C, static_cast<_Float16*>(out_h2), out_h2 ? ldh : 0};
+    const int q4 = (out_h2 ? ldh : C) >> 2;
+    stem_kernel<<<p2w_cdiv((long)n * q4, 256), 256, 0, p2w_s(stream)>>>(reinterpret_cast<const float4*>(xyzr), n, w, b, C, q4, o);
+    return P2W_LAUNCH_STATUS();
+}
 extern "C" int32_t p2w_stem(const float* xyzr, int32_t n, const float* w, const float* b, int32_t C, float* out,
                             p2w_stream_t stream) {
-    if (n == 0) return P2W_OK;
-    P2W_CHECK_PTR(xyzr); P2W_CHECK_PTR(w); P2W_CHECK_PTR(b); P2W_CHECK_PTR(out); P2W_CHECK_ALIGN16(xyzr);
-    if (n < 0 || C <= 0) return P2W_EINVAL;
-    stem_kernel<<<p2w_cdiv((long)n * C, 256), 256, 0, p2w_s(stream)>>>(reinterpret_cast<const float4*>(xyzr), n, w, b, C, out);
-    return P2W_LAUNCH_STATUS();
+    P2W_CHECK_PTR(out);
+    return stem_launch(xyzr, n, w, b, C, out, nullptr, 0, stream);
+}
+extern "C" int32_t p2w_stem_h2(const float* xyzr, int32_t n, const float* w, const float* b, int32_t C, float* out,
+                               void* out_h2, int32_t ldh, p2w_stream_t stream) {
+    return stem_launch(xyzr, n, w, b, C, out, out_h2, ldh, stream);
 }
 
 __global__ __launch_bounds__(256) void interp_concat_kernel(const float* __restrict__ xc, int Fc, const float4* __restrict__ xyzr_c,
                                                             const float4* __restrict__ xyzr_f, const int* __restrict__ nbr,
                                                             const int* __restrict__ deg, int kw, const float* __restrict__ skip,
-                                                            int Fs, int m, float* __restrict__ out, int ldo) {
-    const int q4 = ldo >> 2;  // float4 chunks per output row
-    const long g = (long)blockIdx.x * 256 + threadIdx.x;
+                                                            int Fs, int m, int q4, OutArgs o) {
+    const long g = (long)blockIdx.x * 256 + threadIdx.x;  // q4 = 4-column chunks per output row (incl. zero padding)
     if (g >= (long)m * q4) return;
     const int q = (int)(g / q4), c = (int)(g % q4) * 4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
     if (c < Fc) {
         const int d = min(deg[q], kw);
         const float4 pf = xyzr_f[q];
@@ -592,48 +801,87 @@ __global__ __launch_bounds__(256) void interp_concat_kernel(const float* __restr
             num.x = num.x + x.x * w; num.y = num.y + x.y * w; num.z = num.z + x.z * w; num.w = num.w + x.w * w;
             den = den + w;
         }
-        if (d > 0) v = make_float4(num.x / den, num.y / den, num.z / den, num.w / den);
+        if (d > 0) { v[0] = num.x / den; v[1] = num.y / den; v[2] = num.z / den; v[3] = num.w / den; }
     } else if (c < Fc + Fs) {
-        v = *reinterpret_cast<const float4*>(&skip[(size_t)q * Fs + (c - Fc)]);
+        const float4 t = *reinterpret_cast<const float4*>(&skip[(size_t)q * Fs + (c - Fc)]);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
     }
-    *reinterpret_cast<float4*>(&out[(size_t)q * ldo + c]) = v;
+    store4(o, (size_t)q, c, v);
 }
 
+static int32_t interp_launch(const float* xc, int32_t Fc, const float* xyzr_c, const float* xyzr_f, const int32_t* nbr,
+                             const int32_t* deg, int32_t kw, const float* skip, int32_t Fs, int32_t m, float* out, int32_t ldo,
+                             void* out_h2, int32_t ldh, p2w_stream_t stream) {
+    if (m == 0) return P2W_OK;
+    P2W_CHECK_PTR(xc); P2W_CHECK_PTR(xyzr_c); P2W_CHECK_PTR(xyzr_f); P2W_CHECK_PTR(nbr); P2W_CHECK_PTR(deg);
+    if (!out && !out_h2) return P2W_ENULL;
+    if (Fs > 0) { P2W_CHECK_PTR(skip); P2W_CHECK_ALIGN16(skip); }
+    P2W_CHECK_ALIGN16(xc); P2W_CHECK_ALIGN16(xyzr_c); P2W_CHECK_ALIGN16(xyzr_f);
+    if (out) P2W_CHECK_ALIGN16(out);
+    if (out_h2) P2W_CHECK_ALIGN16(out_h2);
+    if (m < 0 || kw <= 0 || Fc <= 0 || Fs < 0 || (Fc & 3) || (Fs & 3)) return P2W_EINVAL;
+    if (out && ((ldo & 3) || ldo < Fc + Fs)) return P2W_EINVAL;
+    if (out_h2 && ((ldh & 7) || ldh < Fc + Fs)) return P2W_EINVAL;
+    const int width = (out ? ldo : 0) > (out_h2 ? ldh : 0) ? ldo : ldh;
+    OutArgs o = {out, out ? ldo : 0, static_cast<_Float16*>(out_h2), out_h2 ? ldh : 0};
+    interp_concat_kernel<<<p2w_cdiv((long)m * (width >> 2), 256), 256, 0, p2w_s(stream)>>>(
+        xc, Fc, reinterpret_cast<const float4*>(xyzr_c), reinterpret_cast<const float4*>(xyzr_f), nbr, deg, kw, skip, Fs, m,
+        width >> 2, o);
+    return P2W_LAUNCH_STATUS();
+}
 extern "C" int32_t p2w_interp_concat(const float* xc, int32_t Fc, const float* xyzr_c, const float* xyzr_f, const int32_t* nbr,
                                      const int32_t* deg, int32_t kw, const float* skip, int32_t Fs, int32_t m, float* out,
                                      int32_t ldo, p2w_stream_t stream) {
-    if (m == 0) return P2W_OK;
-    P2W_CHECK_PTR(xc); P2W_CHECK_PTR(xyzr_c); P2W_CHECK_PTR(xyzr_f); P2W_CHECK_PTR(nbr); P2W_CHECK_PTR(deg); P2W_CHECK_PTR(out);
-    if (Fs > 0) { P2W_CHECK_PTR(skip); P2W_CHECK_ALIGN16(skip); }
-    P2W_CHECK_ALIGN16(xc); P2W_CHECK_ALIGN16(xyzr_c); P2W_CHECK_ALIGN16(xyzr_f); P2W_CHECK_ALIGN16(out);
-    if (m < 0 || kw <= 0 || Fc <= 0 || Fs < 0 || (Fc & 3) || (Fs & 3) || (ldo & 3) || ldo < Fc + Fs) return P2W_EINVAL;
-    interp_concat_kernel<<<p2w_cdiv((long)m * (ldo >> 2), 256), 256, 0, p2w_s(stream)>>>(
-        xc, Fc, reinterpret_cast<const float4*>(xyzr_c), reinterpret_cast<const float4*>(xyzr_f), nbr, deg, kw, skip, Fs, m,
-        out, ldo);
-    return P2W_LAUNCH_STATUS();
+    P2W_CHECK_PTR(out);
+    return interp_launch(xc, Fc, xyzr_c, xyzr_f, nbr, deg, kw, skip, Fs, m, out, ldo, nullptr, 0, stream);
+}
+extern "C" int32_t p2w_interp_concat_h2(const float* xc, int32_t Fc, const float* xyzr_c, const float* xyzr_f,
+                                        const int32_t* nbr, const int32_t* deg, int32_t kw, const float* skip, int32_t Fs,
+                                        int32_t m, void* out_h2, int32_t ldh, p2w_stream_t stream) {
+    P2W_CHECK_PTR(out_h2);
+    return interp_launch(xc, Fc, xyzr_c, xyzr_f, nbr, deg, kw, skip, Fs, m, nullptr, 0, out_h2, ldh, stream);
 }
 
 __global__ __launch_bounds__(256) void concat_xyz_kernel(const float* __restrict__ x, int F, const float4* __restrict__ xyzr,
-                                                         int m, float* __restrict__ out, int ldo) {
-    const int q4 = ldo >> 2;
+                                                         int m, int q4, OutArgs o) {
     const long g = (long)blockIdx.x * 256 + threadIdx.x;
     if (g >= (long)m * q4) return;
     const int q = (int)(g / q4), c = (int)(g % q4) * 4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (c < F) v = *reinterpret_cast<const float4*>(&x[(size_t)q * F + c]);
-    else if (c == F) { const float4 p = xyzr[q]; v = make_float4(p.x, p.y, p.z, 0.f); }
-    *reinterpret_cast<float4*>(&out[(size_t)q * ldo + c]) = v;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < F) {
+        const float4 t = *reinterpret_cast<const float4*>(&x[(size_t)q * F + c]);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else if (c == F) {
+        const float4 p = xyzr[q];
+        v[0] = p.x; v[1] = p.y; v[2] = p.z;
+    }
+    store4(o, (size_t)q, c, v);
 }
 
+static int32_t concat_launch(const float* x, int32_t F, const float* xyzr, int32_t m, float* out, int32_t ldo, void* out_h2,
+                             int32_t ldh, p2w_stream_t stream) {
+    if (m == 0) return P2W_OK;
+    P2W_CHECK_PTR(x); P2W_CHECK_PTR(xyzr);
+    if (!out && !out_h2) return P2W_ENULL;
+    P2W_CHECK_ALIGN16(x); P2W_CHECK_ALIGN16(xyzr);
+    if (m < 0 || F <= 0 || (F & 3)) return P2W_EINVAL;
+    if (out && ((ldo & 3) || ldo < F + 4)) return P2W_EINVAL;
+    if (out_h2 && ((ldh & 7) || ldh < F + 4)) return P2W_EINVAL;
+    const int width = (out ? ldo : 0) > (out_h2 ? ldh : 0) ? ldo : ldh;
+    OutArgs o = {out, out ? ldo : 0, static_cast<_Float16*>(out_h2), out_h2 ? ldh : 0};
+    concat_xyz_kernel<<<p2w_cdiv((long)m * (width >> 2), 256), 256, 0, p2w_s(stream)>>>(
+        x, F, reinterpret_cast<const float4*>(xyzr), m, width >> 2, o);
+    return P2W_LAUNCH_STATUS();
+}
 extern "C" int32_t p2w_concat_xyz(const float* x, int32_t F, const float* xyzr, int32_t m, float* out, int32_t ldo,
                                   p2w_stream_t stream) {
-    if (m == 0) return P2W_OK;
-    P2W_CHECK_PTR(x); P2W_CHECK_PTR(xyzr); P2W_CHECK_PTR(out);
-    P2W_CHECK_ALIGN16(x); P2W_CHECK_ALIGN16(xyzr); P2W_CHECK_ALIGN16(out);
-    if (m < 0 || F <= 0 || (F & 3) || (ldo & 3) || ldo < F + 4) return P2W_EINVAL;
-    concat_xyz_kernel<<<p2w_cdiv((long)m * (ldo >> 2), 256), 256, 0, p2w_s(stream)>>>(
-        x, F, reinterpret_cast<const float4*>(xyzr), m, out, ldo);
-    return P2W_LAUNCH_STATUS();
+    P2W_CHECK_PTR(out);
+    return concat_launch(x, F, xyzr, m, out, ldo, nullptr, 0, stream);
+}
+extern "C" int32_t p2w_concat_xyz_h2(const float* x, int32_t F, const float* xyzr, int32_t m, void* out_h2, int32_t ldh,
+                                     p2w_stream_t stream) {
+    P2W_CHECK_PTR(out_h2);
+    return concat_launch(x, F, xyzr, m, nullptr, 0, out_h2, ldh, stream);
 }
 
 // global max pool: (voxel, 64-column group, row split) blocks; 4 row lanes x 64 columns per block, LDS combine, then
