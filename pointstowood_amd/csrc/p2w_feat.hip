@@ -9,13 +9,14 @@
 // 8-wide k group, lane half h takes k = 4h..4h+3 and step s uses element s (the k order inside the
 // group is permuted identically for A and B, which leaves the sum unchanged).
 #include "p2w_common.h"
+#include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int G_BM = 128, G_BN = 128, G_BK = 32, G_LD = 36;
 
 extern "C" void p2w_packed_dims(int32_t N, int32_t K, int32_t* N_pad, int32_t* K_pad) {
-    if (N_pad) *N_pad = (N + G_BN - 1) / G_BN * G_BN;
+    if (N_pad) *N_pad = (N + 255) / 256 * 256;  // widest column tile of any kernel
     if (K_pad) *K_pad = (K + G_BK - 1) / G_BK * G_BK;
 }
 
@@ -168,7 +169,7 @@ extern "C" int32_t p2w_gemm(const float* A, int32_t lda, const float* Wp, int32_
     }
     int Npad, Kpad;
     p2w_packed_dims(N, K, &Npad, &Kpad);
-    const int nMt = p2w_cdiv(M, G_BM), nNt = Npad / G_BN;
+    const int nMt = p2w_cdiv(M, G_BM), nNt = p2w_cdiv(N, G_BN);
     gemm_kernel<<<tile_grid(nMt, nNt), 256, 0, p2w_s(stream)>>>(A, lda, Wp, M, N, K, Kpad, nMt, nNt, ep, out, ldo);
     return P2W_LAUNCH_STATUS();
 }
@@ -354,7 +355,7 @@ extern "C" int32_t p2w_sa_conv(const float* P, int32_t ldp, const float* xyzr_sr
     if (M < 0 || kw <= 0 || kw > 32 || C1 <= 0 || C2 <= 0 || (C1 & 3) || (ldp & 3) || ldp < C1 || ldo < C2) return P2W_EINVAL;
     int C2pad, C1pad;
     p2w_packed_dims(C2, C1, &C2pad, &C1pad);
-    const int nMt = p2w_cdiv(M, 4), nNt = C2pad / G_BN;
+    const int nMt = p2w_cdiv(M, 4), nNt = p2w_cdiv(C2, G_BN);
     sa_conv_kernel<<<tile_grid(nMt, nNt), 256, 0, p2w_s(stream)>>>(
         P, ldp, reinterpret_cast<const float4*>(xyzr_src), idx, batch_dst, sf, nbr, deg, kw, M, w1r4, C1, C1pad, W2p, C2,
         nMt, nNt, b2, bn_s, bn_t, out, ldo);
@@ -486,7 +487,7 @@ extern "C" int32_t p2w_gemm_f16x3(const float* A, int32_t lda, const void* Wh, f
     }
     int Npad, Kpad;
     p2w_packed_dims(N, K, &Npad, &Kpad);
-    const int nMt = p2w_cdiv(M, G_BM), nNt = Npad / G_BN;
+    const int nMt = p2w_cdiv(M, G_BM), nNt = p2w_cdiv(N, G_BN);
     gemm16_kernel<<<tile_grid(nMt, nNt), 256, 0, p2w_s(stream)>>>(A, lda, static_cast<const _Float16*>(Wh),
                                                                    (size_t)Npad * Kpad, wscale, M, N, K, Kpad, nMt, nNt, ep,
                                                                    out, ldo);
@@ -552,18 +553,19 @@ __device__ __forceinline__ float epi_value(float a, float wscale, float bias, co
     return v;
 }
 
-__device__ __forceinline__ void gemm_epilogue2(const f32x16 (&acc)[2][2], const EpiArgs& ep, float wscale, int row0, int col0,
+template <int RT, int CT>
+__device__ __forceinline__ void gemm_epilogue2(const f32x16 (&acc)[RT][CT], const EpiArgs& ep, float wscale, int row0, int col0,
                                                int lane, int M, int N, const OutArgs& o) {
     const int h = lane >> 5, odd = lane & 1;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < CT; ++j) {
         const int col = col0 + j * 32 + (lane & 31);
         const bool cv = col < N;
         const float bias = (cv && ep.bias) ? ep.bias[col] : 0.f;
         const float s0 = (cv && ep.sc0) ? ep.sc0[col] : 1.f, t0 = (cv && ep.sc0) ? ep.sh0[col] : 0.f;
         const float s1 = (cv && ep.sc1) ? ep.sc1[col] : 1.f, t1 = (cv && ep.sc1) ? ep.sh1[col] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < RT; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 const int rowa = row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;  // row of register r; r+1 is rowa + 1
@@ -624,7 +626,126 @@ __global__ __launch_bounds__(256) void gemm_h2_kernel(const _Float16* __restrict
         }
         mma16_slab(Ah, Al, Bh, Bl, wr, wc, lane, acc);
     }
-    gemm_epilogue2(acc, ep, wscale, m0 + wr * 64, n0 + wc * 64, lane, M, N, o);
+    gemm_epilogue2<2, 2>(acc, ep, wscale, m0 + wr * 64, n0 + wc * 64, lane, M, N, o);
+}
+
+// ------------------------------------------------------------------------------------------------
+// gemm_h2 v2: both operands are fp16 hi/lo planes in HBM, so a K-slab is staged with direct-to-LDS loads
+// (global_load_lds_dwordx4: no VGPR round trip, no ds_write) into a 2-stage ring; one barrier per slab, the next
+// slab's DMA is in flight during the whole MFMA phase of the current one.
+// LDS image of a stage (16-byte chunks): A plane p, row r, chunk q -> ((p*BM + r)*4 + (q ^ ((r>>2)&3)));  B after A.
+// Rows are 64 B unpadded (the DMA writes 1 KiB linearly per wave-instruction: lane L -> chunk base+L), so the XOR
+// swizzle is applied on the per-lane SOURCE address and again on the ds_read address: conflict-free ds_read_b128.
+// Out-of-range A rows are clamped to M-1 (their results are never stored); K padding is zero in both operands
+// (H2 tensors have ldh % 32 == 0 with zero pad columns when they feed this kernel).
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_vp;
+typedef const __attribute__((address_space(1))) void* glb_vp;
+
+template <int WR, int WC, int RT, int CT>   // waves WR x WC, wave tile (32*RT) x (32*CT)
+__global__ __launch_bounds__(64 * WR * WC) void gemm_h2g_kernel(const _Float16* __restrict__ A, int ldh_a,
+                                                                const _Float16* __restrict__ Wh, size_t plane, float wscale,
+                                                                int M, int N, int Kpad, int nMt, int nNt, EpiArgs ep,
+                                                                OutArgs o, int dbg) {
+    // dbg (profiling ablations, 0 in production): 1 = skip the epilogue, 2 = issue only the first slab's DMA,
+    // 4 = skip the MFMAs
+    constexpr int BM = 32 * RT * WR, BN = 32 * CT * WC, NW = WR * WC;
+    constexpr int A_CH = 8 * BM, STAGE_CH = A_CH + 8 * BN;   // 16-byte chunks per stage (2 planes x rows x 4)
+    constexpr int NI = STAGE_CH / 64 / NW;                   // DMA instructions per wave per stage
+    static_assert(STAGE_CH % (64 * NW) == 0, "stage must split evenly over the waves");
+    __shared__ __attribute__((aligned(16))) char S[2 * STAGE_CH * 16];
+    int mt, nt;
+    if (!tile_coords(nMt, nNt, &mt, &nt)) return;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wave / WC, wc = wave % WC;
+
+    // per-lane DMA sources (advance 64 B per slab) and wave-uniform LDS chunk bases
+    const _Float16* src[NI];
+    int dstc[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int g = wave + NW * i;
+        const int rloc = lane >> 2;
+        if (g < BM / 8) {
+            const int p = g / (BM / 16), rb = g % (BM / 16);
+            const int row = 16 * rb + rloc, q = (lane & 3) ^ ((row >> 2) & 3);
+            const int grow = min(m0 + row, M - 1);
+            src[i] = A + (size_t)grow * (2 * ldh_a) + (size_t)p * ldh_a + 8 * q;
+            dstc[i] = g * 64;
+        } else {
+            const int g2 = g - BM / 8, p = g2 / (BN / 16), rb = g2 % (BN / 16);
+            const int row = 16 * rb + rloc, q = (lane & 3) ^ ((row >> 2) & 3);
+            src[i] = Wh + (size_t)p * plane + (size_t)(n0 + row) * Kpad + 8 * q;
+            dstc[i] = A_CH + g2 * 64;
+        }
+    }
+    auto issue = [&](int stage, int k0) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            __builtin_amdgcn_global_load_lds((glb_vp)(src[i] + k0), (lds_vp)(S + ((size_t)stage * STAGE_CH + dstc[i]) * 16), 16, 0, 0);
+    };
+
+    // fragment read offsets (bytes within a stage) for kk = 0; kk = 16 flips chunk bit 1 (q ^= 2)
+    const int r = lane & 31, h = lane >> 5;
+    int offA[2][RT], offB[2][CT];  // [plane][tile]
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            const int ra = wr * 32 * RT + 32 * t + r;
+            offA[p][t] = ((p * BM + ra) * 4 + (h ^ ((ra >> 2) & 3))) * 16;
+        }
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            const int rb = wc * 32 * CT + 32 * t + r;
+            offB[p][t] = (A_CH + (p * BN + rb) * 4 + (h ^ ((rb >> 2) & 3))) * 16;
+        }
+    }
+
+    f32x16 acc[RT][CT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < CT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nslab = Kpad / G_BK;
+    issue(0, 0);
+    for (int s = 0; s < nslab; ++s) {
+        __syncthreads();  // = s_waitcnt vmcnt(0) + barrier: slab s has landed for every wave, slab s-1's buffer is free
+        if (s + 1 < nslab && !(dbg & 2)) issue((s + 1) & 1, (s + 1) * G_BK);
+        const char* st = S + (size_t)(s & 1) * STAGE_CH * 16;
+        if (dbg & 4) continue;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            h8 ah[RT], al[RT], bh[CT], bl[CT];
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {
+                ah[t] = *reinterpret_cast<const h8*>(st + (offA[0][t] ^ (kk << 5)));
+                al[t] = *reinterpret_cast<const h8*>(st + (offA[1][t] ^ (kk << 5)));
+            }
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+                bh[t] = *reinterpret_cast<const h8*>(st + (offB[0][t] ^ (kk << 5)));
+                bl[t] = *reinterpret_cast<const h8*>(st + (offB[1][t] ^ (kk << 5)));
+            }
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int j = 0; j < CT; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+    if (dbg & 1) {
+        if (acc[0][0][0] + acc[0][CT - 1][1] + acc[RT - 1][0][2] + acc[RT - 1][CT - 1][3] == 12345.678f && o.f32) o.f32[0] = 1.f;
+        return;
+    }
+    gemm_epilogue2<RT, CT>(acc, ep, wscale, m0 + wr * 32 * RT, n0 + wc * 32 * CT, lane, M, N, o);
 }
 
 extern "C" int32_t p2w_gemm_h2(const void* A_h2, int32_t ldh_a, const void* Wh, float wscale, int32_t M, int32_t N, int32_t K,
@@ -648,11 +769,31 @@ extern "C" int32_t p2w_gemm_h2(const void* A_h2, int32_t ldh_a, const void* Wh, 
     int Npad, Kpad;
     p2w_packed_dims(N, K, &Npad, &Kpad);
     if (out_h2 && ldh_o > Npad) return P2W_EINVAL;
-    const int nMt = p2w_cdiv(M, G_BM), nNt = Npad / G_BN;
+    const int nNt = p2w_cdiv(N, G_BN);
     OutArgs o = {out_f32, ldo, static_cast<_Float16*>(out_h2), ldh_o};
-    gemm_h2_kernel<<<tile_grid(nMt, nNt), 256, 0, p2w_s(stream)>>>(static_cast<const _Float16*>(A_h2), ldh_a,
-                                                                    static_cast<const _Float16*>(Wh), (size_t)Npad * Kpad,
-                                                                    wscale, M, N, Kpad, nMt, nNt, ep, o);
+    const _Float16* Ah = static_cast<const _Float16*>(A_h2);
+    const _Float16* Wp = static_cast<const _Float16*>(Wh);
+    if ((ldh_a & 31) == 0 && ldh_a >= Kpad) {  // direct-to-LDS path: K padding must exist (and be zero) in A as well
+        static const int force = []() { const char* e = getenv("P2W_GEMM_TILE"); return e ? atoi(e) : 0; }();
+        const char* de = getenv("P2W_GEMM_DBG");
+        const int dbg = de ? atoi(de) : 0;
+        // 256x256 tiles halve the L2->LDS bytes per MFMA; they need enough tiles to fill 256 CUs and a wide N
+        const long tiles256 = (long)p2w_cdiv(M, 256) * (Npad / 256);
+        const bool big = force ? (force == 256) : (N >= 256 && tiles256 >= 512);
+        if (big) {
+            const int nMt = p2w_cdiv(M, 256), nNt2 = Npad / 256;
+            gemm_h2g_kernel<2, 4, 4, 2><<<tile_grid(nMt, nNt2), 512, 0, p2w_s(stream)>>>(
+                Ah, ldh_a, Wp, (size_t)Npad * Kpad, wscale, M, N, Kpad, nMt, nNt2, ep, o, dbg);
+        } else {
+            const int nMt = p2w_cdiv(M, 128), nNt1 = p2w_cdiv(N, 128);
+            gemm_h2g_kernel<2, 2, 2, 2><<<tile_grid(nMt, nNt1), 256, 0, p2w_s(stream)>>>(
+                Ah, ldh_a, Wp, (size_t)Npad * Kpad, wscale, M, N, Kpad, nMt, nNt1, ep, o, dbg);
+        }
+        return P2W_LAUNCH_STATUS();
+    }
+    const int nMt = p2w_cdiv(M, G_BM);
+    gemm_h2_kernel<<<tile_grid(nMt, nNt), 256, 0, p2w_s(stream)>>>(Ah, ldh_a, Wp, (size_t)Npad * Kpad, wscale, M, N, Kpad, nMt,
+                                                                    nNt, ep, o);
     return P2W_LAUNCH_STATUS();
 }
 
@@ -725,7 +866,7 @@ extern "C" int32_t p2w_sa_conv_f16x3(const float* P, int32_t ldp, const float* x
         return P2W_EINVAL;
     int C2pad, C1pad;
     p2w_packed_dims(C2, C1, &C2pad, &C1pad);
-    const int nMt = p2w_cdiv(M, 4), nNt = C2pad / G_BN;
+    const int nMt = p2w_cdiv(M, 4), nNt = p2w_cdiv(C2, G_BN);
     sa_conv16_kernel<<<tile_grid(nMt, nNt), 256, 0, p2w_s(stream)>>>(
         P, ldp, reinterpret_cast<const float4*>(xyzr_src), idx, batch_dst, sf, nbr, deg, kw, M, w1r4, C1, C1pad,
         static_cast<const _Float16*>(W2h), (size_t)C2pad * C1pad, wscale, C2, nMt, nNt, b2, bn_s, bn_t, out, ldo,

@@ -273,7 +273,7 @@ class Engine:
         dev = geo.sf.device
         Cw = w.C
         new = lambda r, c: torch.empty((r, c), dtype=torch.float32, device=dev)
-        pad8 = lambda f: (f + 7) // 8 * 8
+        pad8 = lambda f: (f + 31) // 32 * 32   # H2 row pitch: zero-padded to the GEMM's K slab so it can be DMA-staged
         newh = lambda r, f: torch.empty((r, 2 * pad8(f)), dtype=torch.float16, device=dev)
         lv, N, B = geo.levels, geo.N, geo.B
         x, xh = [new(N, Cw)], [newh(N, Cw)]

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Time p2w_gemm_h2 on the network's GEMM shapes under the kernel's profiling ablations (P2W_GEMM_DBG)."""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pointstowood_amd import _lib  # noqa: E402
+from pointstowood_amd._lib import Epilogue, check, lib, ptr, stream  # noqa: E402
+
+shapes = [(123046, 512, 512), (81683, 1024, 1024), (17506, 2048, 2048), (123046, 128, 512), (123046, 512, 128),
+          (131072, 544, 512), (81683, 768, 640)]
+dev = torch.device("cuda")
+for M, K, N in shapes:
+    Np, Kp = _lib.packed_dims(N, K)
+    A = (torch.randn(M, 2 * Kp, device=dev) * 0.5).half()
+    W = (torch.randn(2, Np, Kp, device=dev) * 0.5).half()
+    bias = torch.randn(N, device=dev)
+    sc, sh = torch.randn(N, device=dev), torch.randn(N, device=dev)
+    oh = torch.empty(M, 2 * ((N + 31) // 32 * 32), dtype=torch.float16, device=dev)
+    of = torch.empty(M, N, device=dev)
+    ep = Epilogue(ptr(bias), ptr(sc), ptr(sh), None, None, None, 0, 1, 1, 0, 0)
+    res = []
+    for dbg in (0, 1, 2, 3, 4, 6):
+        os.environ["P2W_GEMM_DBG"] = str(dbg)
+        for out_f, out_h in ((None, oh), (of, None)):
+            def run():
+                check(lib().p2w_gemm_h2(ptr(A), Kp, ptr(W), 1.0, M, N, K, C.byref(ep), ptr(out_f), N, ptr(out_h),
+                                        (N + 31) // 32 * 32, stream()))
+            run(); torch.cuda.synchronize()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(5):
+                run()
+            e.record(); torch.cuda.synchronize()
+            res.append((dbg, "h2" if out_h is not None else "f32", s.elapsed_time(e) / 5 * 1e3))
+    gf = 2.0 * M * K * N / 1e9
+    print(f"M={M} K={K} N={N} ({gf:.0f} GFLOP): " + "  ".join(f"dbg{d}/{o}={t:.0f}us({gf/t*1e3/1e3:.0f}TF)" for d, o, t in res), flush=True)
