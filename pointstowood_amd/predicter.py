@@ -1,0 +1,160 @@
+"""Inference driver pieces that feed and consume the forward (reference ``pointstowood/src/predicter.py``).
+
+* ``VoxelDataset``      - ``TestingDataset`` (:65-94): per voxel ``local_shift = mean(xyz)``, centre,
+                          ``sf = max ||p||`` and only then the NaN-row filter (same order as the reference).
+* ``BalancedBatchSampler`` (:23-63): pairs short with long voxels.  ``reference=True`` reproduces the
+                          reference exactly (unseeded numpy shuffles, remainder silently dropped, batch_size 1
+                          is an error); the default keeps the pairing but covers every voxel and is deterministic.
+* ``load_model``        (:97-105): strips ``module.`` prefixes, ``strict=False``.
+* ``classify``          - the loop body (:193-215): forward, ``nan_to_num``, sigmoid, ``>= is_wood``,
+                          un-shift by ``local_shift[3b:3b+3]``; returns ``[sum N, 5]`` = x, y, z, pred, prob.
+* ``classify_sharded``  - the same over ``torch.distributed``: voxel batches are partitioned over ranks
+                          (``dist.partition_batches``), results gathered with ONE collective per call.
+"""
+from __future__ import annotations
+
+import glob
+import os
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from .data import Batch, Data, DataLoader
+from .dist import batch_cost, partition_batches
+
+
+class VoxelDataset(torch.utils.data.Dataset):
+    def __init__(self, voxels, reflectance_index: int = 3):
+        if isinstance(voxels, (str, os.PathLike)):
+            if not voxels:
+                raise ValueError("The 'voxels' parameter cannot be empty.")
+            self.keys = sorted(glob.glob(os.path.join(voxels, "*.pt")))
+            self._mem = None
+        else:
+            self._mem = list(voxels)
+            self.keys = list(range(len(self._mem)))
+        self.reflectance_index = reflectance_index
+
+    def __len__(self):
+        return len(self.keys)
+
+    def raw(self, index):
+        return self._mem[index] if self._mem is not None else torch.load(self.keys[index])
+
+    def __getitem__(self, index):
+        pc = torch.as_tensor(self.raw(index))
+        pos = pc[:, :3].to(torch.float32)
+        refl = pc[:, self.reflectance_index].to(torch.float32)
+        shift = pos.mean(dim=0)
+        pos = pos - shift
+        sf = torch.sqrt((pos ** 2).sum(dim=1)).max()
+        bad = torch.isnan(pos).any(dim=1) | torch.isnan(refl)
+        if bool(bad.any()):
+            print(f"Encountered NaN values in sample at index {index}")
+            pos, refl = pos[~bad], refl[~bad]
+        return Data(pos=pos, reflectance=refl, local_shift=shift, sf=sf)
+
+
+class BalancedBatchSampler(torch.utils.data.Sampler):
+    def __init__(self, dataset, batch_size: int, reference: bool = False, seed: int = 0):
+        self.dataset, self.batch_size, self.reference, self.seed = dataset, int(batch_size), reference, seed
+        self.lengths = [len(dataset.raw(i)) for i in range(len(dataset))]
+        self.indices = np.argsort(self.lengths, kind="stable")
+
+    def __iter__(self):
+        n, half = len(self.indices), self.batch_size // 2
+        short, long_ = self.indices[: n // 2].copy(), self.indices[n // 2:].copy()
+        if self.reference:
+            if half == 0:
+                raise ValueError("range() arg 3 must not be zero")  # the reference's behaviour at batch_size 1
+            np.random.shuffle(short)
+            np.random.shuffle(long_)
+            for i in range(0, len(short) - half + 1, half):
+                if i + half <= len(long_):
+                    batch = list(short[i:i + half]) + list(long_[i:i + half])
+                    np.random.shuffle(batch)
+                    yield [int(b) for b in batch]
+            return
+        rng = np.random.default_rng(self.seed)
+        rng.shuffle(short)
+        rng.shuffle(long_)
+        hs, hl = max(half, 1) if self.batch_size > 1 else 0, self.batch_size - (max(half, 1) if self.batch_size > 1 else 0)
+        i = j = 0
+        while i < len(short) or j < len(long_):
+            batch = list(short[i:i + hs]) + list(long_[j:j + hl])
+            i, j = i + hs, j + hl
+            if len(batch) < self.batch_size:  # top up from whichever half still has voxels
+                need = self.batch_size - len(batch)
+                extra_s = list(short[i:i + need]); i += len(extra_s)
+                extra_l = list(long_[j:j + need - len(extra_s)]); j += len(extra_l)
+                batch += extra_s + extra_l
+            if batch:
+                yield [int(b) for b in batch]
+
+    def __len__(self):
+        n = len(self.dataset)
+        return n // self.batch_size if self.reference else -(-n // self.batch_size)
+
+
+def load_model(path, model, device):
+    ckpt = torch.load(path, map_location=device)
+    sd = OrderedDict()
+    for key, value in ckpt["model_state_dict"].items():
+        sd[key[7:] if key.startswith("module.") else key] = value
+    model.load_state_dict(sd, strict=False)
+    return model
+
+
+@torch.no_grad()
+def classify_batch(model, data, is_wood: float, device):
+    """One iteration of the reference loop; returns a float64 numpy array [n, 5]."""
+    data = data.to(device)
+    logits = torch.nan_to_num(model(data))
+    probs = torch.sigmoid(logits).reshape(-1)
+    preds = (probs >= is_wood).to(torch.int64)
+    shift = data.local_shift.reshape(-1, 3)[data.batch.long()]
+    xyz = data.pos[:, :3] + shift
+    out = torch.cat([xyz, preds[:, None].to(xyz.dtype), probs[:, None].to(xyz.dtype)], dim=1)
+    return out.cpu().numpy()
+
+
+def classify(model, loader, is_wood: float = 0.5, device="cuda"):
+    outs = [classify_batch(model, data, is_wood, device) for data in loader]
+    return np.vstack(outs) if outs else np.zeros((0, 5), dtype=np.float32)
+
+
+def classify_sharded(model, dataset, batches, is_wood, device, dist):
+    """``batches`` = list of voxel-index lists (identical on every rank).  Rank r classifies its share and
+    every rank receives all results, ordered by batch id, via one all-gather of a padded buffer."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    costs = [sum(batch_cost(dataset.lengths[i]) if hasattr(dataset, "lengths") else 1.0 for i in b) for b in batches]
+    plan = partition_batches(costs, world)
+    mine = []
+    for bid in plan[rank]:
+        data = Batch.from_data_list([dataset[i] for i in batches[bid]])
+        mine.append(classify_batch(model, data, is_wood, device))
+    local = torch.from_numpy(np.vstack(mine) if mine else np.zeros((0, 5), dtype=np.float32)).to(device)
+    counts = torch.zeros(world, dtype=torch.int64, device=device)
+    counts[rank] = local.shape[0]
+    dist.all_reduce(counts)
+    counts = [int(c) for c in counts.cpu()]
+    buf = torch.zeros((max(counts + [1]), 5), dtype=local.dtype, device=device)
+    buf[: local.shape[0]] = local
+    out = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf)
+    parts = [o[:c] for o, c in zip(out, counts)]
+    # reorder: rank-major -> batch id order
+    sizes = {}
+    for r in range(world):
+        off = 0
+        for bid in plan[r]:
+            n = sum(_kept_len(dataset, i) for i in batches[bid])
+            sizes[bid] = (r, off, n)
+            off += n
+    ordered = [parts[sizes[b][0]][sizes[b][1]: sizes[b][1] + sizes[b][2]] for b in range(len(batches))]
+    return torch.cat(ordered).cpu().numpy() if ordered else np.zeros((0, 5), dtype=np.float32)
+
+
+def _kept_len(dataset, i):
+    return dataset[i].pos.shape[0]

@@ -1,0 +1,153 @@
+"""CPU tests of the host-side mirror of the reference interface: Data/Batch collation, dataset feed, sampler,
+checkpoint loading, C-ABI symbol export, sharding plan, and the gloo world-size-2 gather."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import host as ohost
+from oracle import synth, weights
+from pointstowood_amd import Batch, Data, DataLoader, Net, checkpoint_layout
+from pointstowood_amd import _lib
+from pointstowood_amd.dist import gather_logits, partition_batches
+from pointstowood_amd.predicter import BalancedBatchSampler, VoxelDataset, load_model
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _raw_voxels():
+    g = torch.Generator().manual_seed(0)
+    out = []
+    for n in (300, 128, 999, 512, 640):
+        pc = torch.rand(n, 5, generator=g) * 3 + 10
+        out.append(pc)
+    out[2][5, 3] = float("nan")      # NaN reflectance: the row is dropped
+    out[2][7, 3] = float("nan")
+    out[4][9, 1] = float("nan")      # NaN coordinate: poisons mean/sf, so the reference drops the WHOLE voxel
+    return out
+
+
+def test_dataset_feed_matches_oracle_restatement():
+    raw = _raw_voxels()
+    ds = VoxelDataset(raw)
+    for i, pc in enumerate(raw):
+        d, ref = ds[i], ohost.feed(pc)
+        for k in ("pos", "reflectance", "local_shift", "sf"):
+            a, b = getattr(d, k), ref[k]
+            assert a.shape == b.shape and torch.allclose(a, b, rtol=0, atol=0, equal_nan=True), k
+    assert ds[2].pos.shape[0] == 997  # two NaN rows dropped AFTER shift/sf were computed
+    assert ds[4].pos.shape[0] == 0    # same quirk as the reference (predicter.py:81-90)
+
+
+def test_collation_contract():
+    ds = VoxelDataset(_raw_voxels())
+    b = Batch.from_data_list([ds[0], ds[1], ds[3]])
+    assert b.pos.shape == (940, 3) and b.reflectance.shape == (940,)
+    assert b.sf.shape == (3,) and b.local_shift.shape == (9,)
+    assert b.batch.dtype == torch.int64 and b.batch.tolist() == [0] * 300 + [1] * 128 + [2] * 512
+    assert b.ptr.tolist() == [0, 300, 428, 940]
+    ref = synth.collate([ohost.feed(_raw_voxels()[i]) for i in (0, 1, 3)])
+    for k in ("pos", "reflectance", "local_shift", "sf", "batch", "ptr"):
+        assert torch.equal(getattr(b, k), ref[k]), k
+    b.x = torch.zeros(3)          # attribute assignment (model.py:228)
+    assert b.to("cpu") is b
+    loader = DataLoader(ds, batch_sampler=[[0, 1], [2, 3, 4]])
+    sizes = [bb.pos.shape[0] for bb in loader]
+    assert sizes == [428, 997 + 512 + 0]
+
+
+def test_consume_unshift_matches_oracle():
+    ds = VoxelDataset(_raw_voxels())
+    b = Batch.from_data_list([ds[0], ds[2]])
+    logits = torch.linspace(-3, 3, b.pos.shape[0])
+    logits[3] = float("nan")
+    ref = ohost.consume(logits, b.pos, b.batch, b.local_shift, 0.5)
+
+    class M:
+        def __call__(self, data):
+            return logits
+    from pointstowood_amd.predicter import classify_batch
+    got = classify_batch(M(), b, 0.5, "cpu")
+    assert np.allclose(got, ref, rtol=0, atol=0)
+
+
+def test_samplers():
+    ds = VoxelDataset(_raw_voxels())
+    s = BalancedBatchSampler(ds, 2)
+    batches = list(s)
+    assert sorted(i for b in batches for i in b) == [0, 1, 2, 3, 4] and len(batches) == len(s) == 3
+    assert list(BalancedBatchSampler(ds, 2)) == batches                 # deterministic
+    ref = list(BalancedBatchSampler(ds, 2, reference=True))
+    assert all(len(b) == 2 for b in ref) and len(ref) == 2               # remainder dropped like the reference
+    with pytest.raises(ValueError):
+        list(BalancedBatchSampler(ds, 1, reference=True))
+
+
+def test_checkpoint_layout_and_load_model(tmp_path):
+    assert [(k, tuple(s)) for k, s, _ in checkpoint_layout(1, 32)] == [(k, tuple(s)) for k, s, _ in weights.key_table(1, 32)]
+    sd = weights.synth_state_dict(1, 8, seed=2)
+    path = tmp_path / "m.pth"
+    torch.save({"model_state_dict": {"module." + k: v for k, v in sd.items()}}, path)
+    net = load_model(str(path), Net(1, C=8), "cpu")
+    got = net.state_dict()
+    assert list(got.keys()) == list(sd.keys()) and all(torch.equal(got[k], sd[k]) for k in sd)
+    with pytest.raises(KeyError):
+        torch.save({"wrong": {}}, path)
+        load_model(str(path), Net(1, C=8), "cpu")
+
+
+def test_forward_refuses_cpu_tensors():
+    net = Net(1, C=8)
+    v = synth.collate([synth.uniform_voxel(2.0, 256, 1)])
+    d = Data(pos=v["pos"], batch=v["batch"], reflectance=v["reflectance"], sf=v["sf"])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net(d)
+
+
+def test_c_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "p2w.h")).read()
+    declared = set(re.findall(r"\b(p2w_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"p2w_stream_t", "p2w_epilogue"}
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    h = ctypes.CDLL(_lib.LIB_PATH) if os.path.exists(_lib.LIB_PATH) else _lib.lib()
+    for name in declared:
+        assert hasattr(h, name), name
+    L = _lib.lib()
+    assert L.p2w_version() >= 100 and L.p2w_strerror(-4) == b"p2w: workspace too small"
+
+
+def test_partition_is_balanced_and_deterministic():
+    costs = [16384, 128, 9000, 700, 16384, 5000, 12000, 300, 8000]
+    plan = partition_batches(costs, 4)
+    assert sorted(i for p in plan for i in p) == list(range(len(costs)))
+    loads = [sum(costs[i] for i in p) for p in plan]
+    assert max(loads) <= 1.35 * (sum(costs) / 4) and plan == partition_batches(costs, 4)
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    counts = [5, 9]
+    mine = torch.arange(counts[rank], dtype=torch.float32) + 100 * rank
+    ragged = gather_logits(mine, dist, counts=counts)
+    equal = gather_logits(torch.full((4,), float(rank)), dist)
+    q.put((rank, ragged.tolist(), equal.tolist()))
+    dist.destroy_process_group()
+
+
+def test_gather_logits_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 1000
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    [p.join(30) for p in ps]
+    expect = list(map(float, range(5))) + [100.0 + i for i in range(9)]
+    for _, ragged, equal in res:
+        assert ragged == expect and equal == [0.0] * 4 + [1.0] * 4
