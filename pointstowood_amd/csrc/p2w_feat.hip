@@ -596,6 +596,79 @@ __device__ __forceinline__ void gemm_epilogue2(const f32x16 (&acc)[RT][CT], cons
     }
 }
 
+// Compile-time specialised epilogue for interior tiles (every row < M, every column < N): no per-element guards,
+// no flag selects, 32-bit offsets.  EF bits: 1 relu0, 2 sc0, 4 relu1, 8 sc1, 16 relu2, 32 residual, 64 relu_final,
+// 128 fp32 out, 256 H2 out.  Edge tiles and unlisted combinations use gemm_epilogue2 (runtime flags).
+template <int RT, int CT, int EF>
+__device__ __forceinline__ void gemm_epilogue3(const f32x16 (&acc)[RT][CT], const EpiArgs& ep, float wscale, int row0, int col0,
+                                               int lane, const OutArgs& o) {
+    constexpr bool R0 = EF & 1, S0 = EF & 2, R1 = EF & 4, S1 = EF & 8, R2 = EF & 16, RES = EF & 32, RF = EF & 64,
+                   OF = EF & 128, OH = EF & 256;
+    const int h = lane >> 5, odd = lane & 1;
+#pragma unroll
+    for (int j = 0; j < CT; ++j) {
+        const int col = col0 + j * 32 + (lane & 31);
+        const float bias = ep.bias ? ep.bias[col] : 0.f;
+        float s0 = 1.f, t0 = 0.f, s1 = 1.f, t1 = 0.f;
+        if (S0) { s0 = ep.sc0[col]; t0 = ep.sh0[col]; }
+        if (S1) { s1 = ep.sc1[col]; t1 = ep.sh1[col]; }
+        auto f = [&](float a, unsigned roff) {
+            float v = fmaf(a, wscale, bias);
+            if (R0) v = fmaxf(v, 0.f);
+            if (S0) v = fmaf(v, s0, t0);
+            if (R1) v = fmaxf(v, 0.f);
+            if (S1) v = fmaf(v, s1, t1);
+            if (R2) v = fmaxf(v, 0.f);
+            if (RES) v += ep.residual[roff];
+            if (RF) v = fmaxf(v, 0.f);
+            return v;
+        };
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+            const unsigned rbase = (unsigned)(row0 + i * 32 + 4 * h);
+            __builtin_amdgcn_sched_barrier(0);  // keep the scheduler from hoisting every tile's loads at once (spills)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                if ((r & 7) == 0) __builtin_amdgcn_sched_barrier(0);
+                const unsigned rowa = rbase + (r & 3) + 8 * (r >> 2);
+                const float va = f(acc[i][j][r], RES ? rowa * (unsigned)ep.ldr + col : 0u);
+                const float vb = f(acc[i][j][r + 1], RES ? (rowa + 1) * (unsigned)ep.ldr + col : 0u);
+                if (OF) {
+                    o.f32[rowa * (unsigned)o.ldo + col] = va;
+                    o.f32[(rowa + 1) * (unsigned)o.ldo + col] = vb;
+                }
+                if (OH) {
+                    const float send = odd ? va : vb;
+                    const float recv = __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(send), 0xB1, 0xf, 0xf, false));
+                    const float c0v = odd ? recv : va, c1v = odd ? vb : recv;
+                    _Float16 h0, l0, h1, l1;
+                    h2_split(c0v, h0, l0);
+                    h2_split(c1v, h1, l1);
+                    _Float16* p = o.h2 + (rowa + odd) * (unsigned)(2 * o.ldh) + (col & ~1);
+                    *reinterpret_cast<unsigned*>(p) = h2_pack(h0, h1);
+                    *reinterpret_cast<unsigned*>(p + o.ldh) = h2_pack(l0, l1);
+                }
+            }
+        }
+    }
+}
+
+template <int RT, int CT>
+__device__ __forceinline__ void gemm_epilogue_dispatch(const f32x16 (&acc)[RT][CT], const EpiArgs& ep, float wscale, int row0,
+                                                       int col0, int lane, int M, int N, const OutArgs& o, int ef) {
+    const bool full = (row0 + 32 * RT <= M) && (col0 + 32 * CT <= N) && ef != 0;
+    if (full) {
+        switch (ef) {
+#define P2W_EPI_CASE(E) case E: gemm_epilogue3<RT, CT, E>(acc, ep, wscale, row0, col0, lane, o); return;
+            P2W_EPI_CASE(128) P2W_EPI_CASE(257) P2W_EPI_CASE(263) P2W_EPI_CASE(287) P2W_EPI_CASE(480) P2W_EPI_CASE(224)
+            P2W_EPI_CASE(131) P2W_EPI_CASE(259) P2W_EPI_CASE(387) P2W_EPI_CASE(129)
+#undef P2W_EPI_CASE
+            default: break;
+        }
+    }
+    gemm_epilogue2<RT, CT>(acc, ep, wscale, row0, col0, lane, M, N, o);
+}
+
 __global__ __launch_bounds__(256) void gemm_h2_kernel(const _Float16* __restrict__ A, int ldh_a, const _Float16* __restrict__ Wh,
                                                       size_t plane, float wscale, int M, int N, int Kpad, int nMt, int nNt,
                                                       EpiArgs ep, OutArgs o) {
@@ -643,10 +716,10 @@ typedef __attribute__((address_space(3))) void* lds_vp;
 typedef const __attribute__((address_space(1))) void* glb_vp;
 
 template <int WR, int WC, int RT, int CT>   // waves WR x WC, wave tile (32*RT) x (32*CT)
-__global__ __launch_bounds__(64 * WR * WC) void gemm_h2g_kernel(const _Float16* __restrict__ A, int ldh_a,
+__global__ __launch_bounds__(64 * WR * WC, 2) void gemm_h2g_kernel(const _Float16* __restrict__ A, int ldh_a,
                                                                 const _Float16* __restrict__ Wh, size_t plane, float wscale,
                                                                 int M, int N, int Kpad, int nMt, int nNt, EpiArgs ep,
-                                                                OutArgs o, int dbg) {
+                                                                OutArgs o, int dbg, int ef) {
     // dbg (profiling ablations, 0 in production): 1 = skip the epilogue, 2 = issue only the first slab's DMA,
     // 4 = skip the MFMAs
     constexpr int BM = 32 * RT * WR, BN = 32 * CT * WC, NW = WR * WC;
@@ -745,7 +818,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_h2g_kernel(const _Float16* 
         if (acc[0][0][0] + acc[0][CT - 1][1] + acc[RT - 1][0][2] + acc[RT - 1][CT - 1][3] == 12345.678f && o.f32) o.f32[0] = 1.f;
         return;
     }
-    gemm_epilogue2<RT, CT>(acc, ep, wscale, m0 + wr * 32 * RT, n0 + wc * 32 * CT, lane, M, N, o);
+    gemm_epilogue_dispatch<RT, CT>(acc, ep, wscale, m0 + wr * 32 * RT, n0 + wc * 32 * CT, lane, M, N, o, ef);
 }
 
 extern "C" int32_t p2w_gemm_h2(const void* A_h2, int32_t ldh_a, const void* Wh, float wscale, int32_t M, int32_t N, int32_t K,
@@ -780,14 +853,21 @@ extern "C" int32_t p2w_gemm_h2(const void* A_h2, int32_t ldh_a, const void* Wh, 
         // 256x256 tiles halve the L2->LDS bytes per MFMA; they need enough tiles to fill 256 CUs and a wide N
         const long tiles256 = (long)p2w_cdiv(M, 256) * (Npad / 256);
         const bool big = force ? (force == 256) : (N >= 256 && tiles256 >= 512);
+        // epilogue class for the specialised interior-tile path (0 = generic); needs 32-bit element offsets
+        int ef = (ep.relu0 ? 1 : 0) | (ep.sc0 ? 2 : 0) | (ep.relu1 ? 4 : 0) | (ep.sc1 ? 8 : 0) | (ep.relu2 ? 16 : 0) |
+                 (ep.residual ? 32 : 0) | (ep.relu_final ? 64 : 0) | (out_f32 ? 128 : 0) | (out_h2 ? 256 : 0);
+        const size_t lim = (size_t)1 << 31;
+        if ((size_t)M * (size_t)(ldo > 2 * ldh_o ? ldo : 2 * ldh_o) >= lim || (ep.residual && (size_t)M * ep.ldr >= lim) ||
+            (N & 1) || getenv("P2W_GEMM_GENERIC_EPI"))
+            ef = 0;
         if (big) {
             const int nMt = p2w_cdiv(M, 256), nNt2 = Npad / 256;
             gemm_h2g_kernel<2, 4, 4, 2><<<tile_grid(nMt, nNt2), 512, 0, p2w_s(stream)>>>(
-                Ah, ldh_a, Wp, (size_t)Npad * Kpad, wscale, M, N, Kpad, nMt, nNt2, ep, o, dbg);
+                Ah, ldh_a, Wp, (size_t)Npad * Kpad, wscale, M, N, Kpad, nMt, nNt2, ep, o, dbg, ef);
         } else {
             const int nMt = p2w_cdiv(M, 128), nNt1 = p2w_cdiv(N, 128);
             gemm_h2g_kernel<2, 2, 2, 2><<<tile_grid(nMt, nNt1), 256, 0, p2w_s(stream)>>>(
-                Ah, ldh_a, Wp, (size_t)Npad * Kpad, wscale, M, N, Kpad, nMt, nNt1, ep, o, dbg);
+                Ah, ldh_a, Wp, (size_t)Npad * Kpad, wscale, M, N, Kpad, nMt, nNt1, ep, o, dbg, ef);
         }
         return P2W_LAUNCH_STATUS();
     }
@@ -850,11 +930,364 @@ __global__ __launch_bounds__(256) void sa_conv16_kernel(const float* __restrict_
     sa_epilogue(acc, wscale, t0, n0, wr, wc, lane, M, kw, deg, C2, b2, bn_s, bn_t, out, ldo, out_h2, ldh);
 }
 
+// ------------------------------------------------------------------------------------------------
+// fused PointNetConv v2 (f16x3): 4 targets (128 edge rows) x 256 output columns per workgroup, 8 waves (2 x 4, each
+// 64 x 64).  B (W2 hi/lo) arrives by direct-to-LDS DMA into a 2-stage ring; A is PRODUCED on the VALU (gather P[j],
+// add the relative-position term, ReLU, split hi/lo) one slab ahead into the other stage, so gather latency and
+// the producer's VALU work overlap with the MFMAs of the current slab.  One barrier per slab.  LDS image and XOR
+// swizzle are those of gemm_h2g_kernel (A: 2 planes x 128 rows, B: 2 planes x 256 rows, 64-byte rows).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void sa_conv16g_kernel(const float* __restrict__ P, int ldp, const float4* __restrict__ xyzr,
+                                                            const int* __restrict__ idx, const int* __restrict__ batch_dst,
+                                                            const float* __restrict__ sf, const int* __restrict__ nbr,
+                                                            const int* __restrict__ deg, int kw, int M,
+                                                            const float* __restrict__ w1r4, int C1, int C1pad,
+                                                            const _Float16* __restrict__ W2h, size_t plane, float wscale, int C2,
+                                                            int nMt, int nNt, const float* __restrict__ b2,
+                                                            const float* __restrict__ bn_s, const float* __restrict__ bn_t,
+                                                            float* __restrict__ out, int ldo, _Float16* __restrict__ out_h2,
+                                                            int ldh, int dbg) {
+    // dbg (profiling ablations, 0 in production): 1 = no epilogue, 2 = no B DMA after slab 0, 4 = no MFMA,
+    // 8 = no A production after slab 0, 16 = produce A without gathering P
+    constexpr int BM = 128, BN = 256, NW = 8;
+    constexpr int A_CH = 8 * BM, STAGE_CH = A_CH + 8 * BN;   // 1024 + 2048 chunks = 48 KiB per stage
+    constexpr int NI = (8 * BN) / 64 / NW;                   // 4 DMA instructions per wave per stage (B only)
+    __shared__ __attribute__((aligned(16))) char S[2 * STAGE_CH * 16];
+    __shared__ int m_j[BM];
+    __shared__ float m_g[BM][4];
+    int mt, nt;
+    if (!tile_coords(nMt, nNt, &mt, &nt)) return;
+    const int t0 = mt * 4, n0 = nt * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wave >> 2, wc = wave & 3;
+
+    sa_row_geometry(tid, t0, M, kw, xyzr, idx, batch_dst, sf, nbr, deg, m_j, m_g);  // threads 0..127
+    // B DMA sources
+    const _Float16* src[NI];
+    int dstc[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int g2 = wave + NW * i, p = g2 / (BN / 16), rb = g2 % (BN / 16);
+        const int row = 16 * rb + (lane >> 2), q = (lane & 3) ^ ((row >> 2) & 3);
+        src[i] = W2h + (size_t)p * plane + (size_t)(n0 + row) * C1pad + 8 * q;
+        dstc[i] = A_CH + g2 * 64;
+    }
+    auto issue = [&](int stage, int k0) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            __builtin_amdgcn_global_load_lds((glb_vp)(src[i] + k0), (lds_vp)(S + ((size_t)stage * STAGE_CH + dstc[i]) * 16), 16, 0, 0);
+    };
+    __syncthreads();
+    // A producer: thread -> edge row (tid>>2), 8 consecutive k (one 16-byte chunk per plane)
+    const int prow = tid >> 2, pq = tid & 3;
+    const int rj = m_j[prow];
+    const float4 rg = *reinterpret_cast<const float4*>(&m_g[prow][0]);
+    const int a_dst = (prow * 4 + (pq ^ ((prow >> 2) & 3))) * 16;           // hi plane; lo plane = + BM*64 bytes
+    const float* prow_ptr = P + (size_t)rj * ldp + 8 * pq;
+    float4 pv[2];
+    auto gather = [&](int k0) {
+        const int k = k0 + 8 * pq;
+        pv[0] = (k < C1) ? *reinterpret_cast<const float4*>(prow_ptr + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        pv[1] = (k + 4 < C1) ? *reinterpret_cast<const float4*>(prow_ptr + k0 + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto produce = [&](int stage, int k0) {
+        const int k = k0 + 8 * pq;
+        h8 hi, lo;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int kk = k + 4 * half;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (kk < C1) {
+                const float4 wx = *reinterpret_cast<const float4*>(&w1r4[0 * C1pad + kk]);
+                const float4 wy = *reinterpret_cast<const float4*>(&w1r4[1 * C1pad + kk]);
+                const float4 wz = *reinterpret_cast<const float4*>(&w1r4[2 * C1pad + kk]);
+                const float4 wf = *reinterpret_cast<const float4*>(&w1r4[3 * C1pad + kk]);
+                const float4 p = pv[half];
+                v[0] = fmaxf(fmaf(rg.w, wf.x, fmaf(rg.z, wz.x, fmaf(rg.y, wy.x, fmaf(rg.x, wx.x, p.x)))), 0.f);
+                v[1] = fmaxf(fmaf(rg.w, wf.y, fmaf(rg.z, wz.y, fmaf(rg.y, wy.y, fmaf(rg.x, wx.y, p.y)))), 0.f);
+                v[2] = fmaxf(fmaf(rg.w, wf.z, fmaf(rg.z, wz.z, fmaf(rg.y, wy.z, fmaf(rg.x, wx.z, p.z)))), 0.f);
+                v[3] = fmaxf(fmaf(rg.w, wf.w, fmaf(rg.z, wz.w, fmaf(rg.y, wy.w, fmaf(rg.x, wx.w, p.w)))), 0.f);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                hi[4 * half + e] = (_Float16)v[e];
+                lo[4 * half + e] = (_Float16)(v[e] - (float)hi[4 * half + e]);
+            }
+        }
+        char* st = S + (size_t)stage * STAGE_CH * 16;
+        *reinterpret_cast<h8*>(st + a_dst) = hi;
+        *reinterpret_cast<h8*>(st + BM * 64 + a_dst) = lo;
+    };
+
+    const int r = lane & 31, h = lane >> 5;
+    int offA[2][2], offB[2][2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int ra = wr * 64 + 32 * t + r, rb = wc * 64 + 32 * t + r;
+            offA[p][t] = ((p * BM + ra) * 4 + (h ^ ((ra >> 2) & 3))) * 16;
+            offB[p][t] = (A_CH + (p * BN + rb) * 4 + (h ^ ((rb >> 2) & 3))) * 16;
+        }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nslab = C1pad / G_BK;
+    issue(0, 0);
+    gather(0);
+    produce(0, 0);
+    for (int s = 0; s < nslab; ++s) {
+        __syncthreads();  // B(s) landed, A(s) written by every thread, stage (s+1)&1 no longer read
+        const bool more = s + 1 < nslab;
+        if (more && !(dbg & 2)) issue((s + 1) & 1, (s + 1) * G_BK);
+        if (more && !(dbg & 24)) gather((s + 1) * G_BK);
+        const char* st = S + (size_t)(s & 1) * STAGE_CH * 16;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            if (dbg & 4) break;
+            h8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                ah[t] = *reinterpret_cast<const h8*>(st + (offA[0][t] ^ (kk << 5)));
+                al[t] = *reinterpret_cast<const h8*>(st + (offA[1][t] ^ (kk << 5)));
+                bh[t] = *reinterpret_cast<const h8*>(st + (offB[0][t] ^ (kk << 5)));
+                bl[t] = *reinterpret_cast<const h8*>(st + (offB[1][t] ^ (kk << 5)));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        if (more && !(dbg & 8)) produce((s + 1) & 1, (s + 1) * G_BK);
+    }
+    if (dbg & 1) {
+        if (acc[0][0][0] + acc[0][1][1] + acc[1][0][2] + acc[1][1][3] == 12345.678f && out) out[0] = 1.f;
+        return;
+    }
+    sa_epilogue(acc, wscale, t0, n0, wr, wc, lane, M, kw, deg, C2, b2, bn_s, bn_t, out, ldo, out_h2, ldh);
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused PointNetConv v3 (f16x3), two kernels:
+//  1. sa_edge_meta_kernel: one thread per (target, slot): source index j and g = (rel/(dmax+1e-8), refl_j)
+//     (pointnet.py:119-129) -> meta_j[M*32], meta_g[M*32] (20 B per slot).  The chain of dependent loads
+//     (deg -> nbr -> xyzr) is hidden by plain occupancy here instead of stalling a GEMM-shaped workgroup.
+//  2. sa_conv16p_kernel: PERSISTENT workgroups (one per CU, 8 waves) walk (row tile, column tile) work items; the
+//     K slabs of consecutive items form ONE software pipeline: while slab g runs on the MFMAs, slab g+1's W2 DMA,
+//     P-row gather and A production (possibly of the NEXT item) are in flight, and the next item's metadata is
+//     prefetched a whole item ahead.  128 edge rows (4 targets) x 256 columns per item.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sa_edge_meta_kernel(const float4* __restrict__ xyzr, const int* __restrict__ idx,
+                                                           const int* __restrict__ batch_dst, const float* __restrict__ sf,
+                                                           const int* __restrict__ nbr, const int* __restrict__ deg, int kw,
+                                                           int M, int* __restrict__ meta_j, float4* __restrict__ meta_g) {
+    const long g = (long)blockIdx.x * 256 + threadIdx.x;
+    const int tgt = (int)(g >> 5), slot = (int)(g & 31);
+    int j = 0;
+    float rx = 0.f, ry = 0.f, rz = 0.f, rf = 0.f, nrm = 0.f;
+    if (tgt < M) {
+        const int d = deg[tgt];
+        const int self = idx[tgt];
+        const float s = sf[batch_dst[tgt]];
+        const float4 pi = xyzr[self];
+        const bool valid = slot < d && slot < kw;
+        j = valid ? nbr[(size_t)tgt * kw + slot] : self;
+        if (j < 0) j = self;
+        const float4 pj = xyzr[j];
+        if (valid) {
+            rx = pj.x / s - pi.x / s; ry = pj.y / s - pi.y / s; rz = pj.z / s - pi.z / s;
+            nrm = sqrtf(((rx * rx) + (ry * ry)) + (rz * rz));
+            rf = pj.w;
+        }
+    }
+    float dmax = nrm;
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off));  // 32 lanes = one target
+    const float den = dmax + 1e-8f;
+    if (tgt < M) {
+        meta_j[g] = j;
+        meta_g[g] = make_float4(rx / den, ry / den, rz / den, rf);
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restrict__ P, int ldp, const int* __restrict__ meta_j,
+                                                            const float4* __restrict__ meta_g, const int* __restrict__ deg,
+                                                            int kw, int M, const float* __restrict__ w1r4, int C1, int C1pad,
+                                                            const _Float16* __restrict__ W2h, size_t plane, float wscale, int C2,
+                                                            int nMt, int nNt, const float* __restrict__ b2,
+                                                            const float* __restrict__ bn_s, const float* __restrict__ bn_t,
+                                                            float* __restrict__ out, int ldo, _Float16* __restrict__ out_h2,
+                                                            int ldh) {
+    constexpr int BM = 128, BN = 256, NW = 8;
+    constexpr int A_CH = 8 * BM, STAGE_CH = A_CH + 8 * BN;
+    constexpr int NI = (8 * BN) / 64 / NW;
+    __shared__ __attribute__((aligned(16))) char S[2 * STAGE_CH * 16];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wave >> 2, wc = wave & 3;
+    const int nitems = nMt * nNt, nslab = C1pad / G_BK;
+    const int first = blockIdx.x, stride = gridDim.x;
+    if (first >= nitems) return;
+    const int my_items = (nitems - first + stride - 1) / stride;
+    const int total = my_items * nslab;
+
+    // item -> (row tile, column tile): column tiles of one row tile are adjacent work items
+    auto item_mt = [&](int it) { return (first + it * stride) / nNt; };
+    auto item_nt = [&](int it) { return (first + it * stride) % nNt; };
+
+    const int prow = tid >> 2, pq = tid & 3;
+    const int a_dst = (prow * 4 + (pq ^ ((prow >> 2) & 3))) * 16;
+    // per-lane pieces of the B DMA source that do not depend on the item
+    size_t boff[NI];
+    int dstc[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int g2 = wave + NW * i, p = g2 / (BN / 16), rb = g2 % (BN / 16);
+        const int row = 16 * rb + (lane >> 2), q = (lane & 3) ^ ((row >> 2) & 3);
+        boff[i] = (size_t)p * plane + (size_t)row * C1pad + 8 * q;
+        dstc[i] = A_CH + g2 * 64;
+    }
+    auto issue = [&](int stage, int nt, int k0) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            __builtin_amdgcn_global_load_lds((glb_vp)(W2h + boff[i] + (size_t)nt * BN * C1pad + k0),
+                                             (lds_vp)(S + ((size_t)stage * STAGE_CH + dstc[i]) * 16), 16, 0, 0);
+    };
+    // metadata of the producer's edge row (clamped: rows past the last target replay the last valid row)
+    auto load_meta = [&](int it, int& mj, float4& mg) {
+        long row = (long)item_mt(it) * BM + prow;
+        const long last = (long)M * 32 - 1;
+        row = row < last ? row : last;
+        mj = meta_j[row];
+        mg = meta_g[row];
+    };
+    float4 pv[2];
+    auto gather = [&](int mj, int k0) {
+        const float* p = P + (size_t)mj * ldp + 8 * pq + k0;
+        const int k = k0 + 8 * pq;
+        pv[0] = (k < C1) ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+        pv[1] = (k + 4 < C1) ? *reinterpret_cast<const float4*>(p + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto produce = [&](int stage, const float4& rg, int k0) {
+        const int k = k0 + 8 * pq;
+        h8 hi, lo;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int kk = k + 4 * half;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (kk < C1) {
+                const float4 wx = *reinterpret_cast<const float4*>(&w1r4[0 * C1pad + kk]);
+                const float4 wy = *reinterpret_cast<const float4*>(&w1r4[1 * C1pad + kk]);
+                const float4 wz = *reinterpret_cast<const float4*>(&w1r4[2 * C1pad + kk]);
+                const float4 wf = *reinterpret_cast<const float4*>(&w1r4[3 * C1pad + kk]);
+                const float4 p = pv[half];
+                v[0] = fmaxf(fmaf(rg.w, wf.x, fmaf(rg.z, wz.x, fmaf(rg.y, wy.x, fmaf(rg.x, wx.x, p.x)))), 0.f);
+                v[1] = fmaxf(fmaf(rg.w, wf.y, fmaf(rg.z, wz.y, fmaf(rg.y, wy.y, fmaf(rg.x, wx.y, p.y)))), 0.f);
+                v[2] = fmaxf(fmaf(rg.w, wf.z, fmaf(rg.z, wz.z, fmaf(rg.y, wy.z, fmaf(rg.x, wx.z, p.z)))), 0.f);
+                v[3] = fmaxf(fmaf(rg.w, wf.w, fmaf(rg.z, wz.w, fmaf(rg.y, wy.w, fmaf(rg.x, wx.w, p.w)))), 0.f);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                hi[4 * half + e] = (_Float16)v[e];
+                lo[4 * half + e] = (_Float16)(v[e] - (float)hi[4 * half + e]);
+            }
+        }
+        char* st = S + (size_t)stage * STAGE_CH * 16;
+        *reinterpret_cast<h8*>(st + a_dst) = hi;
+        *reinterpret_cast<h8*>(st + BM * 64 + a_dst) = lo;
+    };
+
+    const int r = lane & 31, h = lane >> 5;
+    int offA[2][2], offB[2][2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int ra = wr * 64 + 32 * t + r, rb = wc * 64 + 32 * t + r;
+            offA[p][t] = ((p * BM + ra) * 4 + (h ^ ((ra >> 2) & 3))) * 16;
+            offB[p][t] = (A_CH + (p * BN + rb) * 4 + (h ^ ((rb >> 2) & 3))) * 16;
+        }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // pipeline prologue: slab 0 of item 0; metadata of item 1 one item ahead
+    int mj_cur, mj_nxt = 0;
+    float4 mg_cur, mg_nxt = make_float4(0.f, 0.f, 0.f, 0.f);
+    load_meta(0, mj_cur, mg_cur);
+    if (my_items > 1) load_meta(1, mj_nxt, mg_nxt);
+    issue(0, item_nt(0), 0);
+    gather(mj_cur, 0);
+    produce(0, mg_cur, 0);
+    int it = 0, s = 0;                       // item / slab of pipeline step g
+    int mj_p = mj_cur;                       // metadata of the slab being PRODUCED (g+1)
+    float4 mg_p = mg_cur;
+    for (int g = 0; g < total; ++g) {
+        __syncthreads();  // B(g) landed, A(g) written, stage (g+1)&1 free
+        const bool more = g + 1 < total;
+        int s1 = s + 1, it1 = it;
+        if (s1 == nslab) { s1 = 0; it1 = it + 1; }
+        if (more) {
+            if (s1 == 0) {  // the producer moves on to the next item: rotate the prefetched metadata
+                mj_p = mj_nxt; mg_p = mg_nxt;
+                if (it1 + 1 < my_items) load_meta(it1 + 1, mj_nxt, mg_nxt);
+            }
+            issue((g + 1) & 1, item_nt(it1), s1 * G_BK);
+            gather(mj_p, s1 * G_BK);
+        }
+        const char* st = S + (size_t)(g & 1) * STAGE_CH * 16;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            h8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                ah[t] = *reinterpret_cast<const h8*>(st + (offA[0][t] ^ (kk << 5)));
+                al[t] = *reinterpret_cast<const h8*>(st + (offA[1][t] ^ (kk << 5)));
+                bh[t] = *reinterpret_cast<const h8*>(st + (offB[0][t] ^ (kk << 5)));
+                bl[t] = *reinterpret_cast<const h8*>(st + (offB[1][t] ^ (kk << 5)));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        if (more) produce((g + 1) & 1, mg_p, s1 * G_BK);
+        if (s == nslab - 1) {  // item finished: reduce over neighbour slots and store, then start the next accumulation
+            sa_epilogue(acc, wscale, item_mt(it) * 4, item_nt(it) * BN, wr, wc, lane, M, kw, deg, C2, b2, bn_s, bn_t, out,
+                        ldo, out_h2, ldh);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        }
+        s = s1; it = it1;
+    }
+}
+
 extern "C" int32_t p2w_sa_conv_f16x3(const float* P, int32_t ldp, const float* xyzr_src, const int32_t* idx,
                                      const int32_t* batch_dst, const float* sf, const int32_t* nbr, const int32_t* deg,
                                      int32_t kw, int32_t M, const float* w1r4, const void* W2h, float wscale, int32_t C1,
                                      int32_t C2, const float* b2, const float* bn_s, const float* bn_t, float* out,
-                                     int32_t ldo, void* out_h2, int32_t ldh, p2w_stream_t stream) {
+                                     int32_t ldo, void* out_h2, int32_t ldh, void* ws, size_t ws_bytes,
+                                     p2w_stream_t stream) {
     if (M == 0) return P2W_OK;
     P2W_CHECK_PTR(P); P2W_CHECK_PTR(xyzr_src); P2W_CHECK_PTR(idx); P2W_CHECK_PTR(batch_dst); P2W_CHECK_PTR(sf);
     P2W_CHECK_PTR(nbr); P2W_CHECK_PTR(deg); P2W_CHECK_PTR(w1r4); P2W_CHECK_PTR(W2h); P2W_CHECK_PTR(b2);
@@ -866,6 +1299,35 @@ extern "C" int32_t p2w_sa_conv_f16x3(const float* P, int32_t ldp, const float* x
         return P2W_EINVAL;
     int C2pad, C1pad;
     p2w_packed_dims(C2, C1, &C2pad, &C1pad);
+    static const int sa_v1 = []() { const char* e = getenv("P2W_SA_V1"); return e ? atoi(e) : 0; }();
+    if (C2 >= 256 && sa_v1 == 0 && ws != nullptr && ws_bytes >= (size_t)M * 32 * 20) {
+        // v3: edge metadata pre-pass + persistent pipelined kernel (one workgroup per CU)
+        if (reinterpret_cast<uintptr_t>(ws) & 15u) return P2W_EALIGN;
+        float4* meta_g = static_cast<float4*>(ws);
+        int* meta_j = reinterpret_cast<int*>(meta_g + (size_t)M * 32);
+        sa_edge_meta_kernel<<<p2w_cdiv((long)M * 32, 256), 256, 0, p2w_s(stream)>>>(
+            reinterpret_cast<const float4*>(xyzr_src), idx, batch_dst, sf, nbr, deg, kw, M, meta_j, meta_g);
+        static const int n_cu = []() {
+            int dev = 0, n = 256;
+            if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+            return n > 0 ? n : 256;
+        }();
+        const int nMt3 = p2w_cdiv(M, 4), nNt3 = p2w_cdiv(C2, 256);
+        const long items = (long)nMt3 * nNt3;
+        const int grid = (int)(items < n_cu ? items : n_cu);
+        sa_conv16p_kernel<<<grid, 512, 0, p2w_s(stream)>>>(
+            P, ldp, meta_j, meta_g, deg, kw, M, w1r4, C1, C1pad, static_cast<const _Float16*>(W2h), (size_t)C2pad * C1pad,
+            wscale, C2, nMt3, nNt3, b2, bn_s, bn_t, out, ldo, static_cast<_Float16*>(out_h2), ldh);
+        return P2W_LAUNCH_STATUS();
+    }
+    if (C2 >= 256 && sa_v1 != 1) {  // wide layers: 128 x 256 tile, W2 on the DMA ring, A produced one slab ahead
+        const int nMt2 = p2w_cdiv(M, 4), nNt2 = p2w_cdiv(C2, 256);
+        sa_conv16g_kernel<<<tile_grid(nMt2, nNt2), 512, 0, p2w_s(stream)>>>(
+            P, ldp, reinterpret_cast<const float4*>(xyzr_src), idx, batch_dst, sf, nbr, deg, kw, M, w1r4, C1, C1pad,
+            static_cast<const _Float16*>(W2h), (size_t)C2pad * C1pad, wscale, C2, nMt2, nNt2, b2, bn_s, bn_t, out, ldo,
+            static_cast<_Float16*>(out_h2), ldh, getenv("P2W_SA_DBG") ? atoi(getenv("P2W_SA_DBG")) : 0);
+        return P2W_LAUNCH_STATUS();
+    }
     const int nMt = p2w_cdiv(M, 4), nNt = p2w_cdiv(C2, G_BN);
     sa_conv16_kernel<<<tile_grid(nMt, nNt), 256, 0, p2w_s(stream)>>>(
         P, ldp, reinterpret_cast<const float4*>(xyzr_src), idx, batch_dst, sf, nbr, deg, kw, M, w1r4, C1, C1pad,
