@@ -170,7 +170,18 @@ class Geometry:
     k: int
     sf: torch.Tensor
     levels: list = field(default_factory=list)   # 0..3
-    fp_nbr: dict = field(default_factory=dict)   # l -> (nbr [n,2], deg) of fine level l-1... see Engine.geometry
+    fp_nbr: dict = field(default_factory=dict)   # fine level f -> (nbr [n,2], deg) into level f+1
+    counts_dev: torch.Tensor | None = None
+    counts_host: torch.Tensor | None = None
+    done: object = None
+
+    def tensors(self):
+        out = [self.sf, self.counts_dev]
+        for lv in self.levels:
+            out += [t for t in (lv.xyzr, lv.ptr, lv.batch, lv.idx, lv.nbr, lv.deg) if t is not None]
+        for nbr, deg in self.fp_nbr.values():
+            out += [nbr, deg]
+        return [t for t in out if t is not None]
 
 
 class Engine:
@@ -215,7 +226,7 @@ class Engine:
         return self._ws
 
     # -- phase 1 ------------------------------------------------------------------------------
-    def geometry(self, pos, reflectance, ptr0, sf) -> Geometry:
+    def _geometry_async(self, pos, reflectance, ptr0, sf) -> Geometry:
         L = lib()
         dev = pos.device
         N, B, k = pos.shape[0], sf.numel(), self.k
@@ -249,11 +260,22 @@ class Engine:
             self._call("knn2", L.p2w_knn, ptr(coarse.xyzr), ptr(coarse.ptr), ptr(fine.xyzr), None, ptr(fine.ptr), B, N, 2,
                        ptr(nbr), ptr(deg))
             geo.fp_nbr[f] = (nbr, deg)
-        # the only host sync of the forward: three level sizes
-        counts = torch.stack([geo.levels[l].ptr[B] for l in (1, 2, 3)]).cpu()
-        for l in (1, 2, 3):
-            geo.levels[l].n = int(counts[l - 1])
+        geo.counts_dev = torch.stack([geo.levels[l].ptr[B] for l in (1, 2, 3)])
+        geo.counts_host = torch.empty(3, dtype=torch.int32, pin_memory=True)
+        geo.counts_host.copy_(geo.counts_dev, non_blocking=True)
+        geo.done = torch.cuda.Event()
+        geo.done.record()
         return geo
+
+    def _geometry_finish(self, geo):
+        """The only host sync of the forward: wait for the three level sizes."""
+        geo.done.synchronize()
+        for l in (1, 2, 3):
+            geo.levels[l].n = int(geo.counts_host[l - 1])
+        return geo
+
+    def geometry(self, pos, reflectance, ptr0, sf) -> Geometry:
+        return self._geometry_finish(self._geometry_async(pos, reflectance, ptr0, sf))
 
     # -- phase 2 ------------------------------------------------------------------------------
     def features(self, geo: Geometry, keep: dict | None = None):
@@ -429,3 +451,36 @@ class Engine:
         if keep is not None:
             keep["geometry"] = geo
         return self.features(geo, keep)
+
+    # -- two-stream software pipeline over a sequence of batches ---------------------------------------------
+    def forward_stream(self, inputs):
+        """``inputs`` yields (pos, reflectance, ptr0, sf); yields logits per batch, in order.
+
+        The geometry phase (VALU-bound searches) of batch i+1 runs on a second HIP stream while the feature phase
+        (MFMA-bound GEMMs) of batch i runs on the first; the only host wait per batch is for the three level sizes
+        of the NEXT batch's geometry, which has been running concurrently."""
+        cur_stream = torch.cuda.current_stream()
+        if getattr(self, "_s_geo", None) is None:
+            self._s_geo = torch.cuda.Stream()
+        s_geo = self._s_geo
+
+        def launch_geometry(args):
+            s_geo.wait_stream(cur_stream)
+            with torch.cuda.stream(s_geo):
+                geo = self._geometry_async(*args)
+            return geo
+
+        it = iter(inputs)
+        nxt = next(it, None)
+        if nxt is None:
+            return
+        geo = launch_geometry(nxt)
+        while geo is not None:
+            nxt = next(it, None)
+            self._geometry_finish(geo)                    # host waits for THIS batch's level sizes only
+            geo_next = launch_geometry(nxt) if nxt is not None else None
+            cur_stream.wait_event(geo.done)
+            for t in geo.tensors():
+                t.record_stream(cur_stream)               # allocated on s_geo, consumed on the feature stream
+            yield self.features(geo, None)
+            geo = geo_next

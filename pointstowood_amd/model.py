@@ -131,10 +131,7 @@ class Net(torch.nn.Module):
         return self._engine
 
     # -- forward --------------------------------------------------------------------------------
-    @torch.no_grad()
-    def forward(self, data, keep: dict | None = None):
-        if self.training:
-            raise RuntimeError("pointstowood_amd.Net is inference-only: call .eval()")
+    def _inputs(self, data):
         pos, batch, refl, sf = data.pos, data.batch, data.reflectance, data.sf
         _lib.require_cuda(pos, batch, refl, sf)
         _lib.lib()
@@ -151,7 +148,34 @@ class Net(torch.nn.Module):
         else:  # sorted batch vector -> CSR, on the device, no sync
             ptr0 = torch.searchsorted(batch.to(torch.int64).contiguous(),
                                       torch.arange(B + 1, device=dev, dtype=torch.int64)).to(torch.int32)
+        return dev, (pos, refl, ptr0, sf)
+
+    @torch.no_grad()
+    def forward(self, data, keep: dict | None = None):
+        if self.training:
+            raise RuntimeError("pointstowood_amd.Net is inference-only: call .eval()")
+        dev, args = self._inputs(data)
         eng = self._ensure_packed(dev)
-        logits = eng.forward(pos, refl, ptr0, sf, keep=keep)
+        logits = eng.forward(*args, keep=keep)
         data.x = eng.stem_out  # the reference stores the stem features on the batch (model.py:228)
         return logits
+
+    @torch.no_grad()
+    def stream(self, batches):
+        """Pipelined inference over an iterable of batches (already on the GPU): yields one logits tensor per batch,
+        in order, with the geometry phase of batch i+1 overlapped with the feature phase of batch i (two HIP streams).
+        Same results as calling the module once per batch."""
+        if self.training:
+            raise RuntimeError("pointstowood_amd.Net is inference-only: call .eval()")
+        it = iter(batches)
+        first = next(it, None)
+        if first is None:
+            return
+        dev, args0 = self._inputs(first)
+        eng = self._ensure_packed(dev)
+
+        def inputs():
+            yield args0
+            for d in it:
+                yield self._inputs(d)[1]
+        yield from eng.forward_stream(inputs())

@@ -118,3 +118,25 @@ def test_config2_full_size_properties():
         prev_n = lv.n
     # known level sizes of voxel 0 alone are ~15366/10156/2185; in a batch they shift by << 1 %
     assert abs(geo.levels[1].n / 8 - 15366) < 200 and abs(geo.levels[2].n / 8 - 10156) < 200
+
+
+def test_stream_pipeline_equals_sequential_forward():
+    """Net.stream (geometry of batch i+1 overlapped with features of batch i on a second HIP stream) must return
+    bit-identical logits to one forward per batch, in order."""
+    from pointstowood_amd import Net
+    vox = [synth.uniform_voxel(2.0, n, 70 + i, i % 2 == 0) for i, n in enumerate((3000, 800, 5000, 256, 2048, 4096))]
+    batches = [synth.collate(vox[0:2]), synth.collate(vox[2:3]), synth.collate(vox[3:6]), synth.collate(vox[1:3])]
+    net = Net(num_classes=1, C=8, k=32)
+    net.load_state_dict(weights.synth_state_dict(1, 8, seed=5), strict=True)
+    net = net.cuda().eval()
+
+    def mk(b):
+        d = _D()
+        d.pos, d.batch, d.reflectance, d.sf = b["pos"].cuda(), b["batch"].cuda(), b["reflectance"].cuda(), b["sf"].cuda()
+        return d
+    seq = [net(mk(b)).clone() for b in batches]
+    torch.cuda.synchronize()
+    for _ in range(2):
+        got = [o.clone() for o in net.stream(mk(b) for b in batches)]
+        torch.cuda.synchronize()
+        assert len(got) == len(seq) and all(torch.equal(a, b) for a, b in zip(got, seq))
