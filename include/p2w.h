@@ -89,7 +89,13 @@ int32_t p2w_ball_query(const float* xyzr_x, const int32_t* ptr_x, const float* x
  * PyG knn_interpolate (model.py:149).  Ascending (d2, index); deg[q] = min(k, #candidates). */
 int32_t p2w_knn(const float* xyzr_x, const int32_t* ptr_x, const float* xyzr_q, const int32_t* qidx,
                 const int32_t* ptr_q, int32_t B, int32_t m_bound, int32_t k, int32_t* nbr, int32_t* deg,
-                p2w_stream_t stream);
+                const float* tile_bbox, p2w_stream_t stream);
+
+/* Optional accelerator for p2w_knn (results are identical with or without it): bounding boxes (lo xyz, hi xyz) of
+ * the candidate tiles of xyzr_x (1024 consecutive records of one voxel).  bbox holds p2w_tile_bbox_count(B, n_bound)
+ * x 6 floats.  With it, p2w_knn skips tiles whose box is farther than a query's current k-th distance. */
+int32_t p2w_tile_bbox(const float* xyzr, const int32_t* ptr, int32_t B, int32_t n_bound, float* bbox, p2w_stream_t stream);
+int32_t p2w_tile_bbox_count(int32_t B, int32_t n_bound);
 
 /* ---- features ---------------------------------------------------------- */
 

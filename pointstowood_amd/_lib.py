@@ -32,7 +32,9 @@ SIGNATURES = {
     "p2w_consecutive_cluster": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "p2w_level_gather": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "p2w_ball_query": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, C.c_double, _i32, _vp, _vp, _vp]),
-    "p2w_knn": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "p2w_knn": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "p2w_tile_bbox": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp]),
+    "p2w_tile_bbox_count": (_i32, [_i32, _i32]),
     "p2w_stem": (_i32, [_vp, _i32, _vp, _vp, _i32, _vp, _vp]),
     "p2w_packed_dims": (None, [_i32, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
     "p2w_gemm": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, C.POINTER(Epilogue), _vp, _i32, _vp]),

@@ -357,11 +357,80 @@ __device__ __forceinline__ void stage_shuffled(float4* cand, const float4* __res
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// bounding boxes of the candidate tiles (S_TILE consecutive records of one voxel): lo xyz, hi xyz per tile.
+// Tile numbering: voxel b's tiles follow those of voxels < b (sum of ceil(n_b / S_TILE)).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool bbox_tile(const int* __restrict__ ptr, int B, int tile, int* c_lo, int* c_hi) {
+    int acc = 0;
+    for (int b = 0; b < B; ++b) {
+        const int s = ptr[b], e = ptr[b + 1];
+        const int t = (e - s + S_TILE - 1) / S_TILE;
+        if (tile < acc + t) {
+            *c_lo = s + (tile - acc) * S_TILE;
+            *c_hi = min(*c_lo + S_TILE, e);
+            return true;
+        }
+        acc += t;
+    }
+    return false;
+}
+__device__ __forceinline__ int bbox_tile_base(const int* __restrict__ ptr, int b) {
+    int acc = 0;
+    for (int i = 0; i < b; ++i) acc += (ptr[i + 1] - ptr[i] + S_TILE - 1) / S_TILE;
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void tile_bbox_kernel(const float4* __restrict__ x, const int* __restrict__ ptr, int B,
+                                                        float* __restrict__ bbox) {
+    __shared__ float red[4][6];
+    int c_lo, c_hi;
+    if (!bbox_tile(ptr, B, blockIdx.x, &c_lo, &c_hi)) return;
+    float v[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    for (int c = c_lo + threadIdx.x; c < c_hi; c += 256) {
+        const float4 p = x[c];
+        v[0] = fminf(v[0], p.x); v[3] = fmaxf(v[3], p.x);
+        v[1] = fminf(v[1], p.y); v[4] = fmaxf(v[4], p.y);
+        v[2] = fminf(v[2], p.z); v[5] = fmaxf(v[5], p.z);
+    }
+#pragma unroll
+    for (int d = 0; d < 6; ++d) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float o = __shfl_xor(v[d], off);
+            v[d] = d < 3 ? fminf(v[d], o) : fmaxf(v[d], o);
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int d = 0; d < 6; ++d) red[wave][d] = v[d];
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int d = threadIdx.x;
+        float r = red[0][d];
+        for (int w = 1; w < 4; ++w) r = d < 3 ? fminf(r, red[w][d]) : fmaxf(r, red[w][d]);
+        bbox[(size_t)blockIdx.x * 6 + d] = r;
+    }
+}
+
+extern "C" int32_t p2w_tile_bbox(const float* xyzr, const int32_t* ptr, int32_t B, int32_t n_bound, float* bbox,
+                                 p2w_stream_t stream) {
+    if (n_bound == 0) return P2W_OK;
+    P2W_CHECK_PTR(xyzr); P2W_CHECK_PTR(ptr); P2W_CHECK_PTR(bbox); P2W_CHECK_ALIGN16(xyzr);
+    if (B <= 0 || n_bound < 0) return P2W_EINVAL;
+    tile_bbox_kernel<<<p2w_cdiv(n_bound, S_TILE) + B, 256, 0, p2w_s(stream)>>>(reinterpret_cast<const float4*>(xyzr), ptr, B, bbox);
+    return P2W_LAUNCH_STATUS();
+}
+extern "C" int32_t p2w_tile_bbox_count(int32_t B, int32_t n_bound) { return p2w_cdiv(n_bound, S_TILE) + B; }
+
 __global__ __launch_bounds__(256) void knn_kernel(const float4* __restrict__ x, const int* __restrict__ ptr_x,
                                                   const float4* __restrict__ xq, const int* __restrict__ qidx,
                                                   const int* __restrict__ ptr_q, int B, int k, int* __restrict__ nbr,
-                                                  int* __restrict__ deg) {
+                                                  int* __restrict__ deg, const float* __restrict__ bbox) {
     __shared__ float4 cand[S_TILE];
+    __shared__ int need[2][4];
     int b, q0, q1;
     if (!search_tile(ptr_q, B, blockIdx.x, &b, &q0, &q1)) return;
     const int c0 = ptr_x[b], c1 = ptr_x[b + 1];
@@ -387,12 +456,37 @@ __global__ __launch_bounds__(256) void knn_kernel(const float4* __restrict__ x, 
     if (qidx) t0 = (qidx[q0] - c0) / S_TILE;                                    // the query is itself a candidate
     else t0 = (int)(((long long)(q0 - ptr_q[b]) * ntiles) / max(1, ptr_q[b + 1] - ptr_q[b]));  // same storage order
     t0 = min(max(t0, 0), max(ntiles - 1, 0));
+    const float* vb = bbox ? bbox + (size_t)bbox_tile_base(ptr_x, b) * 6 : nullptr;
+    int visit = 0;
     for (int step = 0; step < 2 * ntiles - 1; ++step) {
         const int off = (step + 1) >> 1;
         const int tile = (step & 1) ? t0 + off : t0 - off;
         if (tile < 0 || tile >= ntiles) continue;
         const int base = c0 + tile * S_TILE;
+        // exact pruning: per dimension e = gap between the query and the tile's box; ((ex^2+ey^2)+ez^2) in fp32 is a
+        // lower bound of p2w_d2(query, c) for every c in the tile (fp32 subtract / multiply / add are monotone), so a
+        // tile whose bound exceeds a query's current k-th distance cannot change that query's result.
+        unsigned qmask = (1u << S_QPW) - 1u;
+        if (vb) {
+            const float lx = vb[tile * 6 + 0], ly = vb[tile * 6 + 1], lz = vb[tile * 6 + 2];
+            const float hx = vb[tile * 6 + 3], hy = vb[tile * 6 + 4], hz = vb[tile * 6 + 5];
+            qmask = 0u;
+#pragma unroll
+            for (int j = 0; j < S_QPW; ++j) {
+                const float ex = fmaxf(fmaxf(lx - uq[j].x, uq[j].x - hx), 0.f);
+                const float ey = fmaxf(fmaxf(ly - uq[j].y, uq[j].y - hy), 0.f);
+                const float ez = fmaxf(fmaxf(lz - uq[j].z, uq[j].z - hz), 0.f);
+                const float lb = ((ex * ex) + (ey * ey)) + (ez * ez);
+                if (lb <= thr[j]) qmask |= 1u << j;
+            }
+            if (lane == 0) need[visit & 1][wave] = qmask != 0u;
+        }
         __syncthreads();
+        if (vb) {
+            const int any = need[visit & 1][0] | need[visit & 1][1] | need[visit & 1][2] | need[visit & 1][3];
+            ++visit;
+            if (!any) continue;   // no query of this workgroup can gain from the tile: skip staging it
+        }
         stage_shuffled(cand, x, base, c1, tid);
         __syncthreads();
         // groups of 4 chunks (256 candidates) are held in registers while the wave walks its queries, so the
@@ -404,6 +498,7 @@ __global__ __launch_bounds__(256) void knn_kernel(const float4* __restrict__ x, 
             for (int u = 0; u < 4; ++u) c[u] = cand[gr * 256 + u * 64 + lane];
 #pragma unroll
             for (int j = 0; j < S_QPW; ++j) {
+                if (!((qmask >> j) & 1u)) continue;   // wave-uniform
                 float bd = best_d[j], t = thr[j];
                 int bi = best_i[j], ti = thi[j];
 #pragma unroll
@@ -504,13 +599,14 @@ static int32_t search_args(const float* xyzr_x, const int32_t* ptr_x, const floa
 
 extern "C" int32_t p2w_knn(const float* xyzr_x, const int32_t* ptr_x, const float* xyzr_q, const int32_t* qidx,
                            const int32_t* ptr_q, int32_t B, int32_t m_bound, int32_t k, int32_t* nbr, int32_t* deg,
-                           p2w_stream_t stream) {
+                           const float* tile_bbox, p2w_stream_t stream) {
     if (m_bound == 0) return P2W_OK;
     const int32_t st = search_args(xyzr_x, ptr_x, xyzr_q, ptr_q, B, m_bound, k, nbr, deg);
     if (st != P2W_OK) return st;
     const int grid = p2w_cdiv(m_bound, S_QT) + B;  // upper bound on sum_b ceil(m_b / QT)
     knn_kernel<<<grid, 256, 0, p2w_s(stream)>>>(reinterpret_cast<const float4*>(xyzr_x), ptr_x,
-                                                reinterpret_cast<const float4*>(xyzr_q), qidx, ptr_q, B, k, nbr, deg);
+                                                reinterpret_cast<const float4*>(xyzr_q), qidx, ptr_q, B, k, nbr, deg,
+                                                tile_bbox);
     return P2W_LAUNCH_STATUS();
 }
 

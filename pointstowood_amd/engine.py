@@ -181,6 +181,7 @@ class Geometry:
             out += [t for t in (lv.xyzr, lv.ptr, lv.batch, lv.idx, lv.nbr, lv.deg) if t is not None]
         for nbr, deg in self.fp_nbr.values():
             out += [nbr, deg]
+        out += list(getattr(self, "aux", []))
         return [t for t in out if t is not None]
 
 
@@ -238,6 +239,16 @@ class Engine:
                    ptr(xyzr0), ptr(batch0))
         geo.levels.append(Level(xyzr=xyzr0, ptr=ptr0, batch=batch0, n=N))
         ws = self._workspace(N, dev)
+        nbox = int(L.p2w_tile_bbox_count(B, N))
+        bbox = {}   # level -> tile bounding boxes of that level's records (kNN pruning; results unchanged)
+
+        def boxes(level):
+            if level not in bbox:
+                t = torch.empty((nbox, 6), **f32)
+                lv_ = geo.levels[level]
+                self._call("tile_bbox", L.p2w_tile_bbox, ptr(lv_.xyzr), ptr(lv_.ptr), B, N, ptr(t))
+                bbox[level] = t
+            return bbox[level]
         for l, res in enumerate(SA_RES):
             src = geo.levels[l]
             lv = Level(xyzr=torch.empty((N, 4), **f32), ptr=torch.empty(B + 1, **i32), batch=torch.empty(N, **i32),
@@ -249,7 +260,7 @@ class Engine:
                            ptr(lv.ptr), B, N, res * 2, k, ptr(lv.nbr), ptr(lv.deg))
             else:        # model.py:120
                 self._call("knn", L.p2w_knn, ptr(src.xyzr), ptr(src.ptr), ptr(src.xyzr), ptr(lv.idx), ptr(lv.ptr), B, N,
-                           k, ptr(lv.nbr), ptr(lv.deg))
+                           k, ptr(lv.nbr), ptr(lv.deg), ptr(boxes(l)))
             self._call("level_gather", L.p2w_level_gather, ptr(src.xyzr), ptr(lv.idx), ptr(lv.batch), ptr(lv.ptr), B, N,
                        ptr(sf), ptr(lv.xyzr))
             geo.levels.append(lv)
@@ -258,8 +269,9 @@ class Engine:
             fine, coarse = geo.levels[f], geo.levels[f + 1]
             nbr, deg = torch.empty((N, 2), **i32), torch.empty(N, **i32)
             self._call("knn2", L.p2w_knn, ptr(coarse.xyzr), ptr(coarse.ptr), ptr(fine.xyzr), None, ptr(fine.ptr), B, N, 2,
-                       ptr(nbr), ptr(deg))
+                       ptr(nbr), ptr(deg), ptr(boxes(f + 1)))
             geo.fp_nbr[f] = (nbr, deg)
+        geo.aux = list(bbox.values())
         geo.counts_dev = torch.stack([geo.levels[l].ptr[B] for l in (1, 2, 3)])
         geo.counts_host = torch.empty(3, dtype=torch.int32, pin_memory=True)
         geo.counts_host.copy_(geo.counts_dev, non_blocking=True)

@@ -133,7 +133,7 @@ def test_c_abi_rejects_bad_arguments():
     n = torch.zeros(16, 100, dtype=torch.int32, device="cuda")
     d = torch.zeros(16, dtype=torch.int32, device="cuda")
     L = lib()
-    assert L.p2w_knn(ptr(x), ptr(p), ptr(x), None, ptr(p), 1, 16, 100, ptr(n), ptr(d), stream()) == -1   # k > 64
-    assert L.p2w_knn(None, ptr(p), ptr(x), None, ptr(p), 1, 16, 8, ptr(n), ptr(d), stream()) == -2       # NULL
-    assert L.p2w_knn(x.data_ptr() + 4, ptr(p), ptr(x), None, ptr(p), 1, 16, 8, ptr(n), ptr(d), stream()) == -3  # alignment
+    assert L.p2w_knn(ptr(x), ptr(p), ptr(x), None, ptr(p), 1, 16, 100, ptr(n), ptr(d), None, stream()) == -1   # k > 64
+    assert L.p2w_knn(None, ptr(p), ptr(x), None, ptr(p), 1, 16, 8, ptr(n), ptr(d), None, stream()) == -2       # NULL
+    assert L.p2w_knn(x.data_ptr() + 4, ptr(p), ptr(x), None, ptr(p), 1, 16, 8, ptr(n), ptr(d), None, stream()) == -3  # alignment
     assert b"NULL" in L.p2w_strerror(-2)
