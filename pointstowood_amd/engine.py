@@ -473,7 +473,7 @@ class Engine:
         of the NEXT batch's geometry, which has been running concurrently."""
         cur_stream = torch.cuda.current_stream()
         if getattr(self, "_s_geo", None) is None:
-            self._s_geo = torch.cuda.Stream()
+            self._s_geo = torch.cuda.Stream(priority=-1)   # short, low-footprint kernels: let them slot in first
         s_geo = self._s_geo
 
         def launch_geometry(args):
