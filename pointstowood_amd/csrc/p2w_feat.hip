@@ -852,7 +852,15 @@ extern "C" int32_t p2w_gemm_h2(const void* A_h2, int32_t ldh_a, const void* Wh, 
         const int dbg = de ? atoi(de) : 0;
         // 256x256 tiles halve the L2->LDS bytes per MFMA; they need enough tiles to fill 256 CUs and a wide N
         const long tiles256 = (long)p2w_cdiv(M, 256) * (Npad / 256);
-        const bool big = force ? (force == 256) : (N >= 256 && tiles256 >= 512);
+        static const int n_cu_g = []() {
+            int dev = 0, n = 256;
+            if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+            return n > 0 ? n : 256;
+        }();
+        // one 256x256 workgroup per CU: use it only when the tile count fills whole rounds of the chip reasonably well
+        const long rounds = (tiles256 + n_cu_g - 1) / n_cu_g;
+        const bool fills = tiles256 * 100 >= rounds * n_cu_g * 85;
+        const bool big = force ? (force == 256) : (N >= 256 && tiles256 >= 2 * n_cu_g && fills);
         // epilogue class for the specialised interior-tile path (0 = generic); needs 32-bit element offsets
         int ef = (ep.relu0 ? 1 : 0) | (ep.sc0 ? 2 : 0) | (ep.relu1 ? 4 : 0) | (ep.sc1 ? 8 : 0) | (ep.relu2 ? 16 : 0) |
                  (ep.residual ? 32 : 0) | (ep.relu_final ? 64 : 0) | (out_f32 ? 128 : 0) | (out_h2 ? 256 : 0);
@@ -1223,29 +1231,53 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    // pipeline prologue: slab 0 of item 0; metadata of item 1 one item ahead
-    int mj_cur, mj_nxt = 0;
-    float4 mg_cur, mg_nxt = make_float4(0.f, 0.f, 0.f, 0.f);
-    load_meta(0, mj_cur, mg_cur);
+    // Software pipeline over the flattened slab sequence g = 0..total-1 of this workgroup's items:
+    //   MFMA stage    : slab g        (reads LDS stage g&1)
+    //   produce stage : slab g+1      (A rows: VALU on P values gathered one slab EARLIER, written to stage (g+1)&1;
+    //                                  placed between the two MFMA groups of slab g so it co-issues with MFMAs in flight)
+    //   gather stage  : slab g+2      (global loads of P rows + W2 DMA of slab g+1 issued right after the barrier)
+    // Metadata (source row, normalised offset) of an item is prefetched one item ahead of the gather stage.
+    int it_q = 0, s_q = 0;                   // item / slab of the gather stage
+    int mj_q, mj_nxt = 0;
+    float4 mg_q, mg_nxt = make_float4(0.f, 0.f, 0.f, 0.f);
+    load_meta(0, mj_q, mg_q);
     if (my_items > 1) load_meta(1, mj_nxt, mg_nxt);
+    auto advance_q = [&]() {                 // move the gather stage to the next slab (possibly the next item)
+        if (++s_q == nslab) {
+            s_q = 0; ++it_q;
+            mj_q = mj_nxt; mg_q = mg_nxt;
+            if (it_q + 1 < my_items) load_meta(it_q + 1, mj_nxt, mg_nxt);
+        }
+    };
+    // prologue: slab 0 produced synchronously, slab 1 gathered
     issue(0, item_nt(0), 0);
-    gather(mj_cur, 0);
-    produce(0, mg_cur, 0);
-    int it = 0, s = 0;                       // item / slab of pipeline step g
-    int mj_p = mj_cur;                       // metadata of the slab being PRODUCED (g+1)
-    float4 mg_p = mg_cur;
+    gather(mj_q, 0);
+    produce(0, mg_q, 0);
+    float4 pn[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};  // gathered values of slab g+1
+    float4 mg_n = mg_q;
+    int k_n = 0;
+    if (total > 1) {
+        advance_q();
+        gather(mj_q, s_q * G_BK);
+        pn[0] = pv[0]; pn[1] = pv[1]; mg_n = mg_q; k_n = s_q * G_BK;
+    }
+    int it = 0, s = 0;                       // item / slab of the MFMA stage
+    int it1 = 0, s1 = 0;                     // item / slab of the produce stage (g+1)
     for (int g = 0; g < total; ++g) {
         __syncthreads();  // B(g) landed, A(g) written, stage (g+1)&1 free
         const bool more = g + 1 < total;
-        int s1 = s + 1, it1 = it;
-        if (s1 == nslab) { s1 = 0; it1 = it + 1; }
         if (more) {
-            if (s1 == 0) {  // the producer moves on to the next item: rotate the prefetched metadata
-                mj_p = mj_nxt; mg_p = mg_nxt;
-                if (it1 + 1 < my_items) load_meta(it1 + 1, mj_nxt, mg_nxt);
-            }
+            s1 = s + 1; it1 = it;
+            if (s1 == nslab) { s1 = 0; it1 = it + 1; }
             issue((g + 1) & 1, item_nt(it1), s1 * G_BK);
-            gather(mj_p, s1 * G_BK);
+        }
+        // values for the produce stage were gathered during the previous iteration
+        const float4 pu0 = pn[0], pu1 = pn[1], mg_u = mg_n;
+        const int k_u = k_n;
+        if (g + 2 < total) {
+            advance_q();
+            gather(mj_q, s_q * G_BK);
+            pn[0] = pv[0]; pn[1] = pv[1]; mg_n = mg_q; k_n = s_q * G_BK;
         }
         const char* st = S + (size_t)(g & 1) * STAGE_CH * 16;
 #pragma unroll
@@ -1266,8 +1298,12 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
+            if (kk == 0) {  // producer VALU work runs while the 12 MFMAs above are in the matrix pipe
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) { pv[0] = pu0; pv[1] = pu1; produce((g + 1) & 1, mg_u, k_u); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        if (more) produce((g + 1) & 1, mg_p, s1 * G_BK);
         if (s == nslab - 1) {  // item finished: reduce over neighbour slots and store, then start the next accumulation
             sa_epilogue(acc, wscale, item_mt(it) * 4, item_nt(it) * BN, wr, wc, lane, M, kw, deg, C2, b2, bn_s, bn_t, out,
                         ldo, out_h2, ldh);
