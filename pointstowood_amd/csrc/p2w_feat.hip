@@ -1139,7 +1139,9 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
     constexpr int A_CH = 8 * BM, STAGE_CH = A_CH + 8 * BN;
     constexpr int NI = (8 * BN) / 64 / NW;
     __shared__ __attribute__((aligned(16))) char S[2 * STAGE_CH * 16];
+    __shared__ __attribute__((aligned(16))) float Wr[4 * 512];   // layer-1 geometry weights (rx, ry, rz, refl rows), C1pad <= 512
     const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < 4 * C1pad; i += 512) Wr[i] = w1r4[i];
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wave >> 2, wc = wave & 3;
     const int nitems = nMt * nNt, nslab = C1pad / G_BK;
     const int first = blockIdx.x, stride = gridDim.x;
@@ -1163,10 +1165,10 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
         boff[i] = (size_t)p * plane + (size_t)row * C1pad + 8 * q;
         dstc[i] = A_CH + g2 * 64;
     }
-    auto issue = [&](int stage, int nt, int k0) {
+    auto issue = [&](int stage, const _Float16* wbase, int k0) {   // wbase = W2h + nt * BN * C1pad (per item)
 #pragma unroll
         for (int i = 0; i < NI; ++i)
-            __builtin_amdgcn_global_load_lds((glb_vp)(W2h + boff[i] + (size_t)nt * BN * C1pad + k0),
+            __builtin_amdgcn_global_load_lds((glb_vp)(wbase + boff[i] + k0),
                                              (lds_vp)(S + ((size_t)stage * STAGE_CH + dstc[i]) * 16), 16, 0, 0);
     };
     // metadata of the producer's edge row (clamped: rows past the last target replay the last valid row)
@@ -1192,10 +1194,10 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
             const int kk = k + 4 * half;
             float v[4] = {0.f, 0.f, 0.f, 0.f};
             if (kk < C1) {
-                const float4 wx = *reinterpret_cast<const float4*>(&w1r4[0 * C1pad + kk]);
-                const float4 wy = *reinterpret_cast<const float4*>(&w1r4[1 * C1pad + kk]);
-                const float4 wz = *reinterpret_cast<const float4*>(&w1r4[2 * C1pad + kk]);
-                const float4 wf = *reinterpret_cast<const float4*>(&w1r4[3 * C1pad + kk]);
+                const float4 wx = *reinterpret_cast<const float4*>(&Wr[0 * C1pad + kk]);
+                const float4 wy = *reinterpret_cast<const float4*>(&Wr[1 * C1pad + kk]);
+                const float4 wz = *reinterpret_cast<const float4*>(&Wr[2 * C1pad + kk]);
+                const float4 wf = *reinterpret_cast<const float4*>(&Wr[3 * C1pad + kk]);
                 const float4 p = pv[half];
                 v[0] = fmaxf(fmaf(rg.w, wf.x, fmaf(rg.z, wz.x, fmaf(rg.y, wy.x, fmaf(rg.x, wx.x, p.x)))), 0.f);
                 v[1] = fmaxf(fmaf(rg.w, wf.y, fmaf(rg.z, wz.y, fmaf(rg.y, wy.y, fmaf(rg.x, wx.y, p.y)))), 0.f);
@@ -1250,7 +1252,11 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
         }
     };
     // prologue: slab 0 produced synchronously, slab 1 gathered
-    issue(0, item_nt(0), 0);
+    const _Float16* wb1 = W2h + (size_t)item_nt(0) * BN * C1pad;   // W2 panel of the item in the produce stage
+    int mt_cur = item_mt(0), nt_cur = item_nt(0);                   // item in the MFMA stage
+    int mt_1 = mt_cur, nt_1 = nt_cur;                               // item in the produce stage
+    __syncthreads();   // Wr staged
+    issue(0, wb1, 0);
     gather(mj_q, 0);
     produce(0, mg_q, 0);
     float4 pn[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};  // gathered values of slab g+1
@@ -1268,8 +1274,12 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
         const bool more = g + 1 < total;
         if (more) {
             s1 = s + 1; it1 = it;
-            if (s1 == nslab) { s1 = 0; it1 = it + 1; }
-            issue((g + 1) & 1, item_nt(it1), s1 * G_BK);
+            if (s1 == nslab) {
+                s1 = 0; it1 = it + 1;
+                mt_1 = item_mt(it1); nt_1 = item_nt(it1);
+                wb1 = W2h + (size_t)nt_1 * BN * C1pad;
+            }
+            issue((g + 1) & 1, wb1, s1 * G_BK);
         }
         // values for the produce stage were gathered during the previous iteration
         const float4 pu0 = pn[0], pu1 = pn[1], mg_u = mg_n;
@@ -1305,8 +1315,8 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
             }
         }
         if (s == nslab - 1) {  // item finished: reduce over neighbour slots and store, then start the next accumulation
-            sa_epilogue(acc, wscale, item_mt(it) * 4, item_nt(it) * BN, wr, wc, lane, M, kw, deg, C2, b2, bn_s, bn_t, out,
-                        ldo, out_h2, ldh);
+            sa_epilogue(acc, wscale, mt_cur * 4, nt_cur * BN, wr, wc, lane, M, kw, deg, C2, b2, bn_s, bn_t, out, ldo, out_h2,
+                        ldh);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1314,7 +1324,7 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
         }
-        s = s1; it = it1;
+        s = s1; it = it1; mt_cur = mt_1; nt_cur = nt_1;
     }
 }
 
@@ -1336,7 +1346,7 @@ extern "C" int32_t p2w_sa_conv_f16x3(const float* P, int32_t ldp, const float* x
     int C2pad, C1pad;
     p2w_packed_dims(C2, C1, &C2pad, &C1pad);
     static const int sa_v1 = []() { const char* e = getenv("P2W_SA_V1"); return e ? atoi(e) : 0; }();
-    if (C2 >= 256 && sa_v1 == 0 && ws != nullptr && ws_bytes >= (size_t)M * 32 * 20) {
+    if (C2 >= 256 && sa_v1 == 0 && ws != nullptr && ws_bytes >= (size_t)M * 32 * 20 && C1pad <= 512) {
         // v3: edge metadata pre-pass + persistent pipelined kernel (one workgroup per CU)
         if (reinterpret_cast<uintptr_t>(ws) & 15u) return P2W_EALIGN;
         float4* meta_g = static_cast<float4*>(ws);
