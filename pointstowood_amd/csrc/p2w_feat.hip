@@ -180,8 +180,8 @@ extern "C" int32_t p2w_gemm(const float* A, int32_t lda, const float* Wp, int32_
 // exchange) and the [E, C] edge tensors of the reference never exist in HBM.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void sa_split(float v, _Float16& hi, _Float16& lo) {
-    hi = (_Float16)v;
-    lo = (_Float16)(v - (float)hi);
+    hi = (_Float16)__builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
+    lo = (_Float16)__builtin_amdgcn_fmed3f(v - (float)hi, -65504.f, 65504.f);
 }
 __device__ __forceinline__ unsigned sa_pack(_Float16 a, _Float16 b) {
     typedef _Float16 h2v __attribute__((ext_vector_type(2)));
@@ -383,8 +383,8 @@ __device__ __forceinline__ void split_store(_Float16* __restrict__ Sh, _Float16*
         h4 hi, lo;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            hi[e] = (_Float16)v[e];
-            lo[e] = (_Float16)(v[e] - (float)hi[e]);
+            hi[e] = (_Float16)__builtin_amdgcn_fmed3f(v[e], -65504.f, 65504.f);
+            lo[e] = (_Float16)__builtin_amdgcn_fmed3f(v[e] - (float)hi[e], -65504.f, 65504.f);
         }
         *reinterpret_cast<h4*>(&Sh[(lrow + 32 * i) * H_LD + 4 * lkq]) = hi;
         *reinterpret_cast<h4*>(&Sl[(lrow + 32 * i) * H_LD + 4 * lkq]) = lo;
@@ -499,9 +499,10 @@ extern "C" int32_t p2w_gemm_f16x3(const float* A, int32_t lda, const void* Wh, f
 // ldh = round_up(F, 8) halfs, pad columns zero.  Same bytes as fp32, but a consumer GEMM stages it with plain
 // 16-byte copies (no conversion), exactly like the packed weights.  Producers split once, in their epilogue.
 // ------------------------------------------------------------------------------------------------
+// hi saturates at +-65504 instead of overflowing to inf; the remainder goes to lo (usable range ~1.3e5)
 __device__ __forceinline__ void h2_split(float v, _Float16& hi, _Float16& lo) {
-    hi = (_Float16)v;
-    lo = (_Float16)(v - (float)hi);
+    hi = (_Float16)__builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
+    lo = (_Float16)__builtin_amdgcn_fmed3f(v - (float)hi, -65504.f, 65504.f);
 }
 __device__ __forceinline__ unsigned h2_pack(_Float16 a, _Float16 b) {
     typedef _Float16 h2v __attribute__((ext_vector_type(2)));
@@ -1018,8 +1019,8 @@ __global__ __launch_bounds__(512, 2) void sa_conv16g_kernel(const float* __restr
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                hi[4 * half + e] = (_Float16)v[e];
-                lo[4 * half + e] = (_Float16)(v[e] - (float)hi[4 * half + e]);
+                hi[4 * half + e] = (_Float16)fminf(v[e], 65504.f);   // v >= 0 after the ReLU
+                lo[4 * half + e] = (_Float16)fminf(v[e] - (float)hi[4 * half + e], 65504.f);
             }
         }
         char* st = S + (size_t)stage * STAGE_CH * 16;
@@ -1206,8 +1207,8 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                hi[4 * half + e] = (_Float16)v[e];
-                lo[4 * half + e] = (_Float16)(v[e] - (float)hi[4 * half + e]);
+                hi[4 * half + e] = (_Float16)fminf(v[e], 65504.f);   // v >= 0 after the ReLU
+                lo[4 * half + e] = (_Float16)fminf(v[e] - (float)hi[4 * half + e], 65504.f);
             }
         }
         char* st = S + (size_t)stage * STAGE_CH * 16;

@@ -4,6 +4,7 @@
 Tolerances: indices bit-exact; level features 2e-4 (abs+rel, fp32 accumulation-order noise through
 up to 25 layers, K <= 2048); logits 4e-4 absolute, which bounds the wood probability error by 1e-4
 (|d sigmoid| <= 0.25 |d logit|) - the north-star's parity bar; probabilities checked at 1e-4 too."""
+import numpy as np
 import pytest
 import torch
 
@@ -140,3 +141,41 @@ def test_stream_pipeline_equals_sequential_forward():
         got = [o.clone() for o in net.stream(mk(b) for b in batches)]
         torch.cuda.synchronize()
         assert len(got) == len(seq) and all(torch.equal(a, b) for a, b in zip(got, seq))
+
+
+def test_predict_cli_on_a_voxel_directory(tmp_path):
+    """predict.py --voxels: dataset feed -> sampler -> forward -> sigmoid/threshold/un-shift, against the CPU oracle."""
+    import importlib.util
+    import os
+    from oracle import host as ohost
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("p2w_predict", os.path.join(root, "predict.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    g = torch.Generator().manual_seed(9)
+    vdir = tmp_path / "voxels"
+    vdir.mkdir()
+    raws = []
+    for i, n in enumerate((600, 1500, 300)):
+        pc = torch.cat([torch.rand(n, 3, generator=g) * 2 + 40 * i, torch.rand(n, 1, generator=g) * 2 - 1, torch.rand(n, 2, generator=g)], 1)
+        torch.save(pc, vdir / f"voxel_{i}.pt")
+        raws.append(pc)
+    sd = weights.synth_state_dict(1, 32, seed=0)
+    torch.save({"model_state_dict": {"module." + k: v for k, v in sd.items()}}, tmp_path / "m.pth")
+    out = mod.main(["--voxels", str(vdir), "--model", str(tmp_path / "m.pth"), "--odir", str(tmp_path / "o"),
+                    "--batch_size", "2", "--is-wood", "0.5"])
+    assert out.shape == (2400, 5) and os.path.exists(tmp_path / "o" / "classified_voxels.npy")
+    # oracle: classify every voxel alone is NOT equivalent (batch-global grid origin), so rebuild the same batches
+    from pointstowood_amd.predicter import BalancedBatchSampler, VoxelDataset
+    ds = VoxelDataset(str(vdir))
+    ref_rows = []
+    for batch in BalancedBatchSampler(ds, 2):
+        feeds = [ohost.feed(ds.raw(i)) for i in batch]
+        b = synth.collate(feeds)
+        logits = onet.forward(sd, b["pos"], b["batch"], b["reflectance"], b["sf"], k=32)
+        ref_rows.append(ohost.consume(logits, b["pos"], b["batch"], b["local_shift"], 0.5))
+    ref = np.vstack(ref_rows)
+    assert np.abs(out[:, :3] - ref[:, :3]).max() <= 1e-4            # un-shifted coordinates
+    assert np.abs(out[:, 4] - ref[:, 4]).max() <= 1e-4              # wood probability
+    far = np.abs(ref[:, 4] - 0.5) > 2e-4
+    assert (out[far, 3] == ref[far, 3]).all()                        # labels (away from the decision threshold)

@@ -137,3 +137,25 @@ def test_c_abi_rejects_bad_arguments():
     assert L.p2w_knn(None, ptr(p), ptr(x), None, ptr(p), 1, 16, 8, ptr(n), ptr(d), None, stream()) == -2       # NULL
     assert L.p2w_knn(x.data_ptr() + 4, ptr(p), ptr(x), None, ptr(p), 1, 16, 8, ptr(n), ptr(d), None, stream()) == -3  # alignment
     assert b"NULL" in L.p2w_strerror(-2)
+
+
+def test_f16x3_split_saturates_instead_of_overflowing():
+    """Activations beyond the fp16 range must degrade gracefully (hi saturates at 65504, lo carries the rest), never inf/NaN."""
+    import ctypes as C
+    from pointstowood_amd import _lib
+    from pointstowood_amd._lib import check, lib, ptr, stream
+    g = torch.Generator().manual_seed(3)
+    M, K, N = 300, 64, 32
+    A = (torch.rand(M, K, generator=g) * 2 - 1) * 1.2e5          # up to +-1.2e5 > 65504
+    W = torch.randn(N, K, generator=g) / 8
+    Np, Kp = _lib.packed_dims(N, K)
+    Wp = torch.zeros(Np, Kp); Wp[:N, :K] = W
+    e = int(np.floor(np.log2(1024.0 / float(Wp.abs().max()))))
+    Ws = Wp.double() * 2.0 ** e
+    hi = Ws.float().half(); lo = (Ws - hi.double()).float().half()
+    dW16 = torch.stack([hi, lo]).contiguous().cuda()
+    out = torch.full((M, N), float("nan"), device="cuda")
+    check(lib().p2w_gemm_f16x3(ptr(A.cuda()), K, ptr(dW16), 2.0 ** -e, M, N, K, None, ptr(out), N, stream()))
+    ref = A.double() @ W.double().t()
+    assert bool(torch.isfinite(out).all())
+    assert (out.cpu().double() - ref).abs().max() <= 2e-3 * ref.abs().max()

@@ -151,3 +151,17 @@ def test_gather_logits_gloo_world2():
     expect = list(map(float, range(5))) + [100.0 + i for i in range(9)]
     for _, ragged, equal in res:
         assert ragged == expect and equal == [0.0] * 4 + [1.0] * 4
+
+
+def test_predict_cli_keeps_the_reference_flag_surface():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("p2w_predict", os.path.join(ROOT, "predict.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    a = mod.build_parser().parse_args([])
+    # names, types and defaults of pointstowood/predict.py:61-74
+    assert (a.point_cloud, a.odir, a.batch_size, a.num_procs, a.resolution) == ([], ".", 8, -1, 0.01)
+    assert (a.grid_size, a.min_pts, a.max_pts, a.model) == ([2.0, 4.0], 128, 16384, "model.pth")
+    assert (a.is_wood, a.any_wood, a.output_fmt, a.verbose) == (0.5, 1, "ply", False)
+    b = mod.build_parser().parse_args(["-p", "a.ply", "b.ply", "--is-wood", "0.7", "--grid_size", "2.0"])
+    assert b.point_cloud == ["a.ply", "b.ply"] and b.is_wood == 0.7 and b.grid_size == [2.0]
