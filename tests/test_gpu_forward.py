@@ -165,6 +165,7 @@ def test_predict_cli_on_a_voxel_directory(tmp_path):
     out = mod.main(["--voxels", str(vdir), "--model", str(tmp_path / "m.pth"), "--odir", str(tmp_path / "o"),
                     "--batch_size", "2", "--is-wood", "0.5"])
     assert out.shape == (2400, 5) and os.path.exists(tmp_path / "o" / "classified_voxels.npy")
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))   # predict.py sets all cores like the reference; the oracle crawls there
     # oracle: classify every voxel alone is NOT equivalent (batch-global grid origin), so rebuild the same batches
     from pointstowood_amd.predicter import BalancedBatchSampler, VoxelDataset
     ds = VoxelDataset(str(vdir))
