@@ -1123,11 +1123,13 @@ __global__ __launch_bounds__(256) void sa_edge_meta_kernel(const float4* __restr
     for (int off = 16; off >= 1; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off));  // 32 lanes = one target
     const float den = dmax + 1e-8f;
     if (tgt < M) {
-        meta_j[g] = j;
+        const bool valid = slot < deg[tgt] && slot < kw;
+        meta_j[g] = valid ? j : -1;     // empty slot: the producer writes a zero row, the epilogue masks it
         meta_g[g] = make_float4(rx / den, ry / den, rz / den, rf);
     }
 }
 
+template <int BN>   // 256: 4 targets x 256 columns (waves 2 x 4);  128: 8 targets x 128 columns (waves 4 x 2)
 __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restrict__ P, int ldp, const int* __restrict__ meta_j,
                                                             const float4* __restrict__ meta_g, const int* __restrict__ deg,
                                                             int kw, int M, const float* __restrict__ w1r4, int C1, int C1pad,
@@ -1136,14 +1138,14 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
                                                             const float* __restrict__ bn_s, const float* __restrict__ bn_t,
                                                             float* __restrict__ out, int ldo, _Float16* __restrict__ out_h2,
                                                             int ldh) {
-    constexpr int BM = 128, BN = 256, NW = 8;
+    constexpr int WCn = BN / 64, BM = 64 * (8 / WCn), NW = 8, NR = BM / 128;   // NR producer rows per thread
     constexpr int A_CH = 8 * BM, STAGE_CH = A_CH + 8 * BN;
     constexpr int NI = (8 * BN) / 64 / NW;
     __shared__ __attribute__((aligned(16))) char S[2 * STAGE_CH * 16];
     __shared__ __attribute__((aligned(16))) float Wr[4 * 512];   // layer-1 geometry weights (rx, ry, rz, refl rows), C1pad <= 512
     const int tid = threadIdx.x, lane = tid & 63;
     for (int i = tid; i < 4 * C1pad; i += 512) Wr[i] = w1r4[i];
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wave >> 2, wc = wave & 3;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wave / WCn, wc = wave % WCn;
     const int nitems = nMt * nNt, nslab = C1pad / G_BK;
     const int first = blockIdx.x, stride = gridDim.x;
     if (first >= nitems) return;
@@ -1154,7 +1156,7 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
     auto item_mt = [&](int it) { return (first + it * stride) / nNt; };
     auto item_nt = [&](int it) { return (first + it * stride) % nNt; };
 
-    const int prow = tid >> 2, pq = tid & 3;
+    const int prow = tid >> 2, pq = tid & 3;   // rows prow + 128*u, u < NR ((row>>2)&3 is the same for all of them)
     const int a_dst = (prow * 4 + (pq ^ ((prow >> 2) & 3))) * 16;
     // per-lane pieces of the B DMA source that do not depend on the item
     size_t boff[NI];
@@ -1173,33 +1175,46 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
                                              (lds_vp)(S + ((size_t)stage * STAGE_CH + dstc[i]) * 16), 16, 0, 0);
     };
     // metadata of the producer's edge row (clamped: rows past the last target replay the last valid row)
-    auto load_meta = [&](int it, int& mj, float4& mg) {
-        long row = (long)item_mt(it) * BM + prow;
-        const long last = (long)M * 32 - 1;
-        row = row < last ? row : last;
-        mj = meta_j[row];
-        mg = meta_g[row];
+    struct Meta { int j[NR]; float4 g[NR]; };
+    struct Vals { float4 v[NR][2]; };
+    auto load_meta = [&](int it, Meta& m) {
+#pragma unroll
+        for (int u = 0; u < NR; ++u) {
+            long row = (long)item_mt(it) * BM + prow + 128 * u;
+            const long last = (long)M * 32 - 1;
+            row = row < last ? row : last;
+            m.j[u] = meta_j[row];      // < 0: empty neighbour slot (its row is masked in the epilogue)
+            m.g[u] = meta_g[row];
+        }
     };
-    float4 pv[2];
-    auto gather = [&](int mj, int k0) {
-        const float* p = P + (size_t)mj * ldp + 8 * pq + k0;
+    Vals pv;
+    auto gather = [&](const Meta& m, int k0) {
         const int k = k0 + 8 * pq;
-        pv[0] = (k < C1) ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
-        pv[1] = (k + 4 < C1) ? *reinterpret_cast<const float4*>(p + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < NR; ++u) {
+            const bool on = m.j[u] >= 0;
+            const float* p = P + (size_t)(on ? m.j[u] : 0) * ldp + 8 * pq + k0;
+            pv.v[u][0] = (on && k < C1) ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+            pv.v[u][1] = (on && k + 4 < C1) ? *reinterpret_cast<const float4*>(p + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     };
-    auto produce = [&](int stage, const float4& rg, int k0) {
+    auto produce = [&](int stage, const Meta& m, int k0) {
         const int k = k0 + 8 * pq;
+#pragma unroll
+      for (int u = 0; u < NR; ++u) {
+        const float4 rg = m.g[u];
+        const bool on = m.j[u] >= 0;
         h8 hi, lo;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const int kk = k + 4 * half;
             float v[4] = {0.f, 0.f, 0.f, 0.f};
-            if (kk < C1) {
+            if (on && kk < C1) {
                 const float4 wx = *reinterpret_cast<const float4*>(&Wr[0 * C1pad + kk]);
                 const float4 wy = *reinterpret_cast<const float4*>(&Wr[1 * C1pad + kk]);
                 const float4 wz = *reinterpret_cast<const float4*>(&Wr[2 * C1pad + kk]);
                 const float4 wf = *reinterpret_cast<const float4*>(&Wr[3 * C1pad + kk]);
-                const float4 p = pv[half];
+                const float4 p = pv.v[u][half];
                 v[0] = fmaxf(fmaf(rg.w, wf.x, fmaf(rg.z, wz.x, fmaf(rg.y, wy.x, fmaf(rg.x, wx.x, p.x)))), 0.f);
                 v[1] = fmaxf(fmaf(rg.w, wf.y, fmaf(rg.z, wz.y, fmaf(rg.y, wy.y, fmaf(rg.x, wx.y, p.y)))), 0.f);
                 v[2] = fmaxf(fmaf(rg.w, wf.z, fmaf(rg.z, wz.z, fmaf(rg.y, wy.z, fmaf(rg.x, wx.z, p.z)))), 0.f);
@@ -1212,8 +1227,9 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
             }
         }
         char* st = S + (size_t)stage * STAGE_CH * 16;
-        *reinterpret_cast<h8*>(st + a_dst) = hi;
-        *reinterpret_cast<h8*>(st + BM * 64 + a_dst) = lo;
+        *reinterpret_cast<h8*>(st + a_dst + u * 128 * 64) = hi;
+        *reinterpret_cast<h8*>(st + BM * 64 + a_dst + u * 128 * 64) = lo;
+      }
     };
 
     const int r = lane & 31, h = lane >> 5;
@@ -1241,15 +1257,15 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
     //   gather stage  : slab g+2      (global loads of P rows + W2 DMA of slab g+1 issued right after the barrier)
     // Metadata (source row, normalised offset) of an item is prefetched one item ahead of the gather stage.
     int it_q = 0, s_q = 0;                   // item / slab of the gather stage
-    int mj_q, mj_nxt = 0;
-    float4 mg_q, mg_nxt = make_float4(0.f, 0.f, 0.f, 0.f);
-    load_meta(0, mj_q, mg_q);
-    if (my_items > 1) load_meta(1, mj_nxt, mg_nxt);
+    Meta m_q, m_nxt;
+    load_meta(0, m_q);
+    m_nxt = m_q;
+    if (my_items > 1) load_meta(1, m_nxt);
     auto advance_q = [&]() {                 // move the gather stage to the next slab (possibly the next item)
         if (++s_q == nslab) {
             s_q = 0; ++it_q;
-            mj_q = mj_nxt; mg_q = mg_nxt;
-            if (it_q + 1 < my_items) load_meta(it_q + 1, mj_nxt, mg_nxt);
+            m_q = m_nxt;
+            if (it_q + 1 < my_items) load_meta(it_q + 1, m_nxt);
         }
     };
     // prologue: slab 0 produced synchronously, slab 1 gathered
@@ -1258,15 +1274,15 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
     int mt_1 = mt_cur, nt_1 = nt_cur;                               // item in the produce stage
     __syncthreads();   // Wr staged
     issue(0, wb1, 0);
-    gather(mj_q, 0);
-    produce(0, mg_q, 0);
-    float4 pn[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};  // gathered values of slab g+1
-    float4 mg_n = mg_q;
+    gather(m_q, 0);
+    produce(0, m_q, 0);
+    Vals pn = pv;          // gathered values of slab g+1
+    Meta m_n = m_q;
     int k_n = 0;
     if (total > 1) {
         advance_q();
-        gather(mj_q, s_q * G_BK);
-        pn[0] = pv[0]; pn[1] = pv[1]; mg_n = mg_q; k_n = s_q * G_BK;
+        gather(m_q, s_q * G_BK);
+        pn = pv; m_n = m_q; k_n = s_q * G_BK;
     }
     int it = 0, s = 0;                       // item / slab of the MFMA stage
     int it1 = 0, s1 = 0;                     // item / slab of the produce stage (g+1)
@@ -1283,12 +1299,13 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
             issue((g + 1) & 1, wb1, s1 * G_BK);
         }
         // values for the produce stage were gathered during the previous iteration
-        const float4 pu0 = pn[0], pu1 = pn[1], mg_u = mg_n;
+        const Vals pu = pn;
+        const Meta m_u = m_n;
         const int k_u = k_n;
         if (g + 2 < total) {
             advance_q();
-            gather(mj_q, s_q * G_BK);
-            pn[0] = pv[0]; pn[1] = pv[1]; mg_n = mg_q; k_n = s_q * G_BK;
+            gather(m_q, s_q * G_BK);
+            pn = pv; m_n = m_q; k_n = s_q * G_BK;
         }
         const char* st = S + (size_t)(g & 1) * STAGE_CH * 16;
 #pragma unroll
@@ -1311,13 +1328,13 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
                 }
             if (kk == 0) {  // producer VALU work runs while the 12 MFMAs above are in the matrix pipe
                 __builtin_amdgcn_sched_barrier(0);
-                if (more) { pv[0] = pu0; pv[1] = pu1; produce((g + 1) & 1, mg_u, k_u); }
+                if (more) { pv = pu; produce((g + 1) & 1, m_u, k_u); }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (s == nslab - 1) {  // item finished: reduce over neighbour slots and store, then start the next accumulation
-            sa_epilogue(acc, wscale, mt_cur * 4, nt_cur * BN, wr, wc, lane, M, kw, deg, C2, b2, bn_s, bn_t, out, ldo, out_h2,
-                        ldh);
+            sa_epilogue(acc, wscale, mt_cur * (BM / 32), nt_cur * BN, wr, wc, lane, M, kw, deg, C2, b2, bn_s, bn_t, out, ldo,
+                        out_h2, ldh);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1347,7 +1364,7 @@ extern "C" int32_t p2w_sa_conv_f16x3(const float* P, int32_t ldp, const float* x
     int C2pad, C1pad;
     p2w_packed_dims(C2, C1, &C2pad, &C1pad);
     static const int sa_v1 = []() { const char* e = getenv("P2W_SA_V1"); return e ? atoi(e) : 0; }();
-    if (C2 >= 256 && sa_v1 == 0 && ws != nullptr && ws_bytes >= (size_t)M * 32 * 20 && C1pad <= 512) {
+    if (sa_v1 == 0 && ws != nullptr && ws_bytes >= (size_t)M * 32 * 20 && C1pad <= 512) {
         // v3: edge metadata pre-pass + persistent pipelined kernel (one workgroup per CU)
         if (reinterpret_cast<uintptr_t>(ws) & 15u) return P2W_EALIGN;
         float4* meta_g = static_cast<float4*>(ws);
@@ -1359,12 +1376,18 @@ extern "C" int32_t p2w_sa_conv_f16x3(const float* P, int32_t ldp, const float* x
             if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
             return n > 0 ? n : 256;
         }();
-        const int nMt3 = p2w_cdiv(M, 4), nNt3 = p2w_cdiv(C2, 256);
+        const bool wide = C2 > 128;
+        const int nMt3 = p2w_cdiv(M, wide ? 4 : 8), nNt3 = p2w_cdiv(C2, wide ? 256 : 128);
         const long items = (long)nMt3 * nNt3;
         const int grid = (int)(items < n_cu ? items : n_cu);
-        sa_conv16p_kernel<<<grid, 512, 0, p2w_s(stream)>>>(
-            P, ldp, meta_j, meta_g, deg, kw, M, w1r4, C1, C1pad, static_cast<const _Float16*>(W2h), (size_t)C2pad * C1pad,
-            wscale, C2, nMt3, nNt3, b2, bn_s, bn_t, out, ldo, static_cast<_Float16*>(out_h2), ldh);
+        if (wide)
+            sa_conv16p_kernel<256><<<grid, 512, 0, p2w_s(stream)>>>(
+                P, ldp, meta_j, meta_g, deg, kw, M, w1r4, C1, C1pad, static_cast<const _Float16*>(W2h), (size_t)C2pad * C1pad,
+                wscale, C2, nMt3, nNt3, b2, bn_s, bn_t, out, ldo, static_cast<_Float16*>(out_h2), ldh);
+        else
+            sa_conv16p_kernel<128><<<grid, 512, 0, p2w_s(stream)>>>(
+                P, ldp, meta_j, meta_g, deg, kw, M, w1r4, C1, C1pad, static_cast<const _Float16*>(W2h), (size_t)C2pad * C1pad,
+                wscale, C2, nMt3, nNt3, b2, bn_s, bn_t, out, ldo, static_cast<_Float16*>(out_h2), ldh);
         return P2W_LAUNCH_STATUS();
     }
     if (C2 >= 256 && sa_v1 != 1) {  // wide layers: 128 x 256 tile, W2 on the DMA ring, A produced one slab ahead
