@@ -1147,9 +1147,20 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
     for (int i = tid; i < 4 * C1pad; i += 512) Wr[i] = w1r4[i];
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wave / WCn, wc = wave % WCn;
     const int nitems = nMt * nNt, nslab = C1pad / G_BK;
-    const int first = blockIdx.x, stride = gridDim.x;
-    if (first >= nitems) return;
-    const int my_items = (nitems - first + stride - 1) / stride;
+    // XCD-aware work assignment: workgroups b, b+8, b+16.. share an XCD (round-robin dispatch) and therefore an L2.
+    // Each XCD walks ONE contiguous chunk of work items, its workgroups taking consecutive items at every step, so the
+    // P rows gathered by an XCD at any time belong to spatially adjacent targets (levels are stored in grid-cell
+    // order) and are re-used out of that XCD's L2 instead of being streamed by all eight.
+    int first, stride, limit;
+    if ((gridDim.x & 7) == 0) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per = gridDim.x >> 3;
+        const int chunk = (nitems + 7) >> 3;
+        first = xcd * chunk + slot; stride = per; limit = min((xcd + 1) * chunk, nitems);
+    } else {
+        first = blockIdx.x; stride = gridDim.x; limit = nitems;
+    }
+    if (first >= limit) return;
+    const int my_items = (limit - first + stride - 1) / stride;
     const int total = my_items * nslab;
 
     // item -> (row tile, column tile): column tiles of one row tile are adjacent work items
@@ -1208,18 +1219,19 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const int kk = k + 4 * half;
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
-            if (on && kk < C1) {
-                const float4 wx = *reinterpret_cast<const float4*>(&Wr[0 * C1pad + kk]);
-                const float4 wy = *reinterpret_cast<const float4*>(&Wr[1 * C1pad + kk]);
-                const float4 wz = *reinterpret_cast<const float4*>(&Wr[2 * C1pad + kk]);
-                const float4 wf = *reinterpret_cast<const float4*>(&Wr[3 * C1pad + kk]);
-                const float4 p = pv.v[u][half];
-                v[0] = fmaxf(fmaf(rg.w, wf.x, fmaf(rg.z, wz.x, fmaf(rg.y, wy.x, fmaf(rg.x, wx.x, p.x)))), 0.f);
-                v[1] = fmaxf(fmaf(rg.w, wf.y, fmaf(rg.z, wz.y, fmaf(rg.y, wy.y, fmaf(rg.x, wx.y, p.y)))), 0.f);
-                v[2] = fmaxf(fmaf(rg.w, wf.z, fmaf(rg.z, wz.z, fmaf(rg.y, wy.z, fmaf(rg.x, wx.z, p.z)))), 0.f);
-                v[3] = fmaxf(fmaf(rg.w, wf.w, fmaf(rg.z, wz.w, fmaf(rg.y, wy.w, fmaf(rg.x, wx.w, p.w)))), 0.f);
-            }
+            // branch-free (so the scheduler can interleave it with MFMAs): Wr is zero-padded to C1pad, P values of
+            // empty slots / padded k are zero, and the geometry term is switched off with a select
+            const float4 wx = *reinterpret_cast<const float4*>(&Wr[0 * C1pad + kk]);
+            const float4 wy = *reinterpret_cast<const float4*>(&Wr[1 * C1pad + kk]);
+            const float4 wz = *reinterpret_cast<const float4*>(&Wr[2 * C1pad + kk]);
+            const float4 wf = *reinterpret_cast<const float4*>(&Wr[3 * C1pad + kk]);
+            const float4 p = pv.v[u][half];
+            const float gx = on ? rg.x : 0.f, gy = on ? rg.y : 0.f, gz = on ? rg.z : 0.f, gw = on ? rg.w : 0.f;
+            float v[4];
+            v[0] = fmaxf(fmaf(gw, wf.x, fmaf(gz, wz.x, fmaf(gy, wy.x, fmaf(gx, wx.x, p.x)))), 0.f);
+            v[1] = fmaxf(fmaf(gw, wf.y, fmaf(gz, wz.y, fmaf(gy, wy.y, fmaf(gx, wx.y, p.y)))), 0.f);
+            v[2] = fmaxf(fmaf(gw, wf.z, fmaf(gz, wz.z, fmaf(gy, wy.z, fmaf(gx, wx.z, p.z)))), 0.f);
+            v[3] = fmaxf(fmaf(gw, wf.w, fmaf(gz, wz.w, fmaf(gy, wy.w, fmaf(gx, wx.w, p.w)))), 0.f);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 hi[4 * half + e] = (_Float16)fminf(v[e], 65504.f);   // v >= 0 after the ReLU
@@ -1326,9 +1338,14 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
-            if (kk == 0) {  // producer VALU work runs while the 12 MFMAs above are in the matrix pipe
-                __builtin_amdgcn_sched_barrier(0);
-                if (more) { pv = pu; produce((g + 1) & 1, m_u, k_u); }
+            if (kk == 0) {  // producer VALU work is interleaved into the gaps of the 12 MFMAs above (1 MFMA : 8 VALU)
+                pv = pu;
+                produce((g + 1) & 1, m_u, k_u);   // unconditional: after the last slab it fills a stage nobody reads
+#pragma unroll
+                for (int q = 0; q < 12; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 8 * NR, 0);   // VALU
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -1379,7 +1396,8 @@ extern "C" int32_t p2w_sa_conv_f16x3(const float* P, int32_t ldp, const float* x
         const bool wide = C2 > 128;
         const int nMt3 = p2w_cdiv(M, wide ? 4 : 8), nNt3 = p2w_cdiv(C2, wide ? 256 : 128);
         const long items = (long)nMt3 * nNt3;
-        const int grid = (int)(items < n_cu ? items : n_cu);
+        int grid = (int)(items < n_cu ? items : n_cu);
+        if (grid >= 8) grid &= ~7;   // whole XCD rounds (see the kernel's work assignment)
         if (wide)
             sa_conv16p_kernel<256><<<grid, 512, 0, p2w_s(stream)>>>(
                 P, ldp, meta_j, meta_g, deg, kw, M, w1r4, C1, C1pad, static_cast<const _Float16*>(W2h), (size_t)C2pad * C1pad,
