@@ -231,6 +231,46 @@ __device__ __forceinline__ void sa_epilogue(const f32x16 (&acc)[2][2], float wsc
     }
 }
 
+// same as sa_epilogue with the per-column parameters and the two target degrees already in registers
+struct SaEpiRegs { float bias[2], s[2], t[2]; int d[2]; };
+__device__ __forceinline__ void sa_epilogue_regs(const f32x16 (&acc)[2][2], float wscale, int t0, int n0, int wr, int wc,
+                                                 int lane, int M, const SaEpiRegs& e, int C2, float* __restrict__ out, int ldo,
+                                                 _Float16* __restrict__ out_h2, int ldh) {
+    const int h = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int tgt = t0 + wr * 2 + i;
+        if (tgt >= M) continue;
+        const int d = e.d[i];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wc * 64 + j * 32 + (lane & 31);
+            const bool cv = col < C2;
+            float vmax = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int slot = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float v = fmaf(fmaxf(fmaf(acc[i][j][r], wscale, e.bias[j]), 0.f), e.s[j], e.t[j]);
+                if (slot < d) vmax = fmaxf(vmax, v);
+            }
+            vmax = fmaxf(vmax, __shfl_xor(vmax, 32));
+            if (d == 0) vmax = 0.f;
+            if (cv && h == 0 && out) out[(size_t)tgt * ldo + col] = vmax;
+            if (out_h2) {
+                const float nb = __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(vmax), 0xB1, 0xf, 0xf, false));
+                if (h == 0 && (lane & 1) == 0 && col < ldh) {
+                    _Float16 h0, l0, h1, l1;
+                    sa_split(vmax, h0, l0);
+                    sa_split(nb, h1, l1);
+                    _Float16* p = out_h2 + (size_t)tgt * (2 * ldh) + col;
+                    *reinterpret_cast<unsigned*>(p) = sa_pack(h0, h1);
+                    *reinterpret_cast<unsigned*>(p + ldh) = sa_pack(l0, l1);
+                }
+            }
+        }
+    }
+}
+
 // per-row geometry of a 4-target row tile (pointnet.py:119-129): rows tid<128 = (target t0 + tid/32, slot tid%32);
 // writes the source index and (normalised relative position, source reflectance) of every row to LDS
 __device__ __forceinline__ void sa_row_geometry(int tid, int t0, int M, int kw, const float4* __restrict__ xyzr,
@@ -1137,7 +1177,9 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
                                                             int nMt, int nNt, const float* __restrict__ b2,
                                                             const float* __restrict__ bn_s, const float* __restrict__ bn_t,
                                                             float* __restrict__ out, int ldo, _Float16* __restrict__ out_h2,
-                                                            int ldh) {
+                                                            int ldh, int dbg) {
+    // dbg (profiling ablations, 0 in production): 1 no epilogue, 2 no W2 DMA after the first, 4 no MFMA, 8 no producer,
+    // 16 no P gather
     constexpr int WCn = BN / 64, BM = 64 * (8 / WCn), NW = 8, NR = BM / 128;   // NR producer rows per thread
     constexpr int A_CH = 8 * BM, STAGE_CH = A_CH + 8 * BN;
     constexpr int NI = (8 * BN) / 64 / NW;
@@ -1281,6 +1323,22 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
         }
     };
     // prologue: slab 0 produced synchronously, slab 1 gathered
+    auto load_epi = [&](int mt_, int nt_, SaEpiRegs& e) {   // parameters of an item's epilogue, fetched an item ahead
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = nt_ * BN + wc * 64 + j * 32 + (lane & 31);
+            const bool cv = col < C2;
+            e.bias[j] = cv ? b2[col] : 0.f; e.s[j] = cv ? bn_s[col] : 0.f; e.t[j] = cv ? bn_t[col] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int tgt = mt_ * (BM / 32) + wr * 2 + i;
+            e.d[i] = tgt < M ? min(deg[tgt], kw) : 0;
+        }
+    };
+    SaEpiRegs e_cur, e_1;
+    load_epi(item_mt(0), item_nt(0), e_cur);
+    e_1 = e_cur;
     const _Float16* wb1 = W2h + (size_t)item_nt(0) * BN * C1pad;   // W2 panel of the item in the produce stage
     int mt_cur = item_mt(0), nt_cur = item_nt(0);                   // item in the MFMA stage
     int mt_1 = mt_cur, nt_1 = nt_cur;                               // item in the produce stage
@@ -1307,8 +1365,9 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
                 s1 = 0; it1 = it + 1;
                 mt_1 = item_mt(it1); nt_1 = item_nt(it1);
                 wb1 = W2h + (size_t)nt_1 * BN * C1pad;
+                load_epi(mt_1, nt_1, e_1);
             }
-            issue((g + 1) & 1, wb1, s1 * G_BK);
+            if (!(dbg & 2)) issue((g + 1) & 1, wb1, s1 * G_BK);
         }
         // values for the produce stage were gathered during the previous iteration
         const Vals pu = pn;
@@ -1316,7 +1375,7 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
         const int k_u = k_n;
         if (g + 2 < total) {
             advance_q();
-            gather(m_q, s_q * G_BK);
+            if (!(dbg & 16)) gather(m_q, s_q * G_BK);
             pn = pv; m_n = m_q; k_n = s_q * G_BK;
         }
         const char* st = S + (size_t)(g & 1) * STAGE_CH * 16;
@@ -1330,6 +1389,7 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
                 bh[t] = *reinterpret_cast<const h8*>(st + (offB[0][t] ^ (kk << 5)));
                 bl[t] = *reinterpret_cast<const h8*>(st + (offB[1][t] ^ (kk << 5)));
             }
+            if (!(dbg & 4)) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1338,7 +1398,8 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
-            if (kk == 0) {  // producer VALU work is interleaved into the gaps of the 12 MFMAs above (1 MFMA : 8 VALU)
+            }
+            if (kk == 0 && !(dbg & 8)) {  // producer VALU work is interleaved into the gaps of the 12 MFMAs above (1 MFMA : 8 VALU)
                 pv = pu;
                 produce((g + 1) & 1, m_u, k_u);   // unconditional: after the last slab it fills a stage nobody reads
 #pragma unroll
@@ -1349,9 +1410,8 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (s == nslab - 1) {  // item finished: reduce over neighbour slots and store, then start the next accumulation
-            sa_epilogue(acc, wscale, mt_cur * (BM / 32), nt_cur * BN, wr, wc, lane, M, kw, deg, C2, b2, bn_s, bn_t, out, ldo,
-                        out_h2, ldh);
+        if (s == nslab - 1 && !(dbg & 1)) {  // item finished: reduce over neighbour slots and store, then start the next accumulation
+            sa_epilogue_regs(acc, wscale, mt_cur * (BM / 32), nt_cur * BN, wr, wc, lane, M, e_cur, C2, out, ldo, out_h2, ldh);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1359,6 +1419,7 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
         }
+        if (s == nslab - 1) e_cur = e_1;
         s = s1; it = it1; mt_cur = mt_1; nt_cur = nt_1;
     }
 }
@@ -1394,6 +1455,7 @@ extern "C" int32_t p2w_sa_conv_f16x3(const float* P, int32_t ldp, const float* x
             return n > 0 ? n : 256;
         }();
         const bool wide = C2 > 128;
+        const int sadbg = getenv("P2W_SA_DBG") ? atoi(getenv("P2W_SA_DBG")) : 0;
         const int nMt3 = p2w_cdiv(M, wide ? 4 : 8), nNt3 = p2w_cdiv(C2, wide ? 256 : 128);
         const long items = (long)nMt3 * nNt3;
         int grid = (int)(items < n_cu ? items : n_cu);
@@ -1401,11 +1463,11 @@ extern "C" int32_t p2w_sa_conv_f16x3(const float* P, int32_t ldp, const float* x
         if (wide)
             sa_conv16p_kernel<256><<<grid, 512, 0, p2w_s(stream)>>>(
                 P, ldp, meta_j, meta_g, deg, kw, M, w1r4, C1, C1pad, static_cast<const _Float16*>(W2h), (size_t)C2pad * C1pad,
-                wscale, C2, nMt3, nNt3, b2, bn_s, bn_t, out, ldo, static_cast<_Float16*>(out_h2), ldh);
+                wscale, C2, nMt3, nNt3, b2, bn_s, bn_t, out, ldo, static_cast<_Float16*>(out_h2), ldh, sadbg);
         else
             sa_conv16p_kernel<128><<<grid, 512, 0, p2w_s(stream)>>>(
                 P, ldp, meta_j, meta_g, deg, kw, M, w1r4, C1, C1pad, static_cast<const _Float16*>(W2h), (size_t)C2pad * C1pad,
-                wscale, C2, nMt3, nNt3, b2, bn_s, bn_t, out, ldo, static_cast<_Float16*>(out_h2), ldh);
+                wscale, C2, nMt3, nNt3, b2, bn_s, bn_t, out, ldo, static_cast<_Float16*>(out_h2), ldh, sadbg);
         return P2W_LAUNCH_STATUS();
     }
     if (C2 >= 256 && sa_v1 != 1) {  // wide layers: 128 x 256 tile, W2 on the DMA ring, A produced one slab ahead
