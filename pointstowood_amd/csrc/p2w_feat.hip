@@ -20,16 +20,36 @@ extern "C" void p2w_packed_dims(int32_t N, int32_t K, int32_t* N_pad, int32_t* K
     if (K_pad) *K_pad = (K + G_BK - 1) / G_BK * G_BK;
 }
 
-// XCD-aware tile order: blocks L, L+8, L+16.. share an XCD (round-robin dispatch); give each XCD
-// whole row-tiles so the column tiles of one A row-tile reuse it from that XCD's L2.
-__device__ __forceinline__ bool tile_coords(int nMt, int nNt, int* mt, int* nt) {
+// XCD-aware tile order: blocks L, L+8, L+16.. share an XCD (round-robin dispatch), i.e. one 4 MiB L2.
+//  mode 0 (W fits in L2): an XCD owns whole row tiles and walks their column tiles back to back -> the A row tile is
+//          fetched once, W is always an L2 hit.
+//  mode 1 (W larger than L2, few rows): an XCD owns a slice of column tiles (its W slice stays L2-resident) and sweeps
+//          ALL row tiles; A is streamed once per XCD slice instead of W once per row tile.
+__device__ __forceinline__ bool tile_coords(int nMt, int nNt, int* mt, int* nt, int mode = 0) {
     const int L = blockIdx.x;
     const int xcd = L & 7, w = L >> 3;
-    *mt = xcd + 8 * (w / nNt);
-    *nt = w % nNt;
+    if (mode == 0) {
+        *mt = xcd + 8 * (w / nNt);
+        *nt = w % nNt;
+        return *mt < nMt;
+    }
+    if (nNt >= 8) {
+        const int cpx = (nNt + 7) >> 3;     // column tiles per XCD
+        *mt = w / cpx;
+        *nt = xcd + 8 * (w % cpx);
+        return *mt < nMt && *nt < nNt;
+    }
+    const int r = 8 / nNt;                  // XCDs sharing one column tile (nNt in {1, 2, 4})
+    *nt = xcd % nNt;
+    *mt = xcd / nNt + r * w;
     return *mt < nMt;
 }
-static inline int tile_grid(int nMt, int nNt) { return 8 * ((nMt + 7) / 8) * nNt; }
+static inline int tile_grid(int nMt, int nNt, int mode = 0) {
+    if (mode == 0) return 8 * ((nMt + 7) / 8) * nNt;
+    if (nNt >= 8) return 8 * nMt * ((nNt + 7) / 8);
+    const int r = 8 / nNt;
+    return 8 * ((nMt + r - 1) / r);
+}
 
 // one BK-slab of MFMAs for a 64x64 wave tile
 __device__ __forceinline__ void mma_slab(const float* __restrict__ As, const float* __restrict__ Bs, int wr, int wc, int lane,
@@ -760,7 +780,7 @@ template <int WR, int WC, int RT, int CT>   // waves WR x WC, wave tile (32*RT) 
 __global__ __launch_bounds__(64 * WR * WC, 2) void gemm_h2g_kernel(const _Float16* __restrict__ A, int ldh_a,
                                                                 const _Float16* __restrict__ Wh, size_t plane, float wscale,
                                                                 int M, int N, int Kpad, int nMt, int nNt, EpiArgs ep,
-                                                                OutArgs o, int dbg, int ef) {
+                                                                OutArgs o, int dbg, int ef, int tmode) {
     // dbg (profiling ablations, 0 in production): 1 = skip the epilogue, 2 = issue only the first slab's DMA,
     // 4 = skip the MFMAs
     constexpr int BM = 32 * RT * WR, BN = 32 * CT * WC, NW = WR * WC;
@@ -769,7 +789,7 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void gemm_h2g_kernel(const _Float1
     static_assert(STAGE_CH % (64 * NW) == 0, "stage must split evenly over the waves");
     __shared__ __attribute__((aligned(16))) char S[2 * STAGE_CH * 16];
     int mt, nt;
-    if (!tile_coords(nMt, nNt, &mt, &nt)) return;
+    if (!tile_coords(nMt, nNt, &mt, &nt, tmode)) return;
     const int m0 = mt * BM, n0 = nt * BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wave / WC, wc = wave % WC;
@@ -909,14 +929,25 @@ extern "C" int32_t p2w_gemm_h2(const void* A_h2, int32_t ldh_a, const void* Wh, 
         if ((size_t)M * (size_t)(ldo > 2 * ldh_o ? ldo : 2 * ldh_o) >= lim || (ep.residual && (size_t)M * ep.ldr >= lim) ||
             (N & 1) || getenv("P2W_GEMM_GENERIC_EPI"))
             ef = 0;
+        // tile order: keep W L2-resident per XCD when it does not fit an XCD's L2 (see tile_coords)
+        static const int force_mode = []() { const char* e = getenv("P2W_GEMM_TMODE"); return e ? atoi(e) : -1; }();
+        const size_t w_bytes = (size_t)N * Kpad * 4;
+        auto pick_mode = [&](int nNtx) {
+            const bool ok = nNtx >= 8 || (nNtx > 0 && 8 % nNtx == 0);
+            if (!ok) return 0;
+            if (force_mode >= 0) return force_mode;
+            return w_bytes > (size_t)3 * 1024 * 1024 ? 1 : 0;
+        };
         if (big) {
             const int nMt = p2w_cdiv(M, 256), nNt2 = Npad / 256;
-            gemm_h2g_kernel<2, 4, 4, 2><<<tile_grid(nMt, nNt2), 512, 0, p2w_s(stream)>>>(
-                Ah, ldh_a, Wp, (size_t)Npad * Kpad, wscale, M, N, Kpad, nMt, nNt2, ep, o, dbg, ef);
+            const int tm = pick_mode(nNt2);
+            gemm_h2g_kernel<2, 4, 4, 2><<<tile_grid(nMt, nNt2, tm), 512, 0, p2w_s(stream)>>>(
+                Ah, ldh_a, Wp, (size_t)Npad * Kpad, wscale, M, N, Kpad, nMt, nNt2, ep, o, dbg, ef, tm);
         } else {
             const int nMt = p2w_cdiv(M, 128), nNt1 = p2w_cdiv(N, 128);
-            gemm_h2g_kernel<2, 2, 2, 2><<<tile_grid(nMt, nNt1), 256, 0, p2w_s(stream)>>>(
-                Ah, ldh_a, Wp, (size_t)Npad * Kpad, wscale, M, N, Kpad, nMt, nNt1, ep, o, dbg, ef);
+            const int tm = pick_mode(nNt1);
+            gemm_h2g_kernel<2, 2, 2, 2><<<tile_grid(nMt, nNt1, tm), 256, 0, p2w_s(stream)>>>(
+                Ah, ldh_a, Wp, (size_t)Npad * Kpad, wscale, M, N, Kpad, nMt, nNt1, ep, o, dbg, ef, tm);
         }
         return P2W_LAUNCH_STATUS();
     }
