@@ -196,6 +196,7 @@ class Engine:
         if not 1 <= self.k <= 32:
             raise ValueError("k must be in 1..32 (one 32-row MFMA tile per target)")
         self.feature_streams = int(os.environ.get("P2W_FEATURE_STREAMS", "1"))  # Net.stream(): feature phases in flight
+        self.res_chunk_rows = int(os.environ.get("P2W_RES_CHUNK", "65536"))   # rows (at 4F=512) per residual-block chunk; 0 = whole level
         self.events = None  # set to a list to record (name, start, end) events per launch
         self.stem_out = None
         self._ws = None
@@ -329,14 +330,20 @@ class Engine:
                        ptr(geo.sf), ptr(dst.nbr), ptr(dst.deg), geo.k, M, ptr(p["w1r4"]), ptr(p["W2"].w16),
                        p["W2"].wscale, C1, C2, ptr(p["b2"]), ptr(p["bn_s"]), ptr(p["bn_t"]), ptr(conv), C2, ptr(convh),
                        pad8(C2), ptr(meta), meta.numel())
-            e1, e2 = newh(M, E), newh(M, E)
-            self._gemm_h2("gemm_res", convh, pad8(C2), M, p["g1"], out_h2=e1, ldh_o=pad8(E))
-            self._gemm_h2("gemm_res", e1, pad8(E), M, p["g2"], out_h2=e2, ldh_o=pad8(E))
-            self._gemm_h2("gemm_res", e2, pad8(E), M, p["g3"], out_h2=e1, ldh_o=pad8(E))
             out = new(M, C2)
             outh = newh(M, C2) if l < 3 else None
-            self._gemm_h2("gemm_res", e1, pad8(E), M, p["g4"], out_f32=out, ldo=C2, out_h2=outh, ldh_o=pad8(C2),
-                          residual=conv, ldr=C2)
+            # residual block in row chunks: the two 4F-wide intermediates of a chunk (2 x chunk x 4F x 4 B) are written
+            # and re-read while they still sit in the 256 MiB Infinity Cache instead of round-tripping HBM
+            chunk = self.res_chunk_rows if self.res_chunk_rows > 0 else M
+            chunk = max(256, min(M, (chunk * 512 // E) // 256 * 256))      # same bytes per chunk at every level
+            e1, e2 = newh(min(M, chunk), E), newh(min(M, chunk), E)
+            for r0 in range(0, M, chunk):
+                m = min(chunk, M - r0)
+                self._gemm_h2("gemm_res", convh[r0:], pad8(C2), m, p["g1"], out_h2=e1, ldh_o=pad8(E))
+                self._gemm_h2("gemm_res", e1, pad8(E), m, p["g2"], out_h2=e2, ldh_o=pad8(E))
+                self._gemm_h2("gemm_res", e2, pad8(E), m, p["g3"], out_h2=e1, ldh_o=pad8(E))
+                self._gemm_h2("gemm_res", e1, pad8(E), m, p["g4"], out_f32=out[r0:], ldo=C2,
+                              out_h2=None if outh is None else outh[r0:], ldh_o=pad8(C2), residual=conv[r0:], ldr=C2)
             x.append(out)
             xh.append(outh)
             if keep is not None:
@@ -357,34 +364,43 @@ class Engine:
         deg4 = torch.empty(M3, dtype=torch.int32, device=dev)
         self._call("fill_batch_nbr", L.p2w_fill_batch_nbr, ptr(lv[3].batch), M3, ptr(nbr4), ptr(deg4))
         zeros_c = torch.zeros((B, 4), dtype=torch.float32, device=dev)
-        y, y_xyzr, yh = g, zeros_c, None
+        # Row-chunked chains: interp+concat -> MLP layer 0 -> MLP layer 1 (-> head for fp1) run chunk by chunk so the wide
+        # intermediates of a chunk are consumed out of the Infinity Cache (same trick as the residual blocks).
+        y, y_xyzr = g, zeros_c
+        logits = torch.empty(N, dtype=torch.float32, device=dev) if w.num_classes == 1 else None
+        o_multi = new(N, w.num_classes) if w.num_classes != 1 else None
         for fl in (4, 3, 2, 1):
             fine = lv[fl - 1]
             m, Fc, Fs = fine.n, y.shape[1], x[fl - 1].shape[1]
             nbr, deg, kw = (nbr4, deg4, 1) if fl == 4 else (*geo.fp_nbr[fl - 1], 2)
-            cat = newh(m, Fc + Fs)
-            self._call("interp_concat", L.p2w_interp_concat_h2, ptr(y), Fc, ptr(y_xyzr), ptr(fine.xyzr), ptr(nbr), ptr(deg),
-                       kw, ptr(x[fl - 1]), Fs, m, ptr(cat), pad8(Fc + Fs))
             l0, l1 = w.fp[fl]
-            a = newh(m, l0.N)
-            self._gemm_h2("gemm_mlp", cat, pad8(Fc + Fs), m, l0, out_h2=a, ldh_o=pad8(l0.N))
+            chunk = self.res_chunk_rows if self.res_chunk_rows > 0 else m
+            chunk = max(256, min(m, (chunk * 512 // (Fc + Fs)) // 256 * 256))
+            mc = min(m, chunk)
+            cat, a = newh(mc, Fc + Fs), newh(mc, l0.N)
             need_f32 = fl > 1 or keep is not None
             b = new(m, l1.N) if need_f32 else None
-            yh = newh(m, l1.N) if fl == 1 else None
-            self._gemm_h2("gemm_mlp", a, pad8(l0.N), m, l1, out_f32=b, ldo=l1.N, out_h2=yh, ldh_o=pad8(l1.N))
+            yh = newh(mc, l1.N) if fl == 1 else None
+            hd = new(mc, F3) if fl == 1 else None
+            for r0 in range(0, m, chunk):
+                mm = min(chunk, m - r0)
+                self._call("interp_concat", L.p2w_interp_concat_h2, ptr(y), Fc, ptr(y_xyzr), ptr(fine.xyzr[r0:]),
+                           ptr(nbr[r0:]), ptr(deg[r0:]), kw, ptr(x[fl - 1][r0:]), Fs, mm, ptr(cat), pad8(Fc + Fs))
+                self._gemm_h2("gemm_mlp", cat, pad8(Fc + Fs), mm, l0, out_h2=a, ldh_o=pad8(l0.N))
+                self._gemm_h2("gemm_mlp", a, pad8(l0.N), mm, l1, out_f32=None if b is None else b[r0:], ldo=l1.N,
+                              out_h2=yh, ldh_o=pad8(l1.N))
+                if fl == 1:   # head (model.py:241-243) on the same chunk
+                    self._gemm_h2("gemm_mlp", yh, pad8(F3), mm, w.head1, out_f32=hd, ldo=F3)
+                    if w.num_classes == 1:
+                        self._call("rowdot", L.p2w_rowdot, ptr(hd), F3, F3, ptr(w.head2_w), float(w.head2_b[0]), mm,
+                                   ptr(logits[r0:]))
+                    else:
+                        self._gemm("gemm_mlp", hd, F3, mm, w.head2, o_multi[r0:], w.num_classes)
             y, y_xyzr = b, fine.xyzr
             if keep is not None:
                 keep[f"fp{fl}_module.out"] = b
-        # head (model.py:241-243)
-        hd = new(N, F3)
-        self._gemm_h2("gemm_mlp", yh, pad8(F3), N, w.head1, out_f32=hd, ldo=F3)
-        if w.num_classes == 1:
-            logits = torch.empty(N, dtype=torch.float32, device=dev)
-            self._call("rowdot", L.p2w_rowdot, ptr(hd), F3, F3, ptr(w.head2_w), float(w.head2_b[0]), N, ptr(logits))
-        else:
-            o = new(N, w.num_classes)
-            self._gemm("gemm_mlp", hd, F3, N, w.head2, o, w.num_classes)
-            logits = o.t()
+        if w.num_classes != 1:
+            logits = o_multi.t()
         return torch.squeeze(logits)
 
     def _features_fp32(self, geo: Geometry, keep: dict | None = None):
@@ -562,14 +578,20 @@ class Engine:
                        ptr(geo.sf), ptr(dst.nbr), ptr(dst.deg), geo.k, M, ptr(p["w1r4"]), ptr(p["W2"].w16),
                        p["W2"].wscale, C1, C2, ptr(p["b2"]), ptr(p["bn_s"]), ptr(p["bn_t"]), ptr(conv), C2, ptr(convh),
                        pad8(C2), ptr(meta), meta.numel())
-            e1, e2 = newh(M, E), newh(M, E)
-            self._gemm_h2("gemm_res", convh, pad8(C2), M, p["g1"], out_h2=e1, ldh_o=pad8(E))
-            self._gemm_h2("gemm_res", e1, pad8(E), M, p["g2"], out_h2=e2, ldh_o=pad8(E))
-            self._gemm_h2("gemm_res", e2, pad8(E), M, p["g3"], out_h2=e1, ldh_o=pad8(E))
             out = new(M, C2)
             outh = newh(M, C2) if l < 3 else None
-            self._gemm_h2("gemm_res", e1, pad8(E), M, p["g4"], out_f32=out, ldo=C2, out_h2=outh, ldh_o=pad8(C2),
-                          residual=conv, ldr=C2)
+            # residual block in row chunks: the two 4F-wide intermediates of a chunk (2 x chunk x 4F x 4 B) are written
+            # and re-read while they still sit in the 256 MiB Infinity Cache instead of round-tripping HBM
+            chunk = self.res_chunk_rows if self.res_chunk_rows > 0 else M
+            chunk = max(256, min(M, (chunk * 512 // E) // 256 * 256))      # same bytes per chunk at every level
+            e1, e2 = newh(min(M, chunk), E), newh(min(M, chunk), E)
+            for r0 in range(0, M, chunk):
+                m = min(chunk, M - r0)
+                self._gemm_h2("gemm_res", convh[r0:], pad8(C2), m, p["g1"], out_h2=e1, ldh_o=pad8(E))
+                self._gemm_h2("gemm_res", e1, pad8(E), m, p["g2"], out_h2=e2, ldh_o=pad8(E))
+                self._gemm_h2("gemm_res", e2, pad8(E), m, p["g3"], out_h2=e1, ldh_o=pad8(E))
+                self._gemm_h2("gemm_res", e1, pad8(E), m, p["g4"], out_f32=out[r0:], ldo=C2,
+                              out_h2=None if outh is None else outh[r0:], ldh_o=pad8(C2), residual=conv[r0:], ldr=C2)
             x.append(out)
             xh.append(outh)
             if keep is not None:
