@@ -1,0 +1,57 @@
+"""CPU restatement of the reference voxeliser (``pointstowood/src/preprocessing.py``).  TEST INFRASTRUCTURE.
+
+Follows ``Voxelise.gpu_ground`` (:37-53), ``quantile_normalize_reflectance`` (:18-30), ``grid`` (:55-64) and the
+filtering / capping of ``write_voxels`` (:79-127) statement by statement, on CPU tensors, returning the voxels instead
+of writing ``voxel_*.pt`` files.  Third-party ``voxel_grid`` = ``oracle.ops.voxel_grid`` (which, like PyG's, bins over
+EVERY column it is given - the reference passes x, y, z, reflectance, ..., n_z, so voxels are also split by
+height-above-ground and the single maximum-reflectance point gets its own cell).  Random capping uses the given
+generator (the reference uses the global RNG), so only voxels within the cap are comparable bit for bit.
+"""
+import torch
+
+from . import ops
+
+
+def ground(pos):
+    x, y, z = pos[:, 0].contiguous(), pos[:, 1].contiguous(), pos[:, 2].contiguous()
+    res = 5.0
+    x_bins = torch.arange(float(x.min()), float(x.max()) + res, res)
+    y_bins = torch.arange(float(y.min()), float(y.max()) + res, res)
+    gi = torch.bucketize(x, x_bins) * len(y_bins) + torch.bucketize(y, y_bins)
+    _, inv = torch.unique(gi, return_inverse=True)
+    zmin = torch.full((int(inv.max()) + 1,), float("inf")).scatter_reduce(0, inv, z, reduce="amin")
+    return torch.cat((pos, (z - zmin[inv]).view(-1, 1)), dim=1)
+
+
+def quantile_normalize_reflectance(refl):
+    _, indices = torch.sort(refl, stable=True)
+    ranks = torch.argsort(indices, stable=True)
+    q = torch.clamp((ranks.float() + 1) / (len(ranks) + 1), 1e-7, 1 - 1e-7)
+    n = torch.erfinv(2 * q - 1) * torch.sqrt(torch.tensor(2.0))
+    return 2 * (n - n.min()) / (n.max() - n.min()) - 1
+
+
+def voxelise(pc, grid_sizes=(2.0, 4.0), min_pts=128, max_pts=16384, generator=None):
+    """pc: [N, >=4] float32 (x, y, z, reflectance, ...) without n_z.  Returns (list of voxel tensors [n, cols+1], n_z)."""
+    pos = ground(pc.float())
+    refl_on = not bool(torch.all(pos[:, 3] == 0))
+    if refl_on:
+        pos[:, 3] = quantile_normalize_reflectance(pos[:, 3].view(-1))
+    groups = []
+    for size in grid_sizes:
+        cell = ops.voxel_grid(pos, size)
+        for vx in torch.unique(cell):
+            idx = (cell == vx).nonzero(as_tuple=True)[0]
+            if idx.numel() >= min_pts:
+                groups.append(idx)
+    weight = (pos[:, 3] - pos[:, 3].min() + 1e-8) if refl_on else None
+    out = []
+    for idx in groups:
+        if idx.numel() > max_pts:
+            if refl_on:
+                idx = idx[torch.multinomial(weight[idx], max_pts, generator=generator)]
+            else:
+                idx = idx[torch.randint(0, idx.numel(), (max_pts,), generator=generator)]
+        v = pos[idx]
+        out.append(v[~torch.isnan(v).any(dim=1)])
+    return out, pos[:, -1]

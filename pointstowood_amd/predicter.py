@@ -60,6 +60,7 @@ class BalancedBatchSampler(torch.utils.data.Sampler):
     def __init__(self, dataset, batch_size: int, reference: bool = False, seed: int = 0):
         self.dataset, self.batch_size, self.reference, self.seed = dataset, int(batch_size), reference, seed
         self.lengths = [len(dataset.raw(i)) for i in range(len(dataset))]
+        dataset.lengths = self.lengths
         self.indices = np.argsort(self.lengths, kind="stable")
 
     def __iter__(self):
@@ -95,6 +96,31 @@ class BalancedBatchSampler(torch.utils.data.Sampler):
     def __len__(self):
         n = len(self.dataset)
         return n // self.batch_size if self.reference else -(-n // self.batch_size)
+
+
+def collate_device(voxels, reflectance_index: int = 3):
+    """Feed step for voxels that already live on the GPU (e.g. from ``preprocessing.voxelise``): the per-voxel
+    ``local_shift = mean(xyz)``, centring and ``sf = max ||p||`` of ``TestingDataset.__getitem__`` + PyG collation
+    (predicter.py:78-94,177) for a whole batch in a handful of vectorised device ops and NO host synchronisation.
+    Assumes NaN rows were already removed (the voxeliser does that).  The mean is a sequential per-segment sum on the
+    device, so ``local_shift`` can differ from the reference's CPU mean in the last bits (a pure translation)."""
+    dev = voxels[0].device
+    n = [int(v.shape[0]) for v in voxels]
+    B, total = len(voxels), sum(n)
+    cat = torch.cat(voxels, 0)
+    pos = cat[:, :3].to(torch.float32)
+    refl = cat[:, reflectance_index].to(torch.float32).contiguous()
+    lengths = torch.tensor(n, device=dev)
+    batch = torch.repeat_interleave(torch.arange(B, device=dev), lengths, output_size=total)
+    shift = torch.segment_reduce(pos.contiguous(), "mean", lengths=lengths)
+    pos = pos - shift[batch]
+    sf = torch.segment_reduce(torch.sqrt((pos ** 2).sum(dim=1)), "max", lengths=lengths)
+    ptr = torch.zeros(B + 1, dtype=torch.long)
+    ptr[1:] = torch.cumsum(torch.tensor(n), 0)
+    out = Batch(pos=pos.contiguous(), reflectance=refl, local_shift=shift.reshape(-1), sf=sf, batch=batch,
+                ptr=ptr.to(dev, non_blocking=True))
+    out.num_graphs = B
+    return out
 
 
 def load_model(path, model, device):

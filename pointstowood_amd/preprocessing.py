@@ -1,0 +1,81 @@
+"""Plot -> voxels on the GPU, in memory ("next" row of SURVEY.md 8f: the reference's ``Voxelise``,
+``pointstowood/src/preprocessing.py``, which writes ``voxel_*.pt`` files to disk between preprocessing and inference).
+
+Same arithmetic, without the per-voxel ``nonzero`` scans and without the disk round trip: one stable sort of the cell
+ids per grid size, voxels are contiguous segments of the sorted order.
+
+* ``ground_normalise``   - height above the per-5 m-XY-cell minimum z (``gpu_ground`` :37-53) -> ``n_z`` column.
+* ``quantile_normalize_reflectance`` - rank -> normal quantile -> [-1, 1] (:18-30).
+* ``voxelise``           - multi-resolution grid (:55-64), ``min_pts`` filter, cap at ``max_pts`` by reflectance-weighted
+                           sampling without replacement / uniform sampling WITH replacement (:116-120, as the reference).
+  ``mode="compat"`` bins over every column like the reference (PyG ``voxel_grid`` is handed x, y, z, reflectance,
+  ..., n_z - so voxels are also split by height above ground); ``mode="xyz"`` bins over x, y, z only.
+
+Pure tensor code (runs on whatever device the points are on); the accelerated hot path starts after this step.
+"""
+from __future__ import annotations
+
+import torch
+
+
+def ground_normalise(pos, resolution: float = 5.0):
+    x, y, z = pos[:, 0].contiguous(), pos[:, 1].contiguous(), pos[:, 2].contiguous()
+    # bin edges are built on the host in fp32 exactly like the reference's arange, then moved to the device
+    xb = torch.arange(float(x.min()), float(x.max()) + resolution, resolution).to(pos.device)
+    yb = torch.arange(float(y.min()), float(y.max()) + resolution, resolution).to(pos.device)
+    gi = torch.bucketize(x, xb) * len(yb) + torch.bucketize(y, yb)
+    _, inv = torch.unique(gi, return_inverse=True)
+    zmin = torch.full((int(inv.max()) + 1,), float("inf"), device=pos.device).scatter_reduce(0, inv, z, reduce="amin")
+    return torch.cat((pos, (z - zmin[inv]).view(-1, 1)), dim=1)
+
+
+def quantile_normalize_reflectance(refl):
+    if torch.isnan(refl).any():
+        raise ValueError("Input reflectance tensor contains NaN values.")
+    _, indices = torch.sort(refl, stable=True)
+    ranks = torch.argsort(indices, stable=True)
+    q = torch.clamp((ranks.float() + 1) / (len(ranks) + 1), 1e-7, 1 - 1e-7)
+    n = torch.erfinv(2 * q - 1) * torch.sqrt(torch.tensor(2.0, device=refl.device))
+    return 2 * (n - n.min()) / (n.max() - n.min()) - 1
+
+
+def _cells(P, size):
+    """PyG voxel_grid(P, size) with batch=None: every column of P is binned with the same cell size."""
+    n = P.shape[0]
+    Pb = torch.cat([P, torch.zeros((n, 1), dtype=P.dtype, device=P.device)], dim=1)
+    S = torch.cat([torch.full((P.shape[1],), float(size), dtype=P.dtype, device=P.device),
+                   torch.ones(1, dtype=P.dtype, device=P.device)])
+    lo, hi = Pb.min(dim=0).values, Pb.max(dim=0).values
+    cnt = ((hi - lo) / S).to(torch.long) + 1
+    stride = torch.ones_like(cnt)
+    stride[1:] = torch.cumprod(cnt, 0)[:-1]
+    return (((Pb - lo[None]) / S[None]).to(torch.long) * stride[None]).sum(dim=1)
+
+
+def voxelise(pc, grid_sizes=(2.0, 4.0), min_pts: int = 128, max_pts: int = 16384, mode: str = "compat", generator=None):
+    """pc: [N, >=4] (x, y, z, reflectance, ...) without n_z.  Returns (voxels, n_z): ``voxels`` is a list of
+    ``[n, cols+1]`` float32 tensors on ``pc.device`` in the reference's order (grid size major, ascending cell id)."""
+    if mode not in ("compat", "xyz"):
+        raise ValueError("mode must be 'compat' or 'xyz'")
+    pos = ground_normalise(pc.to(torch.float32))
+    refl_on = not bool(torch.all(pos[:, 3] == 0))
+    if refl_on:
+        pos[:, 3] = quantile_normalize_reflectance(pos[:, 3].reshape(-1))
+    weight = (pos[:, 3] - pos[:, 3].min() + 1e-8) if refl_on else None
+    voxels = []
+    for size in grid_sizes:
+        cell = _cells(pos if mode == "compat" else pos[:, :3], size)
+        order = torch.argsort(cell, stable=True)          # points of a voxel keep their original relative order
+        uniq, counts = torch.unique_consecutive(cell[order], return_counts=True)
+        starts = torch.cumsum(counts, 0) - counts
+        keep = (counts >= min_pts).nonzero(as_tuple=True)[0]
+        for s, c in zip(starts[keep].tolist(), counts[keep].tolist()):
+            idx = order[s:s + c]
+            if c > max_pts:
+                if refl_on:
+                    idx = idx[torch.multinomial(weight[idx], max_pts, generator=generator)]
+                else:
+                    idx = idx[torch.randint(0, c, (max_pts,), generator=generator, device=idx.device)]
+            v = pos[idx]
+            voxels.append(v[~torch.isnan(v).any(dim=1)])
+    return voxels, pos[:, -1]

@@ -165,3 +165,46 @@ def test_predict_cli_keeps_the_reference_flag_surface():
     assert (a.is_wood, a.any_wood, a.output_fmt, a.verbose) == (0.5, 1, "ply", False)
     b = mod.build_parser().parse_args(["-p", "a.ply", "b.ply", "--is-wood", "0.7", "--grid_size", "2.0"])
     assert b.point_cloud == ["a.ply", "b.ply"] and b.is_wood == 0.7 and b.grid_size == [2.0]
+
+
+def _plot(n=60000, seed=0, refl=True):
+    g = torch.Generator().manual_seed(seed)
+    xy = torch.rand(n, 2, generator=g) * torch.tensor([13.0, 9.0]) + torch.tensor([100.0, -40.0])
+    ground = 0.05 * xy[:, :1] + 0.3 * torch.sin(xy[:, 1:] / 3)
+    z = ground + torch.rand(n, 1, generator=g) ** 2 * 11.0
+    cols = [xy, z, (torch.randint(0, 200, (n, 1), generator=g).float() / 7 - 9) if refl else torch.zeros(n, 1),
+            torch.rand(n, 1, generator=g)]
+    return torch.cat(cols, 1)
+
+
+@pytest.mark.parametrize("refl", [True, False])
+def test_voxeliser_matches_reference_restatement(refl):
+    from oracle import preprocess as OP
+    from pointstowood_amd import preprocessing as PP
+    pc = _plot(refl=refl)
+    ref, nz_ref = OP.voxelise(pc, (2.0, 4.0), min_pts=64, max_pts=100000)
+    got, nz = PP.voxelise(pc, (2.0, 4.0), min_pts=64, max_pts=100000, mode="compat")
+    assert torch.equal(nz, nz_ref)
+    assert len(got) == len(ref) and len(got) > 20
+    for a, b in zip(got, ref):
+        assert a.shape == b.shape and torch.equal(a, b)       # same voxels, same order, same rows
+    # capping: sizes and membership (the sampled subset depends on the RNG stream)
+    capped, _ = PP.voxelise(pc, (4.0,), min_pts=64, max_pts=300, mode="compat", generator=torch.Generator().manual_seed(1))
+    full, _ = PP.voxelise(pc, (4.0,), min_pts=64, max_pts=100000, mode="compat")
+    assert len(capped) == len(full) and all(c.shape[0] == min(f.shape[0], 300) for c, f in zip(capped, full))
+    for c, f in zip(capped, full):
+        fs = {tuple(r.tolist()) for r in f}
+        assert all(tuple(r.tolist()) in fs for r in c[:20])
+    xyz, _ = PP.voxelise(pc, (2.0,), min_pts=64, mode="xyz")
+    assert sum(v.shape[0] for v in xyz) >= sum(v.shape[0] for v in PP.voxelise(pc, (2.0,), min_pts=64)[0])
+
+
+def test_collate_device_equals_dataset_path():
+    from pointstowood_amd.predicter import collate_device
+    raw = [r for i, r in enumerate(_raw_voxels()) if i in (0, 1, 3)]      # NaN-free voxels
+    ds = VoxelDataset(raw)
+    ref = Batch.from_data_list([ds[i] for i in range(3)])
+    got = collate_device(raw)
+    assert torch.equal(got.batch, ref.batch) and torch.equal(got.ptr, ref.ptr) and torch.equal(got.reflectance, ref.reflectance)
+    assert (got.local_shift - ref.local_shift).abs().max() <= 1e-5 and (got.sf - ref.sf).abs().max() <= 1e-5
+    assert (got.pos - ref.pos).abs().max() <= 1e-5

@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""Plot-level run (BASELINE configs[3] shape): synthetic forest plot -> GPU voxeliser (2 m + 4 m grids, min/max points)
+-> length-balanced voxel batches -> pipelined classification, sharded over the ranks of torch.distributed when launched
+with `python -m torch.distributed.run --nproc-per-node N tools/run_plot.py ...` (one all-gather of results at the end).
+
+    python tools/run_plot.py [--points 2000000] [--batch_size 8]
+"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import weights  # noqa: E402  (synthetic checkpoint recipe only)
+from pointstowood_amd import Batch, Net  # noqa: E402
+from pointstowood_amd.dist import partition_batches  # noqa: E402
+from pointstowood_amd.predicter import BalancedBatchSampler, VoxelDataset, collate_device  # noqa: E402
+from pointstowood_amd.preprocessing import voxelise  # noqa: E402
+
+
+def synth_plot(n, seed=0, side=100.0, height=30.0):
+    """Tree-like density: stems (thin vertical cylinders), crowns (gaussian blobs), ground sheet."""
+    g = torch.Generator().manual_seed(seed)
+    n_tree = max(4, int(side * side / 60))
+    cx = torch.rand(n_tree, 2, generator=g) * side - side / 2
+    h = 8 + torch.rand(n_tree, generator=g) * (height - 10)
+    which = torch.randint(0, n_tree, (n,), generator=g)
+    kind = torch.rand(n, generator=g)
+    stem, crown = kind < 0.25, (kind >= 0.25) & (kind < 0.85)
+    p = torch.empty(n, 3)
+    ang = torch.rand(n, generator=g) * 6.2832
+    rad = 0.1 + 0.15 * torch.rand(n, generator=g)
+    p[:, 0] = cx[which, 0] + torch.where(stem, rad * torch.cos(ang), torch.randn(n, generator=g) * 1.6)
+    p[:, 1] = cx[which, 1] + torch.where(stem, rad * torch.sin(ang), torch.randn(n, generator=g) * 1.6)
+    p[:, 2] = torch.where(stem, torch.rand(n, generator=g) * h[which] * 0.7,
+                          h[which] * (0.65 + 0.12 * torch.randn(n, generator=g)))
+    gr = ~(stem | crown)
+    p[gr, 0] = torch.rand(int(gr.sum()), generator=g) * side - side / 2
+    p[gr, 1] = torch.rand(int(gr.sum()), generator=g) * side - side / 2
+    p[gr, 2] = 0.05 * torch.randn(int(gr.sum()), generator=g)
+    refl = torch.rand(n, 1, generator=g) * 30 - 25
+    return torch.cat([p, refl], 1)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--points", type=int, default=2_000_000)
+    ap.add_argument("--batch_size", type=int, default=8, help="voxels per forward (the reference default; 64 suits small voxels)")
+    ap.add_argument("--min_pts", type=int, default=128)
+    ap.add_argument("--max_pts", type=int, default=16384)
+    args = ap.parse_args()
+    world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    net = Net(1, C=32, k=32)
+    net.load_state_dict(weights.synth_state_dict(1, 32, seed=0))
+    net = net.to(dev).eval()
+    side = 100.0 * (args.points / 10_000_000) ** 0.5
+    pc = synth_plot(args.points, side=max(side, 10.0)).to(dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    vox, _ = voxelise(pc, (2.0, 4.0), args.min_pts, args.max_pts, generator=torch.Generator(device=dev).manual_seed(0))
+    torch.cuda.synchronize()
+    t_vox = time.perf_counter() - t0
+    ds = VoxelDataset([v for v in vox])
+    batches = list(BalancedBatchSampler(ds, args.batch_size))
+    costs = [sum(ds.lengths[i] if hasattr(ds, "lengths") else vox[i].shape[0] for i in b) for b in batches]
+    mine = partition_batches(costs, world)[rank]
+    net(collate_device([vox[i] for i in batches[mine[0]]]))   # warm-up (weight packing, allocator)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    datas = (collate_device([vox[i] for i in batches[b]]) for b in mine)
+    n_pts, outs = 0, []
+    for logits in net.stream(datas):
+        outs.append(torch.sigmoid(torch.nan_to_num(logits)))
+        n_pts += logits.numel()
+    local_probs = torch.cat(outs)
+    if world > 1:
+        counts = torch.zeros(world, dtype=torch.int64, device=dev)
+        counts[rank] = n_pts
+        dist.all_reduce(counts)
+        from pointstowood_amd.dist import gather_logits
+        allp = gather_logits(local_probs, dist, counts=[int(c) for c in counts.cpu()])
+        n_pts = allp.numel()
+    torch.cuda.synchronize()
+    t_cls = time.perf_counter() - t0
+    if rank == 0:
+        sizes = sorted(v.shape[0] for v in vox)
+        print(f"plot {args.points} pts -> {len(vox)} voxels (min {sizes[0]}, median {sizes[len(sizes)//2]}, max {sizes[-1]}), "
+              f"{sum(sizes)} classified points incl. 2 m / 4 m overlap; voxelise {t_vox:.2f} s; "
+              f"classify {t_cls:.2f} s on {world} GPU(s) = {n_pts / t_cls / 1e6:.2f} M points/s", flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
