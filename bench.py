@@ -175,6 +175,9 @@ def main():
         dom_ms, dom_launches = per[dom]
         achieved = 2.0 * kmacs[dom] / (dom_ms * 1e-3) / 1e12
         pts = world * args.steps * BATCH * NPTS
+        kname = {"gemm_kernel": ("gemm_h2g_kernel (256x256 and 128x128 tile instantiations, all launches)"
+                                 if args.precision == "f16x3" else "gemm_kernel"),
+                 "sa_conv_kernel": ("sa_conv16p_kernel (+ sa_edge_meta_kernel)" if args.precision == "f16x3" else "sa_conv_kernel")}
         line = {
             "metric": "classified points/sec", "value": pts / dt, "unit": "points/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -184,7 +187,7 @@ def main():
                        "level_sizes": sizes, "parallelism": f"voxel-batch sharding x{world}, RCCL all-gather of logits",
                        "pipeline": "2 HIP streams: geometry(i+1) || features(i)" if args.pipeline else "sequential"},
             "end_to_end_tflops_algorithmic": 2.0 * total_macs * args.steps / dt / 1e12,
-            "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": peak,
+            "roofline": {"bound": "mfma", "kernel": kname.get(dom, dom), "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
                          "note": ("f16x3 issues 3 fp16 MFMAs per algorithmic product: ceiling for algorithmic FLOPs is peak/3"
                                   if args.precision == "f16x3" else "exact fp32 MFMA"),

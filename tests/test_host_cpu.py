@@ -208,3 +208,15 @@ def test_collate_device_equals_dataset_path():
     assert torch.equal(got.batch, ref.batch) and torch.equal(got.ptr, ref.ptr) and torch.equal(got.reflectance, ref.reflectance)
     assert (got.local_shift - ref.local_shift).abs().max() <= 1e-5 and (got.sf - ref.sf).abs().max() <= 1e-5
     assert (got.pos - ref.pos).abs().max() <= 1e-5
+
+
+def test_point_budget_sampler_covers_everything_within_budget():
+    from pointstowood_amd.predicter import PointBudgetSampler
+    g = torch.Generator().manual_seed(0)
+    lengths = [int(v) for v in (torch.rand(500, generator=g) ** 3 * 16000 + 128)]
+    s = PointBudgetSampler(lengths, max_points=40000, max_voxels=32)
+    batches = list(s)
+    assert sorted(i for b in batches for i in b) == list(range(500)) and len(batches) == len(s)
+    assert all(sum(lengths[i] for i in b) <= 40000 and len(b) <= 32 for b in batches)
+    fill = sum(lengths) / (len(batches) * 40000)
+    assert fill > 0.8 and list(PointBudgetSampler(lengths, 40000, 32)) == batches

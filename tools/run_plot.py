@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import weights  # noqa: E402  (synthetic checkpoint recipe only)
 from pointstowood_amd import Batch, Net  # noqa: E402
 from pointstowood_amd.dist import partition_batches  # noqa: E402
-from pointstowood_amd.predicter import BalancedBatchSampler, VoxelDataset, collate_device  # noqa: E402
+from pointstowood_amd.predicter import BalancedBatchSampler, PointBudgetSampler, collate_device  # noqa: E402
 from pointstowood_amd.preprocessing import voxelise  # noqa: E402
 
 
@@ -47,7 +47,9 @@ def synth_plot(n, seed=0, side=100.0, height=30.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--points", type=int, default=2_000_000)
-    ap.add_argument("--batch_size", type=int, default=8, help="voxels per forward (the reference default; 64 suits small voxels)")
+    ap.add_argument("--batch_size", type=int, default=0,
+                    help="voxels per forward with the reference-style sampler; 0 (default) = point-budget batching")
+    ap.add_argument("--max_points", type=int, default=131072, help="point budget per forward (point-budget batching)")
     ap.add_argument("--min_pts", type=int, default=128)
     ap.add_argument("--max_pts", type=int, default=16384)
     args = ap.parse_args()
@@ -68,9 +70,13 @@ def main():
     vox, _ = voxelise(pc, (2.0, 4.0), args.min_pts, args.max_pts, generator=torch.Generator(device=dev).manual_seed(0))
     torch.cuda.synchronize()
     t_vox = time.perf_counter() - t0
-    ds = VoxelDataset([v for v in vox])
-    batches = list(BalancedBatchSampler(ds, args.batch_size))
-    costs = [sum(ds.lengths[i] if hasattr(ds, "lengths") else vox[i].shape[0] for i in b) for b in batches]
+    lengths = [int(v.shape[0]) for v in vox]
+    if args.batch_size > 0:
+        from pointstowood_amd.predicter import VoxelDataset
+        batches = list(BalancedBatchSampler(VoxelDataset(vox), args.batch_size))
+    else:
+        batches = list(PointBudgetSampler(lengths, args.max_points))
+    costs = [sum(lengths[i] for i in b) for b in batches]
     mine = partition_batches(costs, world)[rank]
     net(collate_device([vox[i] for i in batches[mine[0]]]))   # warm-up (weight packing, allocator)
     torch.cuda.synchronize()
