@@ -847,14 +847,23 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void gemm_h2g_kernel(const _Float1
 
     const int nslab = Kpad / G_BK;
     issue(0, 0);
+    h8 ah[RT], al[RT], bh[CT], bl[CT];
+    if (dbg & 8) {   // diagnostic: fragments loaded once, the loop below is MFMA (+ optional barrier) only
+        const char* st0 = S;
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < RT; ++t) { ah[t] = *reinterpret_cast<const h8*>(st0 + offA[0][t]); al[t] = *reinterpret_cast<const h8*>(st0 + offA[1][t]); }
+#pragma unroll
+        for (int t = 0; t < CT; ++t) { bh[t] = *reinterpret_cast<const h8*>(st0 + offB[0][t]); bl[t] = *reinterpret_cast<const h8*>(st0 + offB[1][t]); }
+    }
     for (int s = 0; s < nslab; ++s) {
-        __syncthreads();  // = s_waitcnt vmcnt(0) + barrier: slab s has landed for every wave, slab s-1's buffer is free
+        if (!(dbg & 16)) __syncthreads();  // = s_waitcnt vmcnt(0) + barrier: slab s has landed for every wave, slab s-1's buffer is free
         if (s + 1 < nslab && !(dbg & 2)) issue((s + 1) & 1, (s + 1) * G_BK);
         const char* st = S + (size_t)(s & 1) * STAGE_CH * 16;
         if (dbg & 4) continue;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            h8 ah[RT], al[RT], bh[CT], bl[CT];
+            if (!(dbg & 8)) {
 #pragma unroll
             for (int t = 0; t < RT; ++t) {
                 ah[t] = *reinterpret_cast<const h8*>(st + (offA[0][t] ^ (kk << 5)));
@@ -864,6 +873,7 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void gemm_h2g_kernel(const _Float1
             for (int t = 0; t < CT; ++t) {
                 bh[t] = *reinterpret_cast<const h8*>(st + (offB[0][t] ^ (kk << 5)));
                 bl[t] = *reinterpret_cast<const h8*>(st + (offB[1][t] ^ (kk << 5)));
+            }
             }
 #pragma unroll
             for (int i = 0; i < RT; ++i)

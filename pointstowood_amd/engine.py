@@ -539,217 +539,3 @@ class Engine:
             if e is not None:
                 cur_stream.wait_event(e)
             yield out
-
-    # -- phase 2 ------------------------------------------------------------------------------
-    def features(self, geo: Geometry, keep: dict | None = None):
-        if self.precision == "f16x3":
-            return self._features_h2(geo, keep)
-        return self._features_fp32(geo, keep)
-
-    def _gemm_h2(self, name, A, ldh_a, M, lin: Linear, out_f32=None, ldo=0, out_h2=None, ldh_o=0, residual=None, ldr=0):
-        ep = Epilogue(ptr(lin.bias), ptr(lin.sc0), ptr(lin.sh0), ptr(lin.sc1), ptr(lin.sh1), ptr(residual), ldr,
-                      lin.relu0, lin.relu1, lin.relu2, lin.relu_final)
-        self._call(name, lib().p2w_gemm_h2, ptr(A), ldh_a, ptr(lin.w16), lin.wscale, M, lin.N, lin.K, C.byref(ep),
-                   ptr(out_f32), ldo, ptr(out_h2), ldh_o)
-
-    def _features_h2(self, geo: Geometry, keep: dict | None = None):
-        """f16x3 pipeline: every GEMM operand is an H2 tensor (fp16 hi/lo planes) written once by its producer."""
-        L, w = lib(), self.w
-        dev = geo.sf.device
-        Cw = w.C
-        new = lambda r, c: torch.empty((r, c), dtype=torch.float32, device=dev)
-        pad8 = lambda f: (f + 31) // 32 * 32   # H2 row pitch: zero-padded to the GEMM's K slab so it can be DMA-staged
-        newh = lambda r, f: torch.empty((r, 2 * pad8(f)), dtype=torch.float16, device=dev)
-        lv, N, B = geo.levels, geo.N, geo.B
-        x, xh = [new(N, Cw)], [newh(N, Cw)]
-        self._call("stem", L.p2w_stem_h2, ptr(lv[0].xyzr), N, ptr(w.stem_w), ptr(w.stem_b), Cw, ptr(x[0]), ptr(xh[0]),
-                   pad8(Cw))
-        self.stem_out = x[0]
-        if keep is not None:
-            keep["stem"] = x[0]
-        for l in (1, 2, 3):
-            p, src, dst = w.sa[l - 1], lv[l - 1], lv[l]
-            M, C1, C2, E = dst.n, p["C1"], p["C2"], 4 * p["C2"]
-            P = new(src.n, C1)
-            self._gemm_h2("gemm_hoist", xh[l - 1], pad8(p["F_in"]), src.n, p["hoist"], out_f32=P, ldo=C1)
-            conv, convh = new(M, C2), newh(M, C2)
-            meta = torch.empty(M * 32 * 20, dtype=torch.uint8, device=dev)   # per-edge (j, normalised offset) scratch
-            self._call("sa_conv", L.p2w_sa_conv_f16x3, ptr(P), C1, ptr(src.xyzr), ptr(dst.idx), ptr(dst.batch),
-                       ptr(geo.sf), ptr(dst.nbr), ptr(dst.deg), geo.k, M, ptr(p["w1r4"]), ptr(p["W2"].w16),
-                       p["W2"].wscale, C1, C2, ptr(p["b2"]), ptr(p["bn_s"]), ptr(p["bn_t"]), ptr(conv), C2, ptr(convh),
-                       pad8(C2), ptr(meta), meta.numel())
-            out = new(M, C2)
-            outh = newh(M, C2) if l < 3 else None
-            # residual block in row chunks: the two 4F-wide intermediates of a chunk (2 x chunk x 4F x 4 B) are written
-            # and re-read while they still sit in the 256 MiB Infinity Cache instead of round-tripping HBM
-            chunk = self.res_chunk_rows if self.res_chunk_rows > 0 else M
-            chunk = max(256, min(M, (chunk * 512 // E) // 256 * 256))      # same bytes per chunk at every level
-            e1, e2 = newh(min(M, chunk), E), newh(min(M, chunk), E)
-            for r0 in range(0, M, chunk):
-                m = min(chunk, M - r0)
-                self._gemm_h2("gemm_res", convh[r0:], pad8(C2), m, p["g1"], out_h2=e1, ldh_o=pad8(E))
-                self._gemm_h2("gemm_res", e1, pad8(E), m, p["g2"], out_h2=e2, ldh_o=pad8(E))
-                self._gemm_h2("gemm_res", e2, pad8(E), m, p["g3"], out_h2=e1, ldh_o=pad8(E))
-                self._gemm_h2("gemm_res", e1, pad8(E), m, p["g4"], out_f32=out[r0:], ldo=C2,
-                              out_h2=None if outh is None else outh[r0:], ldh_o=pad8(C2), residual=conv[r0:], ldr=C2)
-            x.append(out)
-            xh.append(outh)
-            if keep is not None:
-                keep[f"sa{l}_module.conv"], keep[f"sa{l}_module.out"] = conv, out
-        # GlobalSAModule (model.py:134-140)
-        F3, M3 = 16 * Cw, lv[3].n
-        cat = newh(M3, F3 + 4)
-        self._call("concat_xyz", L.p2w_concat_xyz_h2, ptr(x[3]), F3, ptr(lv[3].xyzr), M3, ptr(cat), pad8(F3 + 4))
-        h1, h2 = newh(M3, F3), new(M3, F3)
-        self._gemm_h2("gemm_mlp", cat, pad8(F3 + 4), M3, w.sa4[0], out_h2=h1, ldh_o=pad8(F3))
-        self._gemm_h2("gemm_mlp", h1, pad8(F3), M3, w.sa4[1], out_f32=h2, ldo=F3)
-        g = new(B, F3)
-        self._call("segment_max", L.p2w_segment_max, ptr(h2), F3, F3, ptr(lv[3].ptr), B, ptr(g))
-        if keep is not None:
-            keep["sa4_module.out"] = g
-        # FPModule 4..1 (model.py:148-153)
-        nbr4 = torch.empty(M3, dtype=torch.int32, device=dev)
-        deg4 = torch.empty(M3, dtype=torch.int32, device=dev)
-        self._call("fill_batch_nbr", L.p2w_fill_batch_nbr, ptr(lv[3].batch), M3, ptr(nbr4), ptr(deg4))
-        zeros_c = torch.zeros((B, 4), dtype=torch.float32, device=dev)
-        y, y_xyzr, yh = g, zeros_c, None
-        for fl in (4, 3, 2, 1):
-            fine = lv[fl - 1]
-            m, Fc, Fs = fine.n, y.shape[1], x[fl - 1].shape[1]
-            nbr, deg, kw = (nbr4, deg4, 1) if fl == 4 else (*geo.fp_nbr[fl - 1], 2)
-            cat = newh(m, Fc + Fs)
-            self._call("interp_concat", L.p2w_interp_concat_h2, ptr(y), Fc, ptr(y_xyzr), ptr(fine.xyzr), ptr(nbr), ptr(deg),
-                       kw, ptr(x[fl - 1]), Fs, m, ptr(cat), pad8(Fc + Fs))
-            l0, l1 = w.fp[fl]
-            a = newh(m, l0.N)
-            self._gemm_h2("gemm_mlp", cat, pad8(Fc + Fs), m, l0, out_h2=a, ldh_o=pad8(l0.N))
-            need_f32 = fl > 1 or keep is not None
-            b = new(m, l1.N) if need_f32 else None
-            yh = newh(m, l1.N) if fl == 1 else None
-            self._gemm_h2("gemm_mlp", a, pad8(l0.N), m, l1, out_f32=b, ldo=l1.N, out_h2=yh, ldh_o=pad8(l1.N))
-            y, y_xyzr = b, fine.xyzr
-            if keep is not None:
-                keep[f"fp{fl}_module.out"] = b
-        # head (model.py:241-243)
-        hd = new(N, F3)
-        self._gemm_h2("gemm_mlp", yh, pad8(F3), N, w.head1, out_f32=hd, ldo=F3)
-        if w.num_classes == 1:
-            logits = torch.empty(N, dtype=torch.float32, device=dev)
-            self._call("rowdot", L.p2w_rowdot, ptr(hd), F3, F3, ptr(w.head2_w), float(w.head2_b[0]), N, ptr(logits))
-        else:
-            o = new(N, w.num_classes)
-            self._gemm("gemm_mlp", hd, F3, N, w.head2, o, w.num_classes)
-            logits = o.t()
-        return torch.squeeze(logits)
-
-    def _features_fp32(self, geo: Geometry, keep: dict | None = None):
-        L, w = lib(), self.w
-        dev = geo.sf.device
-        Cw = w.C
-        new = lambda r, c: torch.empty((r, c), dtype=torch.float32, device=dev)
-        lv = geo.levels
-        N = geo.N
-        x = [new(N, Cw)]
-        self._call("stem", L.p2w_stem, ptr(lv[0].xyzr), N, ptr(w.stem_w), ptr(w.stem_b), Cw, ptr(x[0]))
-        self.stem_out = x[0]
-        if keep is not None:
-            keep["stem"] = x[0]
-        for l in (1, 2, 3):
-            p, src, dst = w.sa[l - 1], lv[l - 1], lv[l]
-            M, C1, C2, E = dst.n, p["C1"], p["C2"], 4 * p["C2"]
-            P = new(src.n, C1)
-            self._gemm("gemm_hoist", x[l - 1], p["F_in"], src.n, p["hoist"], P, C1)
-            conv = new(M, C2)
-            self._call("sa_conv", L.p2w_sa_conv, ptr(P), C1, ptr(src.xyzr), ptr(dst.idx), ptr(dst.batch), ptr(geo.sf),
-                       ptr(dst.nbr), ptr(dst.deg), geo.k, M, ptr(p["w1r4"]), ptr(p["W2"].w), C1, C2, ptr(p["b2"]),
-                       ptr(p["bn_s"]), ptr(p["bn_t"]), ptr(conv), C2)
-            e1, e2 = new(M, E), new(M, E)
-            self._gemm("gemm_res", conv, C2, M, p["g1"], e1, E)
-            self._gemm("gemm_res", e1, E, M, p["g2"], e2, E)
-            self._gemm("gemm_res", e2, E, M, p["g3"], e1, E)
-            out = new(M, C2)
-            self._gemm("gemm_res", e1, E, M, p["g4"], out, C2, residual=conv, ldr=C2)
-            x.append(out)
-            if keep is not None:
-                keep[f"sa{l}_module.conv"], keep[f"sa{l}_module.out"] = conv, out
-        # GlobalSAModule (model.py:134-140)
-        F3, M3, B = 16 * Cw, lv[3].n, geo.B
-        cat = new(M3, F3 + 4)
-        self._call("concat_xyz", L.p2w_concat_xyz, ptr(x[3]), F3, ptr(lv[3].xyzr), M3, ptr(cat), F3 + 4)
-        h1, h2 = new(M3, F3), new(M3, F3)
-        self._gemm("gemm_mlp", cat, F3 + 4, M3, w.sa4[0], h1, F3)
-        self._gemm("gemm_mlp", h1, F3, M3, w.sa4[1], h2, F3)
-        g = new(B, F3)
-        self._call("segment_max", L.p2w_segment_max, ptr(h2), F3, F3, ptr(lv[3].ptr), B, ptr(g))
-        if keep is not None:
-            keep["sa4_module.out"] = g
-        # FPModule 4..1 (model.py:148-153)
-        nbr4 = torch.empty(M3, dtype=torch.int32, device=dev)
-        deg4 = torch.empty(M3, dtype=torch.int32, device=dev)
-        self._call("fill_batch_nbr", L.p2w_fill_batch_nbr, ptr(lv[3].batch), M3, ptr(nbr4), ptr(deg4))
-        zeros_c = torch.zeros((B, 4), dtype=torch.float32, device=dev)
-        y, y_xyzr = g, zeros_c
-        for fl in (4, 3, 2, 1):
-            fine = lv[fl - 1]
-            m, Fc, Fs = fine.n, y.shape[1], x[fl - 1].shape[1]
-            nbr, deg, kw = (nbr4, deg4, 1) if fl == 4 else (*geo.fp_nbr[fl - 1], 2)
-            cat = new(m, Fc + Fs)
-            self._call("interp_concat", L.p2w_interp_concat, ptr(y), Fc, ptr(y_xyzr), ptr(fine.xyzr), ptr(nbr), ptr(deg),
-                       kw, ptr(x[fl - 1]), Fs, m, ptr(cat), Fc + Fs)
-            l0, l1 = w.fp[fl]
-            a, b = new(m, l0.N), new(m, l1.N)
-            self._gemm("gemm_mlp", cat, Fc + Fs, m, l0, a, l0.N)
-            self._gemm("gemm_mlp", a, l0.N, m, l1, b, l1.N)
-            y, y_xyzr = b, fine.xyzr
-            if keep is not None:
-                keep[f"fp{fl}_module.out"] = b
-        # head (model.py:241-243)
-        hd = new(N, F3)
-        self._gemm("gemm_mlp", y, F3, N, w.head1, hd, F3)
-        if w.num_classes == 1:
-            logits = torch.empty(N, dtype=torch.float32, device=dev)
-            self._call("rowdot", L.p2w_rowdot, ptr(hd), F3, F3, ptr(w.head2_w), float(w.head2_b[0]), N, ptr(logits))
-        else:
-            o = new(N, w.num_classes)
-            self._gemm("gemm_mlp", hd, F3, N, w.head2, o, w.num_classes)
-            logits = o.t()
-        return torch.squeeze(logits)
-
-    def forward(self, pos, reflectance, ptr0, sf, keep=None):
-        geo = self.geometry(pos, reflectance, ptr0, sf)
-        if keep is not None:
-            keep["geometry"] = geo
-        return self.features(geo, keep)
-
-    # -- two-stream software pipeline over a sequence of batches ---------------------------------------------
-    def forward_stream(self, inputs):
-        """``inputs`` yields (pos, reflectance, ptr0, sf); yields logits per batch, in order.
-
-        The geometry phase (VALU-bound searches) of batch i+1 runs on a second HIP stream while the feature phase
-        (MFMA-bound GEMMs) of batch i runs on the first; the only host wait per batch is for the three level sizes
-        of the NEXT batch's geometry, which has been running concurrently."""
-        cur_stream = torch.cuda.current_stream()
-        if getattr(self, "_s_geo", None) is None:
-            self._s_geo = torch.cuda.Stream(priority=-1)   # short, low-footprint kernels: let them slot in first
-        s_geo = self._s_geo
-
-        def launch_geometry(args):
-            s_geo.wait_stream(cur_stream)
-            with torch.cuda.stream(s_geo):
-                geo = self._geometry_async(*args)
-            return geo
-
-        it = iter(inputs)
-        nxt = next(it, None)
-        if nxt is None:
-            return
-        geo = launch_geometry(nxt)
-        while geo is not None:
-            nxt = next(it, None)
-            self._geometry_finish(geo)                    # host waits for THIS batch's level sizes only
-            geo_next = launch_geometry(nxt) if nxt is not None else None
-            cur_stream.wait_event(geo.done)
-            for t in geo.tensors():
-                t.record_stream(cur_stream)               # allocated on s_geo, consumed on the feature stream
-            yield self.features(geo, None)
-            geo = geo_next

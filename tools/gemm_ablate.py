@@ -23,7 +23,7 @@ for M, K, N in shapes:
     of = torch.empty(M, N, device=dev)
     ep = Epilogue(ptr(bias), ptr(sc), ptr(sh), None, None, None, 0, 1, 1, 0, 0)
     res = []
-    for dbg in (0, 1, 2, 3, 4, 6):
+    for dbg in [int(v) for v in os.environ.get("ABLATE_MODES", "0,1,2,3,4,6").split(",")]:
         os.environ["P2W_GEMM_DBG"] = str(dbg)
         for out_f, out_h in ((None, oh), (of, None)):
             def run():
