@@ -56,12 +56,18 @@ int32_t p2w_pack_xyzr(const float* pos, int32_t pos_stride, const float* refl, c
  * In : xyzr[n_bound] (records >= ptr[B] ignored), ptr[B+1], cell size `res`.
  * Out: idx_out[<= n_bound] (index into xyzr of the representative = LARGEST point index of each
  *      occupied cell, ascending cell id i.e. voxel-major), ptr_out[B+1] (CSR of the sampled level;
- *      ptr_out[B] = M), batch_out[M].
+ *      ptr_out[B] = M), batch_out[M]; order_out[n] (optional, may be NULL) = the input point indices in
+ *      ascending (voxel, cell id) order - a spatially coherent visiting order for the searches below.
  * ws : p2w_voxel_sample_ws_bytes(n_bound) bytes of scratch. */
 size_t p2w_voxel_sample_ws_bytes(int32_t n_bound);
 int32_t p2w_voxel_sample(const float* xyzr, const int32_t* ptr, int32_t B, int32_t n_bound, float res,
-                         int32_t* idx_out, int32_t* ptr_out, int32_t* batch_out, void* ws, size_t ws_bytes,
-                         p2w_stream_t stream);
+                         int32_t* idx_out, int32_t* ptr_out, int32_t* batch_out, int32_t* order_out, void* ws,
+                         size_t ws_bytes, p2w_stream_t stream);
+
+/* out[i] = (x, y, z, bit pattern of order[i]) of xyzr[order[i]] for i < ptr[B]: the records of a level in another
+ * (e.g. cell-sorted) order, each carrying its own index - input for the P2W_SEARCH_*_IN_W modes below. */
+int32_t p2w_index_records(const float* xyzr, const int32_t* order, const int32_t* ptr, int32_t B, int32_t n_bound,
+                          float* out, p2w_stream_t stream);
 
 /* The two halves of p2w_voxel_sample as separate operators (the reference calls them separately,
  * model.py:104-105): cell ids exactly as PyG voxel_grid(pos, size, batch) returns them (int64), and
@@ -77,23 +83,32 @@ int32_t p2w_consecutive_cluster(const int64_t* cell, int32_t n, int32_t* inv_out
 int32_t p2w_level_gather(const float* xyzr_src, const int32_t* idx, const int32_t* batch_dst, const int32_t* ptr_dst,
                          int32_t B, int32_t m_bound, const float* sf, float* xyzr_dst, p2w_stream_t stream);
 
+/* Search modes (flags of p2w_ball_query / p2w_knn).  Both exist so that a level can be searched in a spatially
+ * coherent storage order (p2w_index_records) while results keep referring to the level's own numbering:
+ *   X_INDEX_IN_W: candidate c is reported as (and ties / "first cap" are ordered by) the int32 in xyzr_x[c].w, not c.
+ *   Q_ROW_IN_W  : the results of query q are written to row (int32 in its record's .w) of nbr / deg, not row q. */
+#define P2W_SEARCH_X_INDEX_IN_W 1
+#define P2W_SEARCH_Q_ROW_IN_W 2
+
 /* Ball query: torch-cluster radius(x, y, r, batch_x, batch_y, max_num_neighbors) - model.py:118.
- * Queries are x[qidx[q]] (qidx NULL = identity).  For query q of voxel b the first `cap` candidates
- * c in ptr_x[b]..ptr_x[b+1] (ascending) with d2 < (float)(r*r) (r is a double, as torch-cluster's host code takes it) are written to
- * nbr[q*cap + 0..deg[q]-1]; remaining slots are -1. */
+ * Queries are x[qidx[q]] (qidx NULL = identity).  For query q of voxel b the `cap` candidates of lowest index among
+ * those of ptr_x[b]..ptr_x[b+1] with d2 < (float)(r*r) (r is a double, as torch-cluster's host code takes it) are
+ * written in ascending index order to nbr[q*cap + 0..deg[q]-1]; remaining slots are -1.  tile_bbox: optional, see
+ * p2w_tile_bbox. */
 int32_t p2w_ball_query(const float* xyzr_x, const int32_t* ptr_x, const float* xyzr_q, const int32_t* qidx,
                        const int32_t* ptr_q, int32_t B, int32_t m_bound, double r, int32_t cap, int32_t* nbr,
-                       int32_t* deg, p2w_stream_t stream);
+                       int32_t* deg, const float* tile_bbox, int32_t flags, p2w_stream_t stream);
 
 /* Exact brute-force kNN: torch-cluster knn(x, y, k, batch_x, batch_y) - model.py:120 and inside
  * PyG knn_interpolate (model.py:149).  Ascending (d2, index); deg[q] = min(k, #candidates). */
 int32_t p2w_knn(const float* xyzr_x, const int32_t* ptr_x, const float* xyzr_q, const int32_t* qidx,
                 const int32_t* ptr_q, int32_t B, int32_t m_bound, int32_t k, int32_t* nbr, int32_t* deg,
-                const float* tile_bbox, p2w_stream_t stream);
+                const float* tile_bbox, int32_t flags, p2w_stream_t stream);
 
-/* Optional accelerator for p2w_knn (results are identical with or without it): bounding boxes (lo xyz, hi xyz) of
- * the candidate tiles of xyzr_x (1024 consecutive records of one voxel).  bbox holds p2w_tile_bbox_count(B, n_bound)
- * x 6 floats.  With it, p2w_knn skips tiles whose box is farther than a query's current k-th distance. */
+/* Optional accelerator for the searches (results are identical with or without it): bounding boxes (lo xyz, hi xyz)
+ * of the candidate tiles of xyzr_x (1024 consecutive records of one voxel).  bbox holds p2w_tile_bbox_count(B,
+ * n_bound) x 6 floats.  With it, p2w_knn skips tiles whose box is farther than a query's current k-th distance and
+ * p2w_ball_query tiles farther than r; it pays when the candidates are stored in a spatially coherent order. */
 int32_t p2w_tile_bbox(const float* xyzr, const int32_t* ptr, int32_t B, int32_t n_bound, float* bbox, p2w_stream_t stream);
 int32_t p2w_tile_bbox_count(int32_t B, int32_t n_bound);
 

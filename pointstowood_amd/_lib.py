@@ -22,17 +22,20 @@ class Epilogue(C.Structure):
 
 
 # name -> (restype, argtypes); must list every symbol declared in include/p2w.h
+SEARCH_X_INDEX_IN_W, SEARCH_Q_ROW_IN_W = 1, 2   # include/p2w.h P2W_SEARCH_*
+
 SIGNATURES = {
     "p2w_version": (_i32, []),
     "p2w_strerror": (C.c_char_p, [_i32]),
     "p2w_pack_xyzr": (_i32, [_vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "p2w_voxel_sample_ws_bytes": (_sz, [_i32]),
-    "p2w_voxel_sample": (_i32, [_vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "p2w_voxel_sample": (_i32, [_vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "p2w_index_records": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp, _vp]),
     "p2w_voxel_grid": (_i32, [_vp, _vp, _i32, _i32, _f32, _vp, _vp, _sz, _vp]),
     "p2w_consecutive_cluster": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "p2w_level_gather": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
-    "p2w_ball_query": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, C.c_double, _i32, _vp, _vp, _vp]),
-    "p2w_knn": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "p2w_ball_query": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, C.c_double, _i32, _vp, _vp, _vp, _i32, _vp]),
+    "p2w_knn": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
     "p2w_tile_bbox": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp]),
     "p2w_tile_bbox_count": (_i32, [_i32, _i32]),
     "p2w_stem": (_i32, [_vp, _i32, _vp, _vp, _i32, _vp, _vp]),

@@ -129,7 +129,8 @@ __global__ __launch_bounds__(256) void vs_scatter_kernel(const int* __restrict__
                                                          const int* __restrict__ vals, const int* __restrict__ ptr, int B,
                                                          const int* __restrict__ n_dev, int n_bound, int* __restrict__ idx_out,
                                                          int* __restrict__ ptr_out, int* __restrict__ batch_out,
-                                                         int* __restrict__ inv_out, int* __restrict__ count_out) {
+                                                         int* __restrict__ inv_out, int* __restrict__ count_out,
+                                                         int* __restrict__ order_out) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int n = n_dev ? *n_dev : n_bound;
     const int total = (n == 0) ? 0 : scan[n - 1] + flags[n - 1];
@@ -140,6 +141,7 @@ __global__ __launch_bounds__(256) void vs_scatter_kernel(const int* __restrict__
     }
     if (i >= n || i >= n_bound) return;
     if (inv_out) inv_out[vals[i]] = scan[i];
+    if (order_out) order_out[i] = vals[i];
     if (flags[i]) {
         const int o = scan[i];
         idx_out[o] = vals[i];
@@ -191,7 +193,7 @@ static int32_t vs_compute_keys(const float4* x4, const int* ptr, int B, int n_bo
 // sort (key, point) pairs, flag the last element of each run, compact
 static int32_t vs_cluster(char* w, const VsLayout& L, const unsigned long long* keys_in, const int* ptr, int B,
                           const int* n_dev, int n_bound, int* idx_out, int* ptr_out, int* batch_out, int* inv_out,
-                          int* count_out, hipStream_t s) {
+                          int* count_out, int* order_out, hipStream_t s) {
     auto* keys_out = reinterpret_cast<unsigned long long*>(w + L.keys_out);
     int* vals_in = reinterpret_cast<int*>(w + L.vals_in);
     int* vals_out = reinterpret_cast<int*>(w + L.vals_out);
@@ -207,13 +209,13 @@ static int32_t vs_cluster(char* w, const VsLayout& L, const unsigned long long* 
     if (e != hipSuccess) return (int32_t)e;
     const int nblk2 = p2w_cdiv((n_bound > B + 1 ? n_bound : B + 1), 256);
     vs_scatter_kernel<<<nblk2, 256, 0, s>>>(flags, scan, vals_out, ptr, B, n_dev, n_bound, idx_out, ptr_out, batch_out,
-                                            inv_out, count_out);
+                                            inv_out, count_out, order_out);
     return P2W_LAUNCH_STATUS();
 }
 
 extern "C" int32_t p2w_voxel_sample(const float* xyzr, const int32_t* ptr, int32_t B, int32_t n_bound, float res,
-                                    int32_t* idx_out, int32_t* ptr_out, int32_t* batch_out, void* ws, size_t ws_bytes,
-                                    p2w_stream_t stream) {
+                                    int32_t* idx_out, int32_t* ptr_out, int32_t* batch_out, int32_t* order_out, void* ws,
+                                    size_t ws_bytes, p2w_stream_t stream) {
     P2W_CHECK_PTR(ptr); P2W_CHECK_PTR(ptr_out);
     if (B <= 0 || n_bound < 0 || !(res > 0.0f)) return P2W_EINVAL;
     hipStream_t s = p2w_s(stream);
@@ -229,7 +231,7 @@ extern "C" int32_t p2w_voxel_sample(const float* xyzr, const int32_t* ptr, int32
     int32_t st = vs_compute_keys(reinterpret_cast<const float4*>(xyzr), ptr, B, n_bound, res,
                                  reinterpret_cast<VsHeader*>(w + L.hdr), keys_in, reinterpret_cast<int*>(w + L.vals_in), s);
     if (st != P2W_OK) return st;
-    return vs_cluster(w, L, keys_in, ptr, B, ptr + B, n_bound, idx_out, ptr_out, batch_out, nullptr, nullptr, s);
+    return vs_cluster(w, L, keys_in, ptr, B, ptr + B, n_bound, idx_out, ptr_out, batch_out, nullptr, nullptr, order_out, s);
 }
 
 extern "C" int32_t p2w_voxel_grid(const float* xyzr, const int32_t* ptr, int32_t B, int32_t n, float res, int64_t* cell_out,
@@ -258,7 +260,7 @@ extern "C" int32_t p2w_consecutive_cluster(const int64_t* cell, int32_t n, int32
     vs_iota_kernel<<<p2w_cdiv(n, 256), 256, 0, s>>>(n, reinterpret_cast<int*>(w + L.vals_in));
     // non-negative int64 cell ids order like their unsigned bit patterns
     return vs_cluster(w, L, reinterpret_cast<const unsigned long long*>(cell), nullptr, 0, nullptr, n, perm_out, nullptr,
-                      nullptr, inv_out, count_out, s);
+                      nullptr, inv_out, count_out, nullptr, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -272,6 +274,27 @@ __global__ __launch_bounds__(256) void level_gather_kernel(const float4* __restr
     const float4 p = src[idx[i]];
     const float s = sf[batch_dst[i]];
     dst[i] = make_float4((p.x / s) * s, (p.y / s) * s, (p.z / s) * s, p.w);
+}
+
+// records in a given order, each carrying its source index in the 4th component (bit pattern of the int32)
+__global__ __launch_bounds__(256) void index_records_kernel(const float4* __restrict__ src, const int* __restrict__ order,
+                                                            const int* __restrict__ n_dev, float4* __restrict__ dst) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= *n_dev) return;
+    const int o = order[i];
+    const float4 p = src[o];
+    dst[i] = make_float4(p.x, p.y, p.z, __int_as_float(o));
+}
+
+extern "C" int32_t p2w_index_records(const float* xyzr, const int32_t* order, const int32_t* ptr, int32_t B, int32_t n_bound,
+                                     float* out, p2w_stream_t stream) {
+    if (n_bound == 0) return P2W_OK;
+    P2W_CHECK_PTR(xyzr); P2W_CHECK_PTR(order); P2W_CHECK_PTR(ptr); P2W_CHECK_PTR(out);
+    P2W_CHECK_ALIGN16(xyzr); P2W_CHECK_ALIGN16(out);
+    if (n_bound < 0 || B <= 0) return P2W_EINVAL;
+    index_records_kernel<<<p2w_cdiv(n_bound, 256), 256, 0, p2w_s(stream)>>>(reinterpret_cast<const float4*>(xyzr), order, ptr + B,
+                                                                            reinterpret_cast<float4*>(out));
+    return P2W_LAUNCH_STATUS();
 }
 
 extern "C" int32_t p2w_level_gather(const float* xyzr_src, const int32_t* idx, const int32_t* batch_dst, const int32_t* ptr_dst,
@@ -346,13 +369,14 @@ __device__ __forceinline__ void stage_candidates(float4* cand, const float4* __r
 // 64-slot chunk samples the whole tile: levels >= 1 are stored in grid-cell order, and a scan in storage order
 // approaches each query monotonically, which makes almost every candidate a new admission.  The candidate's
 // index travels in the record's 4th component; admission is order-independent (lexicographic (d2, index)).
-__device__ __forceinline__ void stage_shuffled(float4* cand, const float4* __restrict__ x, int base, int c1, int tid) {
+__device__ __forceinline__ void stage_shuffled(float4* cand, const float4* __restrict__ x, int base, int c1, int tid,
+                                               bool index_in_w) {
 #pragma unroll
     for (int r = 0; r < S_TILE / 256; ++r) {
         const int s = tid + 256 * r;
         const int c = base + ((s * 389) & (S_TILE - 1));
         float4 v = make_float4(INFINITY, INFINITY, INFINITY, __int_as_float(0x7fffffff));
-        if (c < c1) { v = x[c]; v.w = __int_as_float(c); }
+        if (c < c1) { v = x[c]; if (!index_in_w) v.w = __int_as_float(c); }
         cand[s] = v;
     }
 }
@@ -425,10 +449,29 @@ extern "C" int32_t p2w_tile_bbox(const float* xyzr, const int32_t* ptr, int32_t 
 }
 extern "C" int32_t p2w_tile_bbox_count(int32_t B, int32_t n_bound) { return p2w_cdiv(n_bound, S_TILE) + B; }
 
+// start tile of a workgroup whose queries are not candidates: the tile whose box is nearest to the first query (box gap
+// first, then distance to the box centre).  Only the visiting order depends on this, never a result.
+__device__ __forceinline__ int nearest_tile(const float* __restrict__ vb, int ntiles, const float4 f) {
+    float best_lb = INFINITY, best_c = INFINITY;
+    int t0 = 0;
+    for (int t = 0; t < ntiles; ++t) {
+        const float lx = vb[t * 6 + 0], ly = vb[t * 6 + 1], lz = vb[t * 6 + 2];
+        const float hx = vb[t * 6 + 3], hy = vb[t * 6 + 4], hz = vb[t * 6 + 5];
+        const float ex = fmaxf(fmaxf(lx - f.x, f.x - hx), 0.f), ey = fmaxf(fmaxf(ly - f.y, f.y - hy), 0.f);
+        const float ez = fmaxf(fmaxf(lz - f.z, f.z - hz), 0.f);
+        const float lb = ex * ex + ey * ey + ez * ez;
+        const float cx = 0.5f * (lx + hx) - f.x, cy = 0.5f * (ly + hy) - f.y, cz = 0.5f * (lz + hz) - f.z;
+        const float cd = cx * cx + cy * cy + cz * cz;
+        if (lb < best_lb || (lb == best_lb && cd < best_c)) { best_lb = lb; best_c = cd; t0 = t; }
+    }
+    return t0;
+}
+
 __global__ __launch_bounds__(256) void knn_kernel(const float4* __restrict__ x, const int* __restrict__ ptr_x,
                                                   const float4* __restrict__ xq, const int* __restrict__ qidx,
                                                   const int* __restrict__ ptr_q, int B, int k, int* __restrict__ nbr,
-                                                  int* __restrict__ deg, const float* __restrict__ bbox) {
+                                                  int* __restrict__ deg, const float* __restrict__ bbox,
+                                                  int qidx_is_candidate, int flags) {
     __shared__ float4 cand[S_TILE];
     __shared__ int need[2][4];
     int b, q0, q1;
@@ -457,6 +500,7 @@ __global__ __launch_bounds__(256) void knn_kernel(const float4* __restrict__ x, 
     else t0 = (int)(((long long)(q0 - ptr_q[b]) * ntiles) / max(1, ptr_q[b + 1] - ptr_q[b]));  // same storage order
     t0 = min(max(t0, 0), max(ntiles - 1, 0));
     const float* vb = bbox ? bbox + (size_t)bbox_tile_base(ptr_x, b) * 6 : nullptr;
+    if (vb && !qidx_is_candidate) t0 = nearest_tile(vb, ntiles, xq[qidx ? qidx[q0] : q0]);   // queries of another level
     int visit = 0;
     for (int step = 0; step < 2 * ntiles - 1; ++step) {
         const int off = (step + 1) >> 1;
@@ -487,7 +531,7 @@ __global__ __launch_bounds__(256) void knn_kernel(const float4* __restrict__ x, 
             ++visit;
             if (!any) continue;   // no query of this workgroup can gain from the tile: skip staging it
         }
-        stage_shuffled(cand, x, base, c1, tid);
+        stage_shuffled(cand, x, base, c1, tid, (flags & P2W_SEARCH_X_INDEX_IN_W) != 0);
         __syncthreads();
         // groups of 4 chunks (256 candidates) are held in registers while the wave walks its queries, so the
         // per-query state is in scalars inside the admission loop
@@ -533,49 +577,109 @@ __global__ __launch_bounds__(256) void knn_kernel(const float4* __restrict__ x, 
     for (int j = 0; j < S_QPW; ++j) {
         const int q = qw + j;
         if (q < q1) {
-            if (lane < k) nbr[(size_t)q * k + lane] = (lane < cnt) ? best_i[j] : -1;
-            if (lane == 0) deg[q] = cnt;
+            const int row = (flags & P2W_SEARCH_Q_ROW_IN_W) ? __float_as_int(xq[qidx ? qidx[q] : q].w) : q;
+            if (lane < k) nbr[(size_t)row * k + lane] = (lane < cnt) ? best_i[j] : -1;
+            if (lane == 0) deg[row] = cnt;
         }
     }
 }
 
+// Ball query: the `cap` in-ball candidates (d2 < r2) with the smallest reported indices, ascending - which is
+// torch-cluster's "first cap hits in index order" whatever order the candidates are stored or visited in.  Lane l of
+// best_i[j] = the l-th smallest in-ball index so far of query j (INT_MAX = empty); thi = wave-uniform copy of slot
+// cap-1.  With tile boxes, tiles farther than r from every query of the workgroup are never staged (exact: the box
+// gap is a lower bound of p2w_d2 under fp32 rounding).
 __global__ __launch_bounds__(256) void ball_kernel(const float4* __restrict__ x, const int* __restrict__ ptr_x,
                                                    const float4* __restrict__ xq, const int* __restrict__ qidx,
                                                    const int* __restrict__ ptr_q, int B, float r2, int cap,
-                                                   int* __restrict__ nbr, int* __restrict__ deg) {
+                                                   int* __restrict__ nbr, int* __restrict__ deg,
+                                                   const float* __restrict__ bbox, int flags) {
     __shared__ float4 cand[S_TILE];
+    __shared__ int need[2][4];
     int b, q0, q1;
     if (!search_tile(ptr_q, B, blockIdx.x, &b, &q0, &q1)) return;
     const int c0 = ptr_x[b], c1 = ptr_x[b + 1];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qw = q0 + wave * S_QPW;
+    const bool index_in_w = (flags & P2W_SEARCH_X_INDEX_IN_W) != 0;
     UQuery uq[S_QPW];
-    int cnt[S_QPW];  // wave-uniform: neighbours kept so far (cap = full / unused slot)
+    int best_i[S_QPW], thi[S_QPW], cnt[S_QPW];
 #pragma unroll
     for (int j = 0; j < S_QPW; ++j) {
         uq[j] = load_query(xq, qidx, qw + j, q1);
-        cnt[j] = uq[j].valid ? 0 : cap;
+        best_i[j] = 0x7fffffff;
+        thi[j] = uq[j].valid ? 0x7fffffff : -1;   // -1: nothing is ever admitted for an unused slot
+        cnt[j] = 0;
     }
-    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    for (int base = c0; base < c1; base += S_TILE) {
+    const bool in_cap = lane < cap;
+    const int ntiles = (c1 - c0 + S_TILE - 1) / S_TILE;
+    const float* vb = bbox ? bbox + (size_t)bbox_tile_base(ptr_x, b) * 6 : nullptr;
+    const int t0 = vb ? nearest_tile(vb, ntiles, xq[qidx ? qidx[q0] : q0]) : 0;
+    int visit = 0;
+    for (int step = 0; step < 2 * ntiles - 1; ++step) {
+        const int off = (step + 1) >> 1;
+        const int tile = (step & 1) ? t0 + off : t0 - off;
+        if (tile < 0 || tile >= ntiles) continue;
+        const int base = c0 + tile * S_TILE;
+        unsigned qmask = 0u;
+#pragma unroll
+        for (int j = 0; j < S_QPW; ++j) qmask |= uq[j].valid ? (1u << j) : 0u;
+        if (vb) {
+            const float lx = vb[tile * 6 + 0], ly = vb[tile * 6 + 1], lz = vb[tile * 6 + 2];
+            const float hx = vb[tile * 6 + 3], hy = vb[tile * 6 + 4], hz = vb[tile * 6 + 5];
+            unsigned near = 0u;
+#pragma unroll
+            for (int j = 0; j < S_QPW; ++j) {
+                const float ex = fmaxf(fmaxf(lx - uq[j].x, uq[j].x - hx), 0.f);
+                const float ey = fmaxf(fmaxf(ly - uq[j].y, uq[j].y - hy), 0.f);
+                const float ez = fmaxf(fmaxf(lz - uq[j].z, uq[j].z - hz), 0.f);
+                const float lb = ((ex * ex) + (ey * ey)) + (ez * ez);
+                if (lb < r2) near |= 1u << j;
+            }
+            qmask &= near;
+            if (lane == 0) need[visit & 1][wave] = qmask != 0u;
+        }
         __syncthreads();
-        stage_candidates(cand, x, base, c1, tid);
+        if (vb) {
+            const int any = need[visit & 1][0] | need[visit & 1][1] | need[visit & 1][2] | need[visit & 1][3];
+            ++visit;
+            if (!any) continue;
+        }
+#pragma unroll
+        for (int r = 0; r < S_TILE / 256; ++r) {
+            const int c = base + tid + 256 * r;
+            float4 v = make_float4(INFINITY, INFINITY, INFINITY, __int_as_float(0x7fffffff));
+            if (c < c1) { v = x[c]; if (!index_in_w) v.w = __int_as_float(c); }
+            cand[tid + 256 * r] = v;
+        }
         __syncthreads();
         const int nch = (min(S_TILE, c1 - base) + 63) >> 6;
         for (int ch = 0; ch < nch; ++ch) {
             const float4 c = cand[ch * 64 + lane];
-            const int cidx = base + ch * 64 + lane;
+            const int ci = __float_as_int(c.w);
 #pragma unroll
             for (int j = 0; j < S_QPW; ++j) {
+                if (!((qmask >> j) & 1u)) continue;   // wave-uniform
                 const float d = p2w_d2(uq[j].x, uq[j].y, uq[j].z, c.x, c.y, c.z);
                 const bool hit = d < r2;
-                const unsigned long long m = __ballot(hit);
-                if (m != 0ull && cnt[j] < cap) {  // first `cap` hits in ascending candidate index
-                    const int rank = cnt[j] + __popcll(m & lt_mask);
-                    if (hit && rank < cap) nbr[(size_t)(qw + j) * cap + rank] = cidx;
-                    cnt[j] = min(cap, cnt[j] + __popcll(m));
+                const unsigned long long mh = __ballot(hit);
+                if (mh == 0ull) continue;
+                cnt[j] += __popcll(mh);
+                unsigned long long m = __ballot(hit && ci < thi[j]);
+                int bi = best_i[j], ti = thi[j];
+                while (m) {
+                    const int src = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const int in = __builtin_amdgcn_readlane(ci, src);
+                    if (in < ti) {
+                        const int pos = __popcll(__ballot(bi < in));
+                        const int up_i = shr1(bi);
+                        bi = (lane == pos) ? in : (((lane > pos) & in_cap) ? up_i : bi);
+                        ti = __builtin_amdgcn_readlane(bi, cap - 1);
+                    }
                 }
+                best_i[j] = bi; thi[j] = ti;
             }
         }
     }
@@ -583,8 +687,10 @@ __global__ __launch_bounds__(256) void ball_kernel(const float4* __restrict__ x,
     for (int j = 0; j < S_QPW; ++j) {
         const int q = qw + j;
         if (q < q1) {
-            if (lane >= cnt[j] && lane < cap) nbr[(size_t)q * cap + lane] = -1;
-            if (lane == 0) deg[q] = cnt[j];
+            const int row = (flags & P2W_SEARCH_Q_ROW_IN_W) ? __float_as_int(xq[qidx ? qidx[q] : q].w) : q;
+            const int kept = min(cnt[j], cap);
+            if (lane < cap) nbr[(size_t)row * cap + lane] = (lane < kept) ? best_i[j] : -1;
+            if (lane == 0) deg[row] = kept;
         }
     }
 }
@@ -599,28 +705,31 @@ static int32_t search_args(const float* xyzr_x, const int32_t* ptr_x, const floa
 
 extern "C" int32_t p2w_knn(const float* xyzr_x, const int32_t* ptr_x, const float* xyzr_q, const int32_t* qidx,
                            const int32_t* ptr_q, int32_t B, int32_t m_bound, int32_t k, int32_t* nbr, int32_t* deg,
-                           const float* tile_bbox, p2w_stream_t stream) {
+                           const float* tile_bbox, int32_t flags, p2w_stream_t stream) {
     if (m_bound == 0) return P2W_OK;
     const int32_t st = search_args(xyzr_x, ptr_x, xyzr_q, ptr_q, B, m_bound, k, nbr, deg);
     if (st != P2W_OK) return st;
+    if (flags & ~(P2W_SEARCH_X_INDEX_IN_W | P2W_SEARCH_Q_ROW_IN_W)) return P2W_EINVAL;
     const int grid = p2w_cdiv(m_bound, S_QT) + B;  // upper bound on sum_b ceil(m_b / QT)
     knn_kernel<<<grid, 256, 0, p2w_s(stream)>>>(reinterpret_cast<const float4*>(xyzr_x), ptr_x,
                                                 reinterpret_cast<const float4*>(xyzr_q), qidx, ptr_q, B, k, nbr, deg,
-                                                tile_bbox);
+                                                tile_bbox, xyzr_q == xyzr_x, flags);
     return P2W_LAUNCH_STATUS();
 }
 
 extern "C" int32_t p2w_ball_query(const float* xyzr_x, const int32_t* ptr_x, const float* xyzr_q, const int32_t* qidx,
                                   const int32_t* ptr_q, int32_t B, int32_t m_bound, double r, int32_t cap, int32_t* nbr,
-                                  int32_t* deg, p2w_stream_t stream) {
+                                  int32_t* deg, const float* tile_bbox, int32_t flags, p2w_stream_t stream) {
     if (m_bound == 0) return P2W_OK;
     const int32_t st = search_args(xyzr_x, ptr_x, xyzr_q, ptr_q, B, m_bound, cap, nbr, deg);
     if (st != P2W_OK) return st;
     const float r2 = (float)(r * r);
     if (!(r > 0.0)) return P2W_EINVAL;
+    if (flags & ~(P2W_SEARCH_X_INDEX_IN_W | P2W_SEARCH_Q_ROW_IN_W)) return P2W_EINVAL;
     const int grid = p2w_cdiv(m_bound, S_QT) + B;
     ball_kernel<<<grid, 256, 0, p2w_s(stream)>>>(reinterpret_cast<const float4*>(xyzr_x), ptr_x,
-                                                 reinterpret_cast<const float4*>(xyzr_q), qidx, ptr_q, B, r2, cap, nbr, deg);
+                                                 reinterpret_cast<const float4*>(xyzr_q), qidx, ptr_q, B, r2, cap, nbr, deg,
+                                                 tile_bbox, flags);
     return P2W_LAUNCH_STATUS();
 }
 

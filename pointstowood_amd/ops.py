@@ -95,10 +95,11 @@ def _search(kind, x, y, arg, batch_x, batch_y, k):
     if kind == "knn":
         bb = torch.empty((lib().p2w_tile_bbox_count(nb, x.shape[0]), 6), dtype=torch.float32, device=dev)
         check(lib().p2w_tile_bbox(ptr(xx), ptr(px), nb, x.shape[0], ptr(bb), stream()), "tile_bbox")
-        check(lib().p2w_knn(ptr(xx), ptr(px), ptr(yy), None, ptr(py), nb, m, k, ptr(nbr), ptr(deg), ptr(bb), stream()), "knn")
+        check(lib().p2w_knn(ptr(xx), ptr(px), ptr(yy), None, ptr(py), nb, m, k, ptr(nbr), ptr(deg), ptr(bb), 0, stream()),
+              "knn")
     else:
         check(lib().p2w_ball_query(ptr(xx), ptr(px), ptr(yy), None, ptr(py), nb, m, float(arg), k, ptr(nbr), ptr(deg),
-                                   stream()), "radius")
+                                   None, 0, stream()), "radius")
     return nbr, deg
 
 

@@ -133,9 +133,9 @@ def test_c_abi_rejects_bad_arguments():
     n = torch.zeros(16, 100, dtype=torch.int32, device="cuda")
     d = torch.zeros(16, dtype=torch.int32, device="cuda")
     L = lib()
-    assert L.p2w_knn(ptr(x), ptr(p), ptr(x), None, ptr(p), 1, 16, 100, ptr(n), ptr(d), None, stream()) == -1   # k > 64
-    assert L.p2w_knn(None, ptr(p), ptr(x), None, ptr(p), 1, 16, 8, ptr(n), ptr(d), None, stream()) == -2       # NULL
-    assert L.p2w_knn(x.data_ptr() + 4, ptr(p), ptr(x), None, ptr(p), 1, 16, 8, ptr(n), ptr(d), None, stream()) == -3  # alignment
+    assert L.p2w_knn(ptr(x), ptr(p), ptr(x), None, ptr(p), 1, 16, 100, ptr(n), ptr(d), None, 0, stream()) == -1   # k > 64
+    assert L.p2w_knn(None, ptr(p), ptr(x), None, ptr(p), 1, 16, 8, ptr(n), ptr(d), None, 0, stream()) == -2       # NULL
+    assert L.p2w_knn(x.data_ptr() + 4, ptr(p), ptr(x), None, ptr(p), 1, 16, 8, ptr(n), ptr(d), None, 0, stream()) == -3  # alignment
     assert b"NULL" in L.p2w_strerror(-2)
 
 
@@ -159,3 +159,91 @@ def test_f16x3_split_saturates_instead_of_overflowing():
     ref = A.double() @ W.double().t()
     assert bool(torch.isfinite(out).all())
     assert (out.cpu().double() - ref).abs().max() <= 2e-3 * ref.abs().max()
+
+
+def _sorted_level(b, res):
+    """Level records in the sampler's cell order via the C ABI: (xyzr, ptr, order, sorted records, tile boxes)."""
+    from pointstowood_amd._lib import lib, ptr, stream
+    L = lib()
+    pos, batch = b["pos"].cuda(), b["batch"].cuda()
+    n, B = pos.shape[0], int(batch.max()) + 1
+    xyzr = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
+    xyzr[:, :3] = pos
+    csr = torch.zeros(B + 1, dtype=torch.int32, device="cuda")
+    csr[1:] = torch.cumsum(torch.bincount(batch, minlength=B), 0).int()
+    i32 = dict(dtype=torch.int32, device="cuda")
+    idx, ptr_out, batch_out, order = torch.empty(n, **i32), torch.empty(B + 1, **i32), torch.empty(n, **i32), torch.empty(n, **i32)
+    ws = torch.empty(int(L.p2w_voxel_sample_ws_bytes(n)), dtype=torch.uint8, device="cuda")
+    assert L.p2w_voxel_sample(ptr(xyzr), ptr(csr), B, n, res, ptr(idx), ptr(ptr_out), ptr(batch_out), ptr(order), ptr(ws),
+                              ws.numel(), stream()) == 0
+    rec = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+    assert L.p2w_index_records(ptr(xyzr), ptr(order), ptr(csr), B, n, ptr(rec), stream()) == 0
+    box = torch.empty((L.p2w_tile_bbox_count(B, n), 6), dtype=torch.float32, device="cuda")
+    assert L.p2w_tile_bbox(ptr(rec), ptr(csr), B, n, ptr(box), stream()) == 0
+    m = int(ptr_out[B])
+    return dict(L=L, xyzr=xyzr, csr=csr, B=B, n=n, order=order, rec=rec, box=box, idx=idx[:m], ptr_out=ptr_out, m=m)
+
+
+@pytest.mark.parametrize("sizes,surface", [([5000], False), ([1500, 40, 2600], True), ([16384, 3000], False)])
+def test_voxel_sample_order_is_cell_sorted_permutation(sizes, surface):
+    b = _batch(sizes, seed=21, surface=surface)
+    s = _sorted_level(b, 0.04)
+    order = s["order"].cpu().long()
+    assert torch.equal(torch.sort(order).values, torch.arange(s["n"]))
+    cell = O.voxel_grid(b["pos"], 0.04, b["batch"])
+    assert bool((cell[order][1:] >= cell[order][:-1]).all())          # ascending (voxel, cell id)
+    assert torch.equal(s["rec"][:, :3].cpu(), b["pos"][order])
+    assert torch.equal(s["rec"][:, 3].contiguous().view(torch.int32).cpu().long(), order)
+
+
+@pytest.mark.parametrize("sizes,cap,surface", [([4000], 32, False), ([3000], 8, True), ([1500, 40, 2600], 16, True),
+                                               ([16384, 3000], 32, False)])
+def test_ball_query_over_sorted_candidates_matches_plain(sizes, cap, surface):
+    """P2W_SEARCH_X_INDEX_IN_W + tile boxes (the engine's SA1 search) == the plain search == the oracle."""
+    from pointstowood_amd._lib import SEARCH_X_INDEX_IN_W, ptr, stream
+    b = _batch(sizes, seed=23, surface=surface)
+    s = _sorted_level(b, 0.04)
+    L, m = s["L"], s["m"]
+    out = []
+    for x, box, flags in ((s["xyzr"], None, 0), (s["rec"], s["box"], SEARCH_X_INDEX_IN_W), (s["rec"], None, SEARCH_X_INDEX_IN_W)):
+        nbr = torch.empty((m, cap), dtype=torch.int32, device="cuda")
+        deg = torch.empty(m, dtype=torch.int32, device="cuda")
+        assert L.p2w_ball_query(ptr(x), ptr(s["csr"]), ptr(s["xyzr"]), ptr(s["idx"]), ptr(s["ptr_out"]), s["B"], m, 0.08, cap,
+                                ptr(nbr), ptr(deg), ptr(box), flags, stream()) == 0
+        out.append((nbr.cpu(), deg.cpu()))
+    for nbr, deg in out[1:]:
+        assert torch.equal(nbr, out[0][0]) and torch.equal(deg, out[0][1])
+    idx = s["idx"].cpu().long()
+    ref = O.radius(b["pos"], b["pos"][idx], 0.08, b["batch"], b["batch"][idx], max_num_neighbors=cap)
+    nbr, deg = out[1]
+    mask = torch.arange(cap)[None, :] < deg[:, None]
+    got = torch.stack([torch.arange(m)[:, None].expand(m, cap)[mask], nbr[mask].long()], 0)
+    assert torch.equal(got, ref)
+    if surface:
+        assert int(deg.max()) == cap                                   # the cap is exercised
+
+
+@pytest.mark.parametrize("sizes,k", [([5000], 2), ([1500, 40, 2600], 2), ([16384, 3000], 3)])
+def test_knn_with_sorted_queries_writes_own_rows(sizes, k):
+    """P2W_SEARCH_Q_ROW_IN_W (the engine's last interpolation search): level-0 queries visited in cell order."""
+    from pointstowood_amd._lib import SEARCH_Q_ROW_IN_W, ptr, stream
+    b = _batch(sizes, seed=29)
+    s = _sorted_level(b, 0.04)
+    L, n, B = s["L"], s["n"], s["B"]
+    coarse = s["xyzr"][s["idx"].long()].contiguous()                   # level-1 records (no scale round trip here)
+    cbox = torch.empty((L.p2w_tile_bbox_count(B, s["m"]), 6), dtype=torch.float32, device="cuda")
+    assert L.p2w_tile_bbox(ptr(coarse), ptr(s["ptr_out"]), B, s["m"], ptr(cbox), stream()) == 0
+    res = []
+    for q, flags in ((s["xyzr"], 0), (s["rec"], SEARCH_Q_ROW_IN_W)):
+        nbr = torch.full((n, k), -7, dtype=torch.int32, device="cuda")
+        deg = torch.full((n,), -7, dtype=torch.int32, device="cuda")
+        assert L.p2w_knn(ptr(coarse), ptr(s["ptr_out"]), ptr(q), None, ptr(s["csr"]), B, n, k, ptr(nbr), ptr(deg), ptr(cbox),
+                         flags, stream()) == 0
+        res.append((nbr.cpu(), deg.cpu()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    idx = s["idx"].cpu().long()
+    ref = O.knn(b["pos"][idx], b["pos"], k, b["batch"][idx], b["batch"])
+    nbr, deg = res[1]
+    mask = torch.arange(k)[None, :] < deg[:, None]
+    got = torch.stack([torch.arange(n)[:, None].expand(n, k)[mask], nbr[mask].long()], 0)
+    assert torch.equal(got, ref)
