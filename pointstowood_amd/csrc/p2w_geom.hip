@@ -482,15 +482,14 @@ __global__ __launch_bounds__(256) void knn_kernel(const float4* __restrict__ x, 
     const int qw = q0 + wave * S_QPW;
     UQuery uq[S_QPW];
     // selection state: lane l of (best_d, best_i)[j] = the l-th smallest (d2, index) so far of query j;
-    // empty slots and lanes >= k hold (+inf, INT_MAX); (thr, thi) = wave-uniform copy of slot k-1
+    // empty slots and lanes >= k hold (+inf, INT_MAX); thr = wave-uniform copy of slot k-1's distance
     float best_d[S_QPW], thr[S_QPW];
-    int best_i[S_QPW], thi[S_QPW];
+    int best_i[S_QPW];
 #pragma unroll
     for (int j = 0; j < S_QPW; ++j) {
         uq[j] = load_query(xq, qidx, qw + j, q1);
         best_d[j] = INFINITY; best_i[j] = 0x7fffffff;
         thr[j] = uq[j].valid ? INFINITY : -INFINITY;
-        thi[j] = 0x7fffffff;
     }
     const bool in_k = lane < k;
     // tile visiting order: start where the block's first query most likely has its neighbours and move outwards
@@ -544,7 +543,7 @@ __global__ __launch_bounds__(256) void knn_kernel(const float4* __restrict__ x, 
             for (int j = 0; j < S_QPW; ++j) {
                 if (!((qmask >> j) & 1u)) continue;   // wave-uniform
                 float bd = best_d[j], t = thr[j];
-                int bi = best_i[j], ti = thi[j];
+                int bi = best_i[j];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const float d = p2w_d2(uq[j].x, uq[j].y, uq[j].z, c[u].x, c[u].y, c[u].z);
@@ -555,19 +554,22 @@ __global__ __launch_bounds__(256) void knn_kernel(const float4* __restrict__ x, 
                         m &= m - 1;
                         const float dn = rdlane(d, src);
                         const int in = __builtin_amdgcn_readlane(ci, src);
-                        if (dn < t || (dn == t && in < ti)) {  // scalar branch: (dn, in) < slot k-1
-                            const int pos = __popcll(__ballot(bd < dn || (bd == dn && bi < in)));
+                        // (d2, index) pairs order like the 64-bit integers (bits(d2) << 32 | index): d2 >= +0, index >= 0.
+                        // pos = number of kept pairs below the new one; it enters iff pos < k
+                        const unsigned long long kn = ((unsigned long long)__float_as_uint(dn) << 32) | (unsigned)in;
+                        const unsigned long long kb = ((unsigned long long)__float_as_uint(bd) << 32) | (unsigned)bi;
+                        const int pos = __popcll(__ballot(kb < kn));
+                        if (pos < k) {  // scalar branch
                             const float up_d = shr1(bd);
                             const int up_i = shr1(bi);
                             const bool here = lane == pos, sh = (lane > pos) & in_k;
                             bd = here ? dn : (sh ? up_d : bd);
                             bi = here ? in : (sh ? up_i : bi);
                             t = rdlane(bd, k - 1);
-                            ti = __builtin_amdgcn_readlane(bi, k - 1);
                         }
                     }
                 }
-                best_d[j] = bd; best_i[j] = bi; thr[j] = t; thi[j] = ti;
+                best_d[j] = bd; best_i[j] = bi; thr[j] = t;
             }
         }
         (void)ngr;
