@@ -59,9 +59,23 @@ int32_t p2w_pack_xyzr(const float* pos, int32_t pos_stride, const float* refl, c
  *      ptr_out[B] = M), batch_out[M]; order_out[n] (optional, may be NULL) = the input point indices in
  *      ascending (voxel, cell id) order - a spatially coherent visiting order for the searches below.
  * ws : p2w_voxel_sample_ws_bytes(n_bound) bytes of scratch. */
+/* Geometry of the cell grid a sampling call used (device-resident, written by p2w_voxel_sample): cell (cx, cy, cz)
+ * of voxel b has key ((( (b - b_lo) * dims[2] + cz) * dims[1] + cy) * dims[0] + cx. */
+typedef struct p2w_grid {
+    float lo[3];      /* batch-global minimum of the sampled coordinates = grid origin */
+    float res;        /* cell size */
+    float hi[3];      /* batch-global maximum */
+    int32_t b_lo;     /* first non-empty voxel */
+    int64_t dims[3];  /* cells per axis */
+} p2w_grid;
+
 size_t p2w_voxel_sample_ws_bytes(int32_t n_bound);
+/* Optional outputs (NULL to skip) that make the level searchable through p2w_knn_grid / p2w_ball_query_grid:
+ * sorted_keys_out[n] = the cell keys of all input points in ascending order (the order of order_out),
+ * cell_keys_out[M] = the key of every representative (ascending = the output order), grid_out = the grid. */
 int32_t p2w_voxel_sample(const float* xyzr, const int32_t* ptr, int32_t B, int32_t n_bound, float res,
-                         int32_t* idx_out, int32_t* ptr_out, int32_t* batch_out, int32_t* order_out, void* ws,
+                         int32_t* idx_out, int32_t* ptr_out, int32_t* batch_out, int32_t* order_out,
+                         uint64_t* sorted_keys_out, uint64_t* cell_keys_out, p2w_grid* grid_out, void* ws,
                          size_t ws_bytes, p2w_stream_t stream);
 
 /* out[i] = (x, y, z, bit pattern of order[i]) of xyzr[order[i]] for i < ptr[B]: the records of a level in another
@@ -104,6 +118,18 @@ int32_t p2w_ball_query(const float* xyzr_x, const int32_t* ptr_x, const float* x
 int32_t p2w_knn(const float* xyzr_x, const int32_t* ptr_x, const float* xyzr_q, const int32_t* qidx,
                 const int32_t* ptr_q, int32_t B, int32_t m_bound, int32_t k, int32_t* nbr, int32_t* deg,
                 const float* tile_bbox, int32_t flags, p2w_stream_t stream);
+
+/* The same two searches over candidates stored in ascending cell-key order of `grid` (keys_x[c] = key of candidate c;
+ * both come from the p2w_voxel_sample call that produced or ordered the level).  Only the grid rows within reach of a
+ * workgroup's queries are gathered (two binary searches on the keys per z layer) instead of the whole voxel; the
+ * results are identical to p2w_knn / p2w_ball_query.  Queries should be spatially coherent (any level in its own
+ * storage order is). */
+int32_t p2w_knn_grid(const float* xyzr_x, const uint64_t* keys_x, const int32_t* ptr_x, const p2w_grid* grid,
+                     const float* xyzr_q, const int32_t* qidx, const int32_t* ptr_q, int32_t B, int32_t m_bound,
+                     int32_t k, int32_t* nbr, int32_t* deg, int32_t flags, p2w_stream_t stream);
+int32_t p2w_ball_query_grid(const float* xyzr_x, const uint64_t* keys_x, const int32_t* ptr_x, const p2w_grid* grid,
+                            const float* xyzr_q, const int32_t* qidx, const int32_t* ptr_q, int32_t B, int32_t m_bound,
+                            double r, int32_t cap, int32_t* nbr, int32_t* deg, int32_t flags, p2w_stream_t stream);
 
 /* Optional accelerator for the searches (results are identical with or without it): bounding boxes (lo xyz, hi xyz)
  * of the candidate tiles of xyzr_x (1024 consecutive records of one voxel).  bbox holds p2w_tile_bbox_count(B,

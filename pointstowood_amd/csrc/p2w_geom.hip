@@ -124,17 +124,33 @@ __global__ __launch_bounds__(256) void vs_flags_kernel(const unsigned long long*
     flags[i] = (i < n && (i == n - 1 || keys[i] != keys[i + 1])) ? 1 : 0;  // last of each run = largest point index
 }
 
-// perm (one representative per run, ascending key), optional inv (rank of every point's key), optional CSR of the result
+// perm (one representative per run, ascending key), optional inv (rank of every point's key), optional CSR of the result,
+// optional search index of the result (sorted keys of all points, key of each representative, grid geometry)
 __global__ __launch_bounds__(256) void vs_scatter_kernel(const int* __restrict__ flags, const int* __restrict__ scan,
                                                          const int* __restrict__ vals, const int* __restrict__ ptr, int B,
                                                          const int* __restrict__ n_dev, int n_bound, int* __restrict__ idx_out,
                                                          int* __restrict__ ptr_out, int* __restrict__ batch_out,
                                                          int* __restrict__ inv_out, int* __restrict__ count_out,
-                                                         int* __restrict__ order_out) {
+                                                         int* __restrict__ order_out,
+                                                         const unsigned long long* __restrict__ keys_sorted,
+                                                         unsigned long long* __restrict__ sorted_keys_out,
+                                                         unsigned long long* __restrict__ cell_keys_out,
+                                                         const VsHeader* __restrict__ h, float res, p2w_grid* __restrict__ grid_out) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int n = n_dev ? *n_dev : n_bound;
     const int total = (n == 0) ? 0 : scan[n - 1] + flags[n - 1];
     if (i == 0 && count_out) *count_out = total;
+    if (i == 0 && grid_out && h) {   // the geometry vs_keys_kernel used
+        int b_lo = 0;
+        while (b_lo < B - 1 && ptr[b_lo + 1] == ptr[b_lo]) ++b_lo;
+        p2w_grid g;
+        for (int d = 0; d < 3; ++d) {
+            g.lo[d] = ord2f(h->lo[d]); g.hi[d] = ord2f(h->hi[d]);
+            g.dims[d] = (n == 0) ? 1 : (long long)((g.hi[d] - g.lo[d]) / res) + 1;
+        }
+        g.res = res; g.b_lo = b_lo;
+        *grid_out = g;
+    }
     if (ptr_out && i <= B) {  // sorted position p belongs to voxel b iff ptr[b] <= p < ptr[b+1] (keys are voxel-major)
         const int p = ptr[i];
         ptr_out[i] = (p < n) ? scan[p] : total;
@@ -142,10 +158,12 @@ __global__ __launch_bounds__(256) void vs_scatter_kernel(const int* __restrict__
     if (i >= n || i >= n_bound) return;
     if (inv_out) inv_out[vals[i]] = scan[i];
     if (order_out) order_out[i] = vals[i];
+    if (sorted_keys_out) sorted_keys_out[i] = keys_sorted[i];
     if (flags[i]) {
         const int o = scan[i];
         idx_out[o] = vals[i];
         if (batch_out) batch_out[o] = p2w_find_segment(ptr, B, i);
+        if (cell_keys_out) cell_keys_out[o] = keys_sorted[i];
     }
 }
 
@@ -193,7 +211,8 @@ static int32_t vs_compute_keys(const float4* x4, const int* ptr, int B, int n_bo
 // sort (key, point) pairs, flag the last element of each run, compact
 static int32_t vs_cluster(char* w, const VsLayout& L, const unsigned long long* keys_in, const int* ptr, int B,
                           const int* n_dev, int n_bound, int* idx_out, int* ptr_out, int* batch_out, int* inv_out,
-                          int* count_out, int* order_out, hipStream_t s) {
+                          int* count_out, int* order_out, unsigned long long* sorted_keys_out,
+                          unsigned long long* cell_keys_out, float res, p2w_grid* grid_out, hipStream_t s) {
     auto* keys_out = reinterpret_cast<unsigned long long*>(w + L.keys_out);
     int* vals_in = reinterpret_cast<int*>(w + L.vals_in);
     int* vals_out = reinterpret_cast<int*>(w + L.vals_out);
@@ -209,12 +228,14 @@ static int32_t vs_cluster(char* w, const VsLayout& L, const unsigned long long* 
     if (e != hipSuccess) return (int32_t)e;
     const int nblk2 = p2w_cdiv((n_bound > B + 1 ? n_bound : B + 1), 256);
     vs_scatter_kernel<<<nblk2, 256, 0, s>>>(flags, scan, vals_out, ptr, B, n_dev, n_bound, idx_out, ptr_out, batch_out,
-                                            inv_out, count_out, order_out);
+                                            inv_out, count_out, order_out, keys_out, sorted_keys_out, cell_keys_out,
+                                            reinterpret_cast<const VsHeader*>(w + L.hdr), res, grid_out);
     return P2W_LAUNCH_STATUS();
 }
 
 extern "C" int32_t p2w_voxel_sample(const float* xyzr, const int32_t* ptr, int32_t B, int32_t n_bound, float res,
-                                    int32_t* idx_out, int32_t* ptr_out, int32_t* batch_out, int32_t* order_out, void* ws,
+                                    int32_t* idx_out, int32_t* ptr_out, int32_t* batch_out, int32_t* order_out,
+                                    uint64_t* sorted_keys_out, uint64_t* cell_keys_out, p2w_grid* grid_out, void* ws,
                                     size_t ws_bytes, p2w_stream_t stream) {
     P2W_CHECK_PTR(ptr); P2W_CHECK_PTR(ptr_out);
     if (B <= 0 || n_bound < 0 || !(res > 0.0f)) return P2W_EINVAL;
@@ -231,7 +252,9 @@ extern "C" int32_t p2w_voxel_sample(const float* xyzr, const int32_t* ptr, int32
     int32_t st = vs_compute_keys(reinterpret_cast<const float4*>(xyzr), ptr, B, n_bound, res,
                                  reinterpret_cast<VsHeader*>(w + L.hdr), keys_in, reinterpret_cast<int*>(w + L.vals_in), s);
     if (st != P2W_OK) return st;
-    return vs_cluster(w, L, keys_in, ptr, B, ptr + B, n_bound, idx_out, ptr_out, batch_out, nullptr, nullptr, order_out, s);
+    return vs_cluster(w, L, keys_in, ptr, B, ptr + B, n_bound, idx_out, ptr_out, batch_out, nullptr, nullptr, order_out,
+                      reinterpret_cast<unsigned long long*>(sorted_keys_out),
+                      reinterpret_cast<unsigned long long*>(cell_keys_out), res, grid_out, s);
 }
 
 extern "C" int32_t p2w_voxel_grid(const float* xyzr, const int32_t* ptr, int32_t B, int32_t n, float res, int64_t* cell_out,
@@ -260,7 +283,7 @@ extern "C" int32_t p2w_consecutive_cluster(const int64_t* cell, int32_t n, int32
     vs_iota_kernel<<<p2w_cdiv(n, 256), 256, 0, s>>>(n, reinterpret_cast<int*>(w + L.vals_in));
     // non-negative int64 cell ids order like their unsigned bit patterns
     return vs_cluster(w, L, reinterpret_cast<const unsigned long long*>(cell), nullptr, 0, nullptr, n, perm_out, nullptr,
-                      nullptr, inv_out, count_out, nullptr, s);
+                      nullptr, inv_out, count_out, nullptr, nullptr, nullptr, 0.f, nullptr, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -697,6 +720,308 @@ __global__ __launch_bounds__(256) void ball_kernel(const float4* __restrict__ x,
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// grid-indexed neighbour search
+//
+// The candidates are stored in ascending cell-key order of a p2w_grid (the order p2w_voxel_sample produces), `keys`
+// holds their keys.  A workgroup still owns 32 consecutive queries of one voxel, but instead of streaming the whole
+// voxel it gathers only the rows of the grid within a radius rho of its queries' bounding box: for every z layer the
+// rows [Ylo, Yhi] are one contiguous run of the storage order, found with two binary searches on the keys.  The runs
+// are concatenated into LDS tiles and scanned exactly like the brute-force kernels do.
+//   ball query: rho = r, one pass.
+//   kNN       : rho starts from a local density estimate; after a pass every query checks that its k-th distance is
+//               not larger than its distance to the nearest face of the gathered region (rows outside it can only hold
+//               farther candidates); otherwise the region grows and only the NEW rows are scanned.
+// Exactness: a candidate's key cell comes from fp32 arithmetic on (possibly one level older) coordinates, so faces
+// are pulled in by eps = res/32 + 1e-5*max|coordinate| >> every rounding involved; a candidate that is not gathered
+// is provably farther than the accepted k-th distance (or than r), so the result equals the brute-force one bit for bit.
+// ------------------------------------------------------------------------------------------------
+constexpr int G_MAXRUN = 256;        // runs per pass (2 per z layer)
+
+__device__ __forceinline__ int lower_bound_key(const unsigned long long* __restrict__ keys, int lo, int hi,
+                                               unsigned long long key) {
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (keys[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// cell index of coordinate v on one axis, clamped to [0, dim-1]
+__device__ __forceinline__ int grid_cell(float v, float lo, float res, long long dim) {
+    const float f = floorf((v - lo) / res);
+    const float top = (float)(dim - 1 < (1ll << 30) ? dim - 1 : (1ll << 30));
+    return (int)fminf(fmaxf(f, 0.f), top);   // NaN -> 0
+}
+
+template <int MODE>   // 0 = kNN, 1 = ball query
+__global__ __launch_bounds__(256) void slab_search_kernel(const float4* __restrict__ x, const unsigned long long* __restrict__ keys,
+                                                          const int* __restrict__ ptr_x, const p2w_grid* __restrict__ grid,
+                                                          const float4* __restrict__ xq, const int* __restrict__ qidx,
+                                                          const int* __restrict__ ptr_q, int B, int k, float r, float r2,
+                                                          int* __restrict__ nbr, int* __restrict__ deg, int flags) {
+    __shared__ float4 cand[S_TILE];
+    __shared__ int run_start[G_MAXRUN];
+    __shared__ int run_pre[G_MAXRUN + 1];
+    __shared__ int wsum[4];
+    __shared__ float wred[4][6];
+    int b, q0, q1;
+    if (!search_tile(ptr_q, B, blockIdx.x, &b, &q0, &q1)) return;
+    const int c0 = ptr_x[b], c1 = ptr_x[b + 1];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qw = q0 + wave * S_QPW;
+    const bool index_in_w = (flags & P2W_SEARCH_X_INDEX_IN_W) != 0;
+    // grid geometry (wave-uniform)
+    const float lo_y = grid->lo[1], lo_z = grid->lo[2], res = grid->res;
+    const long long g0 = grid->dims[0], g1 = grid->dims[1], g2 = grid->dims[2];
+    const long long kb = (long long)((float)b - (float)grid->b_lo);
+    float amax = 1.f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) amax = fmaxf(amax, fmaxf(fabsf(grid->lo[d]), fabsf(grid->hi[d])));
+    const float eps = res * (1.f / 32.f) + 1e-5f * amax;
+
+    UQuery uq[S_QPW];
+    float best_d[S_QPW], thr[S_QPW];
+    int best_i[S_QPW], cnt[S_QPW];
+    unsigned active = 0u;   // queries of this wave whose result is not final yet
+    float ymin = INFINITY, ymax = -INFINITY, zmin = INFINITY, zmax = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < S_QPW; ++j) {
+        uq[j] = load_query(xq, qidx, qw + j, q1);
+        best_d[j] = INFINITY; best_i[j] = 0x7fffffff; cnt[j] = 0;
+        thr[j] = MODE == 0 ? INFINITY : __int_as_float(0x7fffffff);   // ball: thr holds the index threshold's bits
+        if (uq[j].valid) {
+            active |= 1u << j;
+            ymin = fminf(ymin, uq[j].y); ymax = fmaxf(ymax, uq[j].y);
+            zmin = fminf(zmin, uq[j].z); zmax = fmaxf(zmax, uq[j].z);
+        }
+    }
+    if (lane == 0) { wred[wave][0] = ymin; wred[wave][1] = ymax; wred[wave][2] = zmin; wred[wave][3] = zmax; }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        ymin = fminf(ymin, wred[w][0]); ymax = fmaxf(ymax, wred[w][1]);
+        zmin = fminf(zmin, wred[w][2]); zmax = fmaxf(zmax, wred[w][3]);
+    }
+    const bool in_k = lane < k;
+    const int total = c1 - c0;
+
+    // rows of the region "bounding box of the queries grown by rho" and the runs that are new relative to the region
+    // scanned so far; returns the number of candidates in those runs (run table in LDS)
+    int oYlo = 0, oYhi = -1, oZlo = 0, oZhi = -1;   // scanned region (empty)
+    int nYlo, nYhi, nZlo, nZhi;
+    bool whole = false;                             // the scanned region is the whole voxel
+    auto plan = [&](float rho, bool force_whole) -> int {
+        nYlo = grid_cell(ymin - rho - eps, lo_y, res, g1); nYhi = grid_cell(ymax + rho + eps, lo_y, res, g1);
+        nZlo = grid_cell(zmin - rho - eps, lo_z, res, g2); nZhi = grid_cell(zmax + rho + eps, lo_z, res, g2);
+        if (oYhi >= oYlo) { nYlo = min(nYlo, oYlo); nYhi = max(nYhi, oYhi); nZlo = min(nZlo, oZlo); nZhi = max(nZhi, oZhi); }
+        const int nz = nZhi - nZlo + 1;
+        __syncthreads();   // run table free
+        if (force_whole || nz > G_MAXRUN / 2 || !(rho == rho)) {   // degenerate geometry: everything, as one run
+            whole = true;
+            if (tid == 0) { run_start[0] = c0; run_pre[0] = 0; run_pre[1] = total; }
+            __syncthreads();
+            return total;
+        }
+        int len = 0;
+        if (tid < 2 * nz) {
+            const int z = nZlo + (tid >> 1), side = tid & 1;
+            int ya, yb;
+            if (oYhi >= oYlo && z >= oZlo && z <= oZhi) { ya = side ? oYhi + 1 : nYlo; yb = side ? nYhi : oYlo - 1; }
+            else { ya = nYlo; yb = side ? nYlo - 1 : nYhi; }
+            if (ya <= yb) {
+                const long long rowbase = (kb * g2 + z) * g1;
+                const unsigned long long ka = (unsigned long long)((rowbase + ya) * g0);
+                const unsigned long long kz = (unsigned long long)((rowbase + yb + 1) * g0);
+                const int s0 = lower_bound_key(keys, c0, c1, ka);
+                const int s1 = lower_bound_key(keys, s0, c1, kz);
+                run_start[tid] = s0;
+                len = s1 - s0;
+            } else {
+                run_start[tid] = c0;
+            }
+        }
+        // exclusive prefix sum of len over the workgroup
+        int inc = len;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(inc, off);
+            if (lane >= off) inc += o;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < wave; ++w) base += wsum[w];
+        run_pre[tid + 1] = base + inc;
+        if (tid == 0) run_pre[0] = 0;
+        __syncthreads();
+        return run_pre[G_MAXRUN];
+    };
+
+    float rho;
+    if (MODE == 1) {
+        rho = r;
+    } else {
+        // local density probe: candidates in the rows that hold the queries themselves
+        const int n0 = plan(0.f, false);
+        float dens = 0.f;
+        if (!whole && n0 >= 8) {
+            const float vol = ((float)g0 * res) * ((float)(nYhi - nYlo + 1) * res) * ((float)(nZhi - nZlo + 1) * res);
+            dens = (float)n0 / vol;
+        } else {
+            dens = (float)total / fmaxf(((float)g0 * res) * ((float)g1 * res) * ((float)g2 * res), 1e-30f);
+        }
+        const float rk = cbrtf(0.75f * (float)k / (3.14159265f * fmaxf(dens, 1e-30f)));
+        rho = fminf(1.25f * rk, 1e30f) + 0.5f * res;
+        whole = false;
+    }
+
+    for (int pass = 0; pass < 12; ++pass) {
+        const bool restart = pass >= 8 && !whole;      // give up on the geometry: rescan everything from scratch
+        if (restart) {
+#pragma unroll
+            for (int j = 0; j < S_QPW; ++j) {
+                if ((active >> j) & 1u) {
+                    best_d[j] = INFINITY; best_i[j] = 0x7fffffff; cnt[j] = 0;
+                    thr[j] = MODE == 0 ? INFINITY : __int_as_float(0x7fffffff);
+                }
+            }
+            oYlo = 0; oYhi = -1; oZlo = 0; oZhi = -1;
+        }
+        const bool was_whole = whole;
+        const int n_c = was_whole ? 0 : plan(rho, restart);
+        const int nruns = whole ? 1 : G_MAXRUN;
+        for (int tbase = 0; tbase < n_c; tbase += S_TILE) {
+            __syncthreads();   // previous tile consumed
+            // slots used by this tile: a power of two >= the candidates left (>= 256), so that the shuffle stays a
+            // permutation and a short gather does not pay for 1024 slots
+            const int left = n_c - tbase;
+            const int tsz = left > 512 ? 1024 : (left > 256 ? 512 : 256);
+#pragma unroll
+            for (int rr = 0; rr < S_TILE / 256; ++rr) {
+                const int s = tid + 256 * rr;
+                if (s >= tsz) break;
+                const int g = tbase + (MODE == 0 ? ((s * 389) & (tsz - 1)) : s);
+                float4 v = make_float4(INFINITY, INFINITY, INFINITY, __int_as_float(0x7fffffff));
+                if (g < n_c) {
+                    int lo = 0, hi = nruns;   // largest run with run_pre[run] <= g
+                    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (run_pre[mid] <= g) lo = mid; else hi = mid; }
+                    const int c = run_start[lo] + (g - run_pre[lo]);
+                    v = x[c];
+                    if (!index_in_w) v.w = __int_as_float(c);
+                }
+                cand[s] = v;
+            }
+            __syncthreads();
+            if (MODE == 0) {
+                for (int gr = 0; gr < (tsz >> 8); ++gr) {
+                    float4 c[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) c[u] = cand[gr * 256 + u * 64 + lane];
+#pragma unroll
+                    for (int j = 0; j < S_QPW; ++j) {
+                        if (!((active >> j) & 1u)) continue;   // wave-uniform
+                        float bd = best_d[j], t = thr[j];
+                        int bi = best_i[j];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const float d = p2w_d2(uq[j].x, uq[j].y, uq[j].z, c[u].x, c[u].y, c[u].z);
+                            const int ci = __float_as_int(c[u].w);
+                            unsigned long long m = __ballot(d <= t);
+                            while (m) {
+                                const int src = __ffsll((long long)m) - 1;
+                                m &= m - 1;
+                                const float dn = rdlane(d, src);
+                                const int in = __builtin_amdgcn_readlane(ci, src);
+                                const unsigned long long kn = ((unsigned long long)__float_as_uint(dn) << 32) | (unsigned)in;
+                                const unsigned long long kbst = ((unsigned long long)__float_as_uint(bd) << 32) | (unsigned)bi;
+                                const int pos = __popcll(__ballot(kbst < kn));
+                                if (pos < k) {
+                                    const float up_d = shr1(bd);
+                                    const int up_i = shr1(bi);
+                                    const bool here = lane == pos, sh = (lane > pos) & in_k;
+                                    bd = here ? dn : (sh ? up_d : bd);
+                                    bi = here ? in : (sh ? up_i : bi);
+                                    t = rdlane(bd, k - 1);
+                                }
+                            }
+                        }
+                        best_d[j] = bd; best_i[j] = bi; thr[j] = t;
+                    }
+                }
+            } else {
+                const int nch = (min(S_TILE, n_c - tbase) + 63) >> 6;
+                for (int ch = 0; ch < nch; ++ch) {
+                    const float4 c = cand[ch * 64 + lane];
+                    const int ci = __float_as_int(c.w);
+#pragma unroll
+                    for (int j = 0; j < S_QPW; ++j) {
+                        if (!((active >> j) & 1u)) continue;
+                        const float d = p2w_d2(uq[j].x, uq[j].y, uq[j].z, c.x, c.y, c.z);
+                        const bool hit = d < r2;
+                        const unsigned long long mh = __ballot(hit);
+                        if (mh == 0ull) continue;
+                        cnt[j] += __popcll(mh);
+                        int bi = best_i[j], ti = __float_as_int(thr[j]);
+                        unsigned long long m = __ballot(hit && ci < ti);
+                        while (m) {
+                            const int src = __ffsll((long long)m) - 1;
+                            m &= m - 1;
+                            const int in = __builtin_amdgcn_readlane(ci, src);
+                            if (in < ti) {
+                                const int pos = __popcll(__ballot(bi < in));
+                                const int up_i = shr1(bi);
+                                bi = (lane == pos) ? in : (((lane > pos) & in_k) ? up_i : bi);
+                                ti = __builtin_amdgcn_readlane(bi, k - 1);
+                            }
+                        }
+                        best_i[j] = bi; thr[j] = __int_as_float(ti);
+                    }
+                }
+            }
+        }
+        if (!was_whole) { oYlo = nYlo; oYhi = nYhi; oZlo = nZlo; oZhi = nZhi; }
+        if (MODE == 1) break;
+        // which queries are final?  k-th distance <= distance to the nearest face of the scanned region
+        float need = 0.f;
+        if (!whole) {
+            const float fy0 = oYlo <= 0 ? -INFINITY : lo_y + (float)oYlo * res;
+            const float fy1 = (long long)oYhi >= g1 - 1 ? INFINITY : lo_y + (float)(oYhi + 1) * res;
+            const float fz0 = oZlo <= 0 ? -INFINITY : lo_z + (float)oZlo * res;
+            const float fz1 = (long long)oZhi >= g2 - 1 ? INFINITY : lo_z + (float)(oZhi + 1) * res;
+#pragma unroll
+            for (int j = 0; j < S_QPW; ++j) {
+                if (!((active >> j) & 1u)) continue;
+                const float gap = fminf(fminf(uq[j].y - fy0, fy1 - uq[j].y), fminf(uq[j].z - fz0, fz1 - uq[j].z)) - eps;
+                const bool ok = gap > 0.f && thr[j] <= gap * gap;      // thr = +inf until k candidates were found
+                if (ok) active &= ~(1u << j);
+                else need = fmaxf(need, thr[j] < INFINITY ? sqrtf(thr[j]) * 1.0001f + 3.f * eps : 2.f * rho + res);
+            }
+        } else {
+            active = 0u;
+        }
+        __syncthreads();
+        if (lane == 0) wred[wave][4] = need;
+        __syncthreads();
+        need = fmaxf(fmaxf(wred[0][4], wred[1][4]), fmaxf(wred[2][4], wred[3][4]));
+        if (!(need > 0.f)) break;          // every query of the workgroup is final
+        rho = fmaxf(need, rho);
+    }
+    const int kept_max = min(k, total);
+#pragma unroll
+    for (int j = 0; j < S_QPW; ++j) {
+        const int q = qw + j;
+        if (q < q1) {
+            const int row = (flags & P2W_SEARCH_Q_ROW_IN_W) ? __float_as_int(xq[qidx ? qidx[q] : q].w) : q;
+            const int kept = MODE == 0 ? kept_max : min(cnt[j], k);
+            if (lane < k) nbr[(size_t)row * k + lane] = (lane < kept) ? best_i[j] : -1;
+            if (lane == 0) deg[row] = kept;
+        }
+    }
+}
+
 static int32_t search_args(const float* xyzr_x, const int32_t* ptr_x, const float* xyzr_q, const int32_t* ptr_q, int32_t B,
                            int32_t m_bound, int32_t k, const int32_t* nbr, const int32_t* deg) {
     P2W_CHECK_PTR(xyzr_x); P2W_CHECK_PTR(ptr_x); P2W_CHECK_PTR(xyzr_q); P2W_CHECK_PTR(ptr_q); P2W_CHECK_PTR(nbr);
@@ -732,6 +1057,44 @@ extern "C" int32_t p2w_ball_query(const float* xyzr_x, const int32_t* ptr_x, con
     ball_kernel<<<grid, 256, 0, p2w_s(stream)>>>(reinterpret_cast<const float4*>(xyzr_x), ptr_x,
                                                  reinterpret_cast<const float4*>(xyzr_q), qidx, ptr_q, B, r2, cap, nbr, deg,
                                                  tile_bbox, flags);
+    return P2W_LAUNCH_STATUS();
+}
+
+
+static int32_t grid_args(const uint64_t* keys, const p2w_grid* grid, int32_t flags) {
+    P2W_CHECK_PTR(keys); P2W_CHECK_PTR(grid);
+    if ((reinterpret_cast<uintptr_t>(keys) & 7u) || (reinterpret_cast<uintptr_t>(grid) & 7u)) return P2W_EALIGN;
+    if (flags & ~(P2W_SEARCH_X_INDEX_IN_W | P2W_SEARCH_Q_ROW_IN_W)) return P2W_EINVAL;
+    return P2W_OK;
+}
+
+extern "C" int32_t p2w_knn_grid(const float* xyzr_x, const uint64_t* keys_x, const int32_t* ptr_x, const p2w_grid* grid,
+                                const float* xyzr_q, const int32_t* qidx, const int32_t* ptr_q, int32_t B, int32_t m_bound,
+                                int32_t k, int32_t* nbr, int32_t* deg, int32_t flags, p2w_stream_t stream) {
+    if (m_bound == 0) return P2W_OK;
+    int32_t st = search_args(xyzr_x, ptr_x, xyzr_q, ptr_q, B, m_bound, k, nbr, deg);
+    if (st != P2W_OK) return st;
+    if ((st = grid_args(keys_x, grid, flags)) != P2W_OK) return st;
+    const int grid_dim = p2w_cdiv(m_bound, S_QT) + B;
+    slab_search_kernel<0><<<grid_dim, 256, 0, p2w_s(stream)>>>(
+        reinterpret_cast<const float4*>(xyzr_x), reinterpret_cast<const unsigned long long*>(keys_x), ptr_x, grid,
+        reinterpret_cast<const float4*>(xyzr_q), qidx, ptr_q, B, k, 0.f, 0.f, nbr, deg, flags);
+    return P2W_LAUNCH_STATUS();
+}
+
+extern "C" int32_t p2w_ball_query_grid(const float* xyzr_x, const uint64_t* keys_x, const int32_t* ptr_x, const p2w_grid* grid,
+                                       const float* xyzr_q, const int32_t* qidx, const int32_t* ptr_q, int32_t B,
+                                       int32_t m_bound, double r, int32_t cap, int32_t* nbr, int32_t* deg, int32_t flags,
+                                       p2w_stream_t stream) {
+    if (m_bound == 0) return P2W_OK;
+    int32_t st = search_args(xyzr_x, ptr_x, xyzr_q, ptr_q, B, m_bound, cap, nbr, deg);
+    if (st != P2W_OK) return st;
+    if ((st = grid_args(keys_x, grid, flags)) != P2W_OK) return st;
+    if (!(r > 0.0)) return P2W_EINVAL;
+    const int grid_dim = p2w_cdiv(m_bound, S_QT) + B;
+    slab_search_kernel<1><<<grid_dim, 256, 0, p2w_s(stream)>>>(
+        reinterpret_cast<const float4*>(xyzr_x), reinterpret_cast<const unsigned long long*>(keys_x), ptr_x, grid,
+        reinterpret_cast<const float4*>(xyzr_q), qidx, ptr_q, B, cap, (float)r, (float)(r * r), nbr, deg, flags);
     return P2W_LAUNCH_STATUS();
 }
 

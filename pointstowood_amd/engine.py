@@ -252,26 +252,41 @@ class Engine:
                 self._call("tile_bbox", L.p2w_tile_bbox, ptr(lv_.xyzr), ptr(lv_.ptr), B, N, ptr(t))
                 bbox[level] = t
             return bbox[level]
-        sorted0 = None   # level 0 in cell order (the level-1 sampler's sort), each record carrying its own index
+        grid_search = os.environ.get("P2W_SEARCH", "grid") != "brute"   # brute: whole-voxel streaming kernels (A/B, tests)
+        i64 = dict(dtype=torch.int64, device=dev)
+        sorted0 = skeys0 = None   # level 0 in cell order (the level-1 sampler's sort), each record carrying its own index
+        ckeys, grids = {}, {}     # level -> cell key of every record (ascending) / p2w_grid of the sampling call
         for l, res in enumerate(SA_RES):
             src = geo.levels[l]
             lv = Level(xyzr=torch.empty((N, 4), **f32), ptr=torch.empty(B + 1, **i32), batch=torch.empty(N, **i32),
                        idx=torch.empty(N, **i32), nbr=torch.empty((N, k), **i32), deg=torch.empty(N, **i32))
             order = torch.empty(N, **i32) if l == 0 else None
+            skeys = torch.empty(N, **i64) if l == 0 else None
+            ckeys[l + 1], grids[l + 1] = torch.empty(N, **i64), torch.empty(8, **i64)
             self._call("voxel_sample", L.p2w_voxel_sample, ptr(src.xyzr), ptr(src.ptr), B, N, res, ptr(lv.idx),
-                       ptr(lv.ptr), ptr(lv.batch), ptr(order), ptr(ws), ws.numel())
+                       ptr(lv.ptr), ptr(lv.batch), ptr(order), ptr(skeys), ptr(ckeys[l + 1]), ptr(grids[l + 1]), ptr(ws),
+                       ws.numel())
             if l == 0:   # model.py:117-118: the 0.04 level uses radius(r = 2*resolution)
                 # The input points arrive in arbitrary order; the searches that touch level 0 (this ball query as
                 # candidates, the last interpolation as queries) run over the cell-sorted copy so that a workgroup's
-                # queries are neighbours in space and whole candidate tiles can be skipped.  Results are unchanged.
-                sorted0 = torch.empty((N, 4), **f32)
+                # queries are neighbours in space and only the grid rows near them are visited.  Results are unchanged.
+                sorted0, skeys0 = torch.empty((N, 4), **f32), skeys
                 self._call("index_records", L.p2w_index_records, ptr(src.xyzr), ptr(order), ptr(src.ptr), B, N, ptr(sorted0))
-                box0 = torch.empty((nbox, 6), **f32)
-                self._call("tile_bbox", L.p2w_tile_bbox, ptr(sorted0), ptr(src.ptr), B, N, ptr(box0))
-                self._call("ball_query", L.p2w_ball_query, ptr(sorted0), ptr(src.ptr), ptr(src.xyzr), ptr(lv.idx),
-                           ptr(lv.ptr), B, N, res * 2, k, ptr(lv.nbr), ptr(lv.deg), ptr(box0), SEARCH_X_INDEX_IN_W)
-                aux0 = [order, box0, sorted0]
-            else:        # model.py:120
+                if grid_search:
+                    self._call("ball_query", L.p2w_ball_query_grid, ptr(sorted0), ptr(skeys0), ptr(src.ptr), ptr(grids[1]),
+                               ptr(src.xyzr), ptr(lv.idx), ptr(lv.ptr), B, N, res * 2, k, ptr(lv.nbr), ptr(lv.deg),
+                               SEARCH_X_INDEX_IN_W)
+                    aux0 = [order, sorted0, skeys0]
+                else:
+                    box0 = torch.empty((nbox, 6), **f32)
+                    self._call("tile_bbox", L.p2w_tile_bbox, ptr(sorted0), ptr(src.ptr), B, N, ptr(box0))
+                    self._call("ball_query", L.p2w_ball_query, ptr(sorted0), ptr(src.ptr), ptr(src.xyzr), ptr(lv.idx),
+                               ptr(lv.ptr), B, N, res * 2, k, ptr(lv.nbr), ptr(lv.deg), ptr(box0), SEARCH_X_INDEX_IN_W)
+                    aux0 = [order, box0, sorted0]
+            elif grid_search:   # model.py:120
+                self._call("knn", L.p2w_knn_grid, ptr(src.xyzr), ptr(ckeys[l]), ptr(src.ptr), ptr(grids[l]), ptr(src.xyzr),
+                           ptr(lv.idx), ptr(lv.ptr), B, N, k, ptr(lv.nbr), ptr(lv.deg), 0)
+            else:
                 self._call("knn", L.p2w_knn, ptr(src.xyzr), ptr(src.ptr), ptr(src.xyzr), ptr(lv.idx), ptr(lv.ptr), B, N,
                            k, ptr(lv.nbr), ptr(lv.deg), ptr(boxes(l)), 0)
             self._call("level_gather", L.p2w_level_gather, ptr(src.xyzr), ptr(lv.idx), ptr(lv.batch), ptr(lv.ptr), B, N,
@@ -282,9 +297,14 @@ class Engine:
             fine, coarse = geo.levels[f], geo.levels[f + 1]
             nbr, deg = torch.empty((N, 2), **i32), torch.empty(N, **i32)
             q, fl = (sorted0, SEARCH_Q_ROW_IN_W) if f == 0 else (fine.xyzr, 0)
-            self._call("knn2", L.p2w_knn, ptr(coarse.xyzr), ptr(coarse.ptr), ptr(q), None, ptr(fine.ptr), B, N, 2,
-                       ptr(nbr), ptr(deg), ptr(boxes(f + 1)), fl)
+            if grid_search:
+                self._call("knn2", L.p2w_knn_grid, ptr(coarse.xyzr), ptr(ckeys[f + 1]), ptr(coarse.ptr), ptr(grids[f + 1]),
+                           ptr(q), None, ptr(fine.ptr), B, N, 2, ptr(nbr), ptr(deg), fl)
+            else:
+                self._call("knn2", L.p2w_knn, ptr(coarse.xyzr), ptr(coarse.ptr), ptr(q), None, ptr(fine.ptr), B, N, 2,
+                           ptr(nbr), ptr(deg), ptr(boxes(f + 1)), fl)
             geo.fp_nbr[f] = (nbr, deg)
+        aux0 += list(ckeys.values()) + list(grids.values())
         geo.aux = list(bbox.values()) + aux0
         geo.counts_dev = torch.stack([geo.levels[l].ptr[B] for l in (1, 2, 3)])
         geo.counts_host = torch.empty(3, dtype=torch.int32, pin_memory=True)

@@ -174,14 +174,18 @@ def _sorted_level(b, res):
     i32 = dict(dtype=torch.int32, device="cuda")
     idx, ptr_out, batch_out, order = torch.empty(n, **i32), torch.empty(B + 1, **i32), torch.empty(n, **i32), torch.empty(n, **i32)
     ws = torch.empty(int(L.p2w_voxel_sample_ws_bytes(n)), dtype=torch.uint8, device="cuda")
-    assert L.p2w_voxel_sample(ptr(xyzr), ptr(csr), B, n, res, ptr(idx), ptr(ptr_out), ptr(batch_out), ptr(order), ptr(ws),
-                              ws.numel(), stream()) == 0
+    skeys = torch.empty(n, dtype=torch.int64, device="cuda")
+    ckeys = torch.empty(n, dtype=torch.int64, device="cuda")
+    grid = torch.zeros(8, dtype=torch.int64, device="cuda")
+    assert L.p2w_voxel_sample(ptr(xyzr), ptr(csr), B, n, res, ptr(idx), ptr(ptr_out), ptr(batch_out), ptr(order), ptr(skeys),
+                              ptr(ckeys), ptr(grid), ptr(ws), ws.numel(), stream()) == 0
     rec = torch.empty((n, 4), dtype=torch.float32, device="cuda")
     assert L.p2w_index_records(ptr(xyzr), ptr(order), ptr(csr), B, n, ptr(rec), stream()) == 0
     box = torch.empty((L.p2w_tile_bbox_count(B, n), 6), dtype=torch.float32, device="cuda")
     assert L.p2w_tile_bbox(ptr(rec), ptr(csr), B, n, ptr(box), stream()) == 0
     m = int(ptr_out[B])
-    return dict(L=L, xyzr=xyzr, csr=csr, B=B, n=n, order=order, rec=rec, box=box, idx=idx[:m], ptr_out=ptr_out, m=m)
+    return dict(L=L, xyzr=xyzr, csr=csr, B=B, n=n, order=order, rec=rec, box=box, idx=idx[:m], ptr_out=ptr_out, m=m,
+                skeys=skeys, ckeys=ckeys[:m], grid=grid)
 
 
 @pytest.mark.parametrize("sizes,surface", [([5000], False), ([1500, 40, 2600], True), ([16384, 3000], False)])
@@ -247,3 +251,149 @@ def test_knn_with_sorted_queries_writes_own_rows(sizes, k):
     mask = torch.arange(k)[None, :] < deg[:, None]
     got = torch.stack([torch.arange(n)[:, None].expand(n, k)[mask], nbr[mask].long()], 0)
     assert torch.equal(got, ref)
+
+
+def _grid_fields(grid):
+    raw = grid.cpu().numpy().view(np.uint8)
+    f = raw[:32].view(np.float32)
+    return dict(lo=f[0:3], res=float(f[3]), hi=f[4:7], b_lo=int(raw[28:32].view(np.int32)[0]), dims=raw[32:56].view(np.int64))
+
+
+@pytest.mark.parametrize("sizes,surface", [([5000], False), ([1500, 40, 2600], True), ([0, 300, 0, 16384], False)])
+def test_voxel_sample_search_index(sizes, surface):
+    """sorted keys / representative keys / grid geometry written by p2w_voxel_sample == PyG voxel_grid's cell ids."""
+    vox = [(synth.surface_voxel if surface else synth.uniform_voxel)(2.0, n, 31 + i, True) for i, n in enumerate(sizes) if n > 0]
+    b = synth.collate(vox)
+    if 0 in sizes:   # empty voxels in between: batch ids of the non-empty ones
+        ids = torch.tensor([i for i, n in enumerate(sizes) if n > 0])
+        b["batch"] = ids[b["batch"]]
+    s = _sorted_level(b, 0.04)
+    cell = O.voxel_grid(b["pos"], 0.04, b["batch"])
+    assert torch.equal(s["skeys"].cpu(), torch.sort(cell).values)
+    assert torch.equal(s["ckeys"].cpu(), torch.unique(cell))
+    g = _grid_fields(s["grid"])
+    pos = b["pos"].numpy()
+    assert np.array_equal(g["lo"], pos.min(0)) and np.array_equal(g["hi"], pos.max(0)) and g["res"] == np.float32(0.04)
+    assert g["b_lo"] == int(b["batch"].min())
+    assert np.array_equal(g["dims"], ((pos.max(0) - pos.min(0)) / np.float32(0.04)).astype(np.int64) + 1)
+
+
+def _level1(s):
+    """level-1 records (plain gather), their CSR, keys and boxes for the searches below."""
+    from pointstowood_amd._lib import ptr, stream
+    L, B, m = s["L"], s["B"], s["m"]
+    coarse = s["xyzr"][s["idx"].long()].contiguous()
+    cbox = torch.empty((L.p2w_tile_bbox_count(B, max(m, 1)), 6), dtype=torch.float32, device="cuda")
+    assert L.p2w_tile_bbox(ptr(coarse), ptr(s["ptr_out"]), B, m, ptr(cbox), stream()) == 0
+    return coarse, cbox
+
+
+@pytest.mark.parametrize("sizes,k,surface", [([5000], 2, False), ([1500, 40, 2600], 2, True), ([16384, 3000], 3, False),
+                                             ([9000], 32, True), ([700, 5, 16384], 32, False), ([60], 64, False)])
+def test_knn_grid_matches_brute_force_other_level_queries(sizes, k, surface):
+    """p2w_knn_grid, queries = level 0 in cell order (row-in-w), candidates = level 1: the interpolation searches."""
+    from pointstowood_amd._lib import SEARCH_Q_ROW_IN_W, ptr, stream
+    b = _batch(sizes, seed=37, surface=surface)
+    s = _sorted_level(b, 0.04)
+    L, n, B = s["L"], s["n"], s["B"]
+    coarse, cbox = _level1(s)
+    out = []
+    for grid in (False, True):
+        nbr = torch.full((n, k), -7, dtype=torch.int32, device="cuda")
+        deg = torch.full((n,), -7, dtype=torch.int32, device="cuda")
+        if grid:
+            st = L.p2w_knn_grid(ptr(coarse), ptr(s["ckeys"]), ptr(s["ptr_out"]), ptr(s["grid"]), ptr(s["rec"]), None,
+                                ptr(s["csr"]), B, n, k, ptr(nbr), ptr(deg), SEARCH_Q_ROW_IN_W, stream())
+        else:
+            st = L.p2w_knn(ptr(coarse), ptr(s["ptr_out"]), ptr(s["xyzr"]), None, ptr(s["csr"]), B, n, k, ptr(nbr), ptr(deg),
+                           ptr(cbox), 0, stream())
+        assert st == 0
+        out.append((nbr.cpu(), deg.cpu()))
+    assert torch.equal(out[0][1], out[1][1])
+    assert torch.equal(out[0][0], out[1][0])
+
+
+@pytest.mark.parametrize("sizes,k,res2,surface", [([5000], 32, 0.08, False), ([3000, 33, 9000], 32, 0.08, True),
+                                                  ([16384], 16, 0.16, False), ([16384, 16384], 32, 0.08, True)])
+def test_knn_grid_matches_brute_force_subset_queries(sizes, k, res2, surface):
+    """p2w_knn_grid, queries = a coarser sample of the candidates themselves (qidx): the SA2 / SA3 searches."""
+    from pointstowood_amd._lib import ptr, stream
+    b = _batch(sizes, seed=41, surface=surface)
+    s = _sorted_level(b, 0.04)
+    L, B = s["L"], s["B"]
+    coarse, cbox = _level1(s)
+    m1 = s["m"]
+    # second sampling over level 1 gives the query subset (indices into level 1) in its own cell order
+    i32 = dict(dtype=torch.int32, device="cuda")
+    idx2, ptr2, batch2 = torch.empty(m1, **i32), torch.empty(B + 1, **i32), torch.empty(m1, **i32)
+    ws = torch.empty(int(L.p2w_voxel_sample_ws_bytes(m1)), dtype=torch.uint8, device="cuda")
+    assert L.p2w_voxel_sample(ptr(coarse), ptr(s["ptr_out"]), B, m1, res2, ptr(idx2), ptr(ptr2), ptr(batch2), None, None, None,
+                              None, ptr(ws), ws.numel(), stream()) == 0
+    m2 = int(ptr2[B])
+    out = []
+    for grid in (False, True):
+        nbr = torch.full((m2, k), -7, dtype=torch.int32, device="cuda")
+        deg = torch.full((m2,), -7, dtype=torch.int32, device="cuda")
+        if grid:
+            st = L.p2w_knn_grid(ptr(coarse), ptr(s["ckeys"]), ptr(s["ptr_out"]), ptr(s["grid"]), ptr(coarse), ptr(idx2),
+                                ptr(ptr2), B, m2, k, ptr(nbr), ptr(deg), 0, stream())
+        else:
+            st = L.p2w_knn(ptr(coarse), ptr(s["ptr_out"]), ptr(coarse), ptr(idx2), ptr(ptr2), B, m2, k, ptr(nbr), ptr(deg),
+                           ptr(cbox), 0, stream())
+        assert st == 0
+        out.append((nbr.cpu(), deg.cpu()))
+    assert torch.equal(out[0][1], out[1][1])
+    assert torch.equal(out[0][0], out[1][0])
+
+
+@pytest.mark.parametrize("sizes,cap,surface", [([4000], 32, False), ([3000], 8, True), ([1500, 40, 2600], 16, True),
+                                               ([16384, 3000], 32, False)])
+def test_ball_query_grid_matches_brute_force(sizes, cap, surface):
+    from pointstowood_amd._lib import SEARCH_X_INDEX_IN_W, ptr, stream
+    b = _batch(sizes, seed=23, surface=surface)
+    s = _sorted_level(b, 0.04)
+    L, m = s["L"], s["m"]
+    out = []
+    for grid in (False, True):
+        nbr = torch.full((m, cap), -7, dtype=torch.int32, device="cuda")
+        deg = torch.full((m,), -7, dtype=torch.int32, device="cuda")
+        if grid:
+            st = L.p2w_ball_query_grid(ptr(s["rec"]), ptr(s["skeys"]), ptr(s["csr"]), ptr(s["grid"]), ptr(s["xyzr"]),
+                                       ptr(s["idx"]), ptr(s["ptr_out"]), s["B"], m, 0.08, cap, ptr(nbr), ptr(deg),
+                                       SEARCH_X_INDEX_IN_W, stream())
+        else:
+            st = L.p2w_ball_query(ptr(s["xyzr"]), ptr(s["csr"]), ptr(s["xyzr"]), ptr(s["idx"]), ptr(s["ptr_out"]), s["B"], m,
+                                  0.08, cap, ptr(nbr), ptr(deg), None, 0, stream())
+        assert st == 0
+        out.append((nbr.cpu(), deg.cpu()))
+    assert torch.equal(out[0][1], out[1][1])
+    assert torch.equal(out[0][0], out[1][0])
+
+
+def test_knn_grid_far_apart_clusters_and_duplicates():
+    """Queries whose neighbours are many cells away (region growth) and coincident points (ties)."""
+    from pointstowood_amd._lib import SEARCH_Q_ROW_IN_W, ptr, stream
+    g = torch.Generator().manual_seed(5)
+    a = torch.rand(300, 3, generator=g) * 0.2                 # dense clump in one corner
+    far = torch.rand(40, 3, generator=g) * 0.05 + 1.9          # a few points in the opposite corner
+    dup = a[:50].clone()                                       # exact duplicates
+    pos = torch.cat([a, far, dup], 0)
+    pos = pos[torch.randperm(pos.shape[0], generator=g)]
+    b = dict(pos=pos, batch=torch.zeros(pos.shape[0], dtype=torch.long))
+    s = _sorted_level(b, 0.04)
+    L, n, B = s["L"], s["n"], s["B"]
+    coarse, cbox = _level1(s)
+    for k in (2, 32, 64):
+        out = []
+        for grid in (False, True):
+            nbr = torch.full((n, k), -7, dtype=torch.int32, device="cuda")
+            deg = torch.full((n,), -7, dtype=torch.int32, device="cuda")
+            if grid:
+                st = L.p2w_knn_grid(ptr(coarse), ptr(s["ckeys"]), ptr(s["ptr_out"]), ptr(s["grid"]), ptr(s["rec"]), None,
+                                    ptr(s["csr"]), B, n, k, ptr(nbr), ptr(deg), SEARCH_Q_ROW_IN_W, stream())
+            else:
+                st = L.p2w_knn(ptr(coarse), ptr(s["ptr_out"]), ptr(s["xyzr"]), None, ptr(s["csr"]), B, n, k, ptr(nbr),
+                               ptr(deg), ptr(cbox), 0, stream())
+            assert st == 0
+            out.append((nbr.cpu(), deg.cpu()))
+        assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][0], out[1][0])
