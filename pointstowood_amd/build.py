@@ -18,7 +18,9 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libp2w_gfx950.so")
 SOURCES = ["p2w_geom.hip", "p2w_feat.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-I", INCLUDE]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+         *os.environ.get("P2W_EXTRA_CFLAGS", "").split(),      # diagnostic builds, e.g. -DP2W_SLAB_PROFILE
+         "-I", INCLUDE]
 
 
 def _hipcc() -> str:

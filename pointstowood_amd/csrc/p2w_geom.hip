@@ -1,6 +1,7 @@
 // Geometry kernels: record packing, grid sub-sampling, level gather, ball query, exact kNN.
 // gfx950 only (wave64, LDS-staged candidate tiles, wave-level ballot/popcount selection).
 #include "p2w_common.h"
+#include <cstdlib>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -755,13 +756,28 @@ __device__ __forceinline__ int grid_cell(float v, float lo, float res, long long
     return (int)fminf(fmaxf(f, 0.f), top);   // NaN -> 0
 }
 
-template <int MODE>   // 0 = kNN, 1 = ball query
+#ifdef P2W_SLAB_PROFILE
+__device__ unsigned long long g_slab_prof[16];
+#define SLAB_STAMP(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); if (tid == 0) atomicAdd(&g_slab_prof[i], now_ - stamp_); stamp_ = now_; } while (0)
+#define SLAB_COUNT(i, v) do { if (tid == 0) atomicAdd(&g_slab_prof[i], (unsigned long long)(v)); } while (0)
+extern "C" int32_t p2w_debug_slab_prof(unsigned long long* out, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_slab_prof), sizeof(unsigned long long) * 16);
+    if (e == hipSuccess && reset) { unsigned long long z[16] = {0}; e = hipMemcpyToSymbol(HIP_SYMBOL(g_slab_prof), z, sizeof(z)); }
+    return (int32_t)e;
+}
+#else
+#define SLAB_STAMP(i) do {} while (0)
+#define SLAB_COUNT(i, v) do {} while (0)
+#endif
+
+// MODE: 0 = kNN, 1 = ball query; TILE: candidates per LDS stage; LADDER: kNN starts from a counted threshold (k >= 8)
+template <int MODE, int TILE, bool LADDER>
 __global__ __launch_bounds__(256) void slab_search_kernel(const float4* __restrict__ x, const unsigned long long* __restrict__ keys,
                                                           const int* __restrict__ ptr_x, const p2w_grid* __restrict__ grid,
                                                           const float4* __restrict__ xq, const int* __restrict__ qidx,
                                                           const int* __restrict__ ptr_q, int B, int k, float r, float r2,
                                                           int* __restrict__ nbr, int* __restrict__ deg, int flags) {
-    __shared__ float4 cand[S_TILE];
+    __shared__ float4 cand[TILE];
     __shared__ int run_start[G_MAXRUN];
     __shared__ int run_pre[G_MAXRUN + 1];
     __shared__ int wsum[4];
@@ -773,6 +789,9 @@ __global__ __launch_bounds__(256) void slab_search_kernel(const float4* __restri
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qw = q0 + wave * S_QPW;
     const bool index_in_w = (flags & P2W_SEARCH_X_INDEX_IN_W) != 0;
+#ifdef P2W_SLAB_PROFILE
+    unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
+#endif
     // grid geometry (wave-uniform)
     const float lo_y = grid->lo[1], lo_z = grid->lo[2], res = grid->res;
     const long long g0 = grid->dims[0], g1 = grid->dims[1], g2 = grid->dims[2];
@@ -807,6 +826,7 @@ __global__ __launch_bounds__(256) void slab_search_kernel(const float4* __restri
     }
     const bool in_k = lane < k;
     const int total = c1 - c0;
+    SLAB_STAMP(0);   // setup
 
     // rows of the region "bounding box of the queries grown by rho" and the runs that are new relative to the region
     // scanned so far; returns the number of candidates in those runs (run table in LDS)
@@ -835,8 +855,9 @@ __global__ __launch_bounds__(256) void slab_search_kernel(const float4* __restri
                 const long long rowbase = (kb * g2 + z) * g1;
                 const unsigned long long ka = (unsigned long long)((rowbase + ya) * g0);
                 const unsigned long long kz = (unsigned long long)((rowbase + yb + 1) * g0);
-                const int s0 = lower_bound_key(keys, c0, c1, ka);
-                const int s1 = lower_bound_key(keys, s0, c1, kz);
+                int s0, s1;
+                s0 = lower_bound_key(keys, c0, c1, ka);   // (an 8-ary variant with independent probes measured slower)
+                s1 = lower_bound_key(keys, s0, c1, kz);
                 run_start[tid] = s0;
                 len = s1 - s0;
             } else {
@@ -860,7 +881,7 @@ __global__ __launch_bounds__(256) void slab_search_kernel(const float4* __restri
         return run_pre[G_MAXRUN];
     };
 
-    float rho;
+    float rho, rk = 0.f;
     if (MODE == 1) {
         rho = r;
     } else {
@@ -873,8 +894,9 @@ __global__ __launch_bounds__(256) void slab_search_kernel(const float4* __restri
         } else {
             dens = (float)total / fmaxf(((float)g0 * res) * ((float)g1 * res) * ((float)g2 * res), 1e-30f);
         }
-        const float rk = cbrtf(0.75f * (float)k / (3.14159265f * fmaxf(dens, 1e-30f)));
-        rho = fminf(1.25f * rk, 1e30f) + 0.5f * res;
+        rk = cbrtf(0.75f * (float)k / (3.14159265f * fmaxf(dens, 1e-30f)));
+        SLAB_STAMP(1);   // probe
+        rho = fminf(1.1f * rk, 1e30f) + 0.5f * res;
         whole = false;
     }
 
@@ -893,14 +915,16 @@ __global__ __launch_bounds__(256) void slab_search_kernel(const float4* __restri
         const bool was_whole = whole;
         const int n_c = was_whole ? 0 : plan(rho, restart);
         const int nruns = whole ? 1 : G_MAXRUN;
-        for (int tbase = 0; tbase < n_c; tbase += S_TILE) {
+        SLAB_STAMP(2);   // plan
+        SLAB_COUNT(8, 1); SLAB_COUNT(9, n_c); SLAB_COUNT(10, __popc(active));
+        for (int tbase = 0; tbase < n_c; tbase += TILE) {
             __syncthreads();   // previous tile consumed
             // slots used by this tile: a power of two >= the candidates left (>= 256), so that the shuffle stays a
             // permutation and a short gather does not pay for 1024 slots
             const int left = n_c - tbase;
-            const int tsz = left > 512 ? 1024 : (left > 256 ? 512 : 256);
+            const int tsz = (TILE > 1024 && left > 1024) ? 2048 : (left > 512 ? 1024 : (left > 256 ? 512 : 256));
 #pragma unroll
-            for (int rr = 0; rr < S_TILE / 256; ++rr) {
+            for (int rr = 0; rr < TILE / 256; ++rr) {
                 const int s = tid + 256 * rr;
                 if (s >= tsz) break;
                 const int g = tbase + (MODE == 0 ? ((s * 389) & (tsz - 1)) : s);
@@ -915,6 +939,35 @@ __global__ __launch_bounds__(256) void slab_search_kernel(const float4* __restri
                 cand[s] = v;
             }
             __syncthreads();
+            SLAB_STAMP(3);   // staging
+            if (MODE == 0 && LADDER && pass == 0 && tbase == 0) {
+                // Threshold ladder: before any insertion, count this tile's candidates inside a few trial radii around
+                // the density estimate and start from the smallest one that already holds k of them - a valid upper
+                // bound of the final k-th distance, so nothing that can end up in the result is refused, while the
+                // ~k*ln(n/k) warm-up insertions of a cold start are not done.
+                const float scale = n_c > tsz ? cbrtf((float)n_c / (float)tsz) : 1.f;   // first tile of several: sparser
+                float u[6];
+                {
+                    const float f[6] = {0.7f, 0.85f, 1.0f, 1.2f, 1.45f, 1.8f};
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) { const float rr_ = f[i] * rk * scale; u[i] = rr_ * rr_; }
+                }
+#pragma unroll
+                for (int j = 0; j < S_QPW; ++j) {
+                    if (!((active >> j) & 1u)) continue;
+                    int c_[6] = {0, 0, 0, 0, 0, 0};
+                    for (int ch = 0; ch < (tsz >> 6); ++ch) {
+                        const float4 c = cand[ch * 64 + lane];
+                        const float d = p2w_d2(uq[j].x, uq[j].y, uq[j].z, c.x, c.y, c.z);
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) c_[i] += __popcll(__ballot(d <= u[i]));
+                    }
+                    float t = INFINITY;
+#pragma unroll
+                    for (int i = 5; i >= 0; --i) t = c_[i] >= k ? u[i] : t;
+                    thr[j] = t;
+                }
+            }
             if (MODE == 0) {
                 for (int gr = 0; gr < (tsz >> 8); ++gr) {
                     float4 c[4];
@@ -944,7 +997,7 @@ __global__ __launch_bounds__(256) void slab_search_kernel(const float4* __restri
                                     const bool here = lane == pos, sh = (lane > pos) & in_k;
                                     bd = here ? dn : (sh ? up_d : bd);
                                     bi = here ? in : (sh ? up_i : bi);
-                                    t = rdlane(bd, k - 1);
+                                    t = fminf(t, rdlane(bd, k - 1));   // slot k-1 is +inf until k pairs are kept
                                 }
                             }
                         }
@@ -952,7 +1005,7 @@ __global__ __launch_bounds__(256) void slab_search_kernel(const float4* __restri
                     }
                 }
             } else {
-                const int nch = (min(S_TILE, n_c - tbase) + 63) >> 6;
+                const int nch = (min(TILE, n_c - tbase) + 63) >> 6;
                 for (int ch = 0; ch < nch; ++ch) {
                     const float4 c = cand[ch * 64 + lane];
                     const int ci = __float_as_int(c.w);
@@ -983,6 +1036,7 @@ __global__ __launch_bounds__(256) void slab_search_kernel(const float4* __restri
             }
         }
         if (!was_whole) { oYlo = nYlo; oYhi = nYhi; oZlo = nZlo; oZhi = nZhi; }
+        SLAB_STAMP(4);   // scan
         if (MODE == 1) break;
         // which queries are final?  k-th distance <= distance to the nearest face of the scanned region
         float need = 0.f;
@@ -1006,6 +1060,7 @@ __global__ __launch_bounds__(256) void slab_search_kernel(const float4* __restri
         if (lane == 0) wred[wave][4] = need;
         __syncthreads();
         need = fmaxf(fmaxf(wred[0][4], wred[1][4]), fmaxf(wred[2][4], wred[3][4]));
+        SLAB_STAMP(5);   // check
         if (!(need > 0.f)) break;          // every query of the workgroup is final
         rho = fmaxf(need, rho);
     }
@@ -1076,7 +1131,8 @@ extern "C" int32_t p2w_knn_grid(const float* xyzr_x, const uint64_t* keys_x, con
     if (st != P2W_OK) return st;
     if ((st = grid_args(keys_x, grid, flags)) != P2W_OK) return st;
     const int grid_dim = p2w_cdiv(m_bound, S_QT) + B;
-    slab_search_kernel<0><<<grid_dim, 256, 0, p2w_s(stream)>>>(
+    auto* kern = (k >= 8) ? slab_search_kernel<0, 2048, true> : slab_search_kernel<0, 1024, false>;
+    kern<<<grid_dim, 256, 0, p2w_s(stream)>>>(
         reinterpret_cast<const float4*>(xyzr_x), reinterpret_cast<const unsigned long long*>(keys_x), ptr_x, grid,
         reinterpret_cast<const float4*>(xyzr_q), qidx, ptr_q, B, k, 0.f, 0.f, nbr, deg, flags);
     return P2W_LAUNCH_STATUS();
@@ -1092,7 +1148,7 @@ extern "C" int32_t p2w_ball_query_grid(const float* xyzr_x, const uint64_t* keys
     if ((st = grid_args(keys_x, grid, flags)) != P2W_OK) return st;
     if (!(r > 0.0)) return P2W_EINVAL;
     const int grid_dim = p2w_cdiv(m_bound, S_QT) + B;
-    slab_search_kernel<1><<<grid_dim, 256, 0, p2w_s(stream)>>>(
+    slab_search_kernel<1, 1024, false><<<grid_dim, 256, 0, p2w_s(stream)>>>(
         reinterpret_cast<const float4*>(xyzr_x), reinterpret_cast<const unsigned long long*>(keys_x), ptr_x, grid,
         reinterpret_cast<const float4*>(xyzr_q), qidx, ptr_q, B, cap, (float)r, (float)(r * r), nbr, deg, flags);
     return P2W_LAUNCH_STATUS();

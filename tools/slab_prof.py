@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""In-kernel phase profile of the grid searches (diagnostic build: P2W_EXTRA_CFLAGS=-DP2W_SLAB_PROFILE).
+Prints, per search launch of one forward, the mean cycles a workgroup spent in each phase."""
+import ctypes as C, os, sys
+os.environ.setdefault("P2W_EXTRA_CFLAGS", "-DP2W_SLAB_PROFILE")
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from oracle import weights
+from pointstowood_amd import Net
+from pointstowood_amd import engine as E
+from pointstowood_amd._lib import lib
+
+dev = torch.device("cuda", 0)
+net = Net(num_classes=1, C=bench.C, k=bench.K_NBR).to(dev).eval()
+net.load_state_dict(weights.synth_state_dict(1, bench.C, seed=0), strict=True)
+net = net.to(dev)
+data = bench.make_batch(0, dev)
+for _ in range(2):
+    net(data)
+torch.cuda.synchronize()
+L = lib()
+L.p2w_debug_slab_prof.argtypes = [C.c_void_p, C.c_int]
+buf = (C.c_ulonglong * 16)()
+L.p2w_debug_slab_prof(buf, 1)
+orig = E.Engine._call
+names = ["setup", "probe", "plan", "stage", "scan", "check", "output"]
+
+def call(self, name, fn, *args):
+    r = orig(self, name, fn, *args)
+    if name in ("knn", "knn2", "ball_query"):
+        torch.cuda.synchronize()
+        L.p2w_debug_slab_prof(buf, 1)
+        blocks = max(buf[11], 1)
+        print(f"{name:10s} blocks={buf[11]:5d} passes/blk={buf[8]/blocks:.2f} cand/pass={buf[9]/max(buf[8],1):7.1f} "
+              f"active/pass={buf[10]/max(buf[8],1):5.1f} | " + " ".join(f"{n}={buf[i]/blocks:7.0f}" for i, n in enumerate(names)))
+    return r
+
+E.Engine._call = call
+net(data)
