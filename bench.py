@@ -70,9 +70,10 @@ def profile_step(net, data):
     eng = net._engine
     eng.events = []
     keep = {}
+    streams, eng.res_streams = eng.res_streams, 1   # per-kernel durations: no two kernels in flight while they are timed
     net(data, keep=keep)
     torch.cuda.synchronize()
-    ev, eng.events = eng.events, None
+    ev, eng.events, eng.res_streams = eng.events, None, streams
     per = {}
     for name, s, e in ev:
         kname = KERNEL_OF.get(name, name)

@@ -604,8 +604,9 @@ __global__ __launch_bounds__(256) void knn_kernel(const float4* __restrict__ x, 
         const int q = qw + j;
         if (q < q1) {
             const int row = (flags & P2W_SEARCH_Q_ROW_IN_W) ? __float_as_int(xq[qidx ? qidx[q] : q].w) : q;
-            if (lane < k) nbr[(size_t)row * k + lane] = (lane < cnt) ? best_i[j] : -1;
-            if (lane == 0) deg[row] = cnt;
+            const int kept = min(cnt, __popcll(__ballot(best_i[j] != 0x7fffffff)));   // NaN query: nothing was admitted
+            if (lane < k) nbr[(size_t)row * k + lane] = (lane < kept) ? best_i[j] : -1;
+            if (lane == 0) deg[row] = kept;
         }
     }
 }
@@ -901,8 +902,11 @@ __global__ __launch_bounds__(256) void slab_search_kernel(const float4* __restri
     }
 
     for (int pass = 0; pass < 12; ++pass) {
-        const bool restart = pass >= 8 && !whole;      // give up on the geometry: rescan everything from scratch
-        if (restart) {
+        const bool was_whole = whole;
+        const int n_c = was_whole ? 0 : plan(rho, pass >= 8);   // give up on the geometry after 8 growth passes
+        if (whole && !was_whole && oYhi >= oYlo) {
+            // the region outgrew the run table (or the pass budget): the whole voxel is scanned as one run, including
+            // what was scanned before, so the unfinished queries start again from scratch
 #pragma unroll
             for (int j = 0; j < S_QPW; ++j) {
                 if ((active >> j) & 1u) {
@@ -910,10 +914,7 @@ __global__ __launch_bounds__(256) void slab_search_kernel(const float4* __restri
                     thr[j] = MODE == 0 ? INFINITY : __int_as_float(0x7fffffff);
                 }
             }
-            oYlo = 0; oYhi = -1; oZlo = 0; oZhi = -1;
         }
-        const bool was_whole = whole;
-        const int n_c = was_whole ? 0 : plan(rho, restart);
         const int nruns = whole ? 1 : G_MAXRUN;
         SLAB_STAMP(2);   // plan
         SLAB_COUNT(8, 1); SLAB_COUNT(9, n_c); SLAB_COUNT(10, __popc(active));
@@ -1070,7 +1071,9 @@ __global__ __launch_bounds__(256) void slab_search_kernel(const float4* __restri
         const int q = qw + j;
         if (q < q1) {
             const int row = (flags & P2W_SEARCH_Q_ROW_IN_W) ? __float_as_int(xq[qidx ? qidx[q] : q].w) : q;
-            const int kept = MODE == 0 ? kept_max : min(cnt[j], k);
+            int kept = MODE == 0 ? kept_max : min(cnt[j], k);
+            // a query with NaN coordinates admits nothing: report what was really found, never an unset slot
+            kept = min(kept, __popcll(__ballot(best_i[j] != 0x7fffffff)));
             if (lane < k) nbr[(size_t)row * k + lane] = (lane < kept) ? best_i[j] : -1;
             if (lane == 0) deg[row] = kept;
         }

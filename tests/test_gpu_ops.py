@@ -370,8 +370,10 @@ def test_ball_query_grid_matches_brute_force(sizes, cap, surface):
     assert torch.equal(out[0][0], out[1][0])
 
 
-def test_knn_grid_far_apart_clusters_and_duplicates():
-    """Queries whose neighbours are many cells away (region growth) and coincident points (ties)."""
+@pytest.mark.parametrize("res", [0.04, 0.01])
+def test_knn_grid_far_apart_clusters_and_duplicates(res):
+    """Queries whose neighbours are many cells away (region growth; at res 0.01 the region outgrows the 128-layer run
+    table and the kernel falls back to the whole voxel) and coincident points (ties)."""
     from pointstowood_amd._lib import SEARCH_Q_ROW_IN_W, ptr, stream
     g = torch.Generator().manual_seed(5)
     a = torch.rand(300, 3, generator=g) * 0.2                 # dense clump in one corner
@@ -380,7 +382,7 @@ def test_knn_grid_far_apart_clusters_and_duplicates():
     pos = torch.cat([a, far, dup], 0)
     pos = pos[torch.randperm(pos.shape[0], generator=g)]
     b = dict(pos=pos, batch=torch.zeros(pos.shape[0], dtype=torch.long))
-    s = _sorted_level(b, 0.04)
+    s = _sorted_level(b, res)
     L, n, B = s["L"], s["n"], s["B"]
     coarse, cbox = _level1(s)
     for k in (2, 32, 64):
@@ -397,3 +399,37 @@ def test_knn_grid_far_apart_clusters_and_duplicates():
             assert st == 0
             out.append((nbr.cpu(), deg.cpu()))
         assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][0], out[1][0])
+
+
+def test_searches_with_nan_queries_report_nothing_for_them():
+    """A query with NaN coordinates admits no candidate: deg 0 / all -1 for it, every other query unaffected."""
+    from pointstowood_amd._lib import ptr, stream
+    b = _batch([4000], seed=43)
+    s = _sorted_level(b, 0.04)
+    L, B = s["L"], s["B"]
+    coarse, cbox = _level1(s)
+    q = s["xyzr"][:200].clone()
+    bad = torch.tensor([3, 77, 199], device="cuda")
+    q[bad, 1] = float("nan")
+    pq = torch.tensor([0, 200], dtype=torch.int32, device="cuda")
+    clean = torch.ones(200, dtype=torch.bool)
+    clean[bad.cpu()] = False
+    ref = None
+    for k in (2, 32):
+        for grid in (False, True):
+            nbr = torch.full((200, k), -7, dtype=torch.int32, device="cuda")
+            deg = torch.full((200,), -7, dtype=torch.int32, device="cuda")
+            if grid:
+                st = L.p2w_knn_grid(ptr(coarse), ptr(s["ckeys"]), ptr(s["ptr_out"]), ptr(s["grid"]), ptr(q), None, ptr(pq), B,
+                                    200, k, ptr(nbr), ptr(deg), 0, stream())
+            else:
+                st = L.p2w_knn(ptr(coarse), ptr(s["ptr_out"]), ptr(q), None, ptr(pq), B, 200, k, ptr(nbr), ptr(deg), ptr(cbox),
+                               0, stream())
+            assert st == 0
+            nbr, deg = nbr.cpu(), deg.cpu()
+            assert bool((deg[~clean] == 0).all()) and bool((nbr[~clean] == -1).all())
+            assert bool((deg[clean] == k).all())
+            if grid:
+                assert torch.equal(nbr[clean], ref)
+            else:
+                ref = nbr[clean]
