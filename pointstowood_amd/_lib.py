@@ -22,7 +22,7 @@ class Epilogue(C.Structure):
 
 
 # name -> (restype, argtypes); must list every symbol declared in include/p2w.h
-SEARCH_X_INDEX_IN_W, SEARCH_Q_ROW_IN_W = 1, 2   # include/p2w.h P2W_SEARCH_*
+SEARCH_X_INDEX_IN_W, SEARCH_Q_ROW_IN_W, SEARCH_BOX = 1, 2, 4   # include/p2w.h P2W_SEARCH_*
 
 SIGNATURES = {
     "p2w_version": (_i32, []),

@@ -771,8 +771,10 @@ extern "C" int32_t p2w_debug_slab_prof(unsigned long long* out, int reset) {
 #define SLAB_COUNT(i, v) do {} while (0)
 #endif
 
-// MODE: 0 = kNN, 1 = ball query; TILE: candidates per LDS stage; LADDER: kNN starts from a counted threshold (k >= 8)
-template <int MODE, int TILE, bool LADDER>
+// MODE: 0 = kNN, 1 = ball query; TILE: candidates per LDS stage; LADDER: kNN starts from a counted threshold (k >= 8);
+// BOX: the gathered region is also bounded in x (one run per grid row instead of one per z layer) - for grids whose
+// rows are much longer than a workgroup's reach (plot-scale searches); per-voxel searches gather whole rows.
+template <int MODE, int TILE, bool LADDER, bool BOX>
 __global__ __launch_bounds__(256) void slab_search_kernel(const float4* __restrict__ x, const unsigned long long* __restrict__ keys,
                                                           const int* __restrict__ ptr_x, const p2w_grid* __restrict__ grid,
                                                           const float4* __restrict__ xq, const int* __restrict__ qidx,
@@ -782,7 +784,7 @@ __global__ __launch_bounds__(256) void slab_search_kernel(const float4* __restri
     __shared__ int run_start[G_MAXRUN];
     __shared__ int run_pre[G_MAXRUN + 1];
     __shared__ int wsum[4];
-    __shared__ float wred[4][6];
+    __shared__ float wred[4][8];
     int b, q0, q1;
     if (!search_tile(ptr_q, B, blockIdx.x, &b, &q0, &q1)) return;
     const int c0 = ptr_x[b], c1 = ptr_x[b + 1];
@@ -794,7 +796,7 @@ __global__ __launch_bounds__(256) void slab_search_kernel(const float4* __restri
     unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
 #endif
     // grid geometry (wave-uniform)
-    const float lo_y = grid->lo[1], lo_z = grid->lo[2], res = grid->res;
+    const float lo_x = grid->lo[0], lo_y = grid->lo[1], lo_z = grid->lo[2], res = grid->res;
     const long long g0 = grid->dims[0], g1 = grid->dims[1], g2 = grid->dims[2];
     const long long kb = (long long)((float)b - (float)grid->b_lo);
     float amax = 1.f;
@@ -806,7 +808,7 @@ __global__ __launch_bounds__(256) void slab_search_kernel(const float4* __restri
     float best_d[S_QPW], thr[S_QPW];
     int best_i[S_QPW], cnt[S_QPW];
     unsigned active = 0u;   // queries of this wave whose result is not final yet
-    float ymin = INFINITY, ymax = -INFINITY, zmin = INFINITY, zmax = -INFINITY;
+    float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY, zmin = INFINITY, zmax = -INFINITY;
 #pragma unroll
     for (int j = 0; j < S_QPW; ++j) {
         uq[j] = load_query(xq, qidx, qw + j, q1);
@@ -814,55 +816,86 @@ __global__ __launch_bounds__(256) void slab_search_kernel(const float4* __restri
         thr[j] = MODE == 0 ? INFINITY : __int_as_float(0x7fffffff);   // ball: thr holds the index threshold's bits
         if (uq[j].valid) {
             active |= 1u << j;
+            if (BOX) { xmin = fminf(xmin, uq[j].x); xmax = fmaxf(xmax, uq[j].x); }
             ymin = fminf(ymin, uq[j].y); ymax = fmaxf(ymax, uq[j].y);
             zmin = fminf(zmin, uq[j].z); zmax = fmaxf(zmax, uq[j].z);
         }
     }
-    if (lane == 0) { wred[wave][0] = ymin; wred[wave][1] = ymax; wred[wave][2] = zmin; wred[wave][3] = zmax; }
+    if (lane == 0) {
+        wred[wave][0] = ymin; wred[wave][1] = ymax; wred[wave][2] = zmin; wred[wave][3] = zmax;
+        wred[wave][5] = xmin; wred[wave][6] = xmax;
+    }
     __syncthreads();
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
         ymin = fminf(ymin, wred[w][0]); ymax = fmaxf(ymax, wred[w][1]);
         zmin = fminf(zmin, wred[w][2]); zmax = fmaxf(zmax, wred[w][3]);
+        if (BOX) { xmin = fminf(xmin, wred[w][5]); xmax = fmaxf(xmax, wred[w][6]); }
     }
     const bool in_k = lane < k;
     const int total = c1 - c0;
     SLAB_STAMP(0);   // setup
 
-    // rows of the region "bounding box of the queries grown by rho" and the runs that are new relative to the region
-    // scanned so far; returns the number of candidates in those runs (run table in LDS)
-    int oYlo = 0, oYhi = -1, oZlo = 0, oZhi = -1;   // scanned region (empty)
-    int nYlo, nYhi, nZlo, nZhi;
-    bool whole = false;                             // the scanned region is the whole voxel
-    auto plan = [&](float rho, bool force_whole) -> int {
+    // The region is the cell box "bounding box of the queries grown by rho" (all of x unless BOX).  region() moves the
+    // target box n* (never shrinking below the scanned box o*) and returns the number of runs that are NEW relative to
+    // the scanned box; build(rb) fills the LDS run table with runs rb .. rb+G_MAXRUN-1 of them and returns how many
+    // candidates they hold.  Runs: !BOX: 2 per z layer (rows below / above the scanned rows, or all rows of a new
+    // layer); BOX: 2 per (z, y) row (cells left / right of the scanned cells, or the whole x range of a new row).
+    int oXlo = 0, oXhi = -1, oYlo = 0, oYhi = -1, oZlo = 0, oZhi = -1;   // scanned box (empty)
+    int nXlo = 0, nXhi = -1, nYlo = 0, nYhi = -1, nZlo = 0, nZhi = -1;
+    bool whole = false;                                                // the scanned region is the whole voxel
+    auto region = [&](float rho, bool force_whole) -> int {
         nYlo = grid_cell(ymin - rho - eps, lo_y, res, g1); nYhi = grid_cell(ymax + rho + eps, lo_y, res, g1);
         nZlo = grid_cell(zmin - rho - eps, lo_z, res, g2); nZhi = grid_cell(zmax + rho + eps, lo_z, res, g2);
-        if (oYhi >= oYlo) { nYlo = min(nYlo, oYlo); nYhi = max(nYhi, oYhi); nZlo = min(nZlo, oZlo); nZhi = max(nZhi, oZhi); }
-        const int nz = nZhi - nZlo + 1;
-        __syncthreads();   // run table free
-        if (force_whole || nz > G_MAXRUN / 2 || !(rho == rho)) {   // degenerate geometry: everything, as one run
+        if (BOX) { nXlo = grid_cell(xmin - rho - eps, lo_x, res, g0); nXhi = grid_cell(xmax + rho + eps, lo_x, res, g0); }
+        else { nXlo = 0; nXhi = (int)(g0 - 1 < (1ll << 30) ? g0 - 1 : (1ll << 30)); }
+        if (oYhi >= oYlo) {
+            nXlo = min(nXlo, oXlo); nXhi = max(nXhi, oXhi); nYlo = min(nYlo, oYlo); nYhi = max(nYhi, oYhi);
+            nZlo = min(nZlo, oZlo); nZhi = max(nZhi, oZhi);
+        }
+        const long long rows = BOX ? (long long)(nZhi - nZlo + 1) * (nYhi - nYlo + 1) : (long long)(nZhi - nZlo + 1);
+        if (force_whole || rows > (BOX ? 32768 : G_MAXRUN / 2) || !(rho == rho)) {   // degenerate: everything, one run
             whole = true;
-            if (tid == 0) { run_start[0] = c0; run_pre[0] = 0; run_pre[1] = total; }
+            return 1;
+        }
+        return (int)(2 * rows);
+    };
+    auto build = [&](int rb) -> int {
+        __syncthreads();   // run table free
+        if (whole) {
+            if (tid == 0) { run_start[0] = c0; run_pre[0] = 0; }
+            run_pre[tid + 1] = total;
             __syncthreads();
             return total;
         }
+        const int ny = nYhi - nYlo + 1;
+        const long long nrt = 2ll * (BOX ? (long long)(nZhi - nZlo + 1) * ny : (long long)(nZhi - nZlo + 1));
+        const long long t = (long long)rb + tid;
         int len = 0;
-        if (tid < 2 * nz) {
-            const int z = nZlo + (tid >> 1), side = tid & 1;
-            int ya, yb;
-            if (oYhi >= oYlo && z >= oZlo && z <= oZhi) { ya = side ? oYhi + 1 : nYlo; yb = side ? nYhi : oYlo - 1; }
-            else { ya = nYlo; yb = side ? nYlo - 1 : nYhi; }
-            if (ya <= yb) {
+        run_start[tid] = c0;
+        if (t < nrt) {
+            const int side = (int)(t & 1);
+            const int row = (int)(t >> 1);
+            const int z = nZlo + (BOX ? row / ny : row);
+            const bool seen_z = oYhi >= oYlo && z >= oZlo && z <= oZhi;
+            int ya, yb, xa = nXlo, xb = nXhi;
+            if (BOX) {
+                const int y = nYlo + row % ny;
+                ya = yb = y;
+                if (seen_z && y >= oYlo && y <= oYhi) { xa = side ? oXhi + 1 : nXlo; xb = side ? nXhi : oXlo - 1; }
+                else if (side) xb = xa - 1;
+            } else {
+                if (seen_z) { ya = side ? oYhi + 1 : nYlo; yb = side ? nYhi : oYlo - 1; }
+                else { ya = nYlo; yb = side ? nYlo - 1 : nYhi; }
+            }
+            if (ya <= yb && xa <= xb) {
                 const long long rowbase = (kb * g2 + z) * g1;
-                const unsigned long long ka = (unsigned long long)((rowbase + ya) * g0);
-                const unsigned long long kz = (unsigned long long)((rowbase + yb + 1) * g0);
-                int s0, s1;
-                s0 = lower_bound_key(keys, c0, c1, ka);   // (an 8-ary variant with independent probes measured slower)
-                s1 = lower_bound_key(keys, s0, c1, kz);
+                const unsigned long long ka = (unsigned long long)((rowbase + ya) * g0 + xa);
+                const unsigned long long kz = (unsigned long long)((rowbase + yb) * g0 + xb + 1);
+                const int s0 = lower_bound_key(keys, c0, c1, ka);   // (an 8-ary variant with independent probes measured slower)
+                const int s1 = lower_bound_key(keys, s0, c1, kz);
                 run_start[tid] = s0;
                 len = s1 - s0;
-            } else {
-                run_start[tid] = c0;
             }
         }
         // exclusive prefix sum of len over the workgroup
@@ -886,11 +919,13 @@ __global__ __launch_bounds__(256) void slab_search_kernel(const float4* __restri
     if (MODE == 1) {
         rho = r;
     } else {
-        // local density probe: candidates in the rows that hold the queries themselves
-        const int n0 = plan(0.f, false);
+        // local density probe: candidates in the rows (BOX: cells) that hold the queries themselves
+        const int nr0 = region(0.f, false);
+        long long n0 = 0;
+        for (int rb = 0; rb < nr0 && !whole; rb += G_MAXRUN) n0 += build(rb);
         float dens = 0.f;
         if (!whole && n0 >= 8) {
-            const float vol = ((float)g0 * res) * ((float)(nYhi - nYlo + 1) * res) * ((float)(nZhi - nZlo + 1) * res);
+            const float vol = ((float)(nXhi - nXlo + 1) * res) * ((float)(nYhi - nYlo + 1) * res) * ((float)(nZhi - nZlo + 1) * res);
             dens = (float)n0 / vol;
         } else {
             dens = (float)total / fmaxf(((float)g0 * res) * ((float)g1 * res) * ((float)g2 * res), 1e-30f);
@@ -903,9 +938,9 @@ __global__ __launch_bounds__(256) void slab_search_kernel(const float4* __restri
 
     for (int pass = 0; pass < 12; ++pass) {
         const bool was_whole = whole;
-        const int n_c = was_whole ? 0 : plan(rho, pass >= 8);   // give up on the geometry after 8 growth passes
+        const int nrt = was_whole ? 0 : region(rho, pass >= 8);   // give up on the geometry after 8 growth passes
         if (whole && !was_whole && oYhi >= oYlo) {
-            // the region outgrew the run table (or the pass budget): the whole voxel is scanned as one run, including
+            // the region outgrew the run budget (or the pass budget): the whole voxel is scanned as one run, including
             // what was scanned before, so the unfinished queries start again from scratch
 #pragma unroll
             for (int j = 0; j < S_QPW; ++j) {
@@ -915,7 +950,8 @@ __global__ __launch_bounds__(256) void slab_search_kernel(const float4* __restri
                 }
             }
         }
-        const int nruns = whole ? 1 : G_MAXRUN;
+        for (int rb = 0; rb < nrt; rb += G_MAXRUN) {
+        const int n_c = build(rb);
         SLAB_STAMP(2);   // plan
         SLAB_COUNT(8, 1); SLAB_COUNT(9, n_c); SLAB_COUNT(10, __popc(active));
         for (int tbase = 0; tbase < n_c; tbase += TILE) {
@@ -931,7 +967,7 @@ __global__ __launch_bounds__(256) void slab_search_kernel(const float4* __restri
                 const int g = tbase + (MODE == 0 ? ((s * 389) & (tsz - 1)) : s);
                 float4 v = make_float4(INFINITY, INFINITY, INFINITY, __int_as_float(0x7fffffff));
                 if (g < n_c) {
-                    int lo = 0, hi = nruns;   // largest run with run_pre[run] <= g
+                    int lo = 0, hi = G_MAXRUN;   // largest run with run_pre[run] <= g
                     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (run_pre[mid] <= g) lo = mid; else hi = mid; }
                     const int c = run_start[lo] + (g - run_pre[lo]);
                     v = x[c];
@@ -941,7 +977,7 @@ __global__ __launch_bounds__(256) void slab_search_kernel(const float4* __restri
             }
             __syncthreads();
             SLAB_STAMP(3);   // staging
-            if (MODE == 0 && LADDER && pass == 0 && tbase == 0) {
+            if (MODE == 0 && LADDER && pass == 0 && rb == 0 && tbase == 0) {
                 // Threshold ladder: before any insertion, count this tile's candidates inside a few trial radii around
                 // the density estimate and start from the smallest one that already holds k of them - a valid upper
                 // bound of the final k-th distance, so nothing that can end up in the result is refused, while the
@@ -1036,12 +1072,15 @@ __global__ __launch_bounds__(256) void slab_search_kernel(const float4* __restri
                 }
             }
         }
-        if (!was_whole) { oYlo = nYlo; oYhi = nYhi; oZlo = nZlo; oZhi = nZhi; }
+        }
+        if (!was_whole) { oXlo = nXlo; oXhi = nXhi; oYlo = nYlo; oYhi = nYhi; oZlo = nZlo; oZhi = nZhi; }
         SLAB_STAMP(4);   // scan
         if (MODE == 1) break;
         // which queries are final?  k-th distance <= distance to the nearest face of the scanned region
         float need = 0.f;
         if (!whole) {
+            const float fx0 = (!BOX || oXlo <= 0) ? -INFINITY : lo_x + (float)oXlo * res;
+            const float fx1 = (!BOX || (long long)oXhi >= g0 - 1) ? INFINITY : lo_x + (float)(oXhi + 1) * res;
             const float fy0 = oYlo <= 0 ? -INFINITY : lo_y + (float)oYlo * res;
             const float fy1 = (long long)oYhi >= g1 - 1 ? INFINITY : lo_y + (float)(oYhi + 1) * res;
             const float fz0 = oZlo <= 0 ? -INFINITY : lo_z + (float)oZlo * res;
@@ -1049,7 +1088,9 @@ __global__ __launch_bounds__(256) void slab_search_kernel(const float4* __restri
 #pragma unroll
             for (int j = 0; j < S_QPW; ++j) {
                 if (!((active >> j) & 1u)) continue;
-                const float gap = fminf(fminf(uq[j].y - fy0, fy1 - uq[j].y), fminf(uq[j].z - fz0, fz1 - uq[j].z)) - eps;
+                float gap = fminf(fminf(uq[j].y - fy0, fy1 - uq[j].y), fminf(uq[j].z - fz0, fz1 - uq[j].z));
+                if (BOX) gap = fminf(gap, fminf(uq[j].x - fx0, fx1 - uq[j].x));
+                gap -= eps;
                 const bool ok = gap > 0.f && thr[j] <= gap * gap;      // thr = +inf until k candidates were found
                 if (ok) active &= ~(1u << j);
                 else need = fmaxf(need, thr[j] < INFINITY ? sqrtf(thr[j]) * 1.0001f + 3.f * eps : 2.f * rho + res);
@@ -1122,7 +1163,7 @@ extern "C" int32_t p2w_ball_query(const float* xyzr_x, const int32_t* ptr_x, con
 static int32_t grid_args(const uint64_t* keys, const p2w_grid* grid, int32_t flags) {
     P2W_CHECK_PTR(keys); P2W_CHECK_PTR(grid);
     if ((reinterpret_cast<uintptr_t>(keys) & 7u) || (reinterpret_cast<uintptr_t>(grid) & 7u)) return P2W_EALIGN;
-    if (flags & ~(P2W_SEARCH_X_INDEX_IN_W | P2W_SEARCH_Q_ROW_IN_W)) return P2W_EINVAL;
+    if (flags & ~(P2W_SEARCH_X_INDEX_IN_W | P2W_SEARCH_Q_ROW_IN_W | P2W_SEARCH_BOX)) return P2W_EINVAL;
     return P2W_OK;
 }
 
@@ -1134,7 +1175,8 @@ extern "C" int32_t p2w_knn_grid(const float* xyzr_x, const uint64_t* keys_x, con
     if (st != P2W_OK) return st;
     if ((st = grid_args(keys_x, grid, flags)) != P2W_OK) return st;
     const int grid_dim = p2w_cdiv(m_bound, S_QT) + B;
-    auto* kern = (k >= 8) ? slab_search_kernel<0, 2048, true> : slab_search_kernel<0, 1024, false>;
+    auto* kern = (flags & P2W_SEARCH_BOX) ? ((k >= 8) ? slab_search_kernel<0, 2048, true, true> : slab_search_kernel<0, 1024, false, true>)
+                                          : ((k >= 8) ? slab_search_kernel<0, 2048, true, false> : slab_search_kernel<0, 1024, false, false>);
     kern<<<grid_dim, 256, 0, p2w_s(stream)>>>(
         reinterpret_cast<const float4*>(xyzr_x), reinterpret_cast<const unsigned long long*>(keys_x), ptr_x, grid,
         reinterpret_cast<const float4*>(xyzr_q), qidx, ptr_q, B, k, 0.f, 0.f, nbr, deg, flags);
@@ -1151,7 +1193,8 @@ extern "C" int32_t p2w_ball_query_grid(const float* xyzr_x, const uint64_t* keys
     if ((st = grid_args(keys_x, grid, flags)) != P2W_OK) return st;
     if (!(r > 0.0)) return P2W_EINVAL;
     const int grid_dim = p2w_cdiv(m_bound, S_QT) + B;
-    slab_search_kernel<1, 1024, false><<<grid_dim, 256, 0, p2w_s(stream)>>>(
+    auto* kern = (flags & P2W_SEARCH_BOX) ? slab_search_kernel<1, 1024, false, true> : slab_search_kernel<1, 1024, false, false>;
+    kern<<<grid_dim, 256, 0, p2w_s(stream)>>>(
         reinterpret_cast<const float4*>(xyzr_x), reinterpret_cast<const unsigned long long*>(keys_x), ptr_x, grid,
         reinterpret_cast<const float4*>(xyzr_q), qidx, ptr_q, B, cap, (float)r, (float)(r * r), nbr, deg, flags);
     return P2W_LAUNCH_STATUS();

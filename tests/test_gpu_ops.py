@@ -288,9 +288,10 @@ def _level1(s):
     return coarse, cbox
 
 
+@pytest.mark.parametrize("box", [0, 4])   # 4 = P2W_SEARCH_BOX: region bounded in x too (one run per grid row)
 @pytest.mark.parametrize("sizes,k,surface", [([5000], 2, False), ([1500, 40, 2600], 2, True), ([16384, 3000], 3, False),
                                              ([9000], 32, True), ([700, 5, 16384], 32, False), ([60], 64, False)])
-def test_knn_grid_matches_brute_force_other_level_queries(sizes, k, surface):
+def test_knn_grid_matches_brute_force_other_level_queries(sizes, k, surface, box):
     """p2w_knn_grid, queries = level 0 in cell order (row-in-w), candidates = level 1: the interpolation searches."""
     from pointstowood_amd._lib import SEARCH_Q_ROW_IN_W, ptr, stream
     b = _batch(sizes, seed=37, surface=surface)
@@ -303,7 +304,7 @@ def test_knn_grid_matches_brute_force_other_level_queries(sizes, k, surface):
         deg = torch.full((n,), -7, dtype=torch.int32, device="cuda")
         if grid:
             st = L.p2w_knn_grid(ptr(coarse), ptr(s["ckeys"]), ptr(s["ptr_out"]), ptr(s["grid"]), ptr(s["rec"]), None,
-                                ptr(s["csr"]), B, n, k, ptr(nbr), ptr(deg), SEARCH_Q_ROW_IN_W, stream())
+                                ptr(s["csr"]), B, n, k, ptr(nbr), ptr(deg), SEARCH_Q_ROW_IN_W | box, stream())
         else:
             st = L.p2w_knn(ptr(coarse), ptr(s["ptr_out"]), ptr(s["xyzr"]), None, ptr(s["csr"]), B, n, k, ptr(nbr), ptr(deg),
                            ptr(cbox), 0, stream())
@@ -315,7 +316,8 @@ def test_knn_grid_matches_brute_force_other_level_queries(sizes, k, surface):
 
 @pytest.mark.parametrize("sizes,k,res2,surface", [([5000], 32, 0.08, False), ([3000, 33, 9000], 32, 0.08, True),
                                                   ([16384], 16, 0.16, False), ([16384, 16384], 32, 0.08, True)])
-def test_knn_grid_matches_brute_force_subset_queries(sizes, k, res2, surface):
+@pytest.mark.parametrize("box", [0, 4])
+def test_knn_grid_matches_brute_force_subset_queries(sizes, k, res2, surface, box):
     """p2w_knn_grid, queries = a coarser sample of the candidates themselves (qidx): the SA2 / SA3 searches."""
     from pointstowood_amd._lib import ptr, stream
     b = _batch(sizes, seed=41, surface=surface)
@@ -336,7 +338,7 @@ def test_knn_grid_matches_brute_force_subset_queries(sizes, k, res2, surface):
         deg = torch.full((m2,), -7, dtype=torch.int32, device="cuda")
         if grid:
             st = L.p2w_knn_grid(ptr(coarse), ptr(s["ckeys"]), ptr(s["ptr_out"]), ptr(s["grid"]), ptr(coarse), ptr(idx2),
-                                ptr(ptr2), B, m2, k, ptr(nbr), ptr(deg), 0, stream())
+                                ptr(ptr2), B, m2, k, ptr(nbr), ptr(deg), box, stream())
         else:
             st = L.p2w_knn(ptr(coarse), ptr(s["ptr_out"]), ptr(coarse), ptr(idx2), ptr(ptr2), B, m2, k, ptr(nbr), ptr(deg),
                            ptr(cbox), 0, stream())
@@ -348,7 +350,8 @@ def test_knn_grid_matches_brute_force_subset_queries(sizes, k, res2, surface):
 
 @pytest.mark.parametrize("sizes,cap,surface", [([4000], 32, False), ([3000], 8, True), ([1500, 40, 2600], 16, True),
                                                ([16384, 3000], 32, False)])
-def test_ball_query_grid_matches_brute_force(sizes, cap, surface):
+@pytest.mark.parametrize("box", [0, 4])
+def test_ball_query_grid_matches_brute_force(sizes, cap, surface, box):
     from pointstowood_amd._lib import SEARCH_X_INDEX_IN_W, ptr, stream
     b = _batch(sizes, seed=23, surface=surface)
     s = _sorted_level(b, 0.04)
@@ -360,7 +363,7 @@ def test_ball_query_grid_matches_brute_force(sizes, cap, surface):
         if grid:
             st = L.p2w_ball_query_grid(ptr(s["rec"]), ptr(s["skeys"]), ptr(s["csr"]), ptr(s["grid"]), ptr(s["xyzr"]),
                                        ptr(s["idx"]), ptr(s["ptr_out"]), s["B"], m, 0.08, cap, ptr(nbr), ptr(deg),
-                                       SEARCH_X_INDEX_IN_W, stream())
+                                       SEARCH_X_INDEX_IN_W | box, stream())
         else:
             st = L.p2w_ball_query(ptr(s["xyzr"]), ptr(s["csr"]), ptr(s["xyzr"]), ptr(s["idx"]), ptr(s["ptr_out"]), s["B"], m,
                                   0.08, cap, ptr(nbr), ptr(deg), None, 0, stream())
@@ -370,8 +373,9 @@ def test_ball_query_grid_matches_brute_force(sizes, cap, surface):
     assert torch.equal(out[0][0], out[1][0])
 
 
+@pytest.mark.parametrize("box", [0, 4])
 @pytest.mark.parametrize("res", [0.04, 0.01])
-def test_knn_grid_far_apart_clusters_and_duplicates(res):
+def test_knn_grid_far_apart_clusters_and_duplicates(res, box):
     """Queries whose neighbours are many cells away (region growth; at res 0.01 the region outgrows the 128-layer run
     table and the kernel falls back to the whole voxel) and coincident points (ties)."""
     from pointstowood_amd._lib import SEARCH_Q_ROW_IN_W, ptr, stream
@@ -392,7 +396,7 @@ def test_knn_grid_far_apart_clusters_and_duplicates(res):
             deg = torch.full((n,), -7, dtype=torch.int32, device="cuda")
             if grid:
                 st = L.p2w_knn_grid(ptr(coarse), ptr(s["ckeys"]), ptr(s["ptr_out"]), ptr(s["grid"]), ptr(s["rec"]), None,
-                                    ptr(s["csr"]), B, n, k, ptr(nbr), ptr(deg), SEARCH_Q_ROW_IN_W, stream())
+                                    ptr(s["csr"]), B, n, k, ptr(nbr), ptr(deg), SEARCH_Q_ROW_IN_W | box, stream())
             else:
                 st = L.p2w_knn(ptr(coarse), ptr(s["ptr_out"]), ptr(s["xyzr"]), None, ptr(s["csr"]), B, n, k, ptr(nbr),
                                ptr(deg), ptr(cbox), 0, stream())
