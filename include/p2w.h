@@ -134,6 +134,22 @@ int32_t p2w_ball_query_grid(const float* xyzr_x, const uint64_t* keys_x, const i
                             const float* xyzr_q, const int32_t* qidx, const int32_t* ptr_q, int32_t B, int32_t m_bound,
                             double r, int32_t cap, int32_t* nbr, int32_t* deg, int32_t flags, p2w_stream_t stream);
 
+/* ---- plot scale: back-projection of the classification onto the original points (predicter.py:107-142) ---- */
+
+/* order_out[i] = index of the i-th record in ascending Morton (Z-curve) order of its cell in `grid` (21 bits per
+ * axis, cells clamped to the grid): consecutive records are close in all three dimensions - the query order for
+ * P2W_SEARCH_BOX searches over a plot.  ws: p2w_morton_order_ws_bytes(n). */
+size_t p2w_morton_order_ws_bytes(int32_t n);
+int32_t p2w_morton_order(const float* xyzr, int32_t n, const p2w_grid* grid, int32_t* order_out, void* ws, size_t ws_bytes,
+                         p2w_stream_t stream);
+
+/* PointCloudClassifier.compute_labels (predicter.py:112-127) over a neighbour table nbr[n,k] (indices into pred /
+ * prob, deg[i] valid entries): pwood_out = median of the neighbours' probabilities (np.median: mean of the two middle
+ * values for an even count); label_out: any_wood != 1 -> 1 if any neighbour's prediction > any_wood else 0;
+ * any_wood == 1 -> argmax_j sum_{pred == j} prob over j in {0, 1} (first maximum, sums in fp64 like numba's). */
+int32_t p2w_vote(const int32_t* nbr, const int32_t* deg, int32_t k, const float* pred, const float* prob, int32_t n,
+                 float any_wood, float* label_out, float* pwood_out, p2w_stream_t stream);
+
 /* Optional accelerator for the searches (results are identical with or without it): bounding boxes (lo xyz, hi xyz)
  * of the candidate tiles of xyzr_x (1024 consecutive records of one voxel).  bbox holds p2w_tile_bbox_count(B,
  * n_bound) x 6 floats.  With it, p2w_knn skips tiles whose box is farther than a query's current k-th distance and

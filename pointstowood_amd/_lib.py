@@ -38,6 +38,9 @@ SIGNATURES = {
     "p2w_level_gather": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "p2w_ball_query": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, C.c_double, _i32, _vp, _vp, _vp, _i32, _vp]),
     "p2w_knn": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
+    "p2w_morton_order_ws_bytes": (_sz, [_i32]),
+    "p2w_morton_order": (_i32, [_vp, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "p2w_vote": (_i32, [_vp, _vp, _i32, _vp, _vp, _i32, _f32, _vp, _vp, _vp]),
     "p2w_tile_bbox": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp]),
     "p2w_tile_bbox_count": (_i32, [_i32, _i32]),
     "p2w_stem": (_i32, [_vp, _i32, _vp, _vp, _i32, _vp, _vp]),

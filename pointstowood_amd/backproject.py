@@ -1,0 +1,86 @@
+"""Back-projection of the per-voxel classification onto the original plot points, on the GPU.
+
+Reference: ``PointCloudClassifier`` (``pointstowood/src/predicter.py:107-142``): a KD-tree (pykdtree, CPU) over ALL
+classified points (every voxel of every grid size, so most plot points occur several times), each original point takes
+its k = 64 (``any_wood == 1``) or 32 nearest classified points, ``pwood`` = median of their probabilities and the label
+by the weighted vote / any-wood rule (numba).  Here: the classified points are sorted once into a uniform cell grid
+(``p2w_voxel_sample``'s order / keys / grid), the queries into Morton order of the same grid, and the grid-indexed exact
+kNN (``p2w_knn_grid`` with ``P2W_SEARCH_BOX``) + ``p2w_vote`` do the rest.  Distances are fp32 on plot-local coordinates
+(the caller subtracts a common offset first), the reference's are fp64 - see DESIGN.md for what that can change.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import SEARCH_BOX, SEARCH_X_INDEX_IN_W, check, lib, ptr
+
+
+def _records(xyz: torch.Tensor) -> torch.Tensor:
+    out = torch.zeros((xyz.shape[0], 4), dtype=torch.float32, device=xyz.device)
+    out[:, :3] = xyz
+    return out
+
+
+def neighbours(cls_xyz: torch.Tensor, query_xyz: torch.Tensor, k: int, cell: float = 0.1, chunk: int = 1 << 22):
+    """Exact k nearest classified points of every query: yields (rows, nbr [len(rows), k] int32, deg) per query chunk.
+    ``rows`` are the original query indices of the chunk (queries are visited in Morton order)."""
+    _lib.require_cuda(cls_xyz, query_xyz)
+    L, dev = lib(), cls_xyz.device
+    nc, nq = cls_xyz.shape[0], query_xyz.shape[0]
+    i32 = dict(dtype=torch.int32, device=dev)
+    cand = _records(cls_xyz)
+    ptr_c = torch.tensor([0, nc], **i32)
+    order = torch.empty(nc, **i32)
+    skeys = torch.empty(nc, dtype=torch.int64, device=dev)
+    grid = torch.zeros(8, dtype=torch.int64, device=dev)
+    ws = torch.empty(int(L.p2w_voxel_sample_ws_bytes(max(nc, 1))), dtype=torch.uint8, device=dev)
+    idx, ptr_out, batch_out = torch.empty(nc, **i32), torch.empty(2, **i32), torch.empty(nc, **i32)
+    check(L.p2w_voxel_sample(ptr(cand), ptr(ptr_c), 1, nc, float(cell), ptr(idx), ptr(ptr_out), ptr(batch_out), ptr(order),
+                             ptr(skeys), None, ptr(grid), ptr(ws), ws.numel(), _lib.stream()), "voxel_sample")
+    del idx, batch_out, ws
+    rec_c = torch.empty((nc, 4), dtype=torch.float32, device=dev)
+    check(L.p2w_index_records(ptr(cand), ptr(order), ptr(ptr_c), 1, nc, ptr(rec_c), _lib.stream()), "index_records")
+    del cand, order
+    qrec = _records(query_xyz)
+    qorder = torch.empty(nq, **i32)
+    ws = torch.empty(int(L.p2w_morton_order_ws_bytes(max(nq, 1))), dtype=torch.uint8, device=dev)
+    check(L.p2w_morton_order(ptr(qrec), nq, ptr(grid), ptr(qorder), ptr(ws), ws.numel(), _lib.stream()), "morton_order")
+    del ws
+    qsorted = qrec[qorder.long()].contiguous()
+    del qrec
+    for s in range(0, nq, chunk):
+        m = min(chunk, nq - s)
+        q = qsorted[s:s + m]
+        ptr_q = torch.tensor([0, m], **i32)
+        nbr = torch.empty((m, k), **i32)
+        deg = torch.empty(m, **i32)
+        check(L.p2w_knn_grid(ptr(rec_c), ptr(skeys), ptr(ptr_c), ptr(grid), ptr(q), None, ptr(ptr_q), 1, m, k, ptr(nbr),
+                             ptr(deg), SEARCH_X_INDEX_IN_W | SEARCH_BOX, _lib.stream()), "knn_grid")
+        yield qorder[s:s + m].long(), nbr, deg
+
+
+def collect_predictions(cls_xyz, cls_pred, cls_prob, query_xyz, any_wood: float = 1.0, cell: float = 0.1,
+                        chunk: int = 1 << 22):
+    """(label [nq], pwood [nq]) float32 - ``PointCloudClassifier.collect_predictions`` (predicter.py:129-142).
+
+    cls_xyz [nc,3], cls_pred [nc] (0/1), cls_prob [nc]: the classified points; query_xyz [nq,3]: the original points.
+    k = 64 when ``any_wood == 1`` else 32 (predicter.py:137)."""
+    L = lib()
+    k = 32 if any_wood != 1 else 64
+    nq, dev = query_xyz.shape[0], query_xyz.device
+    pred = cls_pred.to(torch.float32).contiguous()
+    prob = cls_prob.to(torch.float32).contiguous()
+    label = torch.zeros(nq, dtype=torch.float32, device=dev)
+    pwood = torch.zeros(nq, dtype=torch.float32, device=dev)
+    if cls_xyz.shape[0] == 0 or nq == 0:
+        return label, pwood
+    for rows, nbr, deg in neighbours(cls_xyz.to(torch.float32), query_xyz.to(torch.float32), k, cell, chunk):
+        m = rows.shape[0]
+        lab = torch.empty(m, dtype=torch.float32, device=dev)
+        pw = torch.empty(m, dtype=torch.float32, device=dev)
+        check(L.p2w_vote(ptr(nbr), ptr(deg), k, ptr(pred), ptr(prob), m, float(any_wood), ptr(lab), ptr(pw), _lib.stream()),
+              "vote")
+        label[rows] = lab
+        pwood[rows] = pw
+    return label, pwood

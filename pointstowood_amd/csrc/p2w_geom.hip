@@ -1200,6 +1200,129 @@ extern "C" int32_t p2w_ball_query_grid(const float* xyzr_x, const uint64_t* keys
     return P2W_LAUNCH_STATUS();
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// plot-scale helpers: Morton order of records on a grid, neighbourhood vote
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long spread3(unsigned v) {   // 21 bits -> every third bit
+    unsigned long long x = v & 0x1fffffull;
+    x = (x | x << 32) & 0x1f00000000ffffull;
+    x = (x | x << 16) & 0x1f0000ff0000ffull;
+    x = (x | x << 8) & 0x100f00f00f00f00full;
+    x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+
+__global__ __launch_bounds__(256) void morton_keys_kernel(const float4* __restrict__ xyzr, int n, const p2w_grid* __restrict__ grid,
+                                                          unsigned long long* __restrict__ keys, int* __restrict__ vals) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = xyzr[i];
+    const float res = grid->res;
+    const unsigned cx = (unsigned)grid_cell(p.x, grid->lo[0], res, 1ll << 21);
+    const unsigned cy = (unsigned)grid_cell(p.y, grid->lo[1], res, 1ll << 21);
+    const unsigned cz = (unsigned)grid_cell(p.z, grid->lo[2], res, 1ll << 21);
+    keys[i] = spread3(cx) | (spread3(cy) << 1) | (spread3(cz) << 2);
+    vals[i] = i;
+}
+
+struct MoLayout { size_t keys_in, keys_out, vals_in, temp, temp_bytes, total; };
+static hipError_t mo_layout(int n, MoLayout* L) {
+    auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
+    size_t sort_bytes = 0;
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, sort_bytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr,
+                                             (int*)nullptr, (int*)nullptr, (size_t)n, 0, 63, (hipStream_t)0);
+    if (e != hipSuccess) return e;
+    size_t off = 0;
+    L->keys_in = off; off += up(sizeof(unsigned long long) * n);
+    L->keys_out = off; off += up(sizeof(unsigned long long) * n);
+    L->vals_in = off; off += up(sizeof(int) * n);
+    L->temp = off; L->temp_bytes = up(sort_bytes); off += L->temp_bytes;
+    L->total = off;
+    return hipSuccess;
+}
+
+extern "C" size_t p2w_morton_order_ws_bytes(int32_t n) {
+    if (n <= 0) return 256;
+    MoLayout L;
+    if (mo_layout(n, &L) != hipSuccess) return 0;
+    return L.total;
+}
+
+extern "C" int32_t p2w_morton_order(const float* xyzr, int32_t n, const p2w_grid* grid, int32_t* order_out, void* ws,
+                                    size_t ws_bytes, p2w_stream_t stream) {
+    if (n == 0) return P2W_OK;
+    P2W_CHECK_PTR(xyzr); P2W_CHECK_PTR(grid); P2W_CHECK_PTR(order_out); P2W_CHECK_PTR(ws);
+    P2W_CHECK_ALIGN16(xyzr); P2W_CHECK_ALIGN16(ws);
+    if (n < 0) return P2W_EINVAL;
+    MoLayout L;
+    hipError_t e = mo_layout(n, &L);
+    if (e != hipSuccess) return (int32_t)e;
+    if (ws_bytes < L.total) return P2W_EWORKSPACE;
+    char* w = static_cast<char*>(ws);
+    hipStream_t s = p2w_s(stream);
+    auto* keys_in = reinterpret_cast<unsigned long long*>(w + L.keys_in);
+    morton_keys_kernel<<<p2w_cdiv(n, 256), 256, 0, s>>>(reinterpret_cast<const float4*>(xyzr), n, grid, keys_in,
+                                                       reinterpret_cast<int*>(w + L.vals_in));
+    size_t tb = L.temp_bytes;
+    e = rocprim::radix_sort_pairs(w + L.temp, tb, keys_in, reinterpret_cast<unsigned long long*>(w + L.keys_out),
+                                  reinterpret_cast<int*>(w + L.vals_in), order_out, (size_t)n, 0, 63, s);
+    if (e != hipSuccess) return (int32_t)e;
+    return P2W_LAUNCH_STATUS();
+}
+
+// one wave per point: lane l holds neighbour l's (prediction, probability)
+__global__ __launch_bounds__(256) void vote_kernel(const int* __restrict__ nbr, const int* __restrict__ deg, int k,
+                                                   const float* __restrict__ pred, const float* __restrict__ prob, int n,
+                                                   float any_wood, float* __restrict__ label_out, float* __restrict__ pwood_out) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int m = min(deg[i], k);
+    int j = lane < m ? nbr[(size_t)i * k + lane] : -1;
+    const bool on = j >= 0;
+    const float pr = on ? prob[j] : 0.f;
+    const float pd = on ? pred[j] : 0.f;
+    // label
+    float label;
+    if (any_wood != 1.f) {
+        label = __ballot(on && pd > any_wood) != 0ull ? 1.f : 0.f;
+    } else {
+        double v0 = (on && pd == 0.f) ? (double)pr : 0.0, v1 = (on && pd == 1.f) ? (double)pr : 0.0;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { v0 += __shfl_xor(v0, off); v1 += __shfl_xor(v1, off); }
+        label = v1 > v0 ? 1.f : 0.f;   // argmax keeps the first maximum
+    }
+    // median: ascending bitonic sort of the probabilities across the wave, missing slots = +inf
+    float v = on ? pr : INFINITY;
+    const int cnt = __popcll(__ballot(on));
+#pragma unroll
+    for (int size = 2; size <= 64; size <<= 1) {
+#pragma unroll
+        for (int stride = size >> 1; stride >= 1; stride >>= 1) {
+            const float o = __shfl_xor(v, stride);
+            const bool up = (lane & size) == 0, lower = (lane & stride) == 0;
+            v = (lower == up) ? fminf(v, o) : fmaxf(v, o);
+        }
+    }
+    const float a = rdlane(v, cnt > 0 ? (cnt - 1) >> 1 : 0), b2 = rdlane(v, cnt >> 1);
+    if (lane == 0) {
+        label_out[i] = label;
+        pwood_out[i] = cnt == 0 ? 0.f : ((cnt & 1) ? a : (a + b2) * 0.5f);
+    }
+}
+
+extern "C" int32_t p2w_vote(const int32_t* nbr, const int32_t* deg, int32_t k, const float* pred, const float* prob, int32_t n,
+                            float any_wood, float* label_out, float* pwood_out, p2w_stream_t stream) {
+    if (n == 0) return P2W_OK;
+    P2W_CHECK_PTR(nbr); P2W_CHECK_PTR(deg); P2W_CHECK_PTR(pred); P2W_CHECK_PTR(prob); P2W_CHECK_PTR(label_out);
+    P2W_CHECK_PTR(pwood_out);
+    if (n < 0 || k <= 0 || k > P2W_MAX_K) return P2W_EINVAL;
+    vote_kernel<<<p2w_cdiv(n, 4), 256, 0, p2w_s(stream)>>>(nbr, deg, k, pred, prob, n, any_wood, label_out, pwood_out);
+    return P2W_LAUNCH_STATUS();
+}
+
 __global__ __launch_bounds__(256) void fill_batch_nbr_kernel(const int* __restrict__ batch, int m, int* __restrict__ nbr,
                                                              int* __restrict__ deg) {
     const int i = blockIdx.x * 256 + threadIdx.x;

@@ -45,3 +45,27 @@ def gather_logits(logits: torch.Tensor, dist, counts=None, group=None):
     out = [torch.empty_like(buf) for _ in range(world)]
     dist.all_gather(out, buf, group=group)
     return torch.cat([o[:c] for o, c in zip(out, counts)])
+
+
+def gather_rows(rows: torch.Tensor, dist, group=None):
+    """All-gather of ``[n_r, c]`` row blocks whose lengths differ per rank and are NOT known in advance (e.g. the
+    classified points of each rank's voxel batches): one small all-gather of the lengths, one of the padded blocks.
+    Returns the concatenation in rank order, identical on every rank."""
+    world = dist.get_world_size(group)
+    n = torch.tensor([rows.shape[0]], dtype=torch.int64, device=rows.device)
+    ns = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(ns, n, group=group)
+    counts = [int(v) for v in ns]
+    m = max(counts)
+    buf = torch.zeros((m,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
+    buf[: rows.shape[0]] = rows
+    out = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf, group=group)
+    return torch.cat([o[:c] for o, c in zip(out, counts)])
+
+
+def slice_for_rank(n: int, rank: int, world: int):
+    """Contiguous share of ``n`` items for ``rank`` (sizes differ by at most one; every item has one owner)."""
+    base, rem = divmod(n, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)

@@ -1,0 +1,80 @@
+"""Plot-level inference on one GPU, in memory: voxelise -> classify every voxel -> back-project onto the input points.
+
+The reference does this through the disk (``preprocess`` writes ``voxel_*.pt``, ``SemanticSegmentation`` reads them
+back: ``pointstowood/predict.py:116-156``, ``src/predicter.py:148-236``); here every stage stays in HBM:
+``preprocessing.voxelise`` -> ``PointBudgetSampler`` + ``collate_device`` -> ``Net.stream`` -> ``backproject``.
+"""
+from __future__ import annotations
+
+import collections
+import time
+
+import torch
+
+from .backproject import collect_predictions
+from .dist import gather_rows, partition_batches, slice_for_rank
+from .predicter import PointBudgetSampler, collate_device
+from .preprocessing import voxelise
+
+
+def segment_plot(pc, model, grid_sizes=(2.0, 4.0), min_pts: int = 128, max_pts: int = 16384, is_wood: float = 0.5,
+                 any_wood: float = 1.0, max_points: int = 131072, mode: str = "compat", generator=None, stats=None,
+                 dist=None):
+    """pc: [N, >= 4] float tensor on the GPU (x, y, z, reflectance, ...), plot-local coordinates (fp32-safe).
+    Returns (n_z [N], label [N], pwood [N]) float32 on the device: the three columns the reference appends
+    (``predicter.py:233``).  ``stats`` (dict, optional) receives stage timings and counts.
+
+    ``dist`` (an initialised ``torch.distributed``, one process per GPU, every rank holding the same ``pc`` and the same
+    ``generator`` state): every rank voxelises (cheap, and it makes the voxel list identical everywhere without an
+    exchange), classifies its LPT share of the voxel batches, the classified points are all-gathered once, each rank
+    back-projects a contiguous slice of the plot and the slices are all-gathered: two exchanges in total."""
+    dev = pc.device
+    t0 = time.perf_counter()
+    vox, n_z = voxelise(pc, tuple(grid_sizes), min_pts, max_pts, mode=mode, generator=generator)
+    if stats is not None:
+        torch.cuda.synchronize(dev)
+        stats["voxelise_s"], t0 = time.perf_counter() - t0, time.perf_counter()
+        stats["voxels"] = len(vox)
+    n = pc.shape[0]
+    if not vox:   # nothing dense enough to classify (predicter.py would fail on an empty loader)
+        return n_z, torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    lengths = [int(v.shape[0]) for v in vox]
+    batches = list(PointBudgetSampler(lengths, max_points))
+    world, rank = (dist.get_world_size(), dist.get_rank()) if dist is not None else (1, 0)
+    if world > 1:
+        mine = partition_batches([sum(lengths[i] for i in b) for b in batches], world)[rank]
+        batches = [batches[i] for i in mine]
+    pending = collections.deque()
+
+    def feed():
+        for b in batches:
+            d = collate_device([vox[i] for i in b])
+            pending.append(d)
+            yield d
+
+    xyz, prob = [], []
+    for logits in model.stream(feed()):
+        d = pending.popleft()
+        prob.append(torch.sigmoid(torch.nan_to_num(logits)).reshape(-1))                 # predicter.py:197-199
+        xyz.append(d.pos + d.local_shift.view(-1, 3)[d.batch])                             # predicter.py:211
+    if xyz:
+        cls = torch.cat([torch.cat(xyz), torch.cat(prob)[:, None]], 1)
+    else:
+        cls = torch.zeros((0, 4), dtype=torch.float32, device=dev)
+    if world > 1:
+        cls = gather_rows(cls, dist)
+    cls_xyz, cls_prob = cls[:, :3].contiguous(), cls[:, 3].contiguous()
+    cls_pred = (cls_prob >= is_wood).to(torch.float32)                                       # predicter.py:200
+    if stats is not None:
+        torch.cuda.synchronize(dev)
+        stats["classify_s"], t0 = time.perf_counter() - t0, time.perf_counter()
+        stats["classified_points"] = int(cls_prob.numel())
+    q0, q1 = slice_for_rank(n, rank, world)
+    label, pwood = collect_predictions(cls_xyz, cls_pred, cls_prob, pc[q0:q1, :3].to(torch.float32), any_wood=any_wood)
+    if world > 1:
+        both = gather_rows(torch.stack([label, pwood], 1), dist)
+        label, pwood = both[:, 0].contiguous(), both[:, 1].contiguous()
+    if stats is not None:
+        torch.cuda.synchronize(dev)
+        stats["backproject_s"] = time.perf_counter() - t0
+    return n_z, label, pwood

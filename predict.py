@@ -7,10 +7,10 @@ clouds (``voxel_*.pt`` files as written by the reference's ``Voxelise.write_voxe
 
     python predict.py --voxels DIR --model model.pth [--batch_size 8 --is-wood 0.5 --odir OUT]
 
-The reference's ``--point-cloud`` entry (file I/O -> height normalisation -> voxeliser -> forward -> KD-tree
-back-projection and vote -> PLY) needs the components SURVEY.md section 8f lists as "next" (voxeliser,
-back-projection, PLY I/O); they are not built yet, so ``--point-cloud`` stops with an explanatory error instead of
-silently doing something else.  All other flags are accepted with the reference's names, types and defaults.
+``--point-cloud FILE.ply ...`` runs the reference's whole flow in memory on the GPU (``pointstowood/predict.py:116-156``):
+PLY -> column handling -> height normalisation + voxeliser (2 m / 4 m grids) -> forward over every voxel ->
+back-projection (k-nearest classified points, median probability, vote) -> ``<name>_ours.ply`` next to the input with
+the input's columns + ``n_z, label, pwood``.  All flags carry the reference's names, types and defaults.
 """
 from __future__ import annotations
 
@@ -46,6 +46,47 @@ def build_parser():
     return p
 
 
+def segment_file(path, args):
+    """One point cloud file through the whole flow; returns the output path."""
+    if not torch.cuda.is_available():
+        raise SystemExit('predict.py needs an MI355X: the HIP path has no CPU fallback')
+    from pointstowood_amd import Net
+    from pointstowood_amd import io as pio
+    from pointstowood_amd.pipeline import segment_plot
+    from pointstowood_amd.predicter import load_model
+    if os.path.splitext(path)[1].lower() != '.ply':
+        raise SystemExit(f'{path}: only .ply input is built (the reference also reads .las / .pcd through laspy / its own parser)')
+    device = torch.device('cuda')
+    t0 = time.time()
+    cols, headers, had_refl = pio.prepare_columns(pio.read_ply(path))
+    print('Reflectance detected' if had_refl else 'No reflectance detected, column added with zeros.')
+    names = list(cols)
+    xyz64 = np.stack([np.asarray(cols[c], dtype=np.float64) for c in names[:3]], 1)
+    origin = xyz64.min(0)                                   # plot-local coordinates: fp32 keeps millimetres at any easting
+    arr = np.concatenate([xyz64 - origin] + [np.asarray(cols[c], dtype=np.float64)[:, None] for c in names[3:]], 1)
+    pc = torch.from_numpy(arr.astype(np.float32)).to(device)
+    model = Net(num_classes=1, precision=args.precision).to(device)
+    try:
+        load_model(args.model, model, device)
+    except KeyError:
+        raise Exception(f'No model loaded at {args.model}')
+    model.eval()
+    print(f'Voxelising to {args.grid_size} grid sizes')
+    stats = {}
+    n_z, label, pwood = segment_plot(pc, model, args.grid_size, args.min_pts, args.max_pts, args.is_wood, args.any_wood,
+                                     stats=stats)
+    out = {c: cols[c] for c in names[:3]}
+    for h in dict.fromkeys(headers):                       # predicter.py:233: headers + n_z, label, pwood, de-duplicated
+        out[h] = cols[h]
+    out['n_z'], out['label'], out['pwood'] = n_z.cpu().numpy(), label.cpu().numpy(), pwood.cpu().numpy()
+    opath = os.path.join(os.path.dirname(path), os.path.splitext(os.path.basename(path))[0] + '_ours.ply')
+    pio.write_ply(opath, out)
+    if args.verbose:
+        print({k: (round(v, 3) if isinstance(v, float) else v) for k, v in stats.items()})
+        print(f'{len(arr)} points -> {opath} in {time.time() - t0:.2f} s')
+    return opath
+
+
 def main(argv=None):
     args = build_parser().parse_args(argv)
     torch.set_num_threads(os.cpu_count() if args.num_procs == -1 else args.num_procs)
@@ -59,8 +100,7 @@ def main(argv=None):
         for f in args.point_cloud:
             if not os.path.isfile(f):
                 raise FileNotFoundError(f'Point cloud file not found: {f}')
-        raise SystemExit("--point-cloud needs the voxeliser / back-projection / PLY I/O rows (SURVEY.md 8f), which this "
-                         "build does not contain yet. Voxelise with the reference's preprocessing and pass --voxels DIR.")
+        return [segment_file(f, args) for f in args.point_cloud]
     if not torch.cuda.is_available():
         raise SystemExit('predict.py needs an MI355X: the HIP path has no CPU fallback')
 

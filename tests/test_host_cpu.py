@@ -220,3 +220,103 @@ def test_point_budget_sampler_covers_everything_within_budget():
     assert all(sum(lengths[i] for i in b) <= 40000 and len(b) <= 32 for b in batches)
     fill = sum(lengths) / (len(batches) * 40000)
     assert fill > 0.8 and list(PointBudgetSampler(lengths, 40000, 32)) == batches
+
+
+# ---- PLY I/O and CLI column handling (next row 8f-3) -------------------------------------------------------------
+def test_ply_round_trip_binary_ascii_and_big_endian(tmp_path):
+    from pointstowood_amd import io as pio
+    g = np.random.default_rng(0)
+    n = 257
+    cols = {"x": g.random(n) * 100, "y": g.random(n), "z": g.random(n), "scalar_Reflectance": g.random(n).astype(np.float32),
+            "red": g.integers(0, 255, n), "green": g.integers(0, 255, n), "blue": g.integers(0, 255, n)}
+    p = tmp_path / "a.ply"
+    pio.write_ply(str(p), cols, comments=["unit test"])
+    back = pio.read_ply(str(p))
+    assert list(back) == ["x", "y", "z", "red", "green", "blue", "scalar_Reflectance"]        # io.py:63-78 column order
+    assert back["x"].dtype == np.float64 and back["red"].dtype == np.int32
+    for k in cols:
+        assert np.array_equal(back[k], np.asarray(cols[k]).astype(back[k].dtype))
+    # ascii and big-endian inputs
+    header = "ply\nformat {} 1.0\nelement vertex 3\nproperty float x\nproperty float y\nproperty double z\nproperty uchar intensity\nend_header\n"
+    a = tmp_path / "b.ply"
+    a.write_text(header.format("ascii") + "1 2 3 7\n4 5 6 8\n-1.5 0 2.25 255\n")
+    got = pio.read_ply(str(a))
+    assert got["x"].dtype == np.float32 and got["intensity"].dtype == np.uint8
+    assert np.array_equal(got["z"], [3, 6, 2.25]) and np.array_equal(got["intensity"], [7, 8, 255])
+    rec = np.zeros(3, dtype=[("x", ">f4"), ("y", ">f4"), ("z", ">f8"), ("intensity", "u1")])
+    rec["x"], rec["z"], rec["intensity"] = [1, 4, -1.5], [3, 6, 2.25], [7, 8, 255]
+    b = tmp_path / "c.ply"
+    b.write_bytes(header.format("binary_big_endian").encode() + rec.tobytes())
+    got = pio.read_ply(str(b))
+    assert np.array_equal(got["x"], np.float32([1, 4, -1.5])) and np.array_equal(got["z"], [3, 6, 2.25])
+    m = tmp_path / "mesh.ply"
+    m.write_text("ply\nformat ascii 1.0\nelement vertex 1\nproperty float x\nelement face 1\nproperty list uchar int vertex_indices\nend_header\n0\n3 0 0 0\n")
+    with pytest.raises(ValueError, match="mesh"):
+        pio.read_ply(str(m))
+    t = tmp_path / "trunc.ply"
+    t.write_bytes(header.format("binary_little_endian").encode() + b"\0" * 10)
+    with pytest.raises(ValueError, match="truncated"):
+        pio.read_ply(str(t))
+
+
+def test_prepare_columns_follows_the_reference_cli():
+    """predict.py:36-52: lower-case, drop label/pwood/pleaf, strip scalar_, refl|intensity -> reflectance at column 3."""
+    from pointstowood_amd import io as pio
+    n = 4
+    z = np.zeros(n)
+    cols, headers, had = pio.prepare_columns({"X": z, "Y": z, "Z": z, "red": z, "scalar_Intensity": z + 2, "label": z, "pwood": z})
+    assert list(cols) == ["x", "y", "z", "reflectance", "red"] and headers == ["red", "reflectance"] and had
+    assert np.array_equal(cols["reflectance"], z + 2)
+    cols, headers, had = pio.prepare_columns({"x": z, "y": z, "z": z, "scalar_dev": z})
+    assert list(cols) == ["x", "y", "z", "reflectance", "dev"] and headers == ["dev"] and not had
+    assert np.array_equal(cols["reflectance"], z)
+    cols, headers, had = pio.prepare_columns({"x": z, "y": z, "z": z, "refl": z + 1})
+    assert list(cols) == ["x", "y", "z", "reflectance"] and headers == ["reflectance"] and had
+
+
+def test_backproject_oracle_known_answers():
+    """compute_labels (predicter.py:112-127) on hand-made neighbourhoods."""
+    from oracle import backproject as OB
+    nb = np.zeros((3, 4, 5))
+    nb[0, :, 3], nb[0, :, 4] = [1, 1, 0, 0], [0.9, 0.8, 0.1, 0.2]      # wood votes 1.7 vs 0.3
+    nb[1, :, 3], nb[1, :, 4] = [1, 0, 0, 0], [0.6, 0.4, 0.4, 0.4]      # 0.6 vs 1.2
+    nb[2, :, 3], nb[2, :, 4] = [1, 0, 1, 0], [0.5, 0.5, 0.5, 0.5]      # tie -> first maximum = class 0
+    lab = OB.compute_labels(nb, 1)
+    assert lab[:, 0].tolist() == [1, 0, 0]
+    assert np.allclose(lab[:, 1], [0.5, 0.4, 0.5])                       # medians: (0.2+0.8)/2, 0.4, 0.5
+    assert OB.compute_labels(nb, 0.5)[:, 0].tolist() == [1, 1, 1]       # any neighbour predicted wood
+    nb[1, :, 3] = 0
+    assert OB.compute_labels(nb, 0.5)[:, 0].tolist() == [1, 0, 1]
+
+
+def _rows_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from pointstowood_amd.dist import gather_rows
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = [3, 0][rank] if world == 2 else 1
+    rows = torch.arange(n * 4, dtype=torch.float32).reshape(n, 4) + 100 * rank
+    out = gather_rows(rows, dist)
+    empty = gather_rows(torch.zeros((0, 2)), dist)
+    q.put((rank, out.tolist(), list(empty.shape)))
+    dist.destroy_process_group()
+
+
+def test_gather_rows_gloo_world2_ragged_and_empty():
+    """The plot pipeline's two exchanges (classified points, per-point results) use this: lengths unknown in advance,
+    a rank may contribute nothing."""
+    import torch.multiprocessing as mp
+    from pointstowood_amd.dist import slice_for_rank
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30500 + os.getpid() % 1000
+    ps = [ctx.Process(target=_rows_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    [p.join(30) for p in ps]
+    expect = torch.arange(12, dtype=torch.float32).reshape(3, 4).tolist()
+    for _, out, eshape in res:
+        assert out == expect and eshape == [0, 2]
+    cover = [slice_for_rank(10, r, 4) for r in range(4)]
+    assert cover == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    assert [slice_for_rank(2, r, 4) for r in range(4)] == [(0, 1), (1, 2), (2, 2), (2, 2)]

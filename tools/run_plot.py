@@ -65,42 +65,34 @@ def main():
     net = net.to(dev).eval()
     side = 100.0 * (args.points / 10_000_000) ** 0.5
     pc = synth_plot(args.points, side=max(side, 10.0)).to(dev)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    vox, _ = voxelise(pc, (2.0, 4.0), args.min_pts, args.max_pts, generator=torch.Generator(device=dev).manual_seed(0))
-    torch.cuda.synchronize()
-    t_vox = time.perf_counter() - t0
-    lengths = [int(v.shape[0]) for v in vox]
-    if args.batch_size > 0:
+    from pointstowood_amd.pipeline import segment_plot
+    gen = lambda: torch.Generator(device=dev).manual_seed(0)
+    if args.batch_size > 0:   # reference-style fixed voxel count per forward: classification only (host-bound; for comparison)
         from pointstowood_amd.predicter import VoxelDataset
+        vox, _ = voxelise(pc, (2.0, 4.0), args.min_pts, args.max_pts, generator=gen())
         batches = list(BalancedBatchSampler(VoxelDataset(vox), args.batch_size))
-    else:
-        batches = list(PointBudgetSampler(lengths, args.max_points))
-    costs = [sum(lengths[i] for i in b) for b in batches]
-    mine = partition_batches(costs, world)[rank]
-    net(collate_device([vox[i] for i in batches[mine[0]]]))   # warm-up (weight packing, allocator)
+        torch.cuda.synchronize()
+        t0, n_pts = time.perf_counter(), 0
+        for logits in net.stream(collate_device([vox[i] for i in b]) for b in batches):
+            n_pts += logits.numel()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print(f"reference-style batches of {args.batch_size}: {n_pts} points in {dt:.2f} s = {n_pts / dt / 1e6:.2f} M points/s")
+        return
+    segment_plot(pc[:200000], net, min_pts=args.min_pts, max_pts=args.max_pts, generator=gen(), dist=dist)   # warm-up
     torch.cuda.synchronize()
+    stats = {}
     t0 = time.perf_counter()
-    datas = (collate_device([vox[i] for i in batches[b]]) for b in mine)
-    n_pts, outs = 0, []
-    for logits in net.stream(datas):
-        outs.append(torch.sigmoid(torch.nan_to_num(logits)))
-        n_pts += logits.numel()
-    local_probs = torch.cat(outs)
-    if world > 1:
-        counts = torch.zeros(world, dtype=torch.int64, device=dev)
-        counts[rank] = n_pts
-        dist.all_reduce(counts)
-        from pointstowood_amd.dist import gather_logits
-        allp = gather_logits(local_probs, dist, counts=[int(c) for c in counts.cpu()])
-        n_pts = allp.numel()
+    n_z, label, pwood = segment_plot(pc, net, (2.0, 4.0), args.min_pts, args.max_pts, max_points=args.max_points,
+                                     generator=gen(), stats=stats, dist=dist)
     torch.cuda.synchronize()
-    t_cls = time.perf_counter() - t0
+    total = time.perf_counter() - t0
     if rank == 0:
-        sizes = sorted(v.shape[0] for v in vox)
-        print(f"plot {args.points} pts -> {len(vox)} voxels (min {sizes[0]}, median {sizes[len(sizes)//2]}, max {sizes[-1]}), "
-              f"{sum(sizes)} classified points incl. 2 m / 4 m overlap; voxelise {t_vox:.2f} s; "
-              f"classify {t_cls:.2f} s on {world} GPU(s) = {n_pts / t_cls / 1e6:.2f} M points/s", flush=True)
+        print(f"plot {args.points} pts -> {stats['voxels']} voxels, {stats['classified_points']} classified points incl. "
+              f"2 m / 4 m overlap on {world} GPU(s): voxelise {stats['voxelise_s']:.2f} s, classify {stats['classify_s']:.2f} s "
+              f"({stats['classified_points'] / stats['classify_s'] / 1e6:.2f} M classified points/s), back-project "
+              f"{stats['backproject_s']:.2f} s ({args.points / stats['backproject_s'] / 1e6:.2f} M points/s, k=64); end to end "
+              f"{total:.2f} s = {args.points / total / 1e6:.2f} M plot points/s; wood fraction {float(label.mean()):.3f}", flush=True)
     if world > 1:
         dist.destroy_process_group()
 
