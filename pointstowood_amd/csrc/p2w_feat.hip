@@ -199,9 +199,32 @@ extern "C" int32_t p2w_gemm(const float* A, int32_t lda, const float* Wp, int32_
 // so the max over neighbours is a max over the accumulator tile's rows (16 registers + one lane^32
 // exchange) and the [E, C] edge tensors of the reference never exist in HBM.
 // ------------------------------------------------------------------------------------------------
+// fp16 hi/lo split of two values at once: hi = round-toward-zero fp16 of v (v_cvt_pkrtz_f16_f32 converts a PAIR per
+// instruction and, rounding toward zero, saturates at +-65504 instead of overflowing to inf), lo = round-to-nearest
+// fp16 of the exact fp32 remainder v - hi (v_cvt_pk_f16_f32, also a pair per instruction; nearest keeps the split
+// unbiased).  hi + lo reproduces v to <= 2^-22 relative; |v| up to ~1.3e5 still splits exactly enough.
+// 6 VALU per pair (2 packed conversions, 2 conversions back, 2 subtractions) instead of 14 with clamps and single
+// conversions.
+typedef __fp16 hpair __attribute__((ext_vector_type(2)));
+typedef _Float16 hpairn __attribute__((ext_vector_type(2)));
+typedef float fpair __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo) {
+    const hpair h = __builtin_amdgcn_cvt_pkrtz(a, b);
+    const fpair rem = {a - (float)h[0], b - (float)h[1]};
+#ifdef P2W_SPLIT_RTZ   // A/B (P2W_EXTRA_CFLAGS): remainder toward zero as well: -1.2 % feature time, but biased (worst
+                      // golden logit error 1.1e-4 instead of 9.6e-5; the clamped round-to-nearest split it replaces: +0.8 %)
+    const hpair l = __builtin_amdgcn_cvt_pkrtz(rem[0], rem[1]);
+#else
+    const hpairn l = __builtin_convertvector(rem, hpairn);
+#endif
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
 __device__ __forceinline__ void sa_split(float v, _Float16& hi, _Float16& lo) {
-    hi = (_Float16)__builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
-    lo = (_Float16)__builtin_amdgcn_fmed3f(v - (float)hi, -65504.f, 65504.f);
+    unsigned h, l;
+    split_pair(v, 0.f, h, l);
+    hi = __builtin_bit_cast(_Float16, (unsigned short)(h & 0xffffu));
+    lo = __builtin_bit_cast(_Float16, (unsigned short)(l & 0xffffu));
 }
 __device__ __forceinline__ unsigned sa_pack(_Float16 a, _Float16 b) {
     typedef _Float16 h2v __attribute__((ext_vector_type(2)));
@@ -239,12 +262,11 @@ __device__ __forceinline__ void sa_epilogue(const f32x16 (&acc)[2][2], float wsc
             if (out_h2) {  // lanes (2p, 2p+1) hold adjacent columns: the even lane stores both as one word per plane
                 const float nb = __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(vmax), 0xB1, 0xf, 0xf, false));
                 if (h == 0 && (lane & 1) == 0 && col < ldh) {
-                    _Float16 h0, l0, h1, l1;
-                    sa_split(vmax, h0, l0);
-                    sa_split(nb, h1, l1);
+                    unsigned hw, lw;
+                    split_pair(vmax, nb, hw, lw);
                     _Float16* p = out_h2 + (size_t)tgt * (2 * ldh) + col;
-                    *reinterpret_cast<unsigned*>(p) = sa_pack(h0, h1);
-                    *reinterpret_cast<unsigned*>(p + ldh) = sa_pack(l0, l1);
+                    *reinterpret_cast<unsigned*>(p) = hw;
+                    *reinterpret_cast<unsigned*>(p + ldh) = lw;
                 }
             }
         }
@@ -279,12 +301,11 @@ __device__ __forceinline__ void sa_epilogue_regs(const f32x16 (&acc)[2][2], floa
             if (out_h2) {
                 const float nb = __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(vmax), 0xB1, 0xf, 0xf, false));
                 if (h == 0 && (lane & 1) == 0 && col < ldh) {
-                    _Float16 h0, l0, h1, l1;
-                    sa_split(vmax, h0, l0);
-                    sa_split(nb, h1, l1);
+                    unsigned hw, lw;
+                    split_pair(vmax, nb, hw, lw);
                     _Float16* p = out_h2 + (size_t)tgt * (2 * ldh) + col;
-                    *reinterpret_cast<unsigned*>(p) = sa_pack(h0, h1);
-                    *reinterpret_cast<unsigned*>(p + ldh) = sa_pack(l0, l1);
+                    *reinterpret_cast<unsigned*>(p) = hw;
+                    *reinterpret_cast<unsigned*>(p + ldh) = lw;
                 }
             }
         }
@@ -440,14 +461,11 @@ __device__ __forceinline__ void split_store(_Float16* __restrict__ Sh, _Float16*
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const float v[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
-        h4 hi, lo;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            hi[e] = (_Float16)__builtin_amdgcn_fmed3f(v[e], -65504.f, 65504.f);
-            lo[e] = (_Float16)__builtin_amdgcn_fmed3f(v[e] - (float)hi[e], -65504.f, 65504.f);
-        }
-        *reinterpret_cast<h4*>(&Sh[(lrow + 32 * i) * H_LD + 4 * lkq]) = hi;
-        *reinterpret_cast<h4*>(&Sl[(lrow + 32 * i) * H_LD + 4 * lkq]) = lo;
+        uint2 hi, lo;
+        split_pair(v[0], v[1], hi.x, lo.x);
+        split_pair(v[2], v[3], hi.y, lo.y);
+        *reinterpret_cast<uint2*>(&Sh[(lrow + 32 * i) * H_LD + 4 * lkq]) = hi;
+        *reinterpret_cast<uint2*>(&Sl[(lrow + 32 * i) * H_LD + 4 * lkq]) = lo;
     }
 }
 
@@ -560,10 +578,7 @@ extern "C" int32_t p2w_gemm_f16x3(const float* A, int32_t lda, const void* Wh, f
 // 16-byte copies (no conversion), exactly like the packed weights.  Producers split once, in their epilogue.
 // ------------------------------------------------------------------------------------------------
 // hi saturates at +-65504 instead of overflowing to inf; the remainder goes to lo (usable range ~1.3e5)
-__device__ __forceinline__ void h2_split(float v, _Float16& hi, _Float16& lo) {
-    hi = (_Float16)__builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
-    lo = (_Float16)__builtin_amdgcn_fmed3f(v - (float)hi, -65504.f, 65504.f);
-}
+__device__ __forceinline__ void h2_split(float v, _Float16& hi, _Float16& lo) { sa_split(v, hi, lo); }
 __device__ __forceinline__ unsigned h2_pack(_Float16 a, _Float16 b) {
     typedef _Float16 h2v __attribute__((ext_vector_type(2)));
     h2v p = {a, b};
@@ -571,12 +586,12 @@ __device__ __forceinline__ unsigned h2_pack(_Float16 a, _Float16 b) {
 }
 // store 4 consecutive columns of one row (col % 4 == 0)
 __device__ __forceinline__ void h2_store4(_Float16* __restrict__ base, int ldh, size_t row, int col, const float (&v)[4]) {
-    _Float16 hi[4], lo[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) h2_split(v[e], hi[e], lo[e]);
+    uint2 hi, lo;
+    split_pair(v[0], v[1], hi.x, lo.x);
+    split_pair(v[2], v[3], hi.y, lo.y);
     _Float16* p = base + row * (size_t)(2 * ldh) + col;
-    *reinterpret_cast<uint2*>(p) = make_uint2(h2_pack(hi[0], hi[1]), h2_pack(hi[2], hi[3]));
-    *reinterpret_cast<uint2*>(p + ldh) = make_uint2(h2_pack(lo[0], lo[1]), h2_pack(lo[2], lo[3]));
+    *reinterpret_cast<uint2*>(p) = hi;
+    *reinterpret_cast<uint2*>(p + ldh) = lo;
 }
 
 // A tile from an H2 tensor: 128 rows x 32 halfs per plane; thread -> rows (tid>>2) + 64*i, 8 halfs at k = 8*(tid&3)
@@ -644,12 +659,11 @@ __device__ __forceinline__ void gemm_epilogue2(const f32x16 (&acc)[RT][CT], cons
                     const float c0v = odd ? recv : va, c1v = odd ? vb : recv;  // columns (col & ~1), (col | 1)
                     const int roww = rowa + odd, colw = col & ~1;
                     if (roww < M && colw < o.ldh) {
-                        _Float16 h0, l0, h1, l1;
-                        h2_split(c0v, h0, l0);
-                        h2_split(c1v, h1, l1);
+                        unsigned hw, lw;
+                        split_pair(c0v, c1v, hw, lw);
                         _Float16* p = o.h2 + (size_t)roww * (2 * o.ldh) + colw;
-                        *reinterpret_cast<unsigned*>(p) = h2_pack(h0, h1);
-                        *reinterpret_cast<unsigned*>(p + o.ldh) = h2_pack(l0, l1);
+                        *reinterpret_cast<unsigned*>(p) = hw;
+                        *reinterpret_cast<unsigned*>(p + o.ldh) = lw;
                     }
                 }
             }
@@ -702,12 +716,11 @@ __device__ __forceinline__ void gemm_epilogue3(const f32x16 (&acc)[RT][CT], cons
                     const float send = odd ? va : vb;
                     const float recv = __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(send), 0xB1, 0xf, 0xf, false));
                     const float c0v = odd ? recv : va, c1v = odd ? vb : recv;
-                    _Float16 h0, l0, h1, l1;
-                    h2_split(c0v, h0, l0);
-                    h2_split(c1v, h1, l1);
+                    unsigned hw, lw;
+                    split_pair(c0v, c1v, hw, lw);
                     _Float16* p = o.h2 + (rowa + odd) * (unsigned)(2 * o.ldh) + (col & ~1);
-                    *reinterpret_cast<unsigned*>(p) = h2_pack(h0, h1);
-                    *reinterpret_cast<unsigned*>(p + o.ldh) = h2_pack(l0, l1);
+                    *reinterpret_cast<unsigned*>(p) = hw;
+                    *reinterpret_cast<unsigned*>(p + o.ldh) = lw;
                 }
             }
         }
@@ -1082,7 +1095,7 @@ __global__ __launch_bounds__(512, 2) void sa_conv16g_kernel(const float* __restr
     };
     auto produce = [&](int stage, int k0) {
         const int k = k0 + 8 * pq;
-        h8 hi, lo;
+        unsigned hiw[4], low[4];
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const int kk = k + 4 * half;
@@ -1098,15 +1111,17 @@ __global__ __launch_bounds__(512, 2) void sa_conv16g_kernel(const float* __restr
                 v[2] = fmaxf(fmaf(rg.w, wf.z, fmaf(rg.z, wz.z, fmaf(rg.y, wy.z, fmaf(rg.x, wx.z, p.z)))), 0.f);
                 v[3] = fmaxf(fmaf(rg.w, wf.w, fmaf(rg.z, wz.w, fmaf(rg.y, wy.w, fmaf(rg.x, wx.w, p.w)))), 0.f);
             }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                hi[4 * half + e] = (_Float16)fminf(v[e], 65504.f);   // v >= 0 after the ReLU
-                lo[4 * half + e] = (_Float16)fminf(v[e] - (float)hi[4 * half + e], 65504.f);
+            {
+                unsigned h01, l01, h23, l23;
+                split_pair(v[0], v[1], h01, l01);
+                split_pair(v[2], v[3], h23, l23);
+                hiw[2 * half] = h01; hiw[2 * half + 1] = h23;
+                low[2 * half] = l01; low[2 * half + 1] = l23;
             }
         }
         char* st = S + (size_t)stage * STAGE_CH * 16;
-        *reinterpret_cast<h8*>(st + a_dst) = hi;
-        *reinterpret_cast<h8*>(st + BM * 64 + a_dst) = lo;
+        *reinterpret_cast<uint4*>(st + a_dst) = make_uint4(hiw[0], hiw[1], hiw[2], hiw[3]);
+        *reinterpret_cast<uint4*>(st + BM * 64 + a_dst) = make_uint4(low[0], low[1], low[2], low[3]);
     };
 
     const int r = lane & 31, h = lane >> 5;
@@ -1298,7 +1313,7 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
       for (int u = 0; u < NR; ++u) {
         const float4 rg = m.g[u];
         const bool on = m.j[u] >= 0;
-        h8 hi, lo;
+        unsigned hiw[4], low[4];
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const int kk = k + 4 * half;
@@ -1315,15 +1330,17 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
             v[1] = fmaxf(fmaf(gw, wf.y, fmaf(gz, wz.y, fmaf(gy, wy.y, fmaf(gx, wx.y, p.y)))), 0.f);
             v[2] = fmaxf(fmaf(gw, wf.z, fmaf(gz, wz.z, fmaf(gy, wy.z, fmaf(gx, wx.z, p.z)))), 0.f);
             v[3] = fmaxf(fmaf(gw, wf.w, fmaf(gz, wz.w, fmaf(gy, wy.w, fmaf(gx, wx.w, p.w)))), 0.f);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                hi[4 * half + e] = (_Float16)fminf(v[e], 65504.f);   // v >= 0 after the ReLU
-                lo[4 * half + e] = (_Float16)fminf(v[e] - (float)hi[4 * half + e], 65504.f);
+            {
+                unsigned h01, l01, h23, l23;
+                split_pair(v[0], v[1], h01, l01);
+                split_pair(v[2], v[3], h23, l23);
+                hiw[2 * half] = h01; hiw[2 * half + 1] = h23;
+                low[2 * half] = l01; low[2 * half + 1] = l23;
             }
         }
         char* st = S + (size_t)stage * STAGE_CH * 16;
-        *reinterpret_cast<h8*>(st + a_dst + u * 128 * 64) = hi;
-        *reinterpret_cast<h8*>(st + BM * 64 + a_dst + u * 128 * 64) = lo;
+        *reinterpret_cast<uint4*>(st + a_dst + u * 128 * 64) = make_uint4(hiw[0], hiw[1], hiw[2], hiw[3]);
+        *reinterpret_cast<uint4*>(st + BM * 64 + a_dst + u * 128 * 64) = make_uint4(low[0], low[1], low[2], low[3]);
       }
     };
 
