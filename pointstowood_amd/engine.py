@@ -541,7 +541,7 @@ class Engine:
         of the NEXT batch's geometry, which has been running concurrently."""
         cur_stream = torch.cuda.current_stream()
         if getattr(self, "_s_geo", None) is None:
-            self._s_geo = torch.cuda.Stream(priority=-1)   # short, low-footprint kernels: let them slot in first
+            self._s_geo = torch.cuda.Stream(priority=int(os.environ.get("P2W_GEO_PRIORITY", "-1")))   # short, low-footprint kernels: let them slot in first
             self._s_feat = [torch.cuda.Stream() for _ in range(max(0, self.feature_streams - 1))]
         s_geo = self._s_geo
         f_streams = [cur_stream] + self._s_feat[: max(0, self.feature_streams - 1)]
