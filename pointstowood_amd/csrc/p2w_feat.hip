@@ -817,7 +817,7 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void gemm_h2g_kernel(const _Float1
         if (g < BM / 8) {
             const int p = g / (BM / 16), rb = g % (BM / 16);
             const int row = 16 * rb + rloc, q = (lane & 3) ^ ((row >> 2) & 3);
-            const int grow = min(m0 + row, M - 1);
+            const int grow = (dbg & 32) ? row : min(m0 + row, M - 1);   // dbg 32: every workgroup reads row tile 0 (no A traffic)
             src[i] = A + (size_t)grow * (2 * ldh_a) + (size_t)p * ldh_a + 8 * q;
             dstc[i] = g * 64;
         } else {
