@@ -36,7 +36,7 @@ C, K_NBR, BATCH, NPTS = 32, 32, 8, 16384
 
 
 def make_batch(rank: int, device):
-    from oracle import synth  # synthetic input generator only (no oracle compute on the product path)
+    from pointstowood_amd import synthetic_voxels as synth
     vox = [synth.uniform_voxel(2.0, NPTS, 123 + i + 1000 * rank, False) for i in range(BATCH)]
     b = synth.collate(vox)
 
@@ -84,7 +84,7 @@ def profile_step(net, data):
 
 def cpu_baseline():
     from oracle import net as onet
-    from oracle import synth, weights
+    from pointstowood_amd import synthetic_voxels as synth, synthetic_weights as weights
     torch.set_num_threads(min(os.cpu_count() or 1, 16))  # more threads only add contention on this path
     sd = weights.synth_state_dict(1, C, seed=0)
     v = synth.collate([synth.uniform_voxel(2.0, NPTS, 123, False)])
@@ -129,7 +129,7 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=device)
 
-    from oracle import weights
+    from pointstowood_amd import synthetic_weights as weights
     from pointstowood_amd import Net
     from pointstowood_amd.dist import gather_logits
     net = Net(num_classes=1, C=C, k=K_NBR, precision=args.precision)

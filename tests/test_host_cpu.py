@@ -320,3 +320,17 @@ def test_gather_rows_gloo_world2_ragged_and_empty():
     cover = [slice_for_rank(10, r, 4) for r in range(4)]
     assert cover == [(0, 3), (3, 6), (6, 8), (8, 10)]
     assert [slice_for_rank(2, r, 4) for r in range(4)] == [(0, 1), (1, 2), (2, 2), (2, 2)]
+
+
+def test_product_code_never_imports_the_oracle():
+    """The oracle is the checker: the package, predict.py and the non-baseline part of bench.py must not touch it."""
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b", re.M)
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "pointstowood_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                assert not pat.search(open(os.path.join(dirpath, f)).read()), f
+    assert not pat.search(open(os.path.join(ROOT, "predict.py")).read())
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    hits = [m.start() for m in pat.finditer(src)]
+    a, b = src.index("def cpu_baseline"), src.index("def main")
+    assert hits and all(a < h < b for h in hits)          # only inside cpu_baseline()

@@ -10,7 +10,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
-from oracle import weights  # noqa: E402
+from pointstowood_amd import synthetic_weights as weights  # noqa: E402
 from pointstowood_amd import Net  # noqa: E402
 
 knob, values = sys.argv[1], [int(v) for v in sys.argv[2:]]

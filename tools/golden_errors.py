@@ -4,7 +4,7 @@ import os, sys
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import weights
+from pointstowood_amd import synthetic_weights as weights
 from pointstowood_amd import Net
 from tests import golden_util as G
 

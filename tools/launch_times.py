@@ -4,7 +4,7 @@ import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
-from oracle import weights
+from pointstowood_amd import synthetic_weights as weights
 from pointstowood_amd import Net
 
 dev = torch.device("cuda", 0)

@@ -3,7 +3,7 @@
 import os, sys, collections
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import weights
+from pointstowood_amd import synthetic_weights as weights
 from pointstowood_amd import Net
 from pointstowood_amd.predicter import PointBudgetSampler, collate_device
 from pointstowood_amd.preprocessing import voxelise

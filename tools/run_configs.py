@@ -9,7 +9,7 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import synth, weights  # noqa: E402
+from pointstowood_amd import synthetic_voxels as synth, synthetic_weights as weights  # noqa: E402
 from pointstowood_amd import Net  # noqa: E402
 
 dev = torch.device("cuda", 0)

@@ -9,7 +9,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
-from oracle import weights  # noqa: E402
+from pointstowood_amd import synthetic_weights as weights  # noqa: E402
 from pointstowood_amd import Net  # noqa: E402
 
 phase = sys.argv[1] if len(sys.argv) > 1 else "forward"

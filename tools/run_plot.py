@@ -13,7 +13,7 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import weights  # noqa: E402  (synthetic checkpoint recipe only)
+from pointstowood_amd import synthetic_weights as weights  # noqa: E402
 from pointstowood_amd import Batch, Net  # noqa: E402
 from pointstowood_amd.dist import partition_batches  # noqa: E402
 from pointstowood_amd.predicter import BalancedBatchSampler, PointBudgetSampler, collate_device  # noqa: E402

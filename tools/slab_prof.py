@@ -6,7 +6,7 @@ os.environ.setdefault("P2W_EXTRA_CFLAGS", "-DP2W_SLAB_PROFILE")
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
-from oracle import weights
+from pointstowood_amd import synthetic_weights as weights
 from pointstowood_amd import Net
 from pointstowood_amd import engine as E
 from pointstowood_amd._lib import lib
