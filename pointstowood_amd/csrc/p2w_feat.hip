@@ -1296,18 +1296,18 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
             m.g[u] = meta_g[row];
         }
     };
-    Vals pv;
-    auto gather = [&](const Meta& m, int k0) {
+    Vals pv;    // slab 0 only (prologue)
+    auto gather = [&](const Meta& m, int k0, Vals& dst) {
         const int k = k0 + 8 * pq;
 #pragma unroll
         for (int u = 0; u < NR; ++u) {
             const bool on = m.j[u] >= 0;
             const float* p = P + (size_t)(on ? m.j[u] : 0) * ldp + 8 * pq + k0;
-            pv.v[u][0] = (on && k < C1) ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
-            pv.v[u][1] = (on && k + 4 < C1) ? *reinterpret_cast<const float4*>(p + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            dst.v[u][0] = (on && k < C1) ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+            dst.v[u][1] = (on && k + 4 < C1) ? *reinterpret_cast<const float4*>(p + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    auto produce = [&](int stage, const Meta& m, int k0) {
+    auto produce = [&](int stage, const Meta& m, int k0, const Vals& src) {
         const int k = k0 + 8 * pq;
 #pragma unroll
       for (int u = 0; u < NR; ++u) {
@@ -1323,7 +1323,7 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
             const float4 wy = *reinterpret_cast<const float4*>(&Wr[1 * C1pad + kk]);
             const float4 wz = *reinterpret_cast<const float4*>(&Wr[2 * C1pad + kk]);
             const float4 wf = *reinterpret_cast<const float4*>(&Wr[3 * C1pad + kk]);
-            const float4 p = pv.v[u][half];
+            const float4 p = src.v[u][half];
             const float gx = on ? rg.x : 0.f, gy = on ? rg.y : 0.f, gz = on ? rg.z : 0.f, gw = on ? rg.w : 0.f;
             float v[4];
             v[0] = fmaxf(fmaf(gw, wf.x, fmaf(gz, wz.x, fmaf(gy, wy.x, fmaf(gx, wx.x, p.x)))), 0.f);
@@ -1402,20 +1402,21 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
     int mt_1 = mt_cur, nt_1 = nt_cur;                               // item in the produce stage
     __syncthreads();   // Wr staged
     issue(0, wb1, 0);
-    gather(m_q, 0);
-    produce(0, m_q, 0);
+    gather(m_q, 0, pv);
+    produce(0, m_q, 0, pv);
     Vals pn = pv;          // gathered values of slab g+1
     Meta m_n = m_q;
     int k_n = 0;
     if (total > 1) {
         advance_q();
-        gather(m_q, s_q * G_BK);
-        pn = pv; m_n = m_q; k_n = s_q * G_BK;
+        gather(m_q, s_q * G_BK, pn);
+        m_n = m_q; k_n = s_q * G_BK;
     }
     int it = 0, s = 0;                       // item / slab of the MFMA stage
     int it1 = 0, s1 = 0;                     // item / slab of the produce stage (g+1)
     for (int g = 0; g < total; ++g) {
-        __syncthreads();  // B(g) landed, A(g) written, stage (g+1)&1 free
+        __syncthreads();  // B(g) landed, A(g) written, stage (g+1)&1 free  (a counted vmcnt that leaves the gather in
+                          // flight across the barrier measured 2 % slower)
         const bool more = g + 1 < total;
         if (more) {
             s1 = s + 1; it1 = it;
@@ -1431,10 +1432,17 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
         const Vals pu = pn;
         const Meta m_u = m_n;
         const int k_u = k_n;
-        if (g + 2 < total) {
+        // The gather of slab g+2 is issued here and lands in `pg` while this iteration's MFMAs run; it is only moved
+        // into the loop-carried registers at the END of the iteration (a register copy is a use: placed here, it
+        // would make the compiler wait for the loads before the first MFMA, which is what the kernel used to do).
+        Vals pg = pn;
+        const bool fetch = g + 2 < total;
+        if (fetch) {
             advance_q();
-            if (!(dbg & 16)) gather(m_q, s_q * G_BK);
-            pn = pv; m_n = m_q; k_n = s_q * G_BK;
+            if (!(dbg & 16)) gather(m_q, s_q * G_BK, pg);
+#ifdef P2W_SA_EARLY_COPY   // A/B: the previous placement of the copy (forces the wait before the MFMAs)
+            pn = pg; m_n = m_q; k_n = s_q * G_BK;
+#endif
         }
         const char* st = S + (size_t)(g & 1) * STAGE_CH * 16;
 #pragma unroll
@@ -1458,8 +1466,7 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
                 }
             }
             if (kk == 0 && !(dbg & 8)) {  // producer VALU work is interleaved into the gaps of the 12 MFMAs above (1 MFMA : 8 VALU)
-                pv = pu;
-                produce((g + 1) & 1, m_u, k_u);   // unconditional: after the last slab it fills a stage nobody reads
+                produce((g + 1) & 1, m_u, k_u, pu);   // unconditional: after the last slab it fills a stage nobody reads
 #pragma unroll
                 for (int q = 0; q < 12; ++q) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
@@ -1479,6 +1486,306 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
         }
         if (s == nslab - 1) e_cur = e_1;
         s = s1; it = it1; mt_cur = mt_1; nt_cur = nt_1;
+        __builtin_amdgcn_sched_barrier(0);
+#ifndef P2W_SA_EARLY_COPY
+        if (fetch) { pn = pg; m_n = m_q; k_n = s_q * G_BK; }
+#endif
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// fused PointNetConv v4 (f16x3): producer / consumer wave specialisation
+//
+// The ablation of the v3 kernel shows its parts adding up instead of overlapping (level 2: skeleton 254 + epilogue
+// 140 + W2 DMA 153 + MFMA 394 + producer/gather 169 = 1110 us): all eight waves run the same phase at the same time,
+// re-aligned by the per-slab barrier, so the MFMA pipe idles while everybody produces and vice versa.  Here the two
+// waves of every SIMD have different jobs: waves 0-3 (consumers, 2 x 2) only read fragments and issue MFMAs for the
+// whole BM x BN item tile and run the epilogue; waves 4-7 (producers) issue the W2 DMA, gather the P rows and build
+// the A rows of the NEXT slab.  One workgroup barrier per slab hands a stage of the 2-stage LDS ring over; between two
+// barriers the MFMA pipe and the VALU / memory pipes of a SIMD work on different slabs.
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN>   // (128, 256): 4 targets x 256 columns;  (256, 128): 8 targets x 128 columns
+__global__ __launch_bounds__(512, 1) void sa_conv16w_kernel(const float* __restrict__ P, int ldp, const int* __restrict__ meta_j,
+                                                            const float4* __restrict__ meta_g, const int* __restrict__ deg,
+                                                            int kw, int M, const float* __restrict__ w1r4, int C1, int C1pad,
+                                                            const _Float16* __restrict__ W2h, size_t plane, float wscale, int C2,
+                                                            int nMt, int nNt, const float* __restrict__ b2,
+                                                            const float* __restrict__ bn_s, const float* __restrict__ bn_t,
+                                                            float* __restrict__ out, int ldo, _Float16* __restrict__ out_h2,
+                                                            int ldh, int dbg) {
+    // dbg (profiling ablations, 0 in production): 1 no epilogue, 2 no W2 DMA, 4 no MFMA, 8 no A production, 16 no P gather
+    constexpr int RT = BM / 64, CT = BN / 64;      // consumer wave tile (32 RT) x (32 CT), consumers arranged 2 x 2
+    constexpr int A_CH = 8 * BM, STAGE_CH = A_CH + 8 * BN;
+    constexpr int NRP = BM / 64;                    // producer rows per thread: 256 producer threads, 4 per row
+    constexpr int NIP = (8 * BN) / 64 / 4;          // W2 DMA pieces per producer wave per slab
+    __shared__ __attribute__((aligned(16))) char S[2 * STAGE_CH * 16];
+    __shared__ __attribute__((aligned(16))) float Wr[4 * 512];
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < 4 * C1pad; i += 512) Wr[i] = w1r4[i];
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nitems = nMt * nNt, nslab = C1pad / G_BK;
+    int first, stride, limit;   // XCD-aware work assignment, see sa_conv16p_kernel
+    if ((gridDim.x & 7) == 0) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per = gridDim.x >> 3;
+        const int chunk = (nitems + 7) >> 3;
+        first = xcd * chunk + slot; stride = per; limit = min((xcd + 1) * chunk, nitems);
+    } else {
+        first = blockIdx.x; stride = gridDim.x; limit = nitems;
+    }
+    if (first >= limit) return;
+    const int my_items = (limit - first + stride - 1) / stride;
+    const int total = my_items * nslab;
+    auto item_mt = [&](int it) { return (first + it * stride) / nNt; };
+    auto item_nt = [&](int it) { return (first + it * stride) % nNt; };
+    __syncthreads();   // Wr staged
+
+    if (wave >= 4) {
+        // ---------------------------------------------------------------- producers
+        const int pw = wave - 4, ptid = tid - 256;
+        const int prow = ptid >> 2, pq = ptid & 3;          // rows prow + 64 u, u < NRP ((row >> 2) & 3 is the same for all)
+        const int a_dst = (prow * 4 + (pq ^ ((prow >> 2) & 3))) * 16;
+        size_t boff[NIP];
+        int dstc[NIP];
+#pragma unroll
+        for (int i = 0; i < NIP; ++i) {
+            const int g2 = pw + 4 * i, p = g2 / (BN / 16), rb = g2 % (BN / 16);
+            const int row = 16 * rb + (lane >> 2), q = (lane & 3) ^ ((row >> 2) & 3);
+            boff[i] = (size_t)p * plane + (size_t)row * C1pad + 8 * q;
+            dstc[i] = A_CH + g2 * 64;
+        }
+        auto issue = [&](int stage, const _Float16* wbase, int k0) {
+#pragma unroll
+            for (int i = 0; i < NIP; ++i)
+                __builtin_amdgcn_global_load_lds((glb_vp)(wbase + boff[i] + k0),
+                                                 (lds_vp)(S + ((size_t)stage * STAGE_CH + dstc[i]) * 16), 16, 0, 0);
+        };
+        struct Meta { int j[NRP]; float4 g[NRP]; };
+        struct Buf { float4 v[NRP][2]; Meta m; int k0; };
+        auto load_meta = [&](int it, Meta& m) {
+#pragma unroll
+            for (int u = 0; u < NRP; ++u) {
+                long row = (long)item_mt(it) * BM + prow + 64 * u;
+                const long last = (long)M * 32 - 1;
+                row = row < last ? row : last;
+                m.j[u] = meta_j[row];
+                m.g[u] = meta_g[row];
+            }
+        };
+        auto gather = [&](Buf& b) {   // b.m / b.k0 set by the caller
+            const int k = b.k0 + 8 * pq;
+#pragma unroll
+            for (int u = 0; u < NRP; ++u) {
+                const bool on = b.m.j[u] >= 0;
+                const float* p = P + (size_t)(on ? b.m.j[u] : 0) * ldp + 8 * pq + b.k0;
+                b.v[u][0] = (on && k < C1) ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+                b.v[u][1] = (on && k + 4 < C1) ? *reinterpret_cast<const float4*>(p + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        auto produce = [&](int stage, const Buf& b) {
+            const int k = b.k0 + 8 * pq;
+#pragma unroll
+            for (int u = 0; u < NRP; ++u) {
+                const float4 rg = b.m.g[u];
+                const bool on = b.m.j[u] >= 0;
+                unsigned hiw[4], low[4];
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int kk = k + 4 * half;
+                    const float4 wx = *reinterpret_cast<const float4*>(&Wr[0 * C1pad + kk]);
+                    const float4 wy = *reinterpret_cast<const float4*>(&Wr[1 * C1pad + kk]);
+                    const float4 wz = *reinterpret_cast<const float4*>(&Wr[2 * C1pad + kk]);
+                    const float4 wf = *reinterpret_cast<const float4*>(&Wr[3 * C1pad + kk]);
+                    const float4 p = b.v[u][half];
+                    const float gx = on ? rg.x : 0.f, gy = on ? rg.y : 0.f, gz = on ? rg.z : 0.f, gw = on ? rg.w : 0.f;
+                    float v[4];
+                    v[0] = fmaxf(fmaf(gw, wf.x, fmaf(gz, wz.x, fmaf(gy, wy.x, fmaf(gx, wx.x, p.x)))), 0.f);
+                    v[1] = fmaxf(fmaf(gw, wf.y, fmaf(gz, wz.y, fmaf(gy, wy.y, fmaf(gx, wx.y, p.y)))), 0.f);
+                    v[2] = fmaxf(fmaf(gw, wf.z, fmaf(gz, wz.z, fmaf(gy, wy.z, fmaf(gx, wx.z, p.z)))), 0.f);
+                    v[3] = fmaxf(fmaf(gw, wf.w, fmaf(gz, wz.w, fmaf(gy, wy.w, fmaf(gx, wx.w, p.w)))), 0.f);
+                    unsigned h01, l01, h23, l23;
+                    split_pair(v[0], v[1], h01, l01);
+                    split_pair(v[2], v[3], h23, l23);
+                    hiw[2 * half] = h01; hiw[2 * half + 1] = h23;
+                    low[2 * half] = l01; low[2 * half + 1] = l23;
+                }
+                char* st = S + (size_t)stage * STAGE_CH * 16;
+                *reinterpret_cast<uint4*>(st + a_dst + u * 64 * 64) = make_uint4(hiw[0], hiw[1], hiw[2], hiw[3]);
+                *reinterpret_cast<uint4*>(st + BM * 64 + a_dst + u * 64 * 64) = make_uint4(low[0], low[1], low[2], low[3]);
+            }
+        };
+        // gather stage cursor (item, slab) and its metadata; the next item's metadata is fetched an item ahead
+        int it_q = 0, s_q = 0;
+        Meta m_q, m_nxt;
+        load_meta(0, m_q);
+        m_nxt = m_q;
+        if (my_items > 1) load_meta(1, m_nxt);
+        auto advance_q = [&]() {
+            if (++s_q == nslab) {
+                s_q = 0; ++it_q;
+                m_q = m_nxt;
+                if (it_q + 1 < my_items) load_meta(it_q + 1, m_nxt);
+            }
+        };
+        Buf b0, b1, b2_;
+        // prologue: slab 0 complete in stage 0, slabs 1 and 2 gathered
+        issue(0, W2h + (size_t)item_nt(0) * BN * C1pad, 0);
+        b0.m = m_q; b0.k0 = 0;
+        gather(b0);
+        produce(0, b0);
+        b1 = b0; b2_ = b0;
+        if (total > 1) {
+            advance_q();
+            b1.m = m_q; b1.k0 = s_q * G_BK;
+            gather(b1);
+        }
+        if (total > 2) {
+            advance_q();
+            b2_.m = m_q; b2_.k0 = s_q * G_BK;
+            gather(b2_);
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // step g: W2 DMA + A rows of slab g+1 into stage (g+1)&1 from buffer `use` (gathered TWO steps earlier, so a
+        // whole step of MFMA time covers the latency of the scattered P-row loads), gather of slab g+3 into `fill`
+        // (= the buffer whose slab g was produced in the previous step)
+        int it1 = 0, s1 = 0;   // item / slab of g+1
+        auto pstep = [&](int g, const Buf& use, Buf& fill) {
+            const bool fetch = g + 3 < total;
+            if (g + 1 < total) {
+                if (++s1 == nslab) { s1 = 0; ++it1; }
+                if (!(dbg & 2)) issue((g + 1) & 1, W2h + (size_t)item_nt(it1) * BN * C1pad, s1 * G_BK);
+                if (!(dbg & 8)) produce((g + 1) & 1, use);
+                if (fetch) {
+                    advance_q();
+                    fill.m = m_q; fill.k0 = s_q * G_BK;
+                    if (!(dbg & 16)) gather(fill);
+                }
+            }
+            // the DMA was issued before this step's gather and loads return in order: with at most that gather's
+            // 2 NRP loads outstanding the DMA has landed (the gather issued in the previous step is older still)
+            if (!fetch) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else if (NRP == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        };
+        for (int g = 0; g < total; g += 3) {     // slab g+1 lives in b1 / b2_ / b0, slab g+3 goes where slab g was
+            pstep(g, b1, b0);
+            if (g + 1 < total) pstep(g + 1, b2_, b1);
+            if (g + 2 < total) pstep(g + 2, b0, b2_);
+        }
+        return;
+    }
+
+    // -------------------------------------------------------------------- consumers
+    const int cwr = wave >> 1, cwc = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    int offA[2][RT], offB[2][CT];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            const int ra = cwr * 32 * RT + 32 * t + r;
+            offA[p][t] = ((p * BM + ra) * 4 + (h ^ ((ra >> 2) & 3))) * 16;
+        }
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            const int rb = cwc * 32 * CT + 32 * t + r;
+            offB[p][t] = (A_CH + (p * BN + rb) * 4 + (h ^ ((rb >> 2) & 3))) * 16;
+        }
+    }
+    f32x16 acc[RT][CT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < CT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // prologue done: slab 0 is in stage 0
+    int it = 0, s = 0;
+    float e_bias[CT], e_s[CT], e_t[CT];
+    int e_d[RT];
+    for (int g = 0; g < total; ++g) {
+        const int mt = item_mt(it), nt = item_nt(it);
+        if (s == nslab - 1) {   // epilogue parameters of this item: fetched under its last slab's MFMAs
+#pragma unroll
+            for (int j = 0; j < CT; ++j) {
+                const int col = nt * BN + cwc * 32 * CT + j * 32 + (lane & 31);
+                const bool cv = col < C2;
+                e_bias[j] = cv ? b2[col] : 0.f; e_s[j] = cv ? bn_s[col] : 0.f; e_t[j] = cv ? bn_t[col] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < RT; ++i) {
+                const int tgt = mt * (BM / 32) + cwr * RT + i;
+                e_d[i] = tgt < M ? min(deg[tgt], kw) : 0;
+            }
+        }
+        const char* st = S + (size_t)(g & 1) * STAGE_CH * 16;
+        h8 ah[2][RT], al[2][RT], bh[2][CT], bl[2][CT];   // both half-slabs' fragments are in flight before the first MFMA
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {
+                ah[kk][t] = *reinterpret_cast<const h8*>(st + (offA[0][t] ^ (kk << 5)));
+                al[kk][t] = *reinterpret_cast<const h8*>(st + (offA[1][t] ^ (kk << 5)));
+            }
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+                bh[kk][t] = *reinterpret_cast<const h8*>(st + (offB[0][t] ^ (kk << 5)));
+                bl[kk][t] = *reinterpret_cast<const h8*>(st + (offB[1][t] ^ (kk << 5)));
+            }
+        }
+        if (!(dbg & 4)) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < RT; ++i)
+#pragma unroll
+                    for (int j = 0; j < CT; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[kk][i], bh[kk][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kk][i], bl[kk][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kk][i], bh[kk][j], acc[i][j], 0, 0, 0);
+                    }
+        }
+        if (s == nslab - 1 && !(dbg & 1)) {   // item finished: max over the neighbour slots of each target, store, restart the accumulation
+#pragma unroll
+            for (int i = 0; i < RT; ++i) {
+                const int tgt = mt * (BM / 32) + cwr * RT + i;
+                const int d = e_d[i];
+#pragma unroll
+                for (int j = 0; j < CT; ++j) {
+                    const int col = nt * BN + cwc * 32 * CT + j * 32 + (lane & 31);
+                    // bias + ReLU + BN affine are monotone in the accumulator (wscale > 0; increasing for s >= 0,
+                    // decreasing for s < 0) and fp rounding keeps (weak) monotonicity, so the maximum over the slots
+                    // of the transformed values is the transform of the maximum (s >= 0) or minimum (s < 0) of the
+                    // raw accumulators, bit for bit: 2 VALU per value instead of 5, the transform once per column
+                    const float sgn = e_s[j] < 0.f ? -1.f : 1.f;
+                    float ext = -INFINITY;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int slot = (q & 3) + 8 * (q >> 2) + 4 * h;
+                        if (slot < d) ext = fmaxf(ext, sgn * acc[i][j][q]);
+                        acc[i][j][q] = 0.f;
+                    }
+                    ext = fmaxf(ext, __shfl_xor(ext, 32));
+                    float vmax = fmaf(fmaxf(fmaf(sgn * ext, wscale, e_bias[j]), 0.f), e_s[j], e_t[j]);
+                    if (d == 0) vmax = 0.f;
+                    if (tgt < M) {
+                        if (col < C2 && h == 0 && out) out[(size_t)tgt * ldo + col] = vmax;
+                        if (out_h2) {
+                            const float nb = __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(vmax), 0xB1, 0xf, 0xf, false));
+                            if (h == 0 && (lane & 1) == 0 && col < ldh) {
+                                unsigned hw, lw;
+                                split_pair(vmax, nb, hw, lw);
+                                _Float16* p = out_h2 + (size_t)tgt * (2 * ldh) + col;
+                                *reinterpret_cast<unsigned*>(p) = hw;
+                                *reinterpret_cast<unsigned*>(p + ldh) = lw;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (++s == nslab) { s = 0; ++it; }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // stage g&1 read; stage (g+1)&1 is complete
     }
 }
 
@@ -1518,6 +1825,21 @@ extern "C" int32_t p2w_sa_conv_f16x3(const float* P, int32_t ldp, const float* x
         const long items = (long)nMt3 * nNt3;
         int grid = (int)(items < n_cu ? items : n_cu);
         if (grid >= 8) grid &= ~7;   // whole XCD rounds (see the kernel's work assignment)
+        // P2W_SA_V=4 selects the producer / consumer variant: 4 % less kernel time when it runs alone, but its 232 VGPRs
+        // and 104 KB of LDS leave no room for the geometry stream's workgroups next to it, so the pipelined step is 0.7 %
+        // SLOWER than with the 128-VGPR kernel below (9.85 vs 9.78 ms, alternating runs on one box): not the default
+        static const int sa_ver = []() { const char* e = getenv("P2W_SA_V"); return e ? atoi(e) : 3; }();
+        if (sa_ver == 4) {
+            if (wide)
+                sa_conv16w_kernel<128, 256><<<grid, 512, 0, p2w_s(stream)>>>(
+                    P, ldp, meta_j, meta_g, deg, kw, M, w1r4, C1, C1pad, static_cast<const _Float16*>(W2h),
+                    (size_t)C2pad * C1pad, wscale, C2, nMt3, nNt3, b2, bn_s, bn_t, out, ldo, static_cast<_Float16*>(out_h2), ldh, sadbg);
+            else
+                sa_conv16w_kernel<256, 128><<<grid, 512, 0, p2w_s(stream)>>>(
+                    P, ldp, meta_j, meta_g, deg, kw, M, w1r4, C1, C1pad, static_cast<const _Float16*>(W2h),
+                    (size_t)C2pad * C1pad, wscale, C2, nMt3, nNt3, b2, bn_s, bn_t, out, ldo, static_cast<_Float16*>(out_h2), ldh, sadbg);
+            return P2W_LAUNCH_STATUS();
+        }
         if (wide)
             sa_conv16p_kernel<256><<<grid, 512, 0, p2w_s(stream)>>>(
                 P, ldp, meta_j, meta_g, deg, kw, M, w1r4, C1, C1pad, static_cast<const _Float16*>(W2h), (size_t)C2pad * C1pad,
