@@ -186,7 +186,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: batch_size 8 x 16384-pt 2 m voxels, k=32, xyz-only, 1 batch per GPU per step",
                        "global_batch_voxels": world * BATCH, "points_per_step": world * BATCH * NPTS, "C": C,
                        "level_sizes": sizes, "parallelism": f"voxel-batch sharding x{world}, RCCL all-gather of logits",
-                       "pipeline": "2 HIP streams: geometry(i+1) || features(i)" if args.pipeline else "sequential"},
+                       "pipeline": "2 HIP streams: geometry(i+1) || features(i) (features high priority)" if args.pipeline else "sequential"},
             "end_to_end_tflops_algorithmic": 2.0 * total_macs * args.steps / dt / 1e12,
             "roofline": {"bound": "mfma", "kernel": kname.get(dom, dom), "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
