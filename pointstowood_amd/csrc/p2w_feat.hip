@@ -1911,35 +1911,60 @@ extern "C" int32_t p2w_stem_h2(const float* xyzr, int32_t n, const float* w, con
     return stem_launch(xyzr, n, w, b, C, out, out_h2, ldh, stream);
 }
 
+// One wave per output row: the row's neighbours, their inverse-square-distance weights and the denominator are
+// wave-uniform (scalar loads, computed once per row instead of once per 4-column chunk); the lanes then sweep the row
+// 256 columns at a time with coalesced 16-byte loads of the coarse features.  The arithmetic per element is the same
+// as torch-scatter's: products and sums in neighbour order from 0, then a literal division.
+constexpr int IC_ROWS = 4;   // rows per wave (consecutive)
 __global__ __launch_bounds__(256) void interp_concat_kernel(const float* __restrict__ xc, int Fc, const float4* __restrict__ xyzr_c,
                                                             const float4* __restrict__ xyzr_f, const int* __restrict__ nbr,
                                                             const int* __restrict__ deg, int kw, const float* __restrict__ skip,
                                                             int Fs, int m, int q4, OutArgs o) {
-    const long g = (long)blockIdx.x * 256 + threadIdx.x;  // q4 = 4-column chunks per output row (incl. zero padding)
-    if (g >= (long)m * q4) return;
-    const int q = (int)(g / q4), c = (int)(g % q4) * 4;
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
-    if (c < Fc) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q0 = (blockIdx.x * 4 + wave) * IC_ROWS;
+    for (int rr = 0; rr < IC_ROWS; ++rr) {
+        const int q = q0 + rr;   // wave-uniform
+        if (q >= m) return;
         const int d = min(deg[q], kw);
         const float4 pf = xyzr_f[q];
-        float4 num = make_float4(0.f, 0.f, 0.f, 0.f);
+        // up to 4 neighbours keep (index, weight) in registers; more (not used by the model) are re-derived per chunk
+        int js[4] = {0, 0, 0, 0};
+        float ws[4] = {0.f, 0.f, 0.f, 0.f};
         float den = 0.f;
-        for (int s = 0; s < d; ++s) {  // sums taken in neighbour order from 0 (scatter-add order)
+        for (int s = 0; s < d; ++s) {
             const int j = nbr[(size_t)q * kw + s];
             const float4 pc = xyzr_c[j];
             const float dx = pc.x - pf.x, dy = pc.y - pf.y, dz = pc.z - pf.z;
             const float d2 = ((dx * dx) + (dy * dy)) + (dz * dz);
             const float w = 1.0f / fmaxf(d2, 1e-16f);
-            const float4 x = *reinterpret_cast<const float4*>(&xc[(size_t)j * Fc + c]);
-            num.x = num.x + x.x * w; num.y = num.y + x.y * w; num.z = num.z + x.z * w; num.w = num.w + x.w * w;
+            if (s < 4) { js[s] = j; ws[s] = w; }
             den = den + w;
         }
-        if (d > 0) { v[0] = num.x / den; v[1] = num.y / den; v[2] = num.z / den; v[3] = num.w / den; }
-    } else if (c < Fc + Fs) {
-        const float4 t = *reinterpret_cast<const float4*>(&skip[(size_t)q * Fs + (c - Fc)]);
-        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        for (int c = 4 * lane; c < 4 * q4; c += 256) {
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (c < Fc) {
+                float4 num = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int s = 0; s < d; ++s) {
+                    int j; float w;
+                    if (s < 4) { j = js[s]; w = ws[s]; }
+                    else {
+                        j = nbr[(size_t)q * kw + s];
+                        const float4 pc = xyzr_c[j];
+                        const float dx = pc.x - pf.x, dy = pc.y - pf.y, dz = pc.z - pf.z;
+                        w = 1.0f / fmaxf(((dx * dx) + (dy * dy)) + (dz * dz), 1e-16f);
+                    }
+                    const float4 x = *reinterpret_cast<const float4*>(&xc[(size_t)j * Fc + c]);
+                    num.x = num.x + x.x * w; num.y = num.y + x.y * w; num.z = num.z + x.z * w; num.w = num.w + x.w * w;
+                }
+                if (d > 0) { v[0] = num.x / den; v[1] = num.y / den; v[2] = num.z / den; v[3] = num.w / den; }
+            } else if (c < Fc + Fs) {
+                const float4 t = *reinterpret_cast<const float4*>(&skip[(size_t)q * Fs + (c - Fc)]);
+                v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+            }
+            store4(o, (size_t)q, c, v);
+        }
     }
-    store4(o, (size_t)q, c, v);
 }
 
 static int32_t interp_launch(const float* xc, int32_t Fc, const float* xyzr_c, const float* xyzr_f, const int32_t* nbr,
@@ -1957,7 +1982,7 @@ static int32_t interp_launch(const float* xc, int32_t Fc, const float* xyzr_c, c
     if (out_h2 && ((ldh & 7) || ldh < Fc + Fs)) return P2W_EINVAL;
     const int width = (out ? ldo : 0) > (out_h2 ? ldh : 0) ? ldo : ldh;
     OutArgs o = {out, out ? ldo : 0, static_cast<_Float16*>(out_h2), out_h2 ? ldh : 0};
-    interp_concat_kernel<<<p2w_cdiv((long)m * (width >> 2), 256), 256, 0, p2w_s(stream)>>>(
+    interp_concat_kernel<<<p2w_cdiv(m, 4 * IC_ROWS), 256, 0, p2w_s(stream)>>>(
         xc, Fc, reinterpret_cast<const float4*>(xyzr_c), reinterpret_cast<const float4*>(xyzr_f), nbr, deg, kw, skip, Fs, m,
         width >> 2, o);
     return P2W_LAUNCH_STATUS();
