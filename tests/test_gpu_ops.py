@@ -437,3 +437,15 @@ def test_searches_with_nan_queries_report_nothing_for_them():
                 assert torch.equal(nbr[clean], ref)
             else:
                 ref = nbr[clean]
+
+
+def test_grid_searches_randomised_stress():
+    """tools/stress_search.py: 150 random geometries (clusters, planes, duplicates, lattices, far offsets, tiny and huge
+    cells, BOX on/off, k in 1..64): grid kNN / ball query must equal the whole-voxel kernels bit for bit."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_search.py"), "150", "7"], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
