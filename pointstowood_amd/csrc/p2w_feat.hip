@@ -274,14 +274,15 @@ __device__ __forceinline__ void sa_epilogue(const f32x16 (&acc)[2][2], float wsc
 }
 
 // same as sa_epilogue with the per-column parameters and the two target degrees already in registers
-struct SaEpiRegs { float bias[2], s[2], t[2]; int d[2]; };
-__device__ __forceinline__ void sa_epilogue_regs(const f32x16 (&acc)[2][2], float wscale, int t0, int n0, int wr, int wc,
-                                                 int lane, int M, const SaEpiRegs& e, int C2, float* __restrict__ out, int ldo,
+template <int RT> struct SaEpiRegs { float bias[2], s[2], t[2]; int d[RT]; };
+template <int RT>   // RT 32-row tiles (= targets) per wave
+__device__ __forceinline__ void sa_epilogue_regs(const f32x16 (&acc)[RT][2], float wscale, int t0, int n0, int wr, int wc,
+                                                 int lane, int M, const SaEpiRegs<RT>& e, int C2, float* __restrict__ out, int ldo,
                                                  _Float16* __restrict__ out_h2, int ldh) {
     const int h = lane >> 5;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int tgt = t0 + wr * 2 + i;
+    for (int i = 0; i < RT; ++i) {
+        const int tgt = t0 + wr * RT + i;
         if (tgt >= M) continue;
         const int d = e.d[i];
 #pragma unroll
@@ -1225,8 +1226,11 @@ __global__ __launch_bounds__(256) void sa_edge_meta_kernel(const float4* __restr
     }
 }
 
-template <int BN>   // 256: 4 targets x 256 columns (waves 2 x 4);  128: 8 targets x 128 columns (waves 4 x 2)
-__global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restrict__ P, int ldp, const int* __restrict__ meta_j,
+// <BN, RT>: <256, 2>: 4 targets x 256 columns (waves 2 x 4, wave tile 64 x 64);  <128, 2>: 8 targets x 128 columns (waves 4 x 2);
+// <256, 4>: 8 targets x 256 columns (waves 2 x 4, wave tile 128 x 64): half the W2 DMA, barriers and per-item overhead per
+// FLOP, at 2 x the accumulators (one workgroup per CU either way: LDS)
+template <int BN, int RT>
+__global__ __launch_bounds__(512, RT == 2 ? 2 : 1) void sa_conv16p_kernel(const float* __restrict__ P, int ldp, const int* __restrict__ meta_j,
                                                             const float4* __restrict__ meta_g, const int* __restrict__ deg,
                                                             int kw, int M, const float* __restrict__ w1r4, int C1, int C1pad,
                                                             const _Float16* __restrict__ W2h, size_t plane, float wscale, int C2,
@@ -1236,7 +1240,7 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
                                                             int ldh, int dbg) {
     // dbg (profiling ablations, 0 in production): 1 no epilogue, 2 no W2 DMA after the first, 4 no MFMA, 8 no producer,
     // 16 no P gather
-    constexpr int WCn = BN / 64, BM = 64 * (8 / WCn), NW = 8, NR = BM / 128;   // NR producer rows per thread
+    constexpr int WCn = BN / 64, BM = 32 * RT * (8 / WCn), NW = 8, NR = BM / 128;   // NR producer rows per thread
     constexpr int A_CH = 8 * BM, STAGE_CH = A_CH + 8 * BN;
     constexpr int NI = (8 * BN) / 64 / NW;
     __shared__ __attribute__((aligned(16))) char S[2 * STAGE_CH * 16];
@@ -1345,18 +1349,23 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
     };
 
     const int r = lane & 31, h = lane >> 5;
-    int offA[2][2], offB[2][2];
+    int offA[2][RT], offB[2][2];
 #pragma unroll
-    for (int p = 0; p < 2; ++p)
+    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            const int ra = wr * 32 * RT + 32 * t + r;
+            offA[p][t] = ((p * BM + ra) * 4 + (h ^ ((ra >> 2) & 3))) * 16;
+        }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const int ra = wr * 64 + 32 * t + r, rb = wc * 64 + 32 * t + r;
-            offA[p][t] = ((p * BM + ra) * 4 + (h ^ ((ra >> 2) & 3))) * 16;
+            const int rb = wc * 64 + 32 * t + r;
             offB[p][t] = (A_CH + (p * BN + rb) * 4 + (h ^ ((rb >> 2) & 3))) * 16;
         }
-    f32x16 acc[2][2];
+    }
+    f32x16 acc[RT][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -1381,7 +1390,7 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
         }
     };
     // prologue: slab 0 produced synchronously, slab 1 gathered
-    auto load_epi = [&](int mt_, int nt_, SaEpiRegs& e) {   // parameters of an item's epilogue, fetched an item ahead
+    auto load_epi = [&](int mt_, int nt_, SaEpiRegs<RT>& e) {   // parameters of an item's epilogue, fetched an item ahead
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int col = nt_ * BN + wc * 64 + j * 32 + (lane & 31);
@@ -1389,12 +1398,12 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
             e.bias[j] = cv ? b2[col] : 0.f; e.s[j] = cv ? bn_s[col] : 0.f; e.t[j] = cv ? bn_t[col] : 0.f;
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int tgt = mt_ * (BM / 32) + wr * 2 + i;
+        for (int i = 0; i < RT; ++i) {
+            const int tgt = mt_ * (BM / 32) + wr * RT + i;
             e.d[i] = tgt < M ? min(deg[tgt], kw) : 0;
         }
     };
-    SaEpiRegs e_cur, e_1;
+    SaEpiRegs<RT> e_cur, e_1;
     load_epi(item_mt(0), item_nt(0), e_cur);
     e_1 = e_cur;
     const _Float16* wb1 = W2h + (size_t)item_nt(0) * BN * C1pad;   // W2 panel of the item in the produce stage
@@ -1447,17 +1456,20 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
         const char* st = S + (size_t)(g & 1) * STAGE_CH * 16;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            h8 ah[2], al[2], bh[2], bl[2];
+            h8 ah[RT], al[RT], bh[2], bl[2];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            for (int t = 0; t < RT; ++t) {
                 ah[t] = *reinterpret_cast<const h8*>(st + (offA[0][t] ^ (kk << 5)));
                 al[t] = *reinterpret_cast<const h8*>(st + (offA[1][t] ^ (kk << 5)));
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
                 bh[t] = *reinterpret_cast<const h8*>(st + (offB[0][t] ^ (kk << 5)));
                 bl[t] = *reinterpret_cast<const h8*>(st + (offB[1][t] ^ (kk << 5)));
             }
             if (!(dbg & 4)) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < RT; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
@@ -1468,17 +1480,17 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
             if (kk == 0 && !(dbg & 8)) {  // producer VALU work is interleaved into the gaps of the 12 MFMAs above (1 MFMA : 8 VALU)
                 produce((g + 1) & 1, m_u, k_u, pu);   // unconditional: after the last slab it fills a stage nobody reads
 #pragma unroll
-                for (int q = 0; q < 12; ++q) {
+                for (int q = 0; q < 6 * RT; ++q) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x002, 8 * NR, 0);   // VALU
+                    __builtin_amdgcn_sched_group_barrier(0x002, 16 * NR / RT, 0);   // VALU
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (s == nslab - 1 && !(dbg & 1)) {  // item finished: reduce over neighbour slots and store, then start the next accumulation
-            sa_epilogue_regs(acc, wscale, mt_cur * (BM / 32), nt_cur * BN, wr, wc, lane, M, e_cur, C2, out, ldo, out_h2, ldh);
+            sa_epilogue_regs<RT>(acc, wscale, mt_cur * (BM / 32), nt_cur * BN, wr, wc, lane, M, e_cur, C2, out, ldo, out_h2, ldh);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < RT; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -1821,6 +1833,8 @@ extern "C" int32_t p2w_sa_conv_f16x3(const float* P, int32_t ldp, const float* x
         }();
         const bool wide = C2 > 128;
         const int sadbg = getenv("P2W_SA_DBG") ? atoi(getenv("P2W_SA_DBG")) : 0;
+        // (a <256, 4> instance - 8 targets x 256 columns, wave tile 128 x 64 - halves the DMA / barrier / per-item cost per
+        // FLOP but needs 125 spilled VGPRs next to the producer state and measured 2 x SLOWER: not instantiated)
         const int nMt3 = p2w_cdiv(M, wide ? 4 : 8), nNt3 = p2w_cdiv(C2, wide ? 256 : 128);
         const long items = (long)nMt3 * nNt3;
         int grid = (int)(items < n_cu ? items : n_cu);
@@ -1841,11 +1855,11 @@ extern "C" int32_t p2w_sa_conv_f16x3(const float* P, int32_t ldp, const float* x
             return P2W_LAUNCH_STATUS();
         }
         if (wide)
-            sa_conv16p_kernel<256><<<grid, 512, 0, p2w_s(stream)>>>(
+            sa_conv16p_kernel<256, 2><<<grid, 512, 0, p2w_s(stream)>>>(
                 P, ldp, meta_j, meta_g, deg, kw, M, w1r4, C1, C1pad, static_cast<const _Float16*>(W2h), (size_t)C2pad * C1pad,
                 wscale, C2, nMt3, nNt3, b2, bn_s, bn_t, out, ldo, static_cast<_Float16*>(out_h2), ldh, sadbg);
         else
-            sa_conv16p_kernel<128><<<grid, 512, 0, p2w_s(stream)>>>(
+            sa_conv16p_kernel<128, 2><<<grid, 512, 0, p2w_s(stream)>>>(
                 P, ldp, meta_j, meta_g, deg, kw, M, w1r4, C1, C1pad, static_cast<const _Float16*>(W2h), (size_t)C2pad * C1pad,
                 wscale, C2, nMt3, nNt3, b2, bn_s, bn_t, out, ldo, static_cast<_Float16*>(out_h2), ldh, sadbg);
         return P2W_LAUNCH_STATUS();
