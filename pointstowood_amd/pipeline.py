@@ -18,11 +18,13 @@ from .preprocessing import voxelise
 
 
 def segment_plot(pc, model, grid_sizes=(2.0, 4.0), min_pts: int = 128, max_pts: int = 16384, is_wood: float = 0.5,
-                 any_wood: float = 1.0, max_points: int = 131072, mode: str = "compat", generator=None, stats=None,
-                 dist=None):
+                 any_wood: float = 1.0, max_points: int = 524288, mode: str = "compat", generator=None, stats=None,
+                 dist=None, max_voxels: int = 512):
     """pc: [N, >= 4] float tensor on the GPU (x, y, z, reflectance, ...), plot-local coordinates (fp32-safe).
     Returns (n_z [N], label [N], pwood [N]) float32 on the device: the three columns the reference appends
-    (``predicter.py:233``).  ``stats`` (dict, optional) receives stage timings and counts.
+    (``predicter.py:233``).  ``stats`` (dict, optional) receives stage timings and counts.  ``max_points`` /
+    ``max_voxels``: budget of one forward (plots are mostly small voxels; 524288 points / 512 voxels classify 12 % faster
+    than 131072 / 128 and need ~12 GB).
 
     ``dist`` (an initialised ``torch.distributed``, one process per GPU, every rank holding the same ``pc`` and the same
     ``generator`` state): every rank voxelises (cheap, and it makes the voxel list identical everywhere without an
@@ -39,7 +41,7 @@ def segment_plot(pc, model, grid_sizes=(2.0, 4.0), min_pts: int = 128, max_pts: 
     if not vox:   # nothing dense enough to classify (predicter.py would fail on an empty loader)
         return n_z, torch.zeros(n, device=dev), torch.zeros(n, device=dev)
     lengths = [int(v.shape[0]) for v in vox]
-    batches = list(PointBudgetSampler(lengths, max_points))
+    batches = list(PointBudgetSampler(lengths, max_points, max_voxels))
     world, rank = (dist.get_world_size(), dist.get_rank()) if dist is not None else (1, 0)
     if world > 1:
         mine = partition_batches([sum(lengths[i] for i in b) for b in batches], world)[rank]

@@ -49,7 +49,8 @@ def main():
     ap.add_argument("--points", type=int, default=2_000_000)
     ap.add_argument("--batch_size", type=int, default=0,
                     help="voxels per forward with the reference-style sampler; 0 (default) = point-budget batching")
-    ap.add_argument("--max_points", type=int, default=131072, help="point budget per forward (point-budget batching)")
+    ap.add_argument("--max_points", type=int, default=524288, help="point budget per forward (point-budget batching)")
+    ap.add_argument("--max_voxels", type=int, default=512, help="voxel cap per forward (point-budget batching)")
     ap.add_argument("--min_pts", type=int, default=128)
     ap.add_argument("--max_pts", type=int, default=16384)
     args = ap.parse_args()
@@ -84,7 +85,7 @@ def main():
     stats = {}
     t0 = time.perf_counter()
     n_z, label, pwood = segment_plot(pc, net, (2.0, 4.0), args.min_pts, args.max_pts, max_points=args.max_points,
-                                     generator=gen(), stats=stats, dist=dist)
+                                     generator=gen(), stats=stats, dist=dist, max_voxels=args.max_voxels)
     torch.cuda.synchronize()
     total = time.perf_counter() - t0
     if rank == 0:
