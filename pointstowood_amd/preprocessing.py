@@ -69,7 +69,17 @@ def voxelise(pc, grid_sizes=(2.0, 4.0), min_pts: int = 128, max_pts: int = 16384
         uniq, counts = torch.unique_consecutive(cell[order], return_counts=True)
         starts = torch.cumsum(counts, 0) - counts
         keep = (counts >= min_pts).nonzero(as_tuple=True)[0]
-        for s, c in zip(starts[keep].tolist(), counts[keep].tolist()):
+        # One gather puts every voxel's rows next to each other; a voxel that needs neither the max_pts sampling nor
+        # the NaN-row filter (almost all of them) is then just a VIEW of that tensor: no per-voxel kernels, one sync.
+        gathered = pos[order]
+        nan_row = torch.isnan(gathered).any(dim=1)
+        nan_before = torch.cumsum(nan_row.to(torch.int64), 0) - nan_row.to(torch.int64)      # NaN rows before row i
+        ends = starts[keep] + counts[keep] - 1
+        nan_cnt = nan_before[ends] + nan_row[ends].to(torch.int64) - nan_before[starts[keep]]
+        for s, c, bad in zip(starts[keep].tolist(), counts[keep].tolist(), nan_cnt.tolist()):
+            if c <= max_pts and bad == 0:
+                voxels.append(gathered[s:s + c])
+                continue
             idx = order[s:s + c]
             if c > max_pts:
                 if refl_on:
