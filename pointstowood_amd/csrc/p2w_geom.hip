@@ -959,12 +959,18 @@ __global__ __launch_bounds__(256) void slab_search_kernel(const float4* __restri
             // slots used by this tile: a power of two >= the candidates left (>= 256), so that the shuffle stays a
             // permutation and a short gather does not pay for 1024 slots
             const int left = n_c - tbase;
-            const int tsz = (TILE > 1024 && left > 1024) ? 2048 : (left > 512 ? 1024 : (left > 256 ? 512 : 256));
+            // kNN tiles are staged shuffled (storage order approaches a query monotonically: every candidate would be a new
+            // admission - even k = 2 runs 40 % slower unshuffled).  slot -> (slot * 389) mod tsz is a permutation for
+            // every tsz that is not a multiple of the prime 389; k >= 8 rounds tsz up to a power of two (cheap mask,
+            // whole 256-candidate groups), small k to the next multiple of 256 so that short gathers scan less
+            const bool pow2 = MODE != 0 || LADDER;
+            const int tsz = pow2 ? ((TILE > 1024 && left > 1024) ? 2048 : (left > 512 ? 1024 : (left > 256 ? 512 : 256)))
+                                 : min(TILE, (left + 255) & ~255);
 #pragma unroll
             for (int rr = 0; rr < TILE / 256; ++rr) {
                 const int s = tid + 256 * rr;
                 if (s >= tsz) break;
-                const int g = tbase + (MODE == 0 ? ((s * 389) & (tsz - 1)) : s);
+                const int g = tbase + (MODE != 0 ? s : (pow2 ? ((s * 389) & (tsz - 1)) : ((s * 389) % tsz)));
                 float4 v = make_float4(INFINITY, INFINITY, INFINITY, __int_as_float(0x7fffffff));
                 if (g < n_c) {
                     int lo = 0, hi = G_MAXRUN;   // largest run with run_pre[run] <= g
