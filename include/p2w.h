@@ -72,11 +72,13 @@ typedef struct p2w_grid {
 size_t p2w_voxel_sample_ws_bytes(int32_t n_bound);
 /* Optional outputs (NULL to skip) that make the level searchable through p2w_knn_grid / p2w_ball_query_grid:
  * sorted_keys_out[n] = the cell keys of all input points in ascending order (the order of order_out),
- * cell_keys_out[M] = the key of every representative (ascending = the output order), grid_out = the grid. */
+ * cell_keys_out[M] = the key of every representative (ascending = the output order), grid_out = the grid,
+ * inv_out[n] = for every input point the index (in the output level) of its cell's representative; rank_sorted_out[n]
+ * = the same for the i-th point of the sorted order (order_out[i]). */
 int32_t p2w_voxel_sample(const float* xyzr, const int32_t* ptr, int32_t B, int32_t n_bound, float res,
                          int32_t* idx_out, int32_t* ptr_out, int32_t* batch_out, int32_t* order_out,
-                         uint64_t* sorted_keys_out, uint64_t* cell_keys_out, p2w_grid* grid_out, void* ws,
-                         size_t ws_bytes, p2w_stream_t stream);
+                         uint64_t* sorted_keys_out, uint64_t* cell_keys_out, p2w_grid* grid_out, int32_t* inv_out,
+                         int32_t* rank_sorted_out, void* ws, size_t ws_bytes, p2w_stream_t stream);
 
 /* out[i] = (x, y, z, bit pattern of order[i]) of xyzr[order[i]] for i < ptr[B]: the records of a level in another
  * (e.g. cell-sorted) order, each carrying its own index - input for the P2W_SEARCH_*_IN_W modes below. */
@@ -129,7 +131,15 @@ int32_t p2w_knn(const float* xyzr_x, const int32_t* ptr_x, const float* xyzr_q, 
  * storage order is). */
 int32_t p2w_knn_grid(const float* xyzr_x, const uint64_t* keys_x, const int32_t* ptr_x, const p2w_grid* grid,
                      const float* xyzr_q, const int32_t* qidx, const int32_t* ptr_q, int32_t B, int32_t m_bound,
-                     int32_t k, int32_t* nbr, int32_t* deg, int32_t flags, p2w_stream_t stream);
+                     int32_t k, int32_t* nbr, int32_t* deg, const float* hint, int32_t flags, p2w_stream_t stream);
+/* hint (optional, NULL = none): hint[q] = an upper bound of query q's k-th squared distance (+inf = none for q).  A
+ * workgroup whose queries all have one skips the density probe and gathers exactly the box its bounds require; the
+ * bound is verified (k candidates must turn up inside it), a wrong one only costs a rescan.  p2w_knn_hint2 derives
+ * bounds for k <= 2 when the candidates are the sampled level of the queries' level (the interpolation searches):
+ * rank[i] = index of query i's cell representative among the candidates (p2w_voxel_sample's inv_out, or
+ * rank_sorted_out when the queries are given in sorted order). */
+int32_t p2w_knn_hint2(const float* xyzr_q, const int32_t* rank, const int32_t* ptr_q, int32_t B, int32_t m_bound,
+                      const float* xyzr_c, float* hint, p2w_stream_t stream);
 int32_t p2w_ball_query_grid(const float* xyzr_x, const uint64_t* keys_x, const int32_t* ptr_x, const p2w_grid* grid,
                             const float* xyzr_q, const int32_t* qidx, const int32_t* ptr_q, int32_t B, int32_t m_bound,
                             double r, int32_t cap, int32_t* nbr, int32_t* deg, int32_t flags, p2w_stream_t stream);

@@ -37,7 +37,7 @@ def neighbours(cls_xyz: torch.Tensor, query_xyz: torch.Tensor, k: int, cell: flo
     ws = torch.empty(int(L.p2w_voxel_sample_ws_bytes(max(nc, 1))), dtype=torch.uint8, device=dev)
     idx, ptr_out, batch_out = torch.empty(nc, **i32), torch.empty(2, **i32), torch.empty(nc, **i32)
     check(L.p2w_voxel_sample(ptr(cand), ptr(ptr_c), 1, nc, float(cell), ptr(idx), ptr(ptr_out), ptr(batch_out), ptr(order),
-                             ptr(skeys), None, ptr(grid), ptr(ws), ws.numel(), _lib.stream()), "voxel_sample")
+                             ptr(skeys), None, ptr(grid), None, None, ptr(ws), ws.numel(), _lib.stream()), "voxel_sample")
     del idx, batch_out, ws
     rec_c = torch.empty((nc, 4), dtype=torch.float32, device=dev)
     check(L.p2w_index_records(ptr(cand), ptr(order), ptr(ptr_c), 1, nc, ptr(rec_c), _lib.stream()), "index_records")
@@ -56,7 +56,7 @@ def neighbours(cls_xyz: torch.Tensor, query_xyz: torch.Tensor, k: int, cell: flo
         nbr = torch.empty((m, k), **i32)
         deg = torch.empty(m, **i32)
         check(L.p2w_knn_grid(ptr(rec_c), ptr(skeys), ptr(ptr_c), ptr(grid), ptr(q), None, ptr(ptr_q), 1, m, k, ptr(nbr),
-                             ptr(deg), SEARCH_X_INDEX_IN_W | SEARCH_BOX, _lib.stream()), "knn_grid")
+                             ptr(deg), None, SEARCH_X_INDEX_IN_W | SEARCH_BOX, _lib.stream()), "knn_grid")
         yield qorder[s:s + m].long(), nbr, deg
 
 

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void vs_scatter_kernel(const int* __restrict__
                                                          const int* __restrict__ n_dev, int n_bound, int* __restrict__ idx_out,
                                                          int* __restrict__ ptr_out, int* __restrict__ batch_out,
                                                          int* __restrict__ inv_out, int* __restrict__ count_out,
-                                                         int* __restrict__ order_out,
+                                                         int* __restrict__ order_out, int* __restrict__ rank_sorted_out,
                                                          const unsigned long long* __restrict__ keys_sorted,
                                                          unsigned long long* __restrict__ sorted_keys_out,
                                                          unsigned long long* __restrict__ cell_keys_out,
@@ -159,6 +159,7 @@ __global__ __launch_bounds__(256) void vs_scatter_kernel(const int* __restrict__
     if (i >= n || i >= n_bound) return;
     if (inv_out) inv_out[vals[i]] = scan[i];
     if (order_out) order_out[i] = vals[i];
+    if (rank_sorted_out) rank_sorted_out[i] = scan[i];
     if (sorted_keys_out) sorted_keys_out[i] = keys_sorted[i];
     if (flags[i]) {
         const int o = scan[i];
@@ -212,7 +213,7 @@ static int32_t vs_compute_keys(const float4* x4, const int* ptr, int B, int n_bo
 // sort (key, point) pairs, flag the last element of each run, compact
 static int32_t vs_cluster(char* w, const VsLayout& L, const unsigned long long* keys_in, const int* ptr, int B,
                           const int* n_dev, int n_bound, int* idx_out, int* ptr_out, int* batch_out, int* inv_out,
-                          int* count_out, int* order_out, unsigned long long* sorted_keys_out,
+                          int* count_out, int* order_out, int* rank_sorted_out, unsigned long long* sorted_keys_out,
                           unsigned long long* cell_keys_out, float res, p2w_grid* grid_out, hipStream_t s) {
     auto* keys_out = reinterpret_cast<unsigned long long*>(w + L.keys_out);
     int* vals_in = reinterpret_cast<int*>(w + L.vals_in);
@@ -229,15 +230,15 @@ static int32_t vs_cluster(char* w, const VsLayout& L, const unsigned long long* 
     if (e != hipSuccess) return (int32_t)e;
     const int nblk2 = p2w_cdiv((n_bound > B + 1 ? n_bound : B + 1), 256);
     vs_scatter_kernel<<<nblk2, 256, 0, s>>>(flags, scan, vals_out, ptr, B, n_dev, n_bound, idx_out, ptr_out, batch_out,
-                                            inv_out, count_out, order_out, keys_out, sorted_keys_out, cell_keys_out,
+                                            inv_out, count_out, order_out, rank_sorted_out, keys_out, sorted_keys_out, cell_keys_out,
                                             reinterpret_cast<const VsHeader*>(w + L.hdr), res, grid_out);
     return P2W_LAUNCH_STATUS();
 }
 
 extern "C" int32_t p2w_voxel_sample(const float* xyzr, const int32_t* ptr, int32_t B, int32_t n_bound, float res,
                                     int32_t* idx_out, int32_t* ptr_out, int32_t* batch_out, int32_t* order_out,
-                                    uint64_t* sorted_keys_out, uint64_t* cell_keys_out, p2w_grid* grid_out, void* ws,
-                                    size_t ws_bytes, p2w_stream_t stream) {
+                                    uint64_t* sorted_keys_out, uint64_t* cell_keys_out, p2w_grid* grid_out, int32_t* inv_out,
+                                    int32_t* rank_sorted_out, void* ws, size_t ws_bytes, p2w_stream_t stream) {
     P2W_CHECK_PTR(ptr); P2W_CHECK_PTR(ptr_out);
     if (B <= 0 || n_bound < 0 || !(res > 0.0f)) return P2W_EINVAL;
     hipStream_t s = p2w_s(stream);
@@ -253,8 +254,8 @@ extern "C" int32_t p2w_voxel_sample(const float* xyzr, const int32_t* ptr, int32
     int32_t st = vs_compute_keys(reinterpret_cast<const float4*>(xyzr), ptr, B, n_bound, res,
                                  reinterpret_cast<VsHeader*>(w + L.hdr), keys_in, reinterpret_cast<int*>(w + L.vals_in), s);
     if (st != P2W_OK) return st;
-    return vs_cluster(w, L, keys_in, ptr, B, ptr + B, n_bound, idx_out, ptr_out, batch_out, nullptr, nullptr, order_out,
-                      reinterpret_cast<unsigned long long*>(sorted_keys_out),
+    return vs_cluster(w, L, keys_in, ptr, B, ptr + B, n_bound, idx_out, ptr_out, batch_out, inv_out, nullptr, order_out,
+                      rank_sorted_out, reinterpret_cast<unsigned long long*>(sorted_keys_out),
                       reinterpret_cast<unsigned long long*>(cell_keys_out), res, grid_out, s);
 }
 
@@ -284,7 +285,7 @@ extern "C" int32_t p2w_consecutive_cluster(const int64_t* cell, int32_t n, int32
     vs_iota_kernel<<<p2w_cdiv(n, 256), 256, 0, s>>>(n, reinterpret_cast<int*>(w + L.vals_in));
     // non-negative int64 cell ids order like their unsigned bit patterns
     return vs_cluster(w, L, reinterpret_cast<const unsigned long long*>(cell), nullptr, 0, nullptr, n, perm_out, nullptr,
-                      nullptr, inv_out, count_out, nullptr, nullptr, nullptr, 0.f, nullptr, s);
+                      nullptr, inv_out, count_out, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -779,7 +780,8 @@ __global__ __launch_bounds__(256) void slab_search_kernel(const float4* __restri
                                                           const int* __restrict__ ptr_x, const p2w_grid* __restrict__ grid,
                                                           const float4* __restrict__ xq, const int* __restrict__ qidx,
                                                           const int* __restrict__ ptr_q, int B, int k, float r, float r2,
-                                                          int* __restrict__ nbr, int* __restrict__ deg, int flags) {
+                                                          int* __restrict__ nbr, int* __restrict__ deg, int flags,
+                                                          const float* __restrict__ hint) {
     __shared__ float4 cand[TILE];
     __shared__ int run_start[G_MAXRUN];
     __shared__ int run_pre[G_MAXRUN + 1];
@@ -809,6 +811,7 @@ __global__ __launch_bounds__(256) void slab_search_kernel(const float4* __restri
     int best_i[S_QPW], cnt[S_QPW];
     unsigned active = 0u;   // queries of this wave whose result is not final yet
     float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY, zmin = INFINITY, zmax = -INFINITY;
+    float hmax = 0.f, hinted = (MODE == 0 && hint) ? 1.f : 0.f;   // largest hint / every query of the workgroup has one
 #pragma unroll
     for (int j = 0; j < S_QPW; ++j) {
         uq[j] = load_query(xq, qidx, qw + j, q1);
@@ -816,6 +819,10 @@ __global__ __launch_bounds__(256) void slab_search_kernel(const float4* __restri
         thr[j] = MODE == 0 ? INFINITY : __int_as_float(0x7fffffff);   // ball: thr holds the index threshold's bits
         if (uq[j].valid) {
             active |= 1u << j;
+            if (MODE == 0 && hint) {   // caller's upper bound of this query's k-th distance (checked after the first pass)
+                const float hq = hint[qw + j];
+                if (hq < INFINITY) { thr[j] = hq; hmax = fmaxf(hmax, hq); } else hinted = 0.f;
+            }
             if (BOX) { xmin = fminf(xmin, uq[j].x); xmax = fmaxf(xmax, uq[j].x); }
             ymin = fminf(ymin, uq[j].y); ymax = fmaxf(ymax, uq[j].y);
             zmin = fminf(zmin, uq[j].z); zmax = fmaxf(zmax, uq[j].z);
@@ -824,6 +831,7 @@ __global__ __launch_bounds__(256) void slab_search_kernel(const float4* __restri
     if (lane == 0) {
         wred[wave][0] = ymin; wred[wave][1] = ymax; wred[wave][2] = zmin; wred[wave][3] = zmax;
         wred[wave][5] = xmin; wred[wave][6] = xmax;
+        wred[wave][4] = hmax; wred[wave][7] = hinted;
     }
     __syncthreads();
 #pragma unroll
@@ -831,7 +839,9 @@ __global__ __launch_bounds__(256) void slab_search_kernel(const float4* __restri
         ymin = fminf(ymin, wred[w][0]); ymax = fmaxf(ymax, wred[w][1]);
         zmin = fminf(zmin, wred[w][2]); zmax = fmaxf(zmax, wred[w][3]);
         if (BOX) { xmin = fminf(xmin, wred[w][5]); xmax = fmaxf(xmax, wred[w][6]); }
+        hmax = fmaxf(hmax, wred[w][4]); hinted = fminf(hinted, wred[w][7]);
     }
+    __syncthreads();   // wred[.][4] is reused by the pass loop
     const bool in_k = lane < k;
     const int total = c1 - c0;
     SLAB_STAMP(0);   // setup
@@ -916,8 +926,15 @@ __global__ __launch_bounds__(256) void slab_search_kernel(const float4* __restri
     };
 
     float rho, rk = 0.f;
+    // every query starts from a caller-supplied bound and the largest of them is within a few cells: no density probe,
+    // the region is the box of the queries grown by that bound.  (One loose bound would inflate the region of all 32
+    // queries - on sparse levels the probe's density estimate is the better radius; the bounds still seed thr.)
+    const bool use_hint = MODE == 0 && hinted > 0.f && hmax <= 9.f * res * res;
     if (MODE == 1) {
         rho = r;
+    } else if (use_hint) {
+        rho = sqrtf(hmax) * 1.0001f + 3.f * eps;
+        rk = rho;
     } else {
         // local density probe: candidates in the rows (BOX: cells) that hold the queries themselves
         const int nr0 = region(0.f, false);
@@ -1082,6 +1099,22 @@ __global__ __launch_bounds__(256) void slab_search_kernel(const float4* __restri
         if (!was_whole) { oXlo = nXlo; oXhi = nXhi; oYlo = nYlo; oYhi = nYhi; oZlo = nZlo; oZhi = nZhi; }
         SLAB_STAMP(4);   // scan
         if (MODE == 1) break;
+        if (MODE == 0 && hint && pass == 0) {
+            // a hint is only trusted after the fact: the ball it describes must have yielded k candidates (or all there
+            // are).  Otherwise that query forgets everything and the scanned region is declared empty, so the growth
+            // loop below rescans it without the bogus bound.
+            bool bogus = false;
+#pragma unroll
+            for (int j = 0; j < S_QPW; ++j) {
+                if (!((active >> j) & 1u)) continue;
+                const int found = __popcll(__ballot(best_i[j] != 0x7fffffff));
+                if (found < min(k, total)) { bogus = true; best_d[j] = INFINITY; best_i[j] = 0x7fffffff; thr[j] = INFINITY; }
+            }
+            __syncthreads();
+            if (lane == 0) wred[wave][4] = bogus ? 1.f : 0.f;
+            __syncthreads();
+            if (wred[0][4] + wred[1][4] + wred[2][4] + wred[3][4] > 0.f) { oXlo = 0; oXhi = -1; oYlo = 0; oYhi = -1; oZlo = 0; oZhi = -1; }
+        }
         // which queries are final?  k-th distance <= distance to the nearest face of the scanned region
         float need = 0.f;
         if (!whole) {
@@ -1175,7 +1208,7 @@ static int32_t grid_args(const uint64_t* keys, const p2w_grid* grid, int32_t fla
 
 extern "C" int32_t p2w_knn_grid(const float* xyzr_x, const uint64_t* keys_x, const int32_t* ptr_x, const p2w_grid* grid,
                                 const float* xyzr_q, const int32_t* qidx, const int32_t* ptr_q, int32_t B, int32_t m_bound,
-                                int32_t k, int32_t* nbr, int32_t* deg, int32_t flags, p2w_stream_t stream) {
+                                int32_t k, int32_t* nbr, int32_t* deg, const float* hint, int32_t flags, p2w_stream_t stream) {
     if (m_bound == 0) return P2W_OK;
     int32_t st = search_args(xyzr_x, ptr_x, xyzr_q, ptr_q, B, m_bound, k, nbr, deg);
     if (st != P2W_OK) return st;
@@ -1185,7 +1218,7 @@ extern "C" int32_t p2w_knn_grid(const float* xyzr_x, const uint64_t* keys_x, con
                                           : ((k >= 8) ? slab_search_kernel<0, 2048, true, false> : slab_search_kernel<0, 1024, false, false>);
     kern<<<grid_dim, 256, 0, p2w_s(stream)>>>(
         reinterpret_cast<const float4*>(xyzr_x), reinterpret_cast<const unsigned long long*>(keys_x), ptr_x, grid,
-        reinterpret_cast<const float4*>(xyzr_q), qidx, ptr_q, B, k, 0.f, 0.f, nbr, deg, flags);
+        reinterpret_cast<const float4*>(xyzr_q), qidx, ptr_q, B, k, 0.f, 0.f, nbr, deg, flags, hint);
     return P2W_LAUNCH_STATUS();
 }
 
@@ -1202,10 +1235,53 @@ extern "C" int32_t p2w_ball_query_grid(const float* xyzr_x, const uint64_t* keys
     auto* kern = (flags & P2W_SEARCH_BOX) ? slab_search_kernel<1, 1024, false, true> : slab_search_kernel<1, 1024, false, false>;
     kern<<<grid_dim, 256, 0, p2w_s(stream)>>>(
         reinterpret_cast<const float4*>(xyzr_x), reinterpret_cast<const unsigned long long*>(keys_x), ptr_x, grid,
-        reinterpret_cast<const float4*>(xyzr_q), qidx, ptr_q, B, cap, (float)r, (float)(r * r), nbr, deg, flags);
+        reinterpret_cast<const float4*>(xyzr_q), qidx, ptr_q, B, cap, (float)r, (float)(r * r), nbr, deg, flags, nullptr);
     return P2W_LAUNCH_STATUS();
 }
 
+
+
+// Upper bound of the 2nd-nearest-candidate distance of every fine point from the sampler's own bookkeeping: the point's
+// cell representative (rank[i]) is one coarse point, the representative of the nearest point in storage order (same
+// voxel) that lies in another cell is a second one; hint = the larger of the two squared distances, +inf when no second
+// representative turns up within 8 storage neighbours.  Valid for k <= 2 (the interpolation searches).
+__global__ __launch_bounds__(256) void knn_hint2_kernel(const float4* __restrict__ xq, const int* __restrict__ rank,
+                                                        const int* __restrict__ ptr_q, int B, const float4* __restrict__ xc,
+                                                        float* __restrict__ hint) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= ptr_q[B]) return;
+    const int b = p2w_find_segment(ptr_q, B, i);
+    const int lo = ptr_q[b], hi = ptr_q[b + 1];
+    const float4 q = xq[i];
+    const int c1 = rank[i];
+    const float4 p1 = xc[c1];
+    const float d1 = p2w_d2(q.x, q.y, q.z, p1.x, p1.y, p1.z);
+    float d2nd = INFINITY;
+    for (int s = 1; s <= 8; ++s) {
+        const int ja = i + s, jb = i - s;
+        if (ja < hi) {
+            const int c = rank[ja];
+            if (c != c1) { const float4 p = xc[c]; d2nd = fminf(d2nd, p2w_d2(q.x, q.y, q.z, p.x, p.y, p.z)); }
+        }
+        if (jb >= lo) {
+            const int c = rank[jb];
+            if (c != c1) { const float4 p = xc[c]; d2nd = fminf(d2nd, p2w_d2(q.x, q.y, q.z, p.x, p.y, p.z)); }
+        }
+        if (d2nd < INFINITY && s >= 2) break;
+    }
+    hint[i] = fmaxf(d1, d2nd);
+}
+
+extern "C" int32_t p2w_knn_hint2(const float* xyzr_q, const int32_t* rank, const int32_t* ptr_q, int32_t B, int32_t m_bound,
+                                 const float* xyzr_c, float* hint, p2w_stream_t stream) {
+    if (m_bound == 0) return P2W_OK;
+    P2W_CHECK_PTR(xyzr_q); P2W_CHECK_PTR(rank); P2W_CHECK_PTR(ptr_q); P2W_CHECK_PTR(xyzr_c); P2W_CHECK_PTR(hint);
+    P2W_CHECK_ALIGN16(xyzr_q); P2W_CHECK_ALIGN16(xyzr_c);
+    if (B <= 0 || m_bound < 0) return P2W_EINVAL;
+    knn_hint2_kernel<<<p2w_cdiv(m_bound, 256), 256, 0, p2w_s(stream)>>>(reinterpret_cast<const float4*>(xyzr_q), rank, ptr_q, B,
+                                                                       reinterpret_cast<const float4*>(xyzr_c), hint);
+    return P2W_LAUNCH_STATUS();
+}
 
 // ------------------------------------------------------------------------------------------------
 // plot-scale helpers: Morton order of records on a grid, neighbourhood vote

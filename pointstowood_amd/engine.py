@@ -196,6 +196,7 @@ class Engine:
         if not 1 <= self.k <= 32:
             raise ValueError("k must be in 1..32 (one 32-row MFMA tile per target)")
         self.feature_streams = int(os.environ.get("P2W_FEATURE_STREAMS", "1"))  # Net.stream(): feature phases in flight
+        self.fp_hints = os.environ.get("P2W_FP_HINTS", "1") != "0"           # seed the interpolation searches from the sampler
         self.res_streams = int(os.environ.get("P2W_RES_STREAMS", "1"))      # residual-block chunk chains in flight (2: +0.6 %, measured)
         self.res_chunk_rows = int(os.environ.get("P2W_RES_CHUNK", "65536"))   # rows (at 4F=512) per residual-block chunk; 0 = whole level
         self.events = None  # set to a list to record (name, start, end) events per launch
@@ -256,7 +257,7 @@ class Engine:
         grid_search = os.environ.get("P2W_SEARCH", "grid") != "brute"   # brute: whole-voxel streaming kernels (A/B, tests)
         i64 = dict(dtype=torch.int64, device=dev)
         sorted0 = skeys0 = None   # level 0 in cell order (the level-1 sampler's sort), each record carrying its own index
-        ckeys, grids = {}, {}     # level -> cell key of every record (ascending) / p2w_grid of the sampling call
+        ckeys, grids, ranks = {}, {}, {}     # level -> cell key of every record (ascending) / p2w_grid of the sampling call
         for l, res in enumerate(SA_RES):
             src = geo.levels[l]
             lv = Level(xyzr=torch.empty((N, 4), **f32), ptr=torch.empty(B + 1, **i32), batch=torch.empty(N, **i32),
@@ -264,9 +265,12 @@ class Engine:
             order = torch.empty(N, **i32) if l == 0 else None
             skeys = torch.empty(N, **i64) if l == 0 else None
             ckeys[l + 1], grids[l + 1] = torch.empty(N, **i64), torch.empty(8, **i64)
+            # rank of every source point's cell among the sampled level (= index of its representative): seeds the
+            # interpolation searches (level 0 takes part in its sorted order, so it needs the rank per sorted position)
+            ranks[l] = torch.empty(N, **i32) if (grid_search and self.fp_hints) else None
             self._call("voxel_sample", L.p2w_voxel_sample, ptr(src.xyzr), ptr(src.ptr), B, N, res, ptr(lv.idx),
-                       ptr(lv.ptr), ptr(lv.batch), ptr(order), ptr(skeys), ptr(ckeys[l + 1]), ptr(grids[l + 1]), ptr(ws),
-                       ws.numel())
+                       ptr(lv.ptr), ptr(lv.batch), ptr(order), ptr(skeys), ptr(ckeys[l + 1]), ptr(grids[l + 1]),
+                       ptr(ranks[l]) if l > 0 else None, ptr(ranks[l]) if l == 0 else None, ptr(ws), ws.numel())
             if l == 0:   # model.py:117-118: the 0.04 level uses radius(r = 2*resolution)
                 # The input points arrive in arbitrary order; the searches that touch level 0 (this ball query as
                 # candidates, the last interpolation as queries) run over the cell-sorted copy so that a workgroup's
@@ -286,7 +290,7 @@ class Engine:
                     aux0 = [order, box0, sorted0]
             elif grid_search:   # model.py:120
                 self._call("knn", L.p2w_knn_grid, ptr(src.xyzr), ptr(ckeys[l]), ptr(src.ptr), ptr(grids[l]), ptr(src.xyzr),
-                           ptr(lv.idx), ptr(lv.ptr), B, N, k, ptr(lv.nbr), ptr(lv.deg), 0)
+                           ptr(lv.idx), ptr(lv.ptr), B, N, k, ptr(lv.nbr), ptr(lv.deg), None, 0)
             else:
                 self._call("knn", L.p2w_knn, ptr(src.xyzr), ptr(src.ptr), ptr(src.xyzr), ptr(lv.idx), ptr(lv.ptr), B, N,
                            k, ptr(lv.nbr), ptr(lv.deg), ptr(boxes(l)), 0)
@@ -299,13 +303,19 @@ class Engine:
             nbr, deg = torch.empty((N, 2), **i32), torch.empty(N, **i32)
             q, fl = (sorted0, SEARCH_Q_ROW_IN_W) if f == 0 else (fine.xyzr, 0)
             if grid_search:
+                hint = None
+                if ranks.get(f) is not None:   # both of a point's two nearest coarse points are within its cell
+                    hint = torch.empty(N, **f32)   # representative's / a storage neighbour's representative's distance
+                    self._call("knn_hint", L.p2w_knn_hint2, ptr(q), ptr(ranks[f]), ptr(fine.ptr), B, N, ptr(coarse.xyzr),
+                               ptr(hint))
+                    aux0.append(hint)
                 self._call("knn2", L.p2w_knn_grid, ptr(coarse.xyzr), ptr(ckeys[f + 1]), ptr(coarse.ptr), ptr(grids[f + 1]),
-                           ptr(q), None, ptr(fine.ptr), B, N, 2, ptr(nbr), ptr(deg), fl)
+                           ptr(q), None, ptr(fine.ptr), B, N, 2, ptr(nbr), ptr(deg), ptr(hint), fl)
             else:
                 self._call("knn2", L.p2w_knn, ptr(coarse.xyzr), ptr(coarse.ptr), ptr(q), None, ptr(fine.ptr), B, N, 2,
                            ptr(nbr), ptr(deg), ptr(boxes(f + 1)), fl)
             geo.fp_nbr[f] = (nbr, deg)
-        aux0 += list(ckeys.values()) + list(grids.values())
+        aux0 += list(ckeys.values()) + list(grids.values()) + [t for t in ranks.values() if t is not None]
         geo.aux = list(bbox.values()) + aux0
         geo.counts_dev = torch.stack([geo.levels[l].ptr[B] for l in (1, 2, 3)])
         geo.counts_host = torch.empty(3, dtype=torch.int32, pin_memory=True)

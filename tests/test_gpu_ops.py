@@ -178,7 +178,7 @@ def _sorted_level(b, res):
     ckeys = torch.empty(n, dtype=torch.int64, device="cuda")
     grid = torch.zeros(8, dtype=torch.int64, device="cuda")
     assert L.p2w_voxel_sample(ptr(xyzr), ptr(csr), B, n, res, ptr(idx), ptr(ptr_out), ptr(batch_out), ptr(order), ptr(skeys),
-                              ptr(ckeys), ptr(grid), ptr(ws), ws.numel(), stream()) == 0
+                              ptr(ckeys), ptr(grid), None, None, ptr(ws), ws.numel(), stream()) == 0
     rec = torch.empty((n, 4), dtype=torch.float32, device="cuda")
     assert L.p2w_index_records(ptr(xyzr), ptr(order), ptr(csr), B, n, ptr(rec), stream()) == 0
     box = torch.empty((L.p2w_tile_bbox_count(B, n), 6), dtype=torch.float32, device="cuda")
@@ -304,7 +304,7 @@ def test_knn_grid_matches_brute_force_other_level_queries(sizes, k, surface, box
         deg = torch.full((n,), -7, dtype=torch.int32, device="cuda")
         if grid:
             st = L.p2w_knn_grid(ptr(coarse), ptr(s["ckeys"]), ptr(s["ptr_out"]), ptr(s["grid"]), ptr(s["rec"]), None,
-                                ptr(s["csr"]), B, n, k, ptr(nbr), ptr(deg), SEARCH_Q_ROW_IN_W | box, stream())
+                                ptr(s["csr"]), B, n, k, ptr(nbr), ptr(deg), None, SEARCH_Q_ROW_IN_W | box, stream())
         else:
             st = L.p2w_knn(ptr(coarse), ptr(s["ptr_out"]), ptr(s["xyzr"]), None, ptr(s["csr"]), B, n, k, ptr(nbr), ptr(deg),
                            ptr(cbox), 0, stream())
@@ -330,7 +330,7 @@ def test_knn_grid_matches_brute_force_subset_queries(sizes, k, res2, surface, bo
     idx2, ptr2, batch2 = torch.empty(m1, **i32), torch.empty(B + 1, **i32), torch.empty(m1, **i32)
     ws = torch.empty(int(L.p2w_voxel_sample_ws_bytes(m1)), dtype=torch.uint8, device="cuda")
     assert L.p2w_voxel_sample(ptr(coarse), ptr(s["ptr_out"]), B, m1, res2, ptr(idx2), ptr(ptr2), ptr(batch2), None, None, None,
-                              None, ptr(ws), ws.numel(), stream()) == 0
+                              None, None, None, ptr(ws), ws.numel(), stream()) == 0
     m2 = int(ptr2[B])
     out = []
     for grid in (False, True):
@@ -338,7 +338,7 @@ def test_knn_grid_matches_brute_force_subset_queries(sizes, k, res2, surface, bo
         deg = torch.full((m2,), -7, dtype=torch.int32, device="cuda")
         if grid:
             st = L.p2w_knn_grid(ptr(coarse), ptr(s["ckeys"]), ptr(s["ptr_out"]), ptr(s["grid"]), ptr(coarse), ptr(idx2),
-                                ptr(ptr2), B, m2, k, ptr(nbr), ptr(deg), box, stream())
+                                ptr(ptr2), B, m2, k, ptr(nbr), ptr(deg), None, box, stream())
         else:
             st = L.p2w_knn(ptr(coarse), ptr(s["ptr_out"]), ptr(coarse), ptr(idx2), ptr(ptr2), B, m2, k, ptr(nbr), ptr(deg),
                            ptr(cbox), 0, stream())
@@ -396,7 +396,7 @@ def test_knn_grid_far_apart_clusters_and_duplicates(res, box):
             deg = torch.full((n,), -7, dtype=torch.int32, device="cuda")
             if grid:
                 st = L.p2w_knn_grid(ptr(coarse), ptr(s["ckeys"]), ptr(s["ptr_out"]), ptr(s["grid"]), ptr(s["rec"]), None,
-                                    ptr(s["csr"]), B, n, k, ptr(nbr), ptr(deg), SEARCH_Q_ROW_IN_W | box, stream())
+                                    ptr(s["csr"]), B, n, k, ptr(nbr), ptr(deg), None, SEARCH_Q_ROW_IN_W | box, stream())
             else:
                 st = L.p2w_knn(ptr(coarse), ptr(s["ptr_out"]), ptr(s["xyzr"]), None, ptr(s["csr"]), B, n, k, ptr(nbr),
                                ptr(deg), ptr(cbox), 0, stream())
@@ -425,7 +425,7 @@ def test_searches_with_nan_queries_report_nothing_for_them():
             deg = torch.full((200,), -7, dtype=torch.int32, device="cuda")
             if grid:
                 st = L.p2w_knn_grid(ptr(coarse), ptr(s["ckeys"]), ptr(s["ptr_out"]), ptr(s["grid"]), ptr(q), None, ptr(pq), B,
-                                    200, k, ptr(nbr), ptr(deg), 0, stream())
+                                    200, k, ptr(nbr), ptr(deg), None, 0, stream())
             else:
                 st = L.p2w_knn(ptr(coarse), ptr(s["ptr_out"]), ptr(q), None, ptr(pq), B, 200, k, ptr(nbr), ptr(deg), ptr(cbox),
                                0, stream())
@@ -449,3 +449,48 @@ def test_grid_searches_randomised_stress():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_search.py"), "150", "7"], capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("sizes,surface", [([5000], False), ([1500, 40, 2600], True), ([16384, 3000], False), ([3], False)])
+def test_knn_grid_with_sampler_hints_and_with_bogus_hints(sizes, surface):
+    """k = 2 searches seeded by p2w_knn_hint2 (the engine's interpolation searches) == unseeded == brute force; hints that
+    are far too small must be detected and cost only a rescan."""
+    from pointstowood_amd._lib import SEARCH_Q_ROW_IN_W, lib, ptr, stream
+    b = _batch(sizes, seed=51, surface=surface)
+    L = lib()
+    pos, batch = b["pos"].cuda(), b["batch"].cuda()
+    n, B = pos.shape[0], int(batch.max()) + 1
+    xyzr = torch.zeros((n, 4), dtype=torch.float32, device="cuda"); xyzr[:, :3] = pos
+    csr = torch.zeros(B + 1, dtype=torch.int32, device="cuda")
+    csr[1:] = torch.cumsum(torch.bincount(batch, minlength=B), 0).int()
+    i32 = dict(dtype=torch.int32, device="cuda")
+    idx, ptr_out, bo, order, inv, rks = (torch.empty(n, **i32) for _ in range(6))
+    ptr_out = torch.empty(B + 1, **i32)
+    ckeys = torch.empty(n, dtype=torch.int64, device="cuda"); grid = torch.zeros(8, dtype=torch.int64, device="cuda")
+    ws = torch.empty(int(L.p2w_voxel_sample_ws_bytes(n)), dtype=torch.uint8, device="cuda")
+    assert L.p2w_voxel_sample(ptr(xyzr), ptr(csr), B, n, 0.04, ptr(idx), ptr(ptr_out), ptr(bo), ptr(order), None, ptr(ckeys),
+                              ptr(grid), ptr(inv), ptr(rks), ptr(ws), ws.numel(), stream()) == 0
+    m = int(ptr_out[B])
+    # inv / rank_sorted against the oracle's consecutive_cluster
+    inv_ref, _ = O.consecutive_cluster(O.voxel_grid(b["pos"], 0.04, b["batch"]))
+    assert torch.equal(inv.cpu().long(), inv_ref) and torch.equal(rks.cpu().long(), inv_ref[order.cpu().long()])
+    coarse = xyzr[idx[:m].long()].contiguous()
+    rec = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+    assert L.p2w_index_records(ptr(xyzr), ptr(order), ptr(csr), B, n, ptr(rec), stream()) == 0
+    hint = torch.empty(n, dtype=torch.float32, device="cuda")
+    assert L.p2w_knn_hint2(ptr(rec), ptr(rks), ptr(csr), B, n, ptr(coarse), ptr(hint), stream()) == 0
+    res = []
+    for h in (None, hint, torch.full_like(hint, 1e-12), torch.where(torch.arange(n, device="cuda") % 3 == 0, hint, hint * 0 + float("inf"))):
+        nbr = torch.full((n, 2), -7, **i32); deg = torch.full((n,), -7, **i32)
+        assert L.p2w_knn_grid(ptr(coarse), ptr(ckeys), ptr(ptr_out), ptr(grid), ptr(rec), None, ptr(csr), B, n, 2, ptr(nbr),
+                              ptr(deg), ptr(h), SEARCH_Q_ROW_IN_W, stream()) == 0
+        res.append((nbr.cpu(), deg.cpu()))
+    for r in res[1:]:
+        assert torch.equal(r[0], res[0][0]) and torch.equal(r[1], res[0][1])
+    # the hint really is an upper bound of the 2nd-nearest distance wherever it is finite
+    nb = res[0][0].long()
+    ok = (res[0][1] == 2)
+    q = b["pos"]
+    d2nd = ((q[ok] - coarse.cpu()[nb[ok][:, 1], :3]) ** 2).sum(1)
+    hq = torch.empty(n); hq[order.cpu().long()] = hint.cpu()
+    assert bool((d2nd <= hq[ok] * (1 + 1e-5) + 1e-12).all())

@@ -47,7 +47,7 @@ for case in range(n_cases):
     grid = torch.zeros(8, dtype=torch.int64, device="cuda")
     ws = torch.empty(int(L.p2w_voxel_sample_ws_bytes(n)), dtype=torch.uint8, device="cuda")
     assert L.p2w_voxel_sample(ptr(xyzr), ptr(csr), B, n, res, ptr(idx), ptr(ptr_out), ptr(bo), ptr(order), ptr(skeys), ptr(ckeys),
-                              ptr(grid), ptr(ws), ws.numel(), stream()) == 0
+                              ptr(grid), None, None, ptr(ws), ws.numel(), stream()) == 0
     m = int(ptr_out[B])
     rec = torch.empty((n, 4), dtype=torch.float32, device="cuda")
     assert L.p2w_index_records(ptr(xyzr), ptr(order), ptr(csr), B, n, ptr(rec), stream()) == 0
@@ -61,7 +61,7 @@ for case in range(n_cases):
         nbr = torch.full((n, k), -7, **i32); deg = torch.full((n,), -7, **i32)
         if g:
             st = L.p2w_knn_grid(ptr(coarse), ptr(ckeys), ptr(ptr_out), ptr(grid), ptr(rec), None, ptr(csr), B, n, k, ptr(nbr),
-                                ptr(deg), SEARCH_Q_ROW_IN_W | box, stream())
+                                ptr(deg), None, SEARCH_Q_ROW_IN_W | box, stream())
         else:
             st = L.p2w_knn(ptr(coarse), ptr(ptr_out), ptr(xyzr), None, ptr(csr), B, n, k, ptr(nbr), ptr(deg), None, 0, stream())
         assert st == 0
@@ -74,7 +74,7 @@ for case in range(n_cases):
         nbr = torch.full((m, k), -7, **i32); deg = torch.full((m,), -7, **i32)
         if g:
             st = L.p2w_knn_grid(ptr(rec), ptr(skeys), ptr(csr), ptr(grid), ptr(xyzr), ptr(idx), ptr(ptr_out), B, m, k, ptr(nbr),
-                                ptr(deg), SEARCH_X_INDEX_IN_W | box, stream())
+                                ptr(deg), None, SEARCH_X_INDEX_IN_W | box, stream())
         else:
             st = L.p2w_knn(ptr(xyzr), ptr(csr), ptr(xyzr), ptr(idx), ptr(ptr_out), B, m, k, ptr(nbr), ptr(deg), None, 0, stream())
         assert st == 0
