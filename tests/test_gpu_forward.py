@@ -196,3 +196,29 @@ def test_voxeliser_on_gpu_matches_cpu_restatement():
         cols = [0, 1, 2] + list(range(4, b.shape[1]))
         assert torch.equal(a[:, cols], b[:, cols])                       # membership, order, coordinates, n_z: exact
         assert (a[:, 3] - b[:, 3]).abs().max() <= 5e-5                   # erfinv differs in the last bits between devices
+
+
+def test_bench_contract_line():
+    """bench.py prints ONE JSON line with the contract's keys (driver contract + roofline + cpu_baseline objects)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d, key
+    assert d["metric"] == "classified points/sec" and d["unit"] == "points/s" and d["n_gpus"] == 1 and d["steps"] == 3
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in rf, key
+    assert rf["bound"] in ("hbm", "mfma") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert abs(d["value"] - 8 * 16384 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
