@@ -56,10 +56,21 @@ def segment_file(path, args):
     from pointstowood_amd.predicter import load_model
     if os.path.splitext(path)[1].lower() != '.ply':
         raise SystemExit(f'{path}: only .ply input is built (the reference also reads .las / .pcd through laspy / its own parser)')
-    device = torch.device('cuda')
+    # one process per GPU under `python -m torch.distributed.run --nproc-per-node N predict.py ...`: every rank reads the
+    # file, the voxel batches and the back-projection are sharded (pipeline.segment_plot), rank 0 writes the result
+    world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        if not dist.is_initialized():
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    device = torch.device('cuda', local)
     t0 = time.time()
     cols, headers, had_refl = pio.prepare_columns(pio.read_ply(path))
-    print('Reflectance detected' if had_refl else 'No reflectance detected, column added with zeros.')
+    if rank == 0:
+        print('Reflectance detected' if had_refl else 'No reflectance detected, column added with zeros.')
     names = list(cols)
     xyz64 = np.stack([np.asarray(cols[c], dtype=np.float64) for c in names[:3]], 1)
     origin = xyz64.min(0)                                   # plot-local coordinates: fp32 keeps millimetres at any easting
@@ -71,15 +82,19 @@ def segment_file(path, args):
     except KeyError:
         raise Exception(f'No model loaded at {args.model}')
     model.eval()
-    print(f'Voxelising to {args.grid_size} grid sizes')
+    if rank == 0:
+        print(f'Voxelising to {args.grid_size} grid sizes')
     stats = {}
+    gen = torch.Generator(device=device).manual_seed(0) if world > 1 else None   # identical max_pts sampling on every rank
     n_z, label, pwood = segment_plot(pc, model, args.grid_size, args.min_pts, args.max_pts, args.is_wood, args.any_wood,
-                                     stats=stats)
+                                     stats=stats, generator=gen, dist=dist)
+    opath = os.path.join(os.path.dirname(path), os.path.splitext(os.path.basename(path))[0] + '_ours.ply')
+    if rank != 0:
+        return opath
     out = {c: cols[c] for c in names[:3]}
     for h in dict.fromkeys(headers):                       # predicter.py:233: headers + n_z, label, pwood, de-duplicated
         out[h] = cols[h]
     out['n_z'], out['label'], out['pwood'] = n_z.cpu().numpy(), label.cpu().numpy(), pwood.cpu().numpy()
-    opath = os.path.join(os.path.dirname(path), os.path.splitext(os.path.basename(path))[0] + '_ours.ply')
     pio.write_ply(opath, out)
     if args.verbose:
         print({k: (round(v, 3) if isinstance(v, float) else v) for k, v in stats.items()})
