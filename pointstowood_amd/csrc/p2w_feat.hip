@@ -871,6 +871,12 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void gemm_h2g_kernel(const _Float1
         for (int t = 0; t < CT; ++t) { bh[t] = *reinterpret_cast<const h8*>(st0 + offB[0][t]); bl[t] = *reinterpret_cast<const h8*>(st0 + offB[1][t]); }
     }
     if (WR == 2 && (dbg & 64)) {
+        if (dbg & 8) {
+#pragma unroll
+            for (int t = 0; t < RT; ++t) { ah[t] = *reinterpret_cast<const h8*>(S + offA[0][t]); al[t] = *reinterpret_cast<const h8*>(S + offA[1][t]); }
+#pragma unroll
+            for (int t = 0; t < CT; ++t) { bh[t] = *reinterpret_cast<const h8*>(S + offB[0][t]); bl[t] = *reinterpret_cast<const h8*>(S + offB[1][t]); }
+        }
         // Staggered schedule (experimental, P2W_GEMM_DBG=64): the two wave rows of the tile are two groups; G1 (wr = 1) runs
         // one barrier behind G0.  A slab is four segments - R0: read the kk = 0 fragments, M0: their 24 MFMAs, R1, M1 -
         // each closed by a barrier, so in every interval one wave of a SIMD issues MFMAs while the other reads LDS /
@@ -885,6 +891,7 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void gemm_h2g_kernel(const _Float1
             __builtin_amdgcn_sched_barrier(0);
         };
         auto RD = [&](int stage, int kk) {
+            if (dbg & 8) return;
             const char* st = S + (size_t)stage * STAGE_CH * 16;
 #pragma unroll
             for (int t = 0; t < RT; ++t) {
@@ -899,6 +906,7 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void gemm_h2g_kernel(const _Float1
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         };
         auto MM = [&]() {
+            if (dbg & 4) return;
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < RT; ++i)
@@ -915,7 +923,7 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void gemm_h2g_kernel(const _Float1
         BAR();
         if (wr == 0) {
             for (int s = 0; s < nslab; ++s) {
-                if (s + 1 < nslab) issue((s + 1) & 1, (s + 1) * G_BK);
+                if (s + 1 < nslab && !(dbg & 2)) issue((s + 1) & 1, (s + 1) * G_BK);
                 RD(s & 1, 0); BAR();
                 MM(); BAR();
                 RD(s & 1, 1); BAR();
@@ -925,7 +933,7 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void gemm_h2g_kernel(const _Float1
             }
             BAR();   // G1's last segment
         } else {
-            if (nslab > 1) issue(1, G_BK);   // "M1(-1)": G1's share of slab 1, in its idle first interval
+            if (nslab > 1 && !(dbg & 2)) issue(1, G_BK);   // "M1(-1)": G1's share of slab 1, in its idle first interval
             BAR();
             for (int s = 0; s < nslab; ++s) {
                 RD(s & 1, 0); BAR();
@@ -933,7 +941,7 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void gemm_h2g_kernel(const _Float1
                 RD(s & 1, 1);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own pieces of slab s+1 (issued three intervals ago)
                 BAR();
-                if (s + 2 < nslab) issue(s & 1, (s + 2) * G_BK);
+                if (s + 2 < nslab && !(dbg & 2)) issue(s & 1, (s + 2) * G_BK);
                 MM(); BAR();
             }
         }
