@@ -870,84 +870,6 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void gemm_h2g_kernel(const _Float1
 #pragma unroll
         for (int t = 0; t < CT; ++t) { bh[t] = *reinterpret_cast<const h8*>(st0 + offB[0][t]); bl[t] = *reinterpret_cast<const h8*>(st0 + offB[1][t]); }
     }
-    if (WR == 2 && (dbg & 64)) {
-        if (dbg & 8) {
-#pragma unroll
-            for (int t = 0; t < RT; ++t) { ah[t] = *reinterpret_cast<const h8*>(S + offA[0][t]); al[t] = *reinterpret_cast<const h8*>(S + offA[1][t]); }
-#pragma unroll
-            for (int t = 0; t < CT; ++t) { bh[t] = *reinterpret_cast<const h8*>(S + offB[0][t]); bl[t] = *reinterpret_cast<const h8*>(S + offB[1][t]); }
-        }
-        // Staggered schedule (experimental, P2W_GEMM_DBG=64): the two wave rows of the tile are two groups; G1 (wr = 1) runs
-        // one barrier behind G0.  A slab is four segments - R0: read the kk = 0 fragments, M0: their 24 MFMAs, R1, M1 -
-        // each closed by a barrier, so in every interval one wave of a SIMD issues MFMAs while the other reads LDS /
-        // issues DMA.  Interval 4s+j: G0 runs segment j of slab s, G1 segment j-1.
-        //   DMA(s+1) -> stage (s+1)&1 is issued in interval 4s by both groups (G0 in R0(s), G1 in M1(s-1)); the last
-        //   reads of that stage (slab s-1) were retired with lgkmcnt(0) before the barriers closing intervals 4s-2 (G0)
-        //   and 4s-1 (G1).  Both groups drain their own pieces (vmcnt(0)) before the barrier closing interval 4s+3; the
-        //   first reads of slab s+1 are in intervals 4s+4 (G0) and 4s+5 (G1).
-        auto BAR = [&]() {
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_barrier" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        auto RD = [&](int stage, int kk) {
-            if (dbg & 8) return;
-            const char* st = S + (size_t)stage * STAGE_CH * 16;
-#pragma unroll
-            for (int t = 0; t < RT; ++t) {
-                ah[t] = *reinterpret_cast<const h8*>(st + (offA[0][t] ^ (kk << 5)));
-                al[t] = *reinterpret_cast<const h8*>(st + (offA[1][t] ^ (kk << 5)));
-            }
-#pragma unroll
-            for (int t = 0; t < CT; ++t) {
-                bh[t] = *reinterpret_cast<const h8*>(st + (offB[0][t] ^ (kk << 5)));
-                bl[t] = *reinterpret_cast<const h8*>(st + (offB[1][t] ^ (kk << 5)));
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        };
-        auto MM = [&]() {
-            if (dbg & 4) return;
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int i = 0; i < RT; ++i)
-#pragma unroll
-                for (int j = 0; j < CT; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                }
-            __builtin_amdgcn_s_setprio(0);
-        };
-        // prologue: slab 0 landed for everybody
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        BAR();
-        if (wr == 0) {
-            for (int s = 0; s < nslab; ++s) {
-                if (s + 1 < nslab && !(dbg & 2)) issue((s + 1) & 1, (s + 1) * G_BK);
-                RD(s & 1, 0); BAR();
-                MM(); BAR();
-                RD(s & 1, 1); BAR();
-                MM();
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                BAR();
-            }
-            BAR();   // G1's last segment
-        } else {
-            if (nslab > 1 && !(dbg & 2)) issue(1, G_BK);   // "M1(-1)": G1's share of slab 1, in its idle first interval
-            BAR();
-            for (int s = 0; s < nslab; ++s) {
-                RD(s & 1, 0); BAR();
-                MM(); BAR();
-                RD(s & 1, 1);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own pieces of slab s+1 (issued three intervals ago)
-                BAR();
-                if (s + 2 < nslab && !(dbg & 2)) issue(s & 1, (s + 2) * G_BK);
-                MM(); BAR();
-            }
-        }
-        gemm_epilogue_dispatch<RT, CT>(acc, ep, wscale, m0 + wr * 32 * RT, n0 + wc * 32 * CT, lane, M, N, o, ef);
-        return;
-    }
     for (int s = 0; s < nslab; ++s) {
         if (!(dbg & 16)) __syncthreads();  // = s_waitcnt vmcnt(0) + barrier: slab s has landed for every wave, slab s-1's buffer is free
         if (s + 1 < nslab && !(dbg & 2)) issue((s + 1) & 1, (s + 1) * G_BK);
