@@ -334,3 +334,42 @@ def test_product_code_never_imports_the_oracle():
     hits = [m.start() for m in pat.finditer(src)]
     a, b = src.index("def cpu_baseline"), src.index("def main")
     assert hits and all(a < h < b for h in hits)          # only inside cpu_baseline()
+
+
+def test_hot_kernels_stay_off_the_register_cliff():
+    """The 256x256 GEMM kernel lives at 256 VGPRs with a small, epilogue-only scratch area; compiling extra code paths
+    into it has silently doubled its scratch and halved its speed before.  Pin the resource usage of the hot kernels."""
+    import shutil
+    import subprocess
+    from pointstowood_amd import build as B
+    hipcc = B._hipcc()
+    if shutil.which(hipcc) is None and not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    usage = {}
+    for src in ("p2w_feat.hip", "p2w_geom.hip"):
+        r = subprocess.run([hipcc, *B.FLAGS, "-c", os.path.join(B.CSRC, src), "-o", os.devnull,
+                            "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        name = None
+        for line in r.stderr.splitlines():
+            m = re.search(r"Function Name: (\S+)", line)
+            if m:
+                name = m.group(1)
+                usage[name] = {}
+            for key in ("VGPRs Spill", "ScratchSize [bytes/lane]", "VGPRs", "LDS Size [bytes/block]"):
+                m = re.search(re.escape(key) + r": (\d+)", line)
+                if m and name:
+                    usage[name].setdefault(key, int(m.group(1)))
+
+    def one(substr):
+        hits = [v for k, v in usage.items() if substr in k]
+        assert len(hits) == 1, (substr, [k for k in usage if substr in k])
+        return hits[0]
+    big = one("gemm_h2g_kernelILi2ELi4ELi4ELi2E")
+    assert big["ScratchSize [bytes/lane]"] <= 400, big          # 352 today: interior-epilogue spills only
+    assert one("gemm_h2g_kernelILi2ELi2ELi2ELi2E")["ScratchSize [bytes/lane]"] == 0
+    for k in ("sa_conv16p_kernelILi256ELi2E", "sa_conv16p_kernelILi128ELi2E"):
+        assert one(k)["VGPRs Spill"] == 0 and one(k)["LDS Size [bytes/block]"] <= 112 * 1024
+    for k, v in usage.items():
+        if "slab_search_kernel" in k or k.startswith("_Z10knn_kernel") or k.startswith("_Z11ball_kernel"):
+            assert v["VGPRs Spill"] == 0, (k, v)
