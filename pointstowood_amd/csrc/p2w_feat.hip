@@ -794,9 +794,16 @@ template <int WR, int WC, int RT, int CT>   // waves WR x WC, wave tile (32*RT) 
 __global__ __launch_bounds__(64 * WR * WC, 2) void gemm_h2g_kernel(const _Float16* __restrict__ A, int ldh_a,
                                                                 const _Float16* __restrict__ Wh, size_t plane, float wscale,
                                                                 int M, int N, int Kpad, int nMt, int nNt, EpiArgs ep,
-                                                                OutArgs o, int dbg, int ef, int tmode) {
-    // dbg (profiling ablations, 0 in production): 1 = skip the epilogue, 2 = issue only the first slab's DMA,
-    // 4 = skip the MFMAs
+                                                                OutArgs o, int dbg_, int ef, int tmode) {
+    // dbg (profiling ablations): 1 = skip the epilogue, 2 = issue only the first slab's DMA, 4 = skip the MFMAs,
+    // 8 = fragments loaded once, 16 = no barrier, 32 = every workgroup reads row tile 0.  Compiled in only by diagnostic
+    // builds (P2W_EXTRA_CFLAGS=-DP2W_GEMM_ABLATE): this kernel sits at 256 VGPRs and every extra path costs scratch.
+#ifdef P2W_GEMM_ABLATE
+    const int dbg = dbg_;
+#else
+    constexpr int dbg = 0;
+    (void)dbg_;
+#endif
     constexpr int BM = 32 * RT * WR, BN = 32 * CT * WC, NW = WR * WC;
     constexpr int A_CH = 8 * BM, STAGE_CH = A_CH + 8 * BN;   // 16-byte chunks per stage (2 planes x rows x 4)
     constexpr int NI = STAGE_CH / 64 / NW;                   // DMA instructions per wave per stage

@@ -2,6 +2,7 @@
 """Time p2w_gemm_h2 on the network's GEMM shapes under the kernel's profiling ablations (P2W_GEMM_DBG)."""
 import ctypes as C
 import os
+os.environ.setdefault("P2W_EXTRA_CFLAGS", "-DP2W_GEMM_ABLATE")   # the ablation switches are compiled out of production builds
 import sys
 
 import torch
