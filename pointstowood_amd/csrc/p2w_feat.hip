@@ -949,10 +949,12 @@ extern "C" int32_t p2w_gemm_h2(const void* A_h2, int32_t ldh_a, const void* Wh, 
             if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
             return n > 0 ? n : 256;
         }();
-        // one 256x256 workgroup per CU: use it only when the tile count fills whole rounds of the chip reasonably well
+        // one 256x256 workgroup per CU: worth it when N has no column padding at that width and the tiles fill >= 78 % of
+        // whole rounds of the chip, from 3/4 of one round up (per-launch A/B over the network's 54 GEMMs: 207 tiles on
+        // 256 CUs still win by 8 %, 340 of 512 or N = 640 padded to 768 lose by 10-25 %)
         const long rounds = (tiles256 + n_cu_g - 1) / n_cu_g;
-        const bool fills = tiles256 * 100 >= rounds * n_cu_g * 85;
-        const bool big = force ? (force == 256) : (N >= 256 && tiles256 >= 2 * n_cu_g && fills);
+        const bool fills = tiles256 * 100 >= rounds * n_cu_g * 78;
+        const bool big = force ? (force == 256) : (N >= 256 && (N % 256) == 0 && tiles256 * 4 >= 3 * n_cu_g && fills);
         // epilogue class for the specialised interior-tile path (0 = generic); needs 32-bit element offsets
         int ef = (ep.relu0 ? 1 : 0) | (ep.sc0 ? 2 : 0) | (ep.relu1 ? 4 : 0) | (ep.sc1 ? 8 : 0) | (ep.relu2 ? 16 : 0) |
                  (ep.residual ? 32 : 0) | (ep.relu_final ? 64 : 0) | (out_f32 ? 128 : 0) | (out_h2 ? 256 : 0);
