@@ -186,6 +186,27 @@ class Geometry:
         return [t for t in out if t is not None]
 
 
+def pick_chunk(m: int, budget: int, col_tiles: int, n_cu: int = 256) -> int:
+    """Rows per chunk for a row-chunked GEMM chain over ``m`` rows: a multiple of 256 within [0.6, 1.25] x ``budget`` (the
+    row count that keeps the chain's intermediates cache-resident) that minimises the number of chip rounds of 256 x 256
+    tiles over all chunks (``col_tiles`` column tiles per row tile) - a 1122-row tail chunk or a chunk that fills 1.1
+    rounds costs as much as a full one.  Ties go to the larger chunk."""
+    if m <= 0:
+        return 256
+    budget = max(256, budget // 256 * 256)
+    if m <= budget * 5 // 4:
+        return -(-m // 256) * 256
+    best, best_cost = budget, None
+    lo, hi = max(256, budget * 3 // 5 // 256 * 256), budget * 5 // 4 // 256 * 256
+    for c in range(lo, hi + 1, 256):
+        full, rem = divmod(m, c)
+        rounds = lambda rows: -(-(-(-rows // 256) * col_tiles) // n_cu)
+        cost = full * rounds(c) + (rounds(rem) if rem else 0)
+        if best_cost is None or cost < best_cost or (cost == best_cost and c > best):
+            best, best_cost = c, cost
+    return best
+
+
 class Engine:
     def __init__(self, weights: PackedWeights, k: int = 32, precision: str = "f16x3"):
         self.w = weights
@@ -196,6 +217,7 @@ class Engine:
         if not 1 <= self.k <= 32:
             raise ValueError("k must be in 1..32 (one 32-row MFMA tile per target)")
         self.feature_streams = int(os.environ.get("P2W_FEATURE_STREAMS", "1"))  # Net.stream(): feature phases in flight
+        self.chunk_pick = int(os.environ.get("P2W_CHUNK_PICK", "1"))       # fill-aware chunk sizes (pick_chunk); 0: plain budget
         self.fp_hints = os.environ.get("P2W_FP_HINTS", "1") != "0"           # seed the interpolation searches from the sampler
         self.res_streams = int(os.environ.get("P2W_RES_STREAMS", "1"))      # residual-block chunk chains in flight (2: +0.6 %, measured)
         self.res_chunk_rows = int(os.environ.get("P2W_RES_CHUNK", "65536"))   # rows (at 4F=512) per residual-block chunk; 0 = whole level
@@ -377,7 +399,8 @@ class Engine:
             # residual block in row chunks: the two 4F-wide intermediates of a chunk (2 x chunk x 4F x 4 B) are written
             # and re-read while they still sit in the 256 MiB Infinity Cache instead of round-tripping HBM
             chunk = self.res_chunk_rows if self.res_chunk_rows > 0 else M
-            chunk = max(256, min(M, (chunk * 512 // E) // 256 * 256))      # same bytes per chunk at every level
+            chunk = max(256, min(M, pick_chunk(M, chunk * 512 // E, E // 256) if self.chunk_pick
+                                 else (chunk * 512 // E) // 256 * 256))   # ~same bytes per chunk at every level
             # Chunks are independent chains of four GEMMs; alternating them between two streams lets the tiles of one
             # chain fill the CUs the other leaves idle at its wave tails (a 1122-row tail chunk at level 3 otherwise
             # runs four GEMMs at 16 % chip fill).
@@ -435,7 +458,8 @@ class Engine:
             nbr, deg, kw = (nbr4, deg4, 1) if fl == 4 else (*geo.fp_nbr[fl - 1], 2)
             l0, l1 = w.fp[fl]
             chunk = self.res_chunk_rows if self.res_chunk_rows > 0 else m
-            chunk = max(256, min(m, (chunk * 512 // (Fc + Fs)) // 256 * 256))
+            chunk = max(256, min(m, pick_chunk(m, chunk * 512 // (Fc + Fs), max(1, l0.N // 256)) if self.chunk_pick
+                                 else (chunk * 512 // (Fc + Fs)) // 256 * 256))
             mc = min(m, chunk)
             cat, a = newh(mc, Fc + Fs), newh(mc, l0.N)
             need_f32 = fl > 1 or keep is not None

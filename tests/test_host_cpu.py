@@ -373,3 +373,19 @@ def test_hot_kernels_stay_off_the_register_cliff():
     for k, v in usage.items():
         if "slab_search_kernel" in k or k.startswith("_Z10knn_kernel") or k.startswith("_Z11ball_kernel"):
             assert v["VGPRs Spill"] == 0, (k, v)
+
+
+def test_pick_chunk_properties():
+    from pointstowood_amd.engine import pick_chunk
+    rounds = lambda rows, t: -(-(-(-rows // 256) * t) // 256)
+    for m, budget, t in ((123046, 65536, 2), (81683, 32768, 4), (17506, 16384, 8), (131072, 61680, 2), (123046, 52428, 2),
+                         (5, 65536, 2), (1000000, 65536, 2), (300, 100, 1)):
+        c = pick_chunk(m, budget, t)
+        assert c % 256 == 0 and c >= 256
+        b = max(256, budget // 256 * 256)
+        assert c <= max(b * 5 // 4, -(-m // 256) * 256)
+        full, rem = divmod(m, c)
+        cost = full * rounds(c, t) + (rounds(rem, t) if rem else 0)
+        plain_full, plain_rem = divmod(m, b)
+        assert cost <= plain_full * rounds(b, t) + (rounds(plain_rem, t) if plain_rem else 0)   # never worse than the plain budget
+    assert pick_chunk(131072, 61680, 2) == 65536                                               # FP1: two full chunks, no 8192-row tail
