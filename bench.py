@@ -13,8 +13,8 @@ voxel batches are independent) and each step ends with the path's only collectiv
 all-gather of the per-point logits.  Rank 0 prints ONE JSON line.
 
 ``roofline`` is measured live: after the timed region one extra step is run with HIP events
-around every launch (on the launch stream) and the dominant kernel's algorithmic FLOPs are
-divided by its measured time.  ``cpu_baseline`` times the CPU oracle (``oracle/net.py``, a port
+around every run of consecutive launches of one kernel class (on the launch stream) and the dominant
+kernel's algorithmic FLOPs are divided by its measured time.  ``cpu_baseline`` times the CPU oracle (``oracle/net.py``, a port
 of the reference forward pinned to the reference's own outputs) on one 16384-point voxel.
 """
 from __future__ import annotations
@@ -68,17 +68,18 @@ KERNEL_OF = {"gemm_hoist": "gemm_kernel", "gemm_res": "gemm_kernel", "gemm_mlp":
 
 def profile_step(net, data):
     eng = net._engine
-    eng.events = []
+    eng.events, eng.events_grouped = [], True   # one HIP-event pair per run of consecutive launches of one kernel class
     keep = {}
     streams, eng.res_streams = eng.res_streams, 1   # per-kernel durations: no two kernels in flight while they are timed
     net(data, keep=keep)
+    eng.flush_events()
     torch.cuda.synchronize()
-    ev, eng.events, eng.res_streams = eng.events, None, streams
+    ev, eng.events, eng.events_grouped, eng.res_streams = eng.events, None, False, streams
     per = {}
-    for name, s, e in ev:
+    for name, s, e, launches in ev:
         kname = KERNEL_OF.get(name, name)
         t, n = per.get(kname, (0.0, 0))
-        per[kname] = (t + s.elapsed_time(e), n + 1)
+        per[kname] = (t + s.elapsed_time(e), n + launches)
     return per, keep["geometry"]
 
 

@@ -222,19 +222,44 @@ class Engine:
         self.res_streams = int(os.environ.get("P2W_RES_STREAMS", "1"))      # residual-block chunk chains in flight (2: +0.6 %, measured)
         self.res_chunk_rows = int(os.environ.get("P2W_RES_CHUNK", "65536"))   # rows (at 4F=512) per residual-block chunk; 0 = whole level
         self.events = None  # set to a list to record (name, start, end) events per launch
+        self.events_grouped = False   # True: (name, start, end, launches) per run of consecutive same-name launches
+        self._open = None
         self.stem_out = None
         self._ws = None
 
     # -- small helpers ------------------------------------------------------------------------
     def _call(self, name, fn, *args):
         ev = self.events
-        if ev is not None:
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if ev is None:
+            check(fn(*args, _lib.stream()), name)
+            return
+        if self.events_grouped:
+            # one HIP-event pair per RUN of consecutive launches of the same name (e.g. the four GEMMs of a residual chunk):
+            # an event record between two kernels costs ~8 us of dispatch latency that a per-launch bracket counts as
+            # kernel time; entries are [name, start, end, launches], the open run is closed by the next name / flush_events
+            if self._open is not None and self._open[0] == name:
+                check(fn(*args, _lib.stream()), name)
+                self._open[3] += 1
+                return
+            self.flush_events()
+            s = torch.cuda.Event(enable_timing=True)
             s.record()
+            check(fn(*args, _lib.stream()), name)
+            self._open = [name, s, None, 1]
+            return
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
         check(fn(*args, _lib.stream()), name)
-        if ev is not None:
+        e.record()
+        ev.append((name, s, e))
+
+    def flush_events(self):
+        if self._open is not None:
+            e = torch.cuda.Event(enable_timing=True)
             e.record()
-            ev.append((name, s, e))
+            self._open[2] = e
+            self.events.append(tuple(self._open))
+            self._open = None
 
     def _gemm(self, name, A, lda, M, lin: Linear, out, ldo, residual=None, ldr=0):
         ep = Epilogue(ptr(lin.bias), ptr(lin.sc0), ptr(lin.sh0), ptr(lin.sc1), ptr(lin.sh1), ptr(residual), ldr,
