@@ -1938,7 +1938,10 @@ extern "C" int32_t p2w_stem_h2(const float* xyzr, int32_t n, const float* w, con
 // wave-uniform (scalar loads, computed once per row instead of once per 4-column chunk); the lanes then sweep the row
 // 256 columns at a time with coalesced 16-byte loads of the coarse features.  The arithmetic per element is the same
 // as torch-scatter's: products and sums in neighbour order from 0, then a literal division.
-constexpr int IC_ROWS = 4;   // rows per wave (consecutive)
+#ifndef P2W_IC_ROWS
+#define P2W_IC_ROWS 1   // swept 1..16 on the bench forward: 447 / 473 / 500 / 582 / 682 us for 1 / 2 / 4 / 8 / 16
+#endif
+constexpr int IC_ROWS = P2W_IC_ROWS;   // rows per wave (consecutive)
 __global__ __launch_bounds__(256) void interp_concat_kernel(const float* __restrict__ xc, int Fc, const float4* __restrict__ xyzr_c,
                                                             const float4* __restrict__ xyzr_f, const int* __restrict__ nbr,
                                                             const int* __restrict__ deg, int kw, const float* __restrict__ skip,
