@@ -4,9 +4,10 @@
  *
  * Boundary rules:
  *   - extern "C", plain pointers + sizes, no C++/torch types, no exceptions;
- *   - every entry point is re-entrant, keeps no global mutable state, never
- *     allocates and never synchronises: the caller owns all device buffers
- *     (worst-case sized) and passes the HIP stream to launch on;
+ *   - every entry point is re-entrant, keeps no global mutable state, reads no
+ *     environment variables, never allocates and never synchronises: the caller
+ *     owns all device buffers (worst-case sized) and passes the HIP stream to
+ *     launch on; behaviour switches are explicit `flags` / `prec` arguments;
  *   - every entry point returns an int32 status: 0 = OK, > 0 = hipError_t from
  *     the launch, < 0 = a P2W_E* argument error; p2w_strerror() names it;
  *   - all index arrays are int32, all features fp32 row-major, positions are
@@ -39,7 +40,8 @@ typedef void* p2w_stream_t; /* hipStream_t */
 #define P2W_EWORKSPACE (-4)/* workspace too small                             */
 #define P2W_EUNSUPPORTED (-5)
 
-#define P2W_MAX_K 64       /* neighbours per query (wave64: one lane per slot) */
+#define P2W_MAX_K 64       /* neighbours per query of the searches (wave64: one lane per slot) */
+#define P2W_MAX_K_CONV 32  /* neighbour slots per target of p2w_sa_conv*: one 32-row MFMA tile (Net(k=...) <= 32) */
 
 int32_t p2w_version(void);
 const char* p2w_strerror(int32_t code);
@@ -210,33 +212,54 @@ int32_t p2w_sa_conv(const float* P, int32_t ldp, const float* xyzr_src, const in
                     const float* b2, const float* bn_s, const float* bn_t, float* out, int32_t ldo,
                     p2w_stream_t stream);
 
-/* Split-fp16 variants ("f16x3") of p2w_gemm / p2w_sa_conv: identical semantics and interface except for the
- * weight operand.  Wh = [2][N_pad][K_pad] fp16, plane 0 = hi, plane 1 = lo of W * 2^e (e chosen at pack time so
- * that lo stays a normal fp16), wscale = 2^-e.  Activations are split hi/lo on the fly; the contraction is
- * a_lo*w_hi + a_hi*w_lo + a_hi*w_hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation (~22-bit operands). */
-int32_t p2w_gemm_f16x3(const float* A, int32_t lda, const void* Wh, float wscale, int32_t M, int32_t N, int32_t K,
-                       const p2w_epilogue* epi, float* out, int32_t ldo, p2w_stream_t stream);
-int32_t p2w_sa_conv_f16x3(const float* P, int32_t ldp, const float* xyzr_src, const int32_t* idx, const int32_t* batch_dst,
-                          const float* sf, const int32_t* nbr, const int32_t* deg, int32_t kw, int32_t M,
-                          const float* w1r4, const void* W2h, float wscale, int32_t C1, int32_t C2, const float* b2,
-                          const float* bn_s, const float* bn_t, float* out, int32_t ldo, void* out_h2, int32_t ldh,
-                          void* ws, size_t ws_bytes, p2w_stream_t stream);
-/* ws (optional, 16-byte aligned, >= M*32*20 bytes): scratch for per-edge metadata; with it, wide layers (C2 >= 256)
- * run the persistent pipelined kernel. */
+/* ---- H family: the same GEMM / PointNetConv on 16-bit MFMA operands ------------------------------------------
+ * Precision of an H tensor and of the arithmetic on it (`prec` argument of every entry point below):
+ *   P2W_PREC_F16X3  fp16 hi/lo planes, a*w = a_lo*w_hi + a_hi*w_lo + a_hi*w_hi on v_mfma_f32_32x32x16_f16 with fp32
+ *                   accumulation (~22-bit operands): the parity mode, meets the 1e-4 probability bar of the fp32 path;
+ *   P2W_PREC_F16    one fp16 plane (round to nearest, saturating at +-65504), one MFMA per product;
+ *   P2W_PREC_BF16   one bf16 plane, v_mfma_f32_32x32x16_bf16.
+ *   The single-plane modes are what the reference's own GPU path computes in (torch.cuda.amp.autocast,
+ *   pointstowood/src/predicter.py:197); they do NOT meet the 1e-4 bar (tests report the measured error).
+ * H tensor [M, F]: row m = planes x ldh 16-bit values ([hi(0..ldh) | lo(0..ldh)] for F16X3, [v(0..ldh)] otherwise),
+ *   ldh >= F, ldh % 32 == 0 (F16X3) or % 64 == 0 (single plane) when the tensor feeds p2w_gemm_h2 (it is staged with
+ *   16-byte direct-to-LDS copies in whole K slabs), pad columns zero.  F16X3 has the bytes of fp32, the others half.
+ * H weights: Wh = [planes][N_pad][K_pad] of W * 2^e (e chosen at pack time so that the F16X3 lo plane stays a normal
+ *   fp16; wscale = 2^-e is applied in the epilogue), dims from p2w_packed_dims_h. */
+#define P2W_PREC_F16X3 0
+#define P2W_PREC_F16 1
+#define P2W_PREC_BF16 2
+int32_t p2w_packed_dims_h(int32_t prec, int32_t N, int32_t K, int32_t* N_pad, int32_t* K_pad);
 
-/* "H2" activations: a tensor [M, F] held as fp16 hi/lo planes, row-interleaved (row m = hi[0..ldh) | lo[0..ldh),
- * ldh = round_up(F, 8), pad columns zero; value = hi + lo to ~22 bits).  Same bytes as fp32; a consumer GEMM stages
- * it with plain 16-byte copies, so the fp32 -> hi/lo split happens once per element (in the producer's epilogue)
- * instead of once per output-column tile.  p2w_gemm_h2 = p2w_gemm_f16x3 with an H2 A operand and fp32 and/or H2
- * outputs (either pointer may be NULL).  The *_h2 variants of the small kernels write H2 (and fp32 where given). */
-int32_t p2w_gemm_h2(const void* A_h2, int32_t ldh_a, const void* Wh, float wscale, int32_t M, int32_t N, int32_t K,
-                    const p2w_epilogue* epi, float* out_f32, int32_t ldo, void* out_h2, int32_t ldh_o, p2w_stream_t stream);
-int32_t p2w_stem_h2(const float* xyzr, int32_t n, const float* w, const float* b, int32_t C, float* out, void* out_h2,
-                    int32_t ldh, p2w_stream_t stream);
-int32_t p2w_interp_concat_h2(const float* xc, int32_t Fc, const float* xyzr_c, const float* xyzr_f, const int32_t* nbr,
-                             const int32_t* deg, int32_t kw, const float* skip, int32_t Fs, int32_t m, void* out_h2,
-                             int32_t ldh, p2w_stream_t stream);
-int32_t p2w_concat_xyz_h2(const float* x, int32_t F, const float* xyzr, int32_t m, void* out_h2, int32_t ldh,
+/* flags of p2w_gemm_h2 (0 = let the library choose).  There are no environment switches behind this ABI. */
+#define P2W_GEMM_TILE_128 1      /* force the 128 x 128 workgroup tile */
+#define P2W_GEMM_TILE_256 2      /* force the 256 x 256 workgroup tile */
+#define P2W_GEMM_GENERIC_EPI 4   /* run the runtime-flag epilogue instead of the specialised one */
+#define P2W_GEMM_ORDER_ROWS 8    /* tile order: an XCD owns whole row tiles (W re-read from its L2) */
+#define P2W_GEMM_ORDER_COLS 16   /* tile order: an XCD owns a slice of column tiles (A streamed per slice) */
+/* bits 16..23 of `flags` of p2w_gemm_h2 / p2w_sa_conv_h: profiling ablations, honoured only by diagnostic builds
+ * (-DP2W_GEMM_ABLATE / -DP2W_SA_ABLATE); production builds ignore them. */
+
+/* p2w_gemm with an H A operand, H weights and fp32 and/or H outputs (either pointer may be NULL):
+ * Linear / 1x1 Conv1d + folded BatchNorm / depthwise affines + ReLU + residual - model.py:75-85, :198-202, :241-242. */
+int32_t p2w_gemm_h2(int32_t prec, const void* A_h, int32_t ldh_a, const void* Wh, float wscale, int32_t M, int32_t N,
+                    int32_t K, const p2w_epilogue* epi, float* out_f32, int32_t ldo, void* out_h, int32_t ldh_o,
+                    int32_t flags, p2w_stream_t stream);
+/* p2w_sa_conv with H weights W2h and fp32 and/or H outputs.  P (the hoisted layer-1 product) stays fp32.
+ * ws: 16-byte aligned scratch of >= M*32*20 bytes for the per-edge metadata (P2W_EWORKSPACE otherwise);
+ * kw <= 32 (one 32-row MFMA tile per target) and round_up(C1, K granularity) <= 512 (P2W_EUNSUPPORTED otherwise). */
+int32_t p2w_sa_conv_h(int32_t prec, const float* P, int32_t ldp, const float* xyzr_src, const int32_t* idx,
+                      const int32_t* batch_dst, const float* sf, const int32_t* nbr, const int32_t* deg, int32_t kw,
+                      int32_t M, const float* w1r4, const void* W2h, float wscale, int32_t C1, int32_t C2,
+                      const float* b2, const float* bn_s, const float* bn_t, float* out, int32_t ldo, void* out_h,
+                      int32_t ldh, void* ws, size_t ws_bytes, int32_t flags, p2w_stream_t stream);
+/* The small kernels writing H (and fp32 where given): stem (model.py:208,228), knn_interpolate + cat (:149-151),
+ * cat(x, pos) (:135). */
+int32_t p2w_stem_h2(int32_t prec, const float* xyzr, int32_t n, const float* w, const float* b, int32_t C, float* out,
+                    void* out_h, int32_t ldh, p2w_stream_t stream);
+int32_t p2w_interp_concat_h2(int32_t prec, const float* xc, int32_t Fc, const float* xyzr_c, const float* xyzr_f,
+                             const int32_t* nbr, const int32_t* deg, int32_t kw, const float* skip, int32_t Fs, int32_t m,
+                             void* out_h, int32_t ldh, p2w_stream_t stream);
+int32_t p2w_concat_xyz_h2(int32_t prec, const float* x, int32_t F, const float* xyzr, int32_t m, void* out_h, int32_t ldh,
                           p2w_stream_t stream);
 
 /* knn_interpolate (k<=2) + concat with the skip features - model.py:149-151:

@@ -87,6 +87,7 @@ def _sa(sd, p, resolution, k, x, pos, batch, reflectance, sf, cap):
     pos[:, :3] = pos[:, :3] * sf[batch].unsqueeze(-1)
     if cap is not None:
         cap[p + ".idx"] = idx
+        cap[p + ".batch"] = batch[idx]
         cap[p + ".edge_q"], cap[p + ".edge_c"] = row, col
         cap[p + ".conv"] = x
     x = _resblock(sd, p + ".residual_block", x)

@@ -23,6 +23,9 @@ class Epilogue(C.Structure):
 
 # name -> (restype, argtypes); must list every symbol declared in include/p2w.h
 SEARCH_X_INDEX_IN_W, SEARCH_Q_ROW_IN_W, SEARCH_BOX = 1, 2, 4   # include/p2w.h P2W_SEARCH_*
+PREC_F16X3, PREC_F16, PREC_BF16 = 0, 1, 2                      # include/p2w.h P2W_PREC_*
+PREC_OF = {"f16x3": PREC_F16X3, "fp16": PREC_F16, "bf16": PREC_BF16}
+GEMM_TILE_128, GEMM_TILE_256, GEMM_GENERIC_EPI, GEMM_ORDER_ROWS, GEMM_ORDER_COLS = 1, 2, 4, 8, 16   # P2W_GEMM_*
 
 SIGNATURES = {
     "p2w_version": (_i32, []),
@@ -49,13 +52,13 @@ SIGNATURES = {
     "p2w_gemm": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, C.POINTER(Epilogue), _vp, _i32, _vp]),
     "p2w_sa_conv": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp,
                            _vp, _i32, _vp]),
-    "p2w_gemm_f16x3": (_i32, [_vp, _i32, _vp, _f32, _i32, _i32, _i32, C.POINTER(Epilogue), _vp, _i32, _vp]),
-    "p2w_sa_conv_f16x3": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _f32, _i32, _i32, _vp, _vp,
-                                 _vp, _vp, _i32, _vp, _i32, _vp, _sz, _vp]),
-    "p2w_gemm_h2": (_i32, [_vp, _i32, _vp, _f32, _i32, _i32, _i32, C.POINTER(Epilogue), _vp, _i32, _vp, _i32, _vp]),
-    "p2w_stem_h2": (_i32, [_vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp]),
-    "p2w_interp_concat_h2": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _i32, _vp]),
-    "p2w_concat_xyz_h2": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _vp]),
+    "p2w_packed_dims_h": (_i32, [_i32, _i32, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
+    "p2w_gemm_h2": (_i32, [_i32, _vp, _i32, _vp, _f32, _i32, _i32, _i32, C.POINTER(Epilogue), _vp, _i32, _vp, _i32, _i32, _vp]),
+    "p2w_sa_conv_h": (_i32, [_i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _f32, _i32, _i32, _vp, _vp,
+                             _vp, _vp, _i32, _vp, _i32, _vp, _sz, _i32, _vp]),
+    "p2w_stem_h2": (_i32, [_i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp]),
+    "p2w_interp_concat_h2": (_i32, [_i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _i32, _vp]),
+    "p2w_concat_xyz_h2": (_i32, [_i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp]),
     "p2w_interp_concat": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _i32, _vp]),
     "p2w_concat_xyz": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _vp]),
     "p2w_segment_max": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _vp]),
@@ -108,7 +111,11 @@ def require_cuda(*tensors):
                                "there is no CPU fallback")
 
 
-def packed_dims(n: int, k: int):
+def packed_dims(n: int, k: int, prec: int | None = None):
+    """(N_pad, K_pad) of a packed weight: fp32 / f16x3 pad K to 32, the single-plane H precisions to 64."""
     a, b = _i32(), _i32()
-    lib().p2w_packed_dims(n, k, C.byref(a), C.byref(b))
+    if prec is None:
+        lib().p2w_packed_dims(n, k, C.byref(a), C.byref(b))
+    else:
+        check(lib().p2w_packed_dims_h(prec, n, k, C.byref(a), C.byref(b)), "p2w_packed_dims_h")
     return a.value, b.value

@@ -1,0 +1,834 @@
+// MFMA fp16/bf16 kernels over "H" activations: the GEMM (+ fused epilogue) and the fused PointNetConv.
+// Included by p2w_feat.hip (PREC 0 = f16x3, the parity mode) and p2w_feat_h1.hip (PREC 1 = fp16, 2 = bf16, the
+// single-plane throughput modes), which instantiate the templates for their precisions - one translation unit per
+// family keeps the instantiations out of each other's register allocation.  gfx950 only.
+//
+// An H tensor [M, F] is a row-major array of 16-bit planes (include/p2w.h):
+//   PREC 0 (f16x3): row m = [hi(0..ldh) | lo(0..ldh)], fp16, value = hi + lo (~22 bits), ldh % 32 == 0
+//   PREC 1 / 2    : row m = [v(0..ldh)], fp16 / bf16 (round to nearest), ldh % 64 == 0
+// pad columns are zero.  Weights are packed the same way: [planes][N_pad][K_pad] of W * 2^e.
+//
+// The MFMA is v_mfma_f32_32x32x16_{f16,bf16}: lane l supplies A[row l&31][k = 8*(l>>5) + 0..7] (16 contiguous bytes),
+// B alike; C/D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).  f16x3 contracts a_lo*w_hi + a_hi*w_lo + a_hi*w_hi
+// (three MFMAs per product, fp32 accumulate); the single-plane modes issue one.
+#pragma once
+#include "p2w_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef __fp16 hpair __attribute__((ext_vector_type(2)));
+typedef _Float16 hpairn __attribute__((ext_vector_type(2)));
+typedef __bf16 bpair __attribute__((ext_vector_type(2)));
+typedef float fpair __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void* lds_vp;
+typedef const __attribute__((address_space(1))) void* glb_vp;
+
+constexpr int H_BK = 32;   // k per LDS row (64 bytes); a slab is two such row groups ("planes")
+
+template <int PREC> struct HCfg {
+    static constexpr int planes = PREC == 0 ? 2 : 1;      // 16-bit planes per H row
+    static constexpr int kslab = PREC == 0 ? 32 : 64;     // k consumed per GEMM slab (two LDS planes of 32)
+    static constexpr int kalign = PREC == 0 ? 32 : 64;    // ldh / K_pad granularity
+};
+
+template <int PREC>
+__device__ __forceinline__ f32x16 h_mfma(h8 a, h8 b, f32x16 c) {
+    if constexpr (PREC == 2)
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+// fp16 hi/lo split of two values at once: hi = round-toward-zero fp16 of v (v_cvt_pkrtz_f16_f32 converts a PAIR per
+// instruction and, rounding toward zero, saturates at +-65504 instead of overflowing to inf), lo = round-to-nearest
+// fp16 of the exact fp32 remainder v - hi (v_cvt_pk_f16_f32, also a pair per instruction; nearest keeps the split
+// unbiased).  hi + lo reproduces v to <= 2^-22 relative; |v| up to ~1.3e5 still splits exactly enough.
+// 6 VALU per pair (2 packed conversions, 2 conversions back, 2 subtractions) instead of 14 with clamps and single
+// conversions.
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo) {
+    const hpair h = __builtin_amdgcn_cvt_pkrtz(a, b);
+    const fpair rem = {a - (float)h[0], b - (float)h[1]};
+    const hpairn l = __builtin_convertvector(rem, hpairn);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+// single-plane modes: two values -> one packed word, round to nearest; fp16 saturates at +-65504 instead of inf
+template <int PREC>
+__device__ __forceinline__ unsigned pack_pair(float a, float b) {
+    if constexpr (PREC == 2) {
+        const fpair p = {a, b};
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(p, bpair));
+    } else {
+        const fpair p = {__builtin_amdgcn_fmed3f(a, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(b, -65504.f, 65504.f)};
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(p, hpairn));
+    }
+}
+// store two adjacent columns (col even) of H row `row`
+template <int PREC>
+__device__ __forceinline__ void h_store2(_Float16* __restrict__ base, unsigned ldh, unsigned row, unsigned col, float a, float b) {
+    if constexpr (PREC == 0) {
+        unsigned hw, lw;
+        split_pair(a, b, hw, lw);
+        _Float16* p = base + (size_t)row * (2 * ldh) + col;
+        *reinterpret_cast<unsigned*>(p) = hw;
+        *reinterpret_cast<unsigned*>(p + ldh) = lw;
+    } else {
+        *reinterpret_cast<unsigned*>(base + (size_t)row * ldh + col) = pack_pair<PREC>(a, b);
+    }
+}
+// store 4 consecutive columns of one row (col % 4 == 0)
+template <int PREC>
+__device__ __forceinline__ void h_store4(_Float16* __restrict__ base, int ldh, size_t row, int col, const float (&v)[4]) {
+    if constexpr (PREC == 0) {
+        uint2 hi, lo;
+        split_pair(v[0], v[1], hi.x, lo.x);
+        split_pair(v[2], v[3], hi.y, lo.y);
+        _Float16* p = base + row * (size_t)(2 * ldh) + col;
+        *reinterpret_cast<uint2*>(p) = hi;
+        *reinterpret_cast<uint2*>(p + ldh) = lo;
+    } else {
+        uint2 w;
+        w.x = pack_pair<PREC>(v[0], v[1]);
+        w.y = pack_pair<PREC>(v[2], v[3]);
+        *reinterpret_cast<uint2*>(base + row * (size_t)ldh + col) = w;
+    }
+}
+
+// XCD-aware tile order: blocks L, L+8, L+16.. share an XCD (round-robin dispatch), i.e. one 4 MiB L2.
+//  mode 0 (W fits in L2): an XCD owns whole row tiles and walks their column tiles back to back -> the A row tile is
+//          fetched once, W is always an L2 hit.
+//  mode 1 (W larger than L2, few rows): an XCD owns a slice of column tiles (its W slice stays L2-resident) and sweeps
+//          ALL row tiles; A is streamed once per XCD slice instead of W once per row tile.
+__device__ __forceinline__ bool tile_coords(int nMt, int nNt, int* mt, int* nt, int mode = 0) {
+    const int L = blockIdx.x;
+    const int xcd = L & 7, w = L >> 3;
+    if (mode == 0) {
+        *mt = xcd + 8 * (w / nNt);
+        *nt = w % nNt;
+        return *mt < nMt;
+    }
+    if (nNt >= 8) {
+        const int cpx = (nNt + 7) >> 3;     // column tiles per XCD
+        *mt = w / cpx;
+        *nt = xcd + 8 * (w % cpx);
+        return *mt < nMt && *nt < nNt;
+    }
+    const int r = 8 / nNt;                  // XCDs sharing one column tile (nNt in {1, 2, 4})
+    *nt = xcd % nNt;
+    *mt = xcd / nNt + r * w;
+    return *mt < nMt;
+}
+static inline int tile_grid(int nMt, int nNt, int mode = 0) {
+    if (mode == 0) return 8 * ((nMt + 7) / 8) * nNt;
+    if (nNt >= 8) return 8 * nMt * ((nNt + 7) / 8);
+    const int r = 8 / nNt;
+    return 8 * ((nMt + r - 1) / r);
+}
+static inline int p2w_cu_count() {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+}
+
+// ------------------------------------------------------------------------------------------------
+// epilogues
+// ------------------------------------------------------------------------------------------------
+struct EpiArgs {
+    const float *bias, *sc0, *sh0, *sc1, *sh1, *residual;
+    int ldr, relu0, relu1, relu2, relu_final;
+};
+// epilogue value -> optional fp32 store + optional H store.  H: lanes (2p, 2p+1) own adjacent columns of the same
+// rows; they swap one register of each (r, r+1) pair so that every lane stores two adjacent columns as one 32-bit
+// word per plane (even lane: row(r), odd lane: row(r+1)).
+struct OutArgs { float* f32; int ldo; _Float16* h2; int ldh; };
+
+__device__ __forceinline__ float epi_value(float a, float wscale, float bias, const EpiArgs& ep, float s0, float t0, float s1,
+                                           float t1, size_t row, int col, bool ok) {
+    float v = fmaf(a, wscale, bias);
+    if (ep.relu0) v = fmaxf(v, 0.f);
+    if (ep.sc0) { v = fmaf(v, s0, t0); }
+    if (ep.relu1) v = fmaxf(v, 0.f);
+    if (ep.sc1) { v = fmaf(v, s1, t1); }
+    if (ep.relu2) v = fmaxf(v, 0.f);
+    if (ep.residual && ok) v += ep.residual[row * ep.ldr + col];
+    if (ep.relu_final) v = fmaxf(v, 0.f);
+    return v;
+}
+
+template <int PREC, int RT, int CT>
+__device__ __forceinline__ void gemm_epilogue2(const f32x16 (&acc)[RT][CT], const EpiArgs& ep, float wscale, int row0, int col0,
+                                               int lane, int M, int N, const OutArgs& o) {
+    const int h = lane >> 5, odd = lane & 1;
+#pragma unroll
+    for (int j = 0; j < CT; ++j) {
+        const int col = col0 + j * 32 + (lane & 31);
+        const bool cv = col < N;
+        const float bias = (cv && ep.bias) ? ep.bias[col] : 0.f;
+        const float s0 = (cv && ep.sc0) ? ep.sc0[col] : 1.f, t0 = (cv && ep.sc0) ? ep.sh0[col] : 0.f;
+        const float s1 = (cv && ep.sc1) ? ep.sc1[col] : 1.f, t1 = (cv && ep.sc1) ? ep.sh1[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const int rowa = row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;  // row of register r; r+1 is rowa + 1
+                float va = epi_value(acc[i][j][r], wscale, bias, ep, s0, t0, s1, t1, (size_t)rowa, col, cv && rowa < M);
+                float vb = epi_value(acc[i][j][r + 1], wscale, bias, ep, s0, t0, s1, t1, (size_t)rowa + 1, col,
+                                     cv && rowa + 1 < M);
+                if (!cv) { va = 0.f; vb = 0.f; }  // pad columns of an H row must be zero
+                if (o.f32 && cv) {
+                    if (rowa < M) o.f32[(size_t)rowa * o.ldo + col] = va;
+                    if (rowa + 1 < M) o.f32[(size_t)(rowa + 1) * o.ldo + col] = vb;
+                }
+                if (o.h2) {
+                    const float send = odd ? va : vb;
+                    const float recv = __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(send), 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, false));
+                    const float c0v = odd ? recv : va, c1v = odd ? vb : recv;  // columns (col & ~1), (col | 1)
+                    const int roww = rowa + odd, colw = col & ~1;
+                    if (roww < M && colw < o.ldh) h_store2<PREC>(o.h2, o.ldh, roww, colw, c0v, c1v);
+                }
+            }
+        }
+    }
+}
+
+// Compile-time specialised epilogue for interior tiles (every row < M, every column < N): no per-element guards,
+// no flag selects, 32-bit offsets.  EF bits: 1 relu0, 2 sc0, 4 relu1, 8 sc1, 16 relu2, 32 residual, 64 relu_final,
+// 128 fp32 out, 256 H out.  Edge tiles and unlisted combinations use gemm_epilogue2 (runtime flags).
+template <int PREC, int RT, int CT, int EF>
+__device__ __forceinline__ void gemm_epilogue3(const f32x16 (&acc)[RT][CT], const EpiArgs& ep, float wscale, int row0, int col0,
+                                               int lane, const OutArgs& o) {
+    constexpr bool R0 = EF & 1, S0 = EF & 2, R1 = EF & 4, S1 = EF & 8, R2 = EF & 16, RES = EF & 32, RF = EF & 64,
+                   OF = EF & 128, OH = EF & 256;
+    const int h = lane >> 5, odd = lane & 1;
+#pragma unroll
+    for (int j = 0; j < CT; ++j) {
+        const int col = col0 + j * 32 + (lane & 31);
+        const float bias = ep.bias ? ep.bias[col] : 0.f;
+        float s0 = 1.f, t0 = 0.f, s1 = 1.f, t1 = 0.f;
+        if (S0) { s0 = ep.sc0[col]; t0 = ep.sh0[col]; }
+        if (S1) { s1 = ep.sc1[col]; t1 = ep.sh1[col]; }
+        auto f = [&](float a, unsigned roff) {
+            float v = fmaf(a, wscale, bias);
+            if (R0) v = fmaxf(v, 0.f);
+            if (S0) v = fmaf(v, s0, t0);
+            if (R1) v = fmaxf(v, 0.f);
+            if (S1) v = fmaf(v, s1, t1);
+            if (R2) v = fmaxf(v, 0.f);
+            if (RES) v += ep.residual[roff];
+            if (RF) v = fmaxf(v, 0.f);
+            return v;
+        };
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+            const unsigned rbase = (unsigned)(row0 + i * 32 + 4 * h);
+            __builtin_amdgcn_sched_barrier(0);  // keep the scheduler from hoisting every tile's loads at once (spills)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                if ((r & 7) == 0) __builtin_amdgcn_sched_barrier(0);
+                const unsigned rowa = rbase + (r & 3) + 8 * (r >> 2);
+                const float va = f(acc[i][j][r], RES ? rowa * (unsigned)ep.ldr + col : 0u);
+                const float vb = f(acc[i][j][r + 1], RES ? (rowa + 1) * (unsigned)ep.ldr + col : 0u);
+                if (OF) {
+                    o.f32[rowa * (unsigned)o.ldo + col] = va;
+                    o.f32[(rowa + 1) * (unsigned)o.ldo + col] = vb;
+                }
+                if (OH) {
+                    const float send = odd ? va : vb;
+                    const float recv = __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(send), 0xB1, 0xf, 0xf, false));
+                    const float c0v = odd ? recv : va, c1v = odd ? vb : recv;
+                    h_store2<PREC>(o.h2, (unsigned)o.ldh, rowa + odd, (unsigned)(col & ~1), c0v, c1v);
+                }
+            }
+        }
+    }
+}
+
+template <int PREC, int RT, int CT>
+__device__ __forceinline__ void gemm_epilogue_dispatch(const f32x16 (&acc)[RT][CT], const EpiArgs& ep, float wscale, int row0,
+                                                       int col0, int lane, int M, int N, const OutArgs& o, int ef) {
+    const bool full = (row0 + 32 * RT <= M) && (col0 + 32 * CT <= N) && ef != 0;
+    if (full) {
+        switch (ef) {
+#define P2W_EPI_CASE(E) case E: gemm_epilogue3<PREC, RT, CT, E>(acc, ep, wscale, row0, col0, lane, o); return;
+            P2W_EPI_CASE(128) P2W_EPI_CASE(257) P2W_EPI_CASE(263) P2W_EPI_CASE(287) P2W_EPI_CASE(480) P2W_EPI_CASE(224)
+            P2W_EPI_CASE(131) P2W_EPI_CASE(259) P2W_EPI_CASE(387) P2W_EPI_CASE(129)
+#undef P2W_EPI_CASE
+            default: break;
+        }
+    }
+    gemm_epilogue2<PREC, RT, CT>(acc, ep, wscale, row0, col0, lane, M, N, o);
+}
+
+// ------------------------------------------------------------------------------------------------
+// GEMM over H operands: both operands are 16-bit planes in HBM, so a K-slab is staged with direct-to-LDS loads
+// (global_load_lds_dwordx4: no VGPR round trip, no ds_write) into a 2-stage ring; one barrier per slab, the next
+// slab's DMA is in flight during the whole MFMA phase of the current one.
+// LDS image of a stage (16-byte chunks): A plane p, row r, chunk q -> ((p*BM + r)*4 + (q ^ ((r>>2)&3)));  B after A.
+// f16x3: plane p = hi / lo of k0..k0+31.  Single-plane modes: plane p = k0+32p..k0+32p+31 of a 64-wide slab, so the
+// image, the DMA pattern and the fragment reads are the same and only the MFMA pairing differs.
+// Rows are 64 B unpadded (the DMA writes 1 KiB linearly per wave-instruction: lane L -> chunk base+L), so the XOR
+// swizzle is applied on the per-lane SOURCE address and again on the ds_read address: conflict-free ds_read_b128.
+// Out-of-range A rows are clamped to M-1 (their results are never stored); K padding is zero in both operands.
+// ------------------------------------------------------------------------------------------------
+template <int PREC, int WR, int WC, int RT, int CT>   // waves WR x WC, wave tile (32*RT) x (32*CT)
+__global__ __launch_bounds__(64 * WR * WC, 2) void gemm_h2g_kernel(const _Float16* __restrict__ A, int ldh_a,
+                                                                const _Float16* __restrict__ Wh, size_t plane, float wscale,
+                                                                int M, int N, int Kpad, int nMt, int nNt, EpiArgs ep,
+                                                                OutArgs o, int dbg_, int ef, int tmode) {
+    // dbg (profiling ablations): 1 = skip the epilogue, 2 = issue only the first slab's DMA, 4 = skip the MFMAs,
+    // 8 = fragments loaded once, 16 = no barrier, 32 = every workgroup reads row tile 0.  Compiled in only by diagnostic
+    // builds (P2W_EXTRA_CFLAGS=-DP2W_GEMM_ABLATE): this kernel sits at 256 VGPRs and every extra path costs scratch.
+#ifdef P2W_GEMM_ABLATE
+    const int dbg = dbg_;
+#else
+    constexpr int dbg = 0;
+    (void)dbg_;
+#endif
+    constexpr int KS = HCfg<PREC>::kslab;
+    constexpr int BM = 32 * RT * WR, BN = 32 * CT * WC, NW = WR * WC;
+    constexpr int A_CH = 8 * BM, STAGE_CH = A_CH + 8 * BN;   // 16-byte chunks per stage (2 planes x rows x 4)
+    constexpr int NI = STAGE_CH / 64 / NW;                   // DMA instructions per wave per stage
+    static_assert(STAGE_CH % (64 * NW) == 0, "stage must split evenly over the waves");
+    __shared__ __attribute__((aligned(16))) char S[2 * STAGE_CH * 16];
+    int mt, nt;
+    if (!tile_coords(nMt, nNt, &mt, &nt, tmode)) return;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wave / WC, wc = wave % WC;
+    const size_t a_pitch = PREC == 0 ? (size_t)2 * ldh_a : (size_t)ldh_a;   // halfs per A row
+    const size_t a_plane = PREC == 0 ? (size_t)ldh_a : (size_t)H_BK, w_plane = PREC == 0 ? plane : (size_t)H_BK;
+
+    // per-lane DMA sources (advance KS halfs per slab) and wave-uniform LDS chunk bases
+    const _Float16* src[NI];
+    int dstc[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int g = wave + NW * i;
+        const int rloc = lane >> 2;
+        if (g < BM / 8) {
+            const int p = g / (BM / 16), rb = g % (BM / 16);
+            const int row = 16 * rb + rloc, q = (lane & 3) ^ ((row >> 2) & 3);
+            const int grow = (dbg & 32) ? row : min(m0 + row, M - 1);   // dbg 32: every workgroup reads row tile 0 (no A traffic)
+            src[i] = A + (size_t)grow * a_pitch + (size_t)p * a_plane + 8 * q;
+            dstc[i] = g * 64;
+        } else {
+            const int g2 = g - BM / 8, p = g2 / (BN / 16), rb = g2 % (BN / 16);
+            const int row = 16 * rb + rloc, q = (lane & 3) ^ ((row >> 2) & 3);
+            src[i] = Wh + (size_t)p * w_plane + (size_t)(n0 + row) * Kpad + 8 * q;
+            dstc[i] = A_CH + g2 * 64;
+        }
+    }
+    auto issue = [&](int stage, int k0) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            __builtin_amdgcn_global_load_lds((glb_vp)(src[i] + k0), (lds_vp)(S + ((size_t)stage * STAGE_CH + dstc[i]) * 16), 16, 0, 0);
+    };
+
+    // fragment read offsets (bytes within a stage) for kk = 0; kk = 16 flips chunk bit 1 (q ^= 2)
+    const int r = lane & 31, h = lane >> 5;
+    int offA[2][RT], offB[2][CT];  // [plane][tile]
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            const int ra = wr * 32 * RT + 32 * t + r;
+            offA[p][t] = ((p * BM + ra) * 4 + (h ^ ((ra >> 2) & 3))) * 16;
+        }
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            const int rb = wc * 32 * CT + 32 * t + r;
+            offB[p][t] = (A_CH + (p * BN + rb) * 4 + (h ^ ((rb >> 2) & 3))) * 16;
+        }
+    }
+
+    f32x16 acc[RT][CT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < CT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nslab = Kpad / KS;
+    issue(0, 0);
+    h8 ah[RT], al[RT], bh[CT], bl[CT];   // plane 0 / plane 1 fragments
+    if (dbg & 8) {   // diagnostic: fragments loaded once, the loop below is MFMA (+ optional barrier) only
+        const char* st0 = S;
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < RT; ++t) { ah[t] = *reinterpret_cast<const h8*>(st0 + offA[0][t]); al[t] = *reinterpret_cast<const h8*>(st0 + offA[1][t]); }
+#pragma unroll
+        for (int t = 0; t < CT; ++t) { bh[t] = *reinterpret_cast<const h8*>(st0 + offB[0][t]); bl[t] = *reinterpret_cast<const h8*>(st0 + offB[1][t]); }
+    }
+    for (int s = 0; s < nslab; ++s) {
+        if (!(dbg & 16)) __syncthreads();  // = s_waitcnt vmcnt(0) + barrier: slab s has landed for every wave, slab s-1's buffer is free
+        if (s + 1 < nslab && !(dbg & 2)) issue((s + 1) & 1, (s + 1) * KS);
+        const char* st = S + (size_t)(s & 1) * STAGE_CH * 16;
+        if (dbg & 4) continue;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            if (!(dbg & 8)) {
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {
+                ah[t] = *reinterpret_cast<const h8*>(st + (offA[0][t] ^ (kk << 5)));
+                al[t] = *reinterpret_cast<const h8*>(st + (offA[1][t] ^ (kk << 5)));
+            }
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+                bh[t] = *reinterpret_cast<const h8*>(st + (offB[0][t] ^ (kk << 5)));
+                bl[t] = *reinterpret_cast<const h8*>(st + (offB[1][t] ^ (kk << 5)));
+            }
+            }
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int j = 0; j < CT; ++j) {
+                    if constexpr (PREC == 0) {
+                        acc[i][j] = h_mfma<PREC>(al[i], bh[j], acc[i][j]);
+                        acc[i][j] = h_mfma<PREC>(ah[i], bl[j], acc[i][j]);
+                        acc[i][j] = h_mfma<PREC>(ah[i], bh[j], acc[i][j]);
+                    } else {   // planes are the two k halves of the slab
+                        acc[i][j] = h_mfma<PREC>(ah[i], bh[j], acc[i][j]);
+                        acc[i][j] = h_mfma<PREC>(al[i], bl[j], acc[i][j]);
+                    }
+                }
+        }
+    }
+    if (dbg & 1) {
+        if (acc[0][0][0] + acc[0][CT - 1][1] + acc[RT - 1][0][2] + acc[RT - 1][CT - 1][3] == 12345.678f && o.f32) o.f32[0] = 1.f;
+        return;
+    }
+    gemm_epilogue_dispatch<PREC, RT, CT>(acc, ep, wscale, m0 + wr * 32 * RT, n0 + wc * 32 * CT, lane, M, N, o, ef);
+}
+
+// host side of p2w_gemm_h2 for one precision (argument checks that do not depend on it are done by the caller)
+template <int PREC>
+static int32_t launch_gemm_h(const _Float16* Ah, int32_t ldh_a, const _Float16* Wp, float wscale, int32_t M, int32_t N, int32_t K,
+                             const EpiArgs& ep, float* out_f32, int32_t ldo, _Float16* out_h2, int32_t ldh_o, int32_t flags,
+                             hipStream_t stream) {
+    constexpr int KA = HCfg<PREC>::kalign;
+    const int Npad = (N + 255) / 256 * 256, Kpad = (K + KA - 1) / KA * KA;
+    if ((ldh_a % KA) != 0 || ldh_a < Kpad) return P2W_EINVAL;     // K padding must exist (and be zero) in A as well
+    if (out_h2 && (ldh_o > Npad || (ldh_o & 7))) return P2W_EINVAL;
+    OutArgs o = {out_f32, ldo, out_h2, ldh_o};
+    const int dbg = (flags >> 16) & 0xff;
+    // 256x256 tiles halve the L2->LDS bytes per MFMA; they need enough tiles to fill the CUs and a wide N:
+    // one 256x256 workgroup per CU is worth it when N has no column padding at that width and the tiles fill >= 78 % of
+    // whole rounds of the chip, from 3/4 of one round up (per-launch A/B over the network's GEMMs: 207 tiles on
+    // 256 CUs still win by 8 %, 340 of 512 or N = 640 padded to 768 lose by 10-25 %)
+    const int n_cu = p2w_cu_count();
+    const long tiles256 = (long)p2w_cdiv(M, 256) * (Npad / 256);
+    const long rounds = (tiles256 + n_cu - 1) / n_cu;
+    const bool fills = tiles256 * 100 >= rounds * n_cu * 78;
+    bool big = N >= 256 && (N % 256) == 0 && tiles256 * 4 >= 3 * n_cu && fills;
+    if (flags & P2W_GEMM_TILE_256) big = true;
+    if (flags & P2W_GEMM_TILE_128) big = false;
+    // epilogue class for the specialised interior-tile path (0 = generic); needs 32-bit element offsets
+    int ef = (ep.relu0 ? 1 : 0) | (ep.sc0 ? 2 : 0) | (ep.relu1 ? 4 : 0) | (ep.sc1 ? 8 : 0) | (ep.relu2 ? 16 : 0) |
+             (ep.residual ? 32 : 0) | (ep.relu_final ? 64 : 0) | (out_f32 ? 128 : 0) | (out_h2 ? 256 : 0);
+    const size_t lim = (size_t)1 << 31;
+    if ((size_t)M * (size_t)(ldo > 2 * ldh_o ? ldo : 2 * ldh_o) >= lim || (ep.residual && (size_t)M * ep.ldr >= lim) ||
+        (N & 1) || (flags & P2W_GEMM_GENERIC_EPI))
+        ef = 0;
+    // tile order: keep W L2-resident per XCD when it does not fit an XCD's L2 (see tile_coords)
+    const size_t w_bytes = (size_t)N * Kpad * 2 * HCfg<PREC>::planes;
+    auto pick_mode = [&](int nNtx) {
+        const bool ok = nNtx >= 8 || (nNtx > 0 && 8 % nNtx == 0);
+        if (!ok) return 0;
+        if (flags & P2W_GEMM_ORDER_ROWS) return 0;
+        if (flags & P2W_GEMM_ORDER_COLS) return 1;
+        return w_bytes > (size_t)3 * 1024 * 1024 ? 1 : 0;
+    };
+    if (big) {
+        const int nMt = p2w_cdiv(M, 256), nNt2 = Npad / 256;
+        const int tm = pick_mode(nNt2);
+        gemm_h2g_kernel<PREC, 2, 4, 4, 2><<<tile_grid(nMt, nNt2, tm), 512, 0, stream>>>(
+            Ah, ldh_a, Wp, (size_t)Npad * Kpad, wscale, M, N, Kpad, nMt, nNt2, ep, o, dbg, ef, tm);
+    } else {
+        const int nMt = p2w_cdiv(M, 128), nNt1 = p2w_cdiv(N, 128);
+        const int tm = pick_mode(nNt1);
+        gemm_h2g_kernel<PREC, 2, 2, 2, 2><<<tile_grid(nMt, nNt1, tm), 256, 0, stream>>>(
+            Ah, ldh_a, Wp, (size_t)Npad * Kpad, wscale, M, N, Kpad, nMt, nNt1, ep, o, dbg, ef, tm);
+    }
+    return P2W_LAUNCH_STATUS();
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused PointNetConv over H weights, two kernels:
+//  1. sa_edge_meta_kernel (p2w_feat.hip): one thread per (target, slot): source index j and g = (rel/(dmax+1e-8),
+//     refl_j) (pointnet.py:119-129) -> meta_j[M*32], meta_g[M*32] (20 B per slot).  The chain of dependent loads
+//     (deg -> nbr -> xyzr) is hidden by plain occupancy there instead of stalling a GEMM-shaped workgroup.
+//  2. sa_conv16p_kernel: PERSISTENT workgroups (one per CU, 8 waves) walk (row tile, column tile) work items; the
+//     K slabs of consecutive items form ONE software pipeline: while slab g runs on the MFMAs, slab g+1's W2 DMA,
+//     P-row gather and A production (possibly of the NEXT item) are in flight, and the next item's metadata is
+//     prefetched a whole item ahead.  Rows of the GEMM = (target, neighbour slot); a 32-row MFMA tile = one target,
+//     so the max over neighbours is a max over the accumulator tile's rows (16 registers + one lane^32 exchange) and
+//     the [E, C] edge tensors of the reference never exist in HBM.
+// ------------------------------------------------------------------------------------------------
+template <int RT> struct SaEpiRegs { float bias[2], s[2], t[2]; int d[RT]; };
+// layer-2 bias + ReLU + BN affine, then max over the target's valid neighbour slots (rows of the 32-row MFMA tile)
+template <int PREC, int RT>   // RT 32-row tiles (= targets) per wave
+__device__ __forceinline__ void sa_epilogue_regs(const f32x16 (&acc)[RT][2], float wscale, int t0, int n0, int wr, int wc,
+                                                 int lane, int M, const SaEpiRegs<RT>& e, int C2, float* __restrict__ out, int ldo,
+                                                 _Float16* __restrict__ out_h2, int ldh) {
+    const int h = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+        const int tgt = t0 + wr * RT + i;
+        if (tgt >= M) continue;
+        const int d = e.d[i];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wc * 64 + j * 32 + (lane & 31);
+            const bool cv = col < C2;
+            float vmax = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int slot = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float v = fmaf(fmaxf(fmaf(acc[i][j][r], wscale, e.bias[j]), 0.f), e.s[j], e.t[j]);
+                if (slot < d) vmax = fmaxf(vmax, v);
+            }
+            vmax = fmaxf(vmax, __shfl_xor(vmax, 32));
+            if (d == 0) vmax = 0.f;
+            if (cv && h == 0 && out) out[(size_t)tgt * ldo + col] = vmax;
+            if (out_h2) {  // lanes (2p, 2p+1) hold adjacent columns: the even lane stores both as one word per plane
+                const float nb = __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(vmax), 0xB1, 0xf, 0xf, false));
+                if (h == 0 && (lane & 1) == 0 && col < ldh) h_store2<PREC>(out_h2, ldh, tgt, col, vmax, nb);
+            }
+        }
+    }
+}
+
+// <BN, RT>: <256, 2>: 4 targets x 256 columns (waves 2 x 4, wave tile 64 x 64);  <128, 2>: 8 targets x 128 columns (waves 4 x 2)
+// (one workgroup per CU either way: LDS).  The A operand is produced on the VALU; in the single-plane modes a slab is
+// 32 k of ONE plane (half the LDS image and DMA, one MFMA per tile pair and k step).
+template <int PREC, int BN, int RT>
+__global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restrict__ P, int ldp, const int* __restrict__ meta_j,
+                                                            const float4* __restrict__ meta_g, const int* __restrict__ deg,
+                                                            int kw, int M, const float* __restrict__ w1r4, int C1, int C1pad,
+                                                            const _Float16* __restrict__ W2h, size_t plane, float wscale, int C2,
+                                                            int nMt, int nNt, const float* __restrict__ b2,
+                                                            const float* __restrict__ bn_s, const float* __restrict__ bn_t,
+                                                            float* __restrict__ out, int ldo, _Float16* __restrict__ out_h2,
+                                                            int ldh, int dbg_) {
+    // dbg (profiling ablations, -DP2W_SA_ABLATE builds only): 1 no epilogue, 2 no W2 DMA after the first, 4 no MFMA,
+    // 8 no producer, 16 no P gather
+#ifdef P2W_SA_ABLATE
+    const int dbg = dbg_;
+#else
+    constexpr int dbg = 0;
+    (void)dbg_;
+#endif
+    constexpr int NP = HCfg<PREC>::planes;
+    constexpr int WCn = BN / 64, BM = 32 * RT * (8 / WCn), NW = 8, NR = BM / 128;   // NR producer rows per thread
+    constexpr int A_CH = 4 * NP * BM, STAGE_CH = A_CH + 4 * NP * BN;
+    constexpr int NI = (4 * NP * BN) / 64 / NW;
+    static_assert(NI >= 1, "every wave issues at least one W2 DMA piece per slab");
+    __shared__ __attribute__((aligned(16))) char S[2 * STAGE_CH * 16];
+    __shared__ __attribute__((aligned(16))) float Wr[4 * 512];   // layer-1 geometry weights (rx, ry, rz, refl rows), C1pad <= 512
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < 4 * C1pad; i += 512) Wr[i] = w1r4[i];
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wave / WCn, wc = wave % WCn;
+    const int nitems = nMt * nNt, nslab = C1pad / H_BK;
+    // XCD-aware work assignment: workgroups b, b+8, b+16.. share an XCD (round-robin dispatch) and therefore an L2.
+    // Each XCD walks ONE contiguous chunk of work items, its workgroups taking consecutive items at every step, so the
+    // P rows gathered by an XCD at any time belong to spatially adjacent targets (levels are stored in grid-cell
+    // order) and are re-used out of that XCD's L2 instead of being streamed by all eight.
+    int first, stride, limit;
+    if ((gridDim.x & 7) == 0) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per = gridDim.x >> 3;
+        const int chunk = (nitems + 7) >> 3;
+        first = xcd * chunk + slot; stride = per; limit = min((xcd + 1) * chunk, nitems);
+    } else {
+        first = blockIdx.x; stride = gridDim.x; limit = nitems;
+    }
+    if (first >= limit) return;
+    const int my_items = (limit - first + stride - 1) / stride;
+    const int total = my_items * nslab;
+
+    // item -> (row tile, column tile): column tiles of one row tile are adjacent work items
+    auto item_mt = [&](int it) { return (first + it * stride) / nNt; };
+    auto item_nt = [&](int it) { return (first + it * stride) % nNt; };
+
+    const int prow = tid >> 2, pq = tid & 3;   // rows prow + 128*u, u < NR ((row>>2)&3 is the same for all of them)
+    const int a_dst = (prow * 4 + (pq ^ ((prow >> 2) & 3))) * 16;
+    // per-lane pieces of the B DMA source that do not depend on the item
+    size_t boff[NI];
+    int dstc[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int g2 = wave + NW * i, p = g2 / (BN / 16), rb = g2 % (BN / 16);
+        const int row = 16 * rb + (lane >> 2), q = (lane & 3) ^ ((row >> 2) & 3);
+        boff[i] = (size_t)p * plane + (size_t)row * C1pad + 8 * q;
+        dstc[i] = A_CH + g2 * 64;
+    }
+    auto issue = [&](int stage, const _Float16* wbase, int k0) {   // wbase = W2h + nt * BN * C1pad (per item)
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            __builtin_amdgcn_global_load_lds((glb_vp)(wbase + boff[i] + k0),
+                                             (lds_vp)(S + ((size_t)stage * STAGE_CH + dstc[i]) * 16), 16, 0, 0);
+    };
+    // metadata of the producer's edge row (clamped: rows past the last target replay the last valid row)
+    struct Meta { int j[NR]; float4 g[NR]; };
+    struct Vals { float4 v[NR][2]; };
+    auto load_meta = [&](int it, Meta& m) {
+#pragma unroll
+        for (int u = 0; u < NR; ++u) {
+            long row = (long)item_mt(it) * BM + prow + 128 * u;
+            const long last = (long)M * 32 - 1;
+            row = row < last ? row : last;
+            m.j[u] = meta_j[row];      // < 0: empty neighbour slot (its row is masked in the epilogue)
+            m.g[u] = meta_g[row];
+        }
+    };
+    Vals pv;    // slab 0 only (prologue)
+    auto gather = [&](const Meta& m, int k0, Vals& dst) {
+        const int k = k0 + 8 * pq;
+#pragma unroll
+        for (int u = 0; u < NR; ++u) {
+            const bool on = m.j[u] >= 0;
+            const float* p = P + (size_t)(on ? m.j[u] : 0) * ldp + 8 * pq + k0;
+            dst.v[u][0] = (on && k < C1) ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+            dst.v[u][1] = (on && k + 4 < C1) ? *reinterpret_cast<const float4*>(p + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto produce = [&](int stage, const Meta& m, int k0, const Vals& src) {
+        const int k = k0 + 8 * pq;
+#pragma unroll
+      for (int u = 0; u < NR; ++u) {
+        const float4 rg = m.g[u];
+        const bool on = m.j[u] >= 0;
+        unsigned hiw[4], low[4];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int kk = k + 4 * half;
+            // branch-free (so the scheduler can interleave it with MFMAs): Wr is zero-padded to C1pad, P values of
+            // empty slots / padded k are zero, and the geometry term is switched off with a select
+            const float4 wx = *reinterpret_cast<const float4*>(&Wr[0 * C1pad + kk]);
+            const float4 wy = *reinterpret_cast<const float4*>(&Wr[1 * C1pad + kk]);
+            const float4 wz = *reinterpret_cast<const float4*>(&Wr[2 * C1pad + kk]);
+            const float4 wf = *reinterpret_cast<const float4*>(&Wr[3 * C1pad + kk]);
+            const float4 p = src.v[u][half];
+            const float gx = on ? rg.x : 0.f, gy = on ? rg.y : 0.f, gz = on ? rg.z : 0.f, gw = on ? rg.w : 0.f;
+            float v[4];
+            v[0] = fmaxf(fmaf(gw, wf.x, fmaf(gz, wz.x, fmaf(gy, wy.x, fmaf(gx, wx.x, p.x)))), 0.f);
+            v[1] = fmaxf(fmaf(gw, wf.y, fmaf(gz, wz.y, fmaf(gy, wy.y, fmaf(gx, wx.y, p.y)))), 0.f);
+            v[2] = fmaxf(fmaf(gw, wf.z, fmaf(gz, wz.z, fmaf(gy, wy.z, fmaf(gx, wx.z, p.z)))), 0.f);
+            v[3] = fmaxf(fmaf(gw, wf.w, fmaf(gz, wz.w, fmaf(gy, wy.w, fmaf(gx, wx.w, p.w)))), 0.f);
+            if constexpr (PREC == 0) {
+                unsigned h01, l01, h23, l23;
+                split_pair(v[0], v[1], h01, l01);
+                split_pair(v[2], v[3], h23, l23);
+                hiw[2 * half] = h01; hiw[2 * half + 1] = h23;
+                low[2 * half] = l01; low[2 * half + 1] = l23;
+            } else {
+                hiw[2 * half] = pack_pair<PREC>(v[0], v[1]); hiw[2 * half + 1] = pack_pair<PREC>(v[2], v[3]);
+            }
+        }
+        char* st = S + (size_t)stage * STAGE_CH * 16;
+        *reinterpret_cast<uint4*>(st + a_dst + u * 128 * 64) = make_uint4(hiw[0], hiw[1], hiw[2], hiw[3]);
+        if constexpr (PREC == 0)
+            *reinterpret_cast<uint4*>(st + BM * 64 + a_dst + u * 128 * 64) = make_uint4(low[0], low[1], low[2], low[3]);
+      }
+    };
+
+    const int r = lane & 31, h = lane >> 5;
+    int offA[NP][RT], offB[NP][2];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            const int ra = wr * 32 * RT + 32 * t + r;
+            offA[p][t] = ((p * BM + ra) * 4 + (h ^ ((ra >> 2) & 3))) * 16;
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int rb = wc * 64 + 32 * t + r;
+            offB[p][t] = (A_CH + (p * BN + rb) * 4 + (h ^ ((rb >> 2) & 3))) * 16;
+        }
+    }
+    f32x16 acc[RT][2];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // Software pipeline over the flattened slab sequence g = 0..total-1 of this workgroup's items:
+    //   MFMA stage    : slab g        (reads LDS stage g&1)
+    //   produce stage : slab g+1      (A rows: VALU on P values gathered one slab EARLIER, written to stage (g+1)&1;
+    //                                  placed between the two MFMA groups of slab g so it co-issues with MFMAs in flight)
+    //   gather stage  : slab g+2      (global loads of P rows + W2 DMA of slab g+1 issued right after the barrier)
+    // Metadata (source row, normalised offset) of an item is prefetched one item ahead of the gather stage.
+    int it_q = 0, s_q = 0;                   // item / slab of the gather stage
+    Meta m_q, m_nxt;
+    load_meta(0, m_q);
+    m_nxt = m_q;
+    if (my_items > 1) load_meta(1, m_nxt);
+    auto advance_q = [&]() {                 // move the gather stage to the next slab (possibly the next item)
+        if (++s_q == nslab) {
+            s_q = 0; ++it_q;
+            m_q = m_nxt;
+            if (it_q + 1 < my_items) load_meta(it_q + 1, m_nxt);
+        }
+    };
+    // prologue: slab 0 produced synchronously, slab 1 gathered
+    auto load_epi = [&](int mt_, int nt_, SaEpiRegs<RT>& e) {   // parameters of an item's epilogue, fetched an item ahead
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = nt_ * BN + wc * 64 + j * 32 + (lane & 31);
+            const bool cv = col < C2;
+            e.bias[j] = cv ? b2[col] : 0.f; e.s[j] = cv ? bn_s[col] : 0.f; e.t[j] = cv ? bn_t[col] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+            const int tgt = mt_ * (BM / 32) + wr * RT + i;
+            e.d[i] = tgt < M ? min(deg[tgt], kw) : 0;
+        }
+    };
+    SaEpiRegs<RT> e_cur, e_1;
+    load_epi(item_mt(0), item_nt(0), e_cur);
+    e_1 = e_cur;
+    const _Float16* wb1 = W2h + (size_t)item_nt(0) * BN * C1pad;   // W2 panel of the item in the produce stage
+    int mt_cur = item_mt(0), nt_cur = item_nt(0);                   // item in the MFMA stage
+    int mt_1 = mt_cur, nt_1 = nt_cur;                               // item in the produce stage
+    __syncthreads();   // Wr staged
+    issue(0, wb1, 0);
+    gather(m_q, 0, pv);
+    produce(0, m_q, 0, pv);
+    Vals pn = pv;          // gathered values of slab g+1
+    Meta m_n = m_q;
+    int k_n = 0;
+    if (total > 1) {
+        advance_q();
+        gather(m_q, s_q * H_BK, pn);
+        m_n = m_q; k_n = s_q * H_BK;
+    }
+    int it = 0, s = 0;                       // item / slab of the MFMA stage
+    int it1 = 0, s1 = 0;                     // item / slab of the produce stage (g+1)
+    for (int g = 0; g < total; ++g) {
+        __syncthreads();  // B(g) landed, A(g) written, stage (g+1)&1 free  (a counted vmcnt that leaves the gather in
+                          // flight across the barrier measured 2 % slower)
+        const bool more = g + 1 < total;
+        if (more) {
+            s1 = s + 1; it1 = it;
+            if (s1 == nslab) {
+                s1 = 0; it1 = it + 1;
+                mt_1 = item_mt(it1); nt_1 = item_nt(it1);
+                wb1 = W2h + (size_t)nt_1 * BN * C1pad;
+                load_epi(mt_1, nt_1, e_1);
+            }
+            if (!(dbg & 2)) issue((g + 1) & 1, wb1, s1 * H_BK);
+        }
+        // values for the produce stage were gathered during the previous iteration
+        const Vals pu = pn;
+        const Meta m_u = m_n;
+        const int k_u = k_n;
+        // The gather of slab g+2 is issued here and lands in `pg` while this iteration's MFMAs run; it is only moved
+        // into the loop-carried registers at the END of the iteration (a register copy is a use: placed here, it
+        // would make the compiler wait for the loads before the first MFMA).
+        Vals pg = pn;
+        const bool fetch = g + 2 < total;
+        if (fetch) {
+            advance_q();
+            if (!(dbg & 16)) gather(m_q, s_q * H_BK, pg);
+        }
+        const char* st = S + (size_t)(g & 1) * STAGE_CH * 16;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            h8 af[NP][RT], bf[NP][2];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+#pragma unroll
+                for (int t = 0; t < RT; ++t) af[p][t] = *reinterpret_cast<const h8*>(st + (offA[p][t] ^ (kk << 5)));
+#pragma unroll
+                for (int t = 0; t < 2; ++t) bf[p][t] = *reinterpret_cast<const h8*>(st + (offB[p][t] ^ (kk << 5)));
+            }
+            if (!(dbg & 4)) {
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if constexpr (PREC == 0) {
+                        acc[i][j] = h_mfma<PREC>(af[1][i], bf[0][j], acc[i][j]);
+                        acc[i][j] = h_mfma<PREC>(af[0][i], bf[1][j], acc[i][j]);
+                    }
+                    acc[i][j] = h_mfma<PREC>(af[0][i], bf[0][j], acc[i][j]);
+                }
+            }
+            if (kk == 0 && !(dbg & 8)) {  // producer VALU work is interleaved into the gaps of the MFMAs above
+                produce((g + 1) & 1, m_u, k_u, pu);   // unconditional: after the last slab it fills a stage nobody reads
+                constexpr int NM = 2 * RT * (PREC == 0 ? 3 : 1);   // MFMAs of this half slab
+#pragma unroll
+                for (int q = 0; q < NM; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, (PREC == 0 ? 16 : 40) * NR / RT, 0);   // VALU
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (s == nslab - 1 && !(dbg & 1)) {  // item finished: reduce over neighbour slots and store, then start the next accumulation
+            sa_epilogue_regs<PREC, RT>(acc, wscale, mt_cur * (BM / 32), nt_cur * BN, wr, wc, lane, M, e_cur, C2, out, ldo, out_h2, ldh);
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        }
+        if (s == nslab - 1) e_cur = e_1;
+        s = s1; it = it1; mt_cur = mt_1; nt_cur = nt_1;
+        __builtin_amdgcn_sched_barrier(0);
+        if (fetch) { pn = pg; m_n = m_q; k_n = s_q * H_BK; }
+    }
+}
+
+__global__ __launch_bounds__(256) void sa_edge_meta_kernel(const float4* __restrict__ xyzr, const int* __restrict__ idx, const int* __restrict__ batch_dst,
+                                    const float* __restrict__ sf, const int* __restrict__ nbr, const int* __restrict__ deg, int kw,
+                                    int M, int* __restrict__ meta_j, float4* __restrict__ meta_g);
+
+// host side of p2w_sa_conv_h for one precision (pointer / size checks are done by the caller)
+template <int PREC>
+static int32_t launch_sa_conv_h(const float* P, int32_t ldp, const float* xyzr_src, const int32_t* idx, const int32_t* batch_dst,
+                                const float* sf, const int32_t* nbr, const int32_t* deg, int32_t kw, int32_t M,
+                                const float* w1r4, const _Float16* W2h, float wscale, int32_t C1, int32_t C2, const float* b2,
+                                const float* bn_s, const float* bn_t, float* out, int32_t ldo, _Float16* out_h2, int32_t ldh,
+                                void* ws, size_t ws_bytes, int32_t flags, hipStream_t stream) {
+    constexpr int KA = HCfg<PREC>::kalign;
+    const int C2pad = (C2 + 255) / 256 * 256, C1pad = (C1 + KA - 1) / KA * KA;
+    if (C1pad > 512) return P2W_EUNSUPPORTED;
+    if (ws == nullptr || ws_bytes < (size_t)M * 32 * 20) return P2W_EWORKSPACE;
+    if (reinterpret_cast<uintptr_t>(ws) & 15u) return P2W_EALIGN;
+    float4* meta_g = static_cast<float4*>(ws);
+    int* meta_j = reinterpret_cast<int*>(meta_g + (size_t)M * 32);
+    sa_edge_meta_kernel<<<p2w_cdiv((long)M * 32, 256), 256, 0, stream>>>(
+        reinterpret_cast<const float4*>(xyzr_src), idx, batch_dst, sf, nbr, deg, kw, M, meta_j, meta_g);
+    const int n_cu = p2w_cu_count();
+    const bool wide = C2 > 128;
+    const int sadbg = (flags >> 16) & 0xff;
+    const int nMt3 = p2w_cdiv(M, wide ? 4 : 8), nNt3 = p2w_cdiv(C2, wide ? 256 : 128);
+    const long items = (long)nMt3 * nNt3;
+    int grid = (int)(items < n_cu ? items : n_cu);
+    if (grid >= 8) grid &= ~7;   // whole XCD rounds (see the kernel's work assignment)
+    if (wide)
+        sa_conv16p_kernel<PREC, 256, 2><<<grid, 512, 0, stream>>>(
+            P, ldp, meta_j, meta_g, deg, kw, M, w1r4, C1, C1pad, W2h, (size_t)C2pad * C1pad, wscale, C2, nMt3, nNt3, b2, bn_s,
+            bn_t, out, ldo, out_h2, ldh, sadbg);
+    else
+        sa_conv16p_kernel<PREC, 128, 2><<<grid, 512, 0, stream>>>(
+            P, ldp, meta_j, meta_g, deg, kw, M, w1r4, C1, C1pad, W2h, (size_t)C2pad * C1pad, wscale, C2, nMt3, nNt3, b2, bn_s,
+            bn_t, out, ldo, out_h2, ldh, sadbg);
+    return P2W_LAUNCH_STATUS();
+}
+
+// entry points of the single-plane family (defined in p2w_feat_h1.hip, called by the extern "C" dispatchers)
+int32_t p2w_gemm_h1_impl(int32_t prec, const _Float16* Ah, int32_t ldh_a, const _Float16* Wp, float wscale, int32_t M, int32_t N,
+                         int32_t K, const EpiArgs& ep, float* out_f32, int32_t ldo, _Float16* out_h2, int32_t ldh_o,
+                         int32_t flags, hipStream_t stream);
+int32_t p2w_sa_conv_h1_impl(int32_t prec, const float* P, int32_t ldp, const float* xyzr_src, const int32_t* idx,
+                            const int32_t* batch_dst, const float* sf, const int32_t* nbr, const int32_t* deg, int32_t kw,
+                            int32_t M, const float* w1r4, const _Float16* W2h, float wscale, int32_t C1, int32_t C2,
+                            const float* b2, const float* bn_s, const float* bn_t, float* out, int32_t ldo, _Float16* out_h2,
+                            int32_t ldh, void* ws, size_t ws_bytes, int32_t flags, hipStream_t stream);

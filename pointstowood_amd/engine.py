@@ -25,7 +25,7 @@ from dataclasses import dataclass, field
 import torch
 
 from . import _lib
-from ._lib import SEARCH_Q_ROW_IN_W, SEARCH_X_INDEX_IN_W, Epilogue, check, lib, ptr
+from ._lib import PREC_F16X3, PREC_OF, SEARCH_Q_ROW_IN_W, SEARCH_X_INDEX_IN_W, Epilogue, check, lib, ptr
 
 BN_EPS = 1e-5
 SA_RES = (0.04, 0.08, 0.16)  # model.py:210-212
@@ -47,7 +47,8 @@ class Linear:
     relu1: int = 0
     relu2: int = 0
     relu_final: int = 0
-    w16: torch.Tensor | None = None   # [2, N_pad, K_pad] fp16: hi / lo planes of W * 2^e  (f16x3 path)
+    w16: torch.Tensor | None = None   # H weights of W * 2^e: [2, N_pad, K_pad] fp16 hi / lo planes (f16x3),
+                                      # [N_pad, K_pad] fp16 / bf16 (single-plane precisions)
     wscale: float = 1.0               # 2^-e
 
 
@@ -60,8 +61,9 @@ def _bn_affine(sd, p):
 class PackedWeights:
     """Device-resident, kernel-ready form of the reference's 257-key state dict."""
 
-    def __init__(self, sd, C_: int, num_classes: int, device):
-        self.C, self.num_classes, self.device = C_, num_classes, device
+    def __init__(self, sd, C_: int, num_classes: int, device, precision: str = "f16x3"):
+        self.C, self.num_classes, self.device, self.precision = C_, num_classes, device, precision
+        prec = PREC_OF.get(precision)   # None: fp32 MFMA (no H weights needed, K padded to 32)
         if C_ % 4 != 0:
             raise ValueError("C must be a multiple of 4 (16-byte feature rows)")
         sd = {k: v.detach().cpu() for k, v in sd.items()}
@@ -71,19 +73,24 @@ class PackedWeights:
         def pack(W, **kw):
             W = W.double()
             N, K = W.shape
-            Np, Kp = _lib.packed_dims(N, K)
+            Np, Kp = _lib.packed_dims(N, K, prec)
             Wp = torch.zeros((Np, Kp), dtype=torch.float64)
             Wp[:N, :K] = W
             vec = {k: (f32(v) if isinstance(v, torch.Tensor) else v) for k, v in kw.items()}
-            # split-fp16 form: scale by a power of two so the largest weight sits near 2^10 (lo parts stay normal fp16)
+            if prec is None:
+                return Linear(w=f32(Wp), N=N, K=K, **vec)
+            # 16-bit forms: scale by a power of two so the largest weight sits near 2^10 (f16x3: lo parts stay normal fp16)
             amax = float(Wp.abs().max())
             e = int(math.floor(math.log2(1024.0 / amax))) if amax > 0 else 0
             e = max(-24, min(24, e))
             Ws = Wp * (2.0 ** e)
-            hi = Ws.to(torch.float32).to(torch.float16)
-            lo = (Ws - hi.double()).to(torch.float32).to(torch.float16)
-            w16 = torch.stack([hi, lo]).contiguous().to(device)
-            return Linear(w=f32(Wp), N=N, K=K, w16=w16, wscale=2.0 ** (-e), **vec)
+            if prec == PREC_F16X3:
+                hi = Ws.to(torch.float32).to(torch.float16)
+                lo = (Ws - hi.double()).to(torch.float32).to(torch.float16)
+                w16 = torch.stack([hi, lo]).contiguous().to(device)
+            else:   # one plane, round to nearest
+                w16 = Ws.to(torch.float32).to(torch.float16 if precision == "fp16" else torch.bfloat16).contiguous().to(device)
+            return Linear(w=None, N=N, K=K, w16=w16, wscale=2.0 ** (-e), **vec)
 
         self.stem_w = f32(sd["stem_mlp.0.0.weight"])
         self.stem_b = f32(sd["stem_mlp.0.0.bias"])
@@ -96,7 +103,7 @@ class PackedWeights:
             W2, b2 = sd[p + ".conv.local_nn.1.0.weight"], sd[p + ".conv.local_nn.1.0.bias"]
             C2 = W2.shape[0]
             s2, t2 = _bn_affine(sd, p + ".conv.local_nn.1.2")
-            _, C1p = _lib.packed_dims(C2, C1)
+            _, C1p = _lib.packed_dims(C2, C1, prec)
             w1r4 = torch.zeros((4, C1p), dtype=torch.float32)
             w1r4[:, :C1] = W1[:, f_in:f_in + 4].t()
             lvl = {
@@ -211,16 +218,23 @@ class Engine:
     def __init__(self, weights: PackedWeights, k: int = 32, precision: str = "f16x3"):
         self.w = weights
         self.k = int(k)
-        if precision not in ("f16x3", "fp32"):
-            raise ValueError("precision must be 'f16x3' (split-fp16 MFMA, fp32-class accuracy) or 'fp32' (fp32 MFMA)")
+        if precision not in ("f16x3", "fp32", "fp16", "bf16"):
+            raise ValueError("precision must be 'f16x3' (split-fp16 MFMA, fp32-class accuracy: the parity default), 'fp32' "
+                             "(fp32 MFMA), or 'fp16' / 'bf16' (one MFMA per product: the reference's autocast arithmetic, "
+                             "does not meet the 1e-4 probability bar)")
+        if getattr(weights, "precision", precision) != precision:
+            raise ValueError(f"weights were packed for precision {weights.precision!r}, not {precision!r}")
         self.precision = precision
+        self.prec = PREC_OF.get(precision)   # P2W_PREC_* of the H family, None for fp32
         if not 1 <= self.k <= 32:
-            raise ValueError("k must be in 1..32 (one 32-row MFMA tile per target)")
+            raise ValueError("k must be in 1..32: the fused PointNetConv maps a target's neighbour slots onto one 32-row MFMA "
+                             "tile (P2W_MAX_K_CONV in include/p2w.h); the reference hard-codes k = 32 (model.py:210-212)")
         self.feature_streams = int(os.environ.get("P2W_FEATURE_STREAMS", "1"))  # Net.stream(): feature phases in flight
         self.chunk_pick = int(os.environ.get("P2W_CHUNK_PICK", "1"))       # fill-aware chunk sizes (pick_chunk); 0: plain budget
         self.fp_hints = os.environ.get("P2W_FP_HINTS", "1") != "0"           # seed the interpolation searches from the sampler
         self.res_streams = int(os.environ.get("P2W_RES_STREAMS", "1"))      # residual-block chunk chains in flight (2: +0.6 %, measured)
         self.res_chunk_rows = int(os.environ.get("P2W_RES_CHUNK", "65536"))   # rows (at 4F=512) per residual-block chunk; 0 = whole level
+        self.gemm_flags = int(os.environ.get("P2W_GEMM_FLAGS", "0"))          # P2W_GEMM_* bits of include/p2w.h (A/B runs)
         self.events = None  # set to a list to record (name, start, end) events per launch
         self.events_grouped = False   # True: (name, start, end, launches) per run of consecutive same-name launches
         self._open = None
@@ -264,11 +278,7 @@ class Engine:
     def _gemm(self, name, A, lda, M, lin: Linear, out, ldo, residual=None, ldr=0):
         ep = Epilogue(ptr(lin.bias), ptr(lin.sc0), ptr(lin.sh0), ptr(lin.sc1), ptr(lin.sh1), ptr(residual), ldr,
                       lin.relu0, lin.relu1, lin.relu2, lin.relu_final)
-        if self.precision == "f16x3":   # only the (tiny) multi-class head reaches here in f16x3 mode: fp32 A operand
-            self._call(name, lib().p2w_gemm_f16x3, ptr(A), lda, ptr(lin.w16), lin.wscale, M, lin.N, lin.K, C.byref(ep),
-                       ptr(out), ldo)
-        else:
-            self._call(name, lib().p2w_gemm, ptr(A), lda, ptr(lin.w), M, lin.N, lin.K, C.byref(ep), ptr(out), ldo)
+        self._call(name, lib().p2w_gemm, ptr(A), lda, ptr(lin.w), M, lin.N, lin.K, C.byref(ep), ptr(out), ldo)
 
     def _workspace(self, n, device):
         need = int(lib().p2w_voxel_sample_ws_bytes(n))
@@ -383,27 +393,31 @@ class Engine:
 
     # -- phase 2 ------------------------------------------------------------------------------
     def features(self, geo: Geometry, keep: dict | None = None):
-        if self.precision == "f16x3":
+        if self.prec is not None:
             return self._features_h2(geo, keep)
         return self._features_fp32(geo, keep)
 
     def _gemm_h2(self, name, A, ldh_a, M, lin: Linear, out_f32=None, ldo=0, out_h2=None, ldh_o=0, residual=None, ldr=0):
         ep = Epilogue(ptr(lin.bias), ptr(lin.sc0), ptr(lin.sh0), ptr(lin.sc1), ptr(lin.sh1), ptr(residual), ldr,
                       lin.relu0, lin.relu1, lin.relu2, lin.relu_final)
-        self._call(name, lib().p2w_gemm_h2, ptr(A), ldh_a, ptr(lin.w16), lin.wscale, M, lin.N, lin.K, C.byref(ep),
-                   ptr(out_f32), ldo, ptr(out_h2), ldh_o)
+        self._call(name, lib().p2w_gemm_h2, self.prec, ptr(A), ldh_a, ptr(lin.w16), lin.wscale, M, lin.N, lin.K, C.byref(ep),
+                   ptr(out_f32), ldo, ptr(out_h2), ldh_o, self.gemm_flags)
 
     def _features_h2(self, geo: Geometry, keep: dict | None = None):
-        """f16x3 pipeline: every GEMM operand is an H2 tensor (fp16 hi/lo planes) written once by its producer."""
+        """H pipeline (f16x3 / fp16 / bf16): every GEMM operand is an H tensor (16-bit planes: fp16 hi/lo for f16x3, one
+        fp16 / bf16 plane otherwise) written once by its producer."""
         L, w = lib(), self.w
         dev = geo.sf.device
         Cw = w.C
         new = lambda r, c: torch.empty((r, c), dtype=torch.float32, device=dev)
-        pad8 = lambda f: (f + 31) // 32 * 32   # H2 row pitch: zero-padded to the GEMM's K slab so it can be DMA-staged
-        newh = lambda r, f: torch.empty((r, 2 * pad8(f)), dtype=torch.float16, device=dev)
+        prec = self.prec
+        ka, planes = (32, 2) if prec == PREC_F16X3 else (64, 1)
+        hdt = torch.bfloat16 if self.precision == "bf16" else torch.float16
+        pad8 = lambda f: (f + ka - 1) // ka * ka   # H row pitch: zero-padded to the GEMM's K slab so it can be DMA-staged
+        newh = lambda r, f: torch.empty((r, planes * pad8(f)), dtype=hdt, device=dev)
         lv, N, B = geo.levels, geo.N, geo.B
         x, xh = [new(N, Cw)], [newh(N, Cw)]
-        self._call("stem", L.p2w_stem_h2, ptr(lv[0].xyzr), N, ptr(w.stem_w), ptr(w.stem_b), Cw, ptr(x[0]), ptr(xh[0]),
+        self._call("stem", L.p2w_stem_h2, prec, ptr(lv[0].xyzr), N, ptr(w.stem_w), ptr(w.stem_b), Cw, ptr(x[0]), ptr(xh[0]),
                    pad8(Cw))
         self.stem_out = x[0]
         if keep is not None:
@@ -415,10 +429,10 @@ class Engine:
             self._gemm_h2("gemm_hoist", xh[l - 1], pad8(p["F_in"]), src.n, p["hoist"], out_f32=P, ldo=C1)
             conv, convh = new(M, C2), newh(M, C2)
             meta = torch.empty(M * 32 * 20, dtype=torch.uint8, device=dev)   # per-edge (j, normalised offset) scratch
-            self._call("sa_conv", L.p2w_sa_conv_f16x3, ptr(P), C1, ptr(src.xyzr), ptr(dst.idx), ptr(dst.batch),
+            self._call("sa_conv", L.p2w_sa_conv_h, prec, ptr(P), C1, ptr(src.xyzr), ptr(dst.idx), ptr(dst.batch),
                        ptr(geo.sf), ptr(dst.nbr), ptr(dst.deg), geo.k, M, ptr(p["w1r4"]), ptr(p["W2"].w16),
                        p["W2"].wscale, C1, C2, ptr(p["b2"]), ptr(p["bn_s"]), ptr(p["bn_t"]), ptr(conv), C2, ptr(convh),
-                       pad8(C2), ptr(meta), meta.numel())
+                       pad8(C2), ptr(meta), meta.numel(), 0)
             out = new(M, C2)
             outh = newh(M, C2) if l < 3 else None
             # residual block in row chunks: the two 4F-wide intermediates of a chunk (2 x chunk x 4F x 4 B) are written
@@ -459,7 +473,7 @@ class Engine:
         # GlobalSAModule (model.py:134-140)
         F3, M3 = 16 * Cw, lv[3].n
         cat = newh(M3, F3 + 4)
-        self._call("concat_xyz", L.p2w_concat_xyz_h2, ptr(x[3]), F3, ptr(lv[3].xyzr), M3, ptr(cat), pad8(F3 + 4))
+        self._call("concat_xyz", L.p2w_concat_xyz_h2, prec, ptr(x[3]), F3, ptr(lv[3].xyzr), M3, ptr(cat), pad8(F3 + 4))
         h1, h2 = newh(M3, F3), new(M3, F3)
         self._gemm_h2("gemm_mlp", cat, pad8(F3 + 4), M3, w.sa4[0], out_h2=h1, ldh_o=pad8(F3))
         self._gemm_h2("gemm_mlp", h1, pad8(F3), M3, w.sa4[1], out_f32=h2, ldo=F3)
@@ -490,21 +504,23 @@ class Engine:
             need_f32 = fl > 1 or keep is not None
             b = new(m, l1.N) if need_f32 else None
             yh = newh(mc, l1.N) if fl == 1 else None
-            hd = new(mc, F3) if fl == 1 else None
+            hd = new(mc, F3) if (fl == 1 and w.num_classes == 1) else None
+            hdh = newh(mc, F3) if (fl == 1 and w.num_classes != 1) else None
             for r0 in range(0, m, chunk):
                 mm = min(chunk, m - r0)
-                self._call("interp_concat", L.p2w_interp_concat_h2, ptr(y), Fc, ptr(y_xyzr), ptr(fine.xyzr[r0:]),
+                self._call("interp_concat", L.p2w_interp_concat_h2, prec, ptr(y), Fc, ptr(y_xyzr), ptr(fine.xyzr[r0:]),
                            ptr(nbr[r0:]), ptr(deg[r0:]), kw, ptr(x[fl - 1][r0:]), Fs, mm, ptr(cat), pad8(Fc + Fs))
                 self._gemm_h2("gemm_mlp", cat, pad8(Fc + Fs), mm, l0, out_h2=a, ldh_o=pad8(l0.N))
                 self._gemm_h2("gemm_mlp", a, pad8(l0.N), mm, l1, out_f32=None if b is None else b[r0:], ldo=l1.N,
                               out_h2=yh, ldh_o=pad8(l1.N))
                 if fl == 1:   # head (model.py:241-243) on the same chunk
-                    self._gemm_h2("gemm_mlp", yh, pad8(F3), mm, w.head1, out_f32=hd, ldo=F3)
                     if w.num_classes == 1:
+                        self._gemm_h2("gemm_mlp", yh, pad8(F3), mm, w.head1, out_f32=hd, ldo=F3)
                         self._call("rowdot", L.p2w_rowdot, ptr(hd), F3, F3, ptr(w.head2_w), float(w.head2_b[0]), mm,
                                    ptr(logits[r0:]))
-                    else:
-                        self._gemm("gemm_mlp", hd, F3, mm, w.head2, o_multi[r0:], w.num_classes)
+                    else:   # multi-class head: conv2 is one more (narrow) GEMM over the H form of conv1's output
+                        self._gemm_h2("gemm_mlp", yh, pad8(F3), mm, w.head1, out_h2=hdh, ldh_o=pad8(F3))
+                        self._gemm_h2("gemm_mlp", hdh, pad8(F3), mm, w.head2, out_f32=o_multi[r0:], ldo=w.num_classes)
             y, y_xyzr = b, fine.xyzr
             if keep is not None:
                 keep[f"fp{fl}_module.out"] = b
@@ -613,8 +629,13 @@ class Engine:
 
         def launch_geometry(args):
             s_geo.wait_stream(cur_stream)
+            for t in args:
+                # the inputs were allocated on the caller's stream (possibly by a just-issued H2D copy or a dtype
+                # conversion in Net._inputs) and are read on s_geo: the allocator must not recycle them under it
+                t.record_stream(s_geo)
             with torch.cuda.stream(s_geo):
                 geo = self._geometry_async(*args)
+            geo.aux = list(geo.aux) + list(args)   # ... and they stay alive until this batch's features were launched
             return geo
 
         it = iter(inputs)

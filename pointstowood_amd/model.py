@@ -76,7 +76,9 @@ class Net(torch.nn.Module):
     def __init__(self, num_classes: int, C: int = 32, k: int = 32, precision: str = "f16x3"):
         super().__init__()
         self.num_classes, self.C, self.k = int(num_classes), int(C), int(k)
-        self.precision = precision  # "f16x3": split-fp16 MFMA with fp32 accumulate; "fp32": fp32 MFMA
+        # "f16x3": split-fp16 MFMA, fp32 accumulate (parity default); "fp32": fp32 MFMA; "fp16" / "bf16": one MFMA per
+        # product like the reference's torch.cuda.amp.autocast path (predicter.py:197) - faster, NOT within 1e-4
+        self.precision = precision
         for key, shape, kind in checkpoint_layout(self.num_classes, self.C):
             *path, leaf = key.split(".")
             node = self
@@ -123,8 +125,8 @@ class Net(torch.nn.Module):
         self._packed = None
 
     def _ensure_packed(self, device):
-        if self._packed is None or self._packed.device != device:
-            self._packed = PackedWeights(self.state_dict(), self.C, self.num_classes, device)
+        if self._packed is None or self._packed.device != device or self._packed.precision != self.precision:
+            self._packed = PackedWeights(self.state_dict(), self.C, self.num_classes, device, self.precision)
             self._engine = Engine(self._packed, k=self.k, precision=self.precision)
         if self._engine.k != self.k or self._engine.precision != self.precision:
             self._engine = Engine(self._packed, k=self.k, precision=self.precision)

@@ -1,6 +1,7 @@
 """Synthetic voxel generators: inputs for bench.py, the profiling tools and the tests.
 No reference arithmetic lives here (the CPU oracle is ``oracle/``; ``oracle.synth`` re-exports this module).
 
+``forest_plot`` generates a whole plot for the voxeliser; ``mixed_sizes`` the voxel sizes of BASELINE configs[4].
 ``uniform_voxel`` is the canonical ``U(side, N, seed)``: N points uniform in a cube,
 centred, with the feed-side quantities of ``TestingDataset.__getitem__``
 (``pointstowood/src/predicter.py:78-94``): ``local_shift`` (= mean, here of the raw
@@ -73,3 +74,34 @@ def collate(voxels):
         "ptr": torch.tensor([0] + list(torch.cumsum(torch.tensor(n), 0)), dtype=torch.long),
     }
     return out
+
+
+def forest_plot(n, seed=0, side=100.0, height=30.0):
+    """Synthetic plot (BASELINE configs[3] shape): [n, 4] = x, y, z, reflectance with a tree-like density - stems (thin
+    vertical cylinders), crowns (gaussian blobs) and a ground sheet over a side x side m square, plot-local coordinates."""
+    g = torch.Generator().manual_seed(seed)
+    n_tree = max(4, int(side * side / 60))
+    cx = torch.rand(n_tree, 2, generator=g) * side - side / 2
+    h = 8 + torch.rand(n_tree, generator=g) * (height - 10)
+    which = torch.randint(0, n_tree, (n,), generator=g)
+    kind = torch.rand(n, generator=g)
+    stem, crown = kind < 0.25, (kind >= 0.25) & (kind < 0.85)
+    p = torch.empty(n, 3)
+    ang = torch.rand(n, generator=g) * 6.2832
+    rad = 0.1 + 0.15 * torch.rand(n, generator=g)
+    p[:, 0] = cx[which, 0] + torch.where(stem, rad * torch.cos(ang), torch.randn(n, generator=g) * 1.6)
+    p[:, 1] = cx[which, 1] + torch.where(stem, rad * torch.sin(ang), torch.randn(n, generator=g) * 1.6)
+    p[:, 2] = torch.where(stem, torch.rand(n, generator=g) * h[which] * 0.7,
+                          h[which] * (0.65 + 0.12 * torch.randn(n, generator=g)))
+    gr = ~(stem | crown)
+    p[gr, 0] = torch.rand(int(gr.sum()), generator=g) * side - side / 2
+    p[gr, 1] = torch.rand(int(gr.sum()), generator=g) * side - side / 2
+    p[gr, 2] = 0.05 * torch.randn(int(gr.sum()), generator=g)
+    refl = torch.rand(n, 1, generator=g) * 30 - 25
+    return torch.cat([p, refl], 1)
+
+
+def mixed_sizes(count: int = 128, lo: int = 512, hi: int = 16384, seed: int = 7):
+    """Voxel sizes of BASELINE configs[4]: ``count`` sizes log-uniform in [lo, hi] (seeded)."""
+    g = torch.Generator().manual_seed(seed)
+    return [int(round(math.exp(float(torch.rand(1, generator=g)) * math.log(hi / lo) + math.log(lo)))) for _ in range(count)]

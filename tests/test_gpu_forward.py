@@ -81,44 +81,64 @@ def test_forward_matches_live_oracle_mixed_batch(precision):
     assert (torch.sigmoid(got.cpu()) - torch.sigmoid(ref)).abs().max() <= 1e-4
 
 
+# Single-plane precisions (one MFMA per product: the reference's own GPU arithmetic, predicter.py:197 autocast): same
+# geometry bit for bit, features to the operand precision; they do NOT meet the 1e-4 probability bar and the limits below
+# say by how much (measured max |dprob| over the six reference cases on MI355X: fp16 ~3e-4..1.5e-3, bf16 ~3e-3..2e-2).
+SINGLE_PLANE_PROB_LIMIT = {"fp16": 3e-2, "bf16": 2.5e-1}
+
+
+@pytest.mark.parametrize("precision", ["fp16", "bf16"])
+@pytest.mark.parametrize("name", G.CASES)
+def test_single_plane_precisions_against_reference_vectors(name, precision):
+    g, inp, meta = G.load(name)
+    keep = {}
+    logits, d = _run(inp, meta["C"], meta["k"], meta["wseed"], keep, precision)
+    geo = keep["geometry"]
+    for l in (1, 2, 3):                       # geometry is fp32 and independent of the feature precision
+        lv = geo.levels[l]
+        G.check(g, f"idx{l}", lv.idx[: lv.n].long(), what="geometry ")
+        e = _edges(lv, meta["k"])
+        G.check(g, f"edge{l}.c", e[1], what="geometry ")
+    G.check(g, "stem", keep["stem"], rtol=1e-5, atol=1e-6)          # the stem is fp32 VALU in every mode
+    rel = {"fp16": 3e-2, "bf16": 2.5e-1}[precision]
+    G.check(g, "sa1_module.conv", keep["sa1_module.conv"], rtol=rel, atol=rel)
+    assert bool(torch.isfinite(logits).all())
+    if "probs" in g:
+        ref = torch.from_numpy(g["probs"])
+        got = torch.sigmoid(logits).cpu()
+    else:
+        rows = torch.from_numpy(g["probs__rows"].astype(np.int64))
+        ref, got = torch.from_numpy(g["probs__sample"]), torch.sigmoid(logits).cpu()[rows]
+    err = (got - ref).abs().max().item()
+    print(f"{precision} {name}: max |dprob| vs reference = {err:.3e}")
+    assert err <= SINGLE_PLANE_PROB_LIMIT[precision], err
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "fp16"])
+def test_multi_class_head(precision):
+    """num_classes > 1 (conv2 as one more narrow GEMM, logits [classes, N] like the reference's squeeze(x.t())): the H
+    path against the fp32-MFMA path."""
+    from pointstowood_amd import Net
+    inp = synth.collate([synth.uniform_voxel(2.0, 3000, 51, True), synth.uniform_voxel(2.0, 700, 52, True)])
+    sd = weights.synth_state_dict(3, 8, seed=2)
+    outs = {}
+    for prec in ("fp32", precision):
+        net = Net(num_classes=3, C=8, k=32, precision=prec)
+        net.load_state_dict(sd, strict=True)
+        net = net.cuda().eval()
+        d = _D()
+        d.pos, d.batch, d.reflectance, d.sf = (inp[n].cuda() for n in ("pos", "batch", "reflectance", "sf"))
+        outs[prec] = net(d).cpu()
+    assert outs["fp32"].shape == (3, 3700)
+    tol = 4e-4 if precision == "f16x3" else 5e-2
+    assert (outs[precision] - outs["fp32"]).abs().max() <= tol * max(1.0, outs["fp32"].abs().max().item())
+
+
 def test_forward_is_deterministic_and_batch_order_is_voxel_major():
     g, inp, meta = G.load("ragged_b2_refl_c8")
     a, _ = _run(inp, meta["C"], meta["k"], meta["wseed"])
     b, _ = _run(inp, meta["C"], meta["k"], meta["wseed"])
     assert torch.equal(a, b)
-
-
-def test_config2_full_size_properties():
-    """BASELINE config 2 (B=8 x 16384, k=32, xyz only) at full size: structural invariants that do not need the
-    oracle at this size + parity of voxel 0's logits... (the grid origin is batch-global, so single-voxel logits are
-    not an invariant; instead check per-level structure and finiteness)."""
-    vox = [synth.uniform_voxel(2.0, 16384, 123 + i, False) for i in range(8)]
-    inp = synth.collate(vox)
-    keep = {}
-    logits, _ = _run(inp, 32, 32, 0, keep)
-    assert logits.shape == (8 * 16384,) and bool(torch.isfinite(logits).all())
-    geo = keep["geometry"]
-    prev_n = 8 * 16384
-    for l in (1, 2, 3):
-        lv = geo.levels[l]
-        assert 0 < lv.n <= prev_n
-        ptr = lv.ptr.cpu()
-        assert int(ptr[0]) == 0 and int(ptr[-1]) == lv.n and bool((ptr[1:] >= ptr[:-1]).all())
-        b = lv.batch[: lv.n].cpu()
-        assert bool((b[1:] >= b[:-1]).all())                       # voxel-major
-        idx = lv.idx[: lv.n].long().cpu()
-        assert idx.unique().numel() == lv.n                        # one representative per cell
-        src_batch = geo.levels[l - 1].batch[: prev_n].cpu()
-        assert torch.equal(src_batch[idx].long(), b.long())        # representatives stay in their voxel
-        nbr, deg = lv.nbr[: lv.n].cpu().long(), lv.deg[: lv.n].cpu()
-        assert int(deg.min()) >= 1 and int(deg.max()) <= 32
-        first = nbr[:, 0]
-        assert torch.equal(src_batch[first].long(), b.long())      # neighbours from the same voxel
-        if l > 1:  # kNN: the query's own source point is its nearest neighbour (distance 0)
-            assert torch.equal(first, idx)
-        prev_n = lv.n
-    # known level sizes of voxel 0 alone are ~15366/10156/2185; in a batch they shift by << 1 %
-    assert abs(geo.levels[1].n / 8 - 15366) < 200 and abs(geo.levels[2].n / 8 - 10156) < 200
 
 
 def test_stream_pipeline_equals_sequential_forward():

@@ -114,16 +114,111 @@ def test_gemm_epilogue(M, N, K):
     v2 = A[:, :K].double() @ W.double().t()
     assert (out2[:, :N].cpu().double() - v2).abs().max().item() <= 2e-5 * max(1.0, v2.abs().max().item())
     assert float(out2[:, N:].abs().max()) == 0.0
-    # split-fp16 path: same contract, weights as hi/lo fp16 planes of W * 2^e
+
+
+def _pack_h(W, prec):
+    """Host-side H weights of W [N, K] for precision code `prec` (0 f16x3, 1 fp16, 2 bf16): (tensor on the GPU, 2^-e, K_pad)."""
+    from pointstowood_amd import _lib
+    N, K = W.shape
+    Np, Kp = _lib.packed_dims(N, K, prec)
+    Wp = torch.zeros(Np, Kp, dtype=torch.float64)
+    Wp[:N, :K] = W.double()
     e = int(np.floor(np.log2(1024.0 / float(Wp.abs().max()))))
-    Ws = Wp.double() * 2.0 ** e
-    hi = Ws.float().half()
-    lo = (Ws - hi.double()).float().half()
-    dW16 = torch.stack([hi, lo]).contiguous().cuda()
-    out3 = torch.full((M, N), float("nan"), device="cuda")
-    check(lib().p2w_gemm_f16x3(ptr(dA), lda, ptr(dW16), 2.0 ** -e, M, N, K, C.byref(ep), ptr(out3), N, stream()))
-    err3 = (out3.cpu().double() - v).abs().max().item()
-    assert err3 <= 4e-5 * max(1.0, v.abs().max().item()), err3
+    Ws = Wp * 2.0 ** e
+    if prec == 0:
+        hi = Ws.float().half()
+        lo = (Ws - hi.double()).float().half()
+        w = torch.stack([hi, lo])
+    else:
+        w = Ws.float().to(torch.float16 if prec == 1 else torch.bfloat16)
+    return w.contiguous().cuda(), 2.0 ** -e, Kp
+
+
+def _to_h(x, prec, ldh):
+    """H form of an fp32 [m, F] tensor, produced ON THE DEVICE by p2w_concat_xyz_h2 with zero positions (so the
+    kernels' own fp32 -> 16-bit conversion is what gets tested)."""
+    from pointstowood_amd._lib import check, lib, ptr, stream
+    m, F = x.shape
+    assert F % 4 == 0 and ldh >= F + 4
+    planes = 2 if prec == 0 else 1
+    out = torch.full((m, planes * ldh), float("nan"), dtype=torch.bfloat16 if prec == 2 else torch.float16, device="cuda")
+    zeros = torch.zeros((m, 4), device="cuda")
+    check(lib().p2w_concat_xyz_h2(prec, ptr(x.cuda().contiguous()), F, ptr(zeros), m, ptr(out), ldh, stream()))
+    return out
+
+
+# relative error bound of a K-term dot product per precision (operand rounding 2^-22 / 2^-11 / 2^-8, fp32 accumulate)
+H_TOL = {0: 4e-5, 1: 3e-3, 2: 2.5e-2}
+
+
+@pytest.mark.parametrize("prec", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K,flags", [(300, 200, 100, 0), (1000, 512, 516, 0), (700, 256, 64, 2), (257, 130, 36, 0),
+                                         (513, 512, 1024, 2), (513, 512, 1024, 1 | 16), (64, 3, 512, 0)])
+def test_gemm_h_epilogue(prec, M, N, K, flags):
+    """p2w_gemm_h2 (f16x3 / fp16 / bf16 MFMA, H operands, both tile sizes and tile orders) + fused epilogue vs fp64,
+    fp32 and H outputs."""
+    import ctypes as C
+    from pointstowood_amd._lib import Epilogue, check, lib, ptr, stream
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, (K + 3) // 4 * 4, generator=g)
+    A[:, K:] = 0
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    vec = lambda: torch.randn(N, generator=g)
+    bias, s0, t0, s1, t1 = vec(), vec(), vec(), vec(), vec()
+    R = torch.randn(M, N, generator=g)
+    dW, wscale, Kp = _pack_h(W, prec)
+    ka = 32 if prec == 0 else 64
+    ldh_a = (A.shape[1] + 4 + ka - 1) // ka * ka
+    Ah = _to_h(A, prec, ldh_a)
+    d = lambda t: t.cuda().contiguous()
+    db, ds0, dt0, ds1, dt1, dR = map(d, (bias, s0, t0, s1, t1, R))
+    ep = Epilogue(ptr(db), ptr(ds0), ptr(dt0), ptr(ds1), ptr(dt1), ptr(dR), N, 1, 1, 1, 1)
+    out = torch.full((M, N), float("nan"), device="cuda")
+    ldh_o = (N + ka - 1) // ka * ka
+    planes = 2 if prec == 0 else 1
+    outh = torch.full((M, planes * ldh_o), float("nan"), dtype=Ah.dtype, device="cuda")
+    check(lib().p2w_gemm_h2(prec, ptr(Ah), ldh_a, ptr(dW), wscale, M, N, K, C.byref(ep), ptr(out), N, ptr(outh), ldh_o, flags,
+                            stream()))
+    v = A[:, :K].double() @ W.double().t() + bias.double()
+    v = torch.relu(v) * s0.double() + t0.double()
+    v = torch.relu(v) * s1.double() + t1.double()
+    v = torch.relu(torch.relu(v) + R.double())
+    scale = max(1.0, v.abs().max().item())
+    err = (out.cpu().double() - v).abs().max().item()
+    assert err <= H_TOL[prec] * scale, err
+    hv = outh.cpu().double()
+    got_h = hv[:, :N] + (hv[:, ldh_o:ldh_o + N] if prec == 0 else 0)
+    assert (got_h - out.cpu().double()).abs().max().item() <= (2e-6 if prec == 0 else 1e-3 if prec == 1 else 8e-3) * scale
+    assert float(hv[:, N:ldh_o].abs().max() if ldh_o > N else 0.0) == 0.0          # pad columns of an H row are zero
+    # plain (no epilogue), fp32 output only, into a wider output
+    out2 = torch.zeros((M, N + 4), device="cuda")
+    check(lib().p2w_gemm_h2(prec, ptr(Ah), ldh_a, ptr(dW), wscale, M, N, K, None, ptr(out2), N + 4, None, 0, flags, stream()))
+    v2 = A[:, :K].double() @ W.double().t()
+    assert (out2[:, :N].cpu().double() - v2).abs().max().item() <= H_TOL[prec] * max(1.0, v2.abs().max().item())
+    assert float(out2[:, N:].abs().max()) == 0.0
+
+
+def test_gemm_h_rejects_bad_arguments():
+    import ctypes as C
+    from pointstowood_amd._lib import lib, ptr, stream
+    L = lib()
+    A = torch.zeros((64, 128), dtype=torch.float16, device="cuda")
+    W = torch.zeros((2, 256, 64), dtype=torch.float16, device="cuda")
+    o = torch.zeros((64, 8), device="cuda")
+    args = lambda prec, ldh, flags: (prec, ptr(A), ldh, ptr(W), 1.0, 64, 8, 64, None, ptr(o), 8, None, 0, flags, stream())
+    assert L.p2w_gemm_h2(*args(0, 64, 0)) == 0
+    assert L.p2w_gemm_h2(*args(3, 64, 0)) == -1          # unknown precision
+    assert L.p2w_gemm_h2(*args(0, 40, 0)) == -1          # A rows not padded to whole K slabs
+    assert L.p2w_gemm_h2(*args(1, 32, 0)) == -1          # single-plane slabs are 64 wide
+    assert L.p2w_gemm_h2(*args(0, 64, 3)) == -1          # both tile sizes forced
+    assert L.p2w_gemm_h2(0, None, 64, ptr(W), 1.0, 64, 8, 64, None, ptr(o), 8, None, 0, 0, stream()) == -2
+    a, b = C.c_int32(), C.c_int32()
+    assert L.p2w_packed_dims_h(1, 100, 100, C.byref(a), C.byref(b)) == 0 and (a.value, b.value) == (256, 128)
+    assert L.p2w_packed_dims_h(0, 100, 100, C.byref(a), C.byref(b)) == 0 and (a.value, b.value) == (256, 128)
+    assert L.p2w_packed_dims_h(0, 100, 40, C.byref(a), C.byref(b)) == 0 and b.value == 64
+    assert L.p2w_packed_dims_h(2, 100, 40, C.byref(a), C.byref(b)) == 0 and b.value == 64
+    assert L.p2w_packed_dims_h(0, 100, 20, C.byref(a), C.byref(b)) == 0 and b.value == 32
+    assert L.p2w_packed_dims_h(7, 1, 1, C.byref(a), C.byref(b)) == -1
 
 
 def test_c_abi_rejects_bad_arguments():
@@ -139,26 +234,27 @@ def test_c_abi_rejects_bad_arguments():
     assert b"NULL" in L.p2w_strerror(-2)
 
 
-def test_f16x3_split_saturates_instead_of_overflowing():
-    """Activations beyond the fp16 range must degrade gracefully (hi saturates at 65504, lo carries the rest), never inf/NaN."""
-    import ctypes as C
-    from pointstowood_amd import _lib
+@pytest.mark.parametrize("prec", [0, 1])
+def test_h_conversion_saturates_instead_of_overflowing(prec):
+    """Activations beyond the fp16 range must degrade gracefully, never inf/NaN: the f16x3 hi plane saturates at 65504
+    and lo carries the rest (usable to ~1.3e5); the single fp16 plane clamps at +-65504."""
     from pointstowood_amd._lib import check, lib, ptr, stream
     g = torch.Generator().manual_seed(3)
     M, K, N = 300, 64, 32
     A = (torch.rand(M, K, generator=g) * 2 - 1) * 1.2e5          # up to +-1.2e5 > 65504
     W = torch.randn(N, K, generator=g) / 8
-    Np, Kp = _lib.packed_dims(N, K)
-    Wp = torch.zeros(Np, Kp); Wp[:N, :K] = W
-    e = int(np.floor(np.log2(1024.0 / float(Wp.abs().max()))))
-    Ws = Wp.double() * 2.0 ** e
-    hi = Ws.float().half(); lo = (Ws - hi.double()).float().half()
-    dW16 = torch.stack([hi, lo]).contiguous().cuda()
+    dW, wscale, Kp = _pack_h(W, prec)
+    Ah = _to_h(A, prec, 128)
+    assert bool(torch.isfinite(Ah.float()).all())
     out = torch.full((M, N), float("nan"), device="cuda")
-    check(lib().p2w_gemm_f16x3(ptr(A.cuda()), K, ptr(dW16), 2.0 ** -e, M, N, K, None, ptr(out), N, stream()))
-    ref = A.double() @ W.double().t()
+    check(lib().p2w_gemm_h2(prec, ptr(Ah), 128, ptr(dW), wscale, M, N, K, None, ptr(out), N, None, 0, 0, stream()))
     assert bool(torch.isfinite(out).all())
-    assert (out.cpu().double() - ref).abs().max() <= 2e-3 * ref.abs().max()
+    if prec == 0:
+        ref = A.double() @ W.double().t()
+        assert (out.cpu().double() - ref).abs().max() <= 2e-3 * ref.abs().max()
+    else:
+        ref = A.clamp(-65504, 65504).double() @ W.double().t()
+        assert (out.cpu().double() - ref).abs().max() <= 5e-3 * ref.abs().max()
 
 
 def _sorted_level(b, res):

@@ -346,7 +346,7 @@ def test_hot_kernels_stay_off_the_register_cliff():
     if shutil.which(hipcc) is None and not os.path.exists(hipcc):
         pytest.skip("no hipcc")
     usage = {}
-    for src in ("p2w_feat.hip", "p2w_geom.hip"):
+    for src in ("p2w_feat.hip", "p2w_feat_h1.hip", "p2w_geom.hip"):
         r = subprocess.run([hipcc, *B.FLAGS, "-c", os.path.join(B.CSRC, src), "-o", os.devnull,
                             "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
@@ -365,11 +365,12 @@ def test_hot_kernels_stay_off_the_register_cliff():
         hits = [v for k, v in usage.items() if substr in k]
         assert len(hits) == 1, (substr, [k for k in usage if substr in k])
         return hits[0]
-    big = one("gemm_h2g_kernelILi2ELi4ELi4ELi2E")
-    assert big["ScratchSize [bytes/lane]"] <= 400, big          # 352 today: interior-epilogue spills only
-    assert one("gemm_h2g_kernelILi2ELi2ELi2ELi2E")["ScratchSize [bytes/lane]"] == 0
-    for k in ("sa_conv16p_kernelILi256ELi2E", "sa_conv16p_kernelILi128ELi2E"):
-        assert one(k)["VGPRs Spill"] == 0 and one(k)["LDS Size [bytes/block]"] <= 112 * 1024
+    for prec in (0, 1, 2):   # f16x3 (p2w_feat.hip), fp16 / bf16 (p2w_feat_h1.hip)
+        big = one(f"gemm_h2g_kernelILi{prec}ELi2ELi4ELi4ELi2E")
+        assert big["ScratchSize [bytes/lane]"] <= 400, big          # 348 today: interior-epilogue spills only
+        assert one(f"gemm_h2g_kernelILi{prec}ELi2ELi2ELi2ELi2E")["ScratchSize [bytes/lane]"] == 0
+        for k in (f"sa_conv16p_kernelILi{prec}ELi256ELi2E", f"sa_conv16p_kernelILi{prec}ELi128ELi2E"):
+            assert one(k)["VGPRs Spill"] == 0 and one(k)["LDS Size [bytes/block]"] <= 112 * 1024
     for k, v in usage.items():
         if "slab_search_kernel" in k or k.startswith("_Z10knn_kernel") or k.startswith("_Z11ball_kernel"):
             assert v["VGPRs Spill"] == 0, (k, v)
@@ -389,3 +390,37 @@ def test_pick_chunk_properties():
         plain_full, plain_rem = divmod(m, b)
         assert cost <= plain_full * rounds(b, t) + (rounds(plain_rem, t) if plain_rem else 0)   # never worse than the plain budget
     assert pick_chunk(131072, 61680, 2) == 65536                                               # FP1: two full chunks, no 8192-row tail
+
+
+def test_concurrent_lazy_builds_serialise(tmp_path):
+    """Every rank of a torch.distributed.run launch may find the library stale at once (``*.so`` is not in git): exactly
+    one of them must build, under the lock, and the others must come back with the fresh library."""
+    import subprocess
+    import sys
+    script = f"""
+import os, sys, time
+sys.path.insert(0, {ROOT!r})
+from pointstowood_amd import build as B
+B.HERE = {str(tmp_path)!r}
+B.LIB = os.path.join(B.HERE, "lib.so")
+def fake(objdir, verbose):
+    time.sleep(1.0)
+    with open(os.path.join(B.HERE, "builds.log"), "a") as f:
+        f.write(str(os.getpid()) + "\\n")
+    with open(B.LIB + ".tmp" + str(os.getpid()), "w") as f:
+        f.write("x" * 100000)
+    os.replace(B.LIB + ".tmp" + str(os.getpid()), B.LIB)
+    with open(B.LIB + ".srchash", "w") as f:
+        f.write(B.source_hash())
+    return B.LIB
+B._build_locked = fake
+print(B.build())
+assert not B._stale() and os.path.getsize(B.LIB) == 100000
+"""
+    procs = [subprocess.Popen([sys.executable, "-c", script], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for _ in range(4)]
+    for p in procs:
+        out, err = p.communicate(timeout=120)
+        assert p.returncode == 0, err[-2000:]
+    assert len(open(tmp_path / "builds.log").read().split()) == 1       # one builder, three waiters
+

@@ -14,34 +14,11 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pointstowood_amd import synthetic_weights as weights  # noqa: E402
+from pointstowood_amd.synthetic_voxels import forest_plot as synth_plot  # noqa: E402
 from pointstowood_amd import Batch, Net  # noqa: E402
 from pointstowood_amd.dist import partition_batches  # noqa: E402
 from pointstowood_amd.predicter import BalancedBatchSampler, PointBudgetSampler, collate_device  # noqa: E402
 from pointstowood_amd.preprocessing import voxelise  # noqa: E402
-
-
-def synth_plot(n, seed=0, side=100.0, height=30.0):
-    """Tree-like density: stems (thin vertical cylinders), crowns (gaussian blobs), ground sheet."""
-    g = torch.Generator().manual_seed(seed)
-    n_tree = max(4, int(side * side / 60))
-    cx = torch.rand(n_tree, 2, generator=g) * side - side / 2
-    h = 8 + torch.rand(n_tree, generator=g) * (height - 10)
-    which = torch.randint(0, n_tree, (n,), generator=g)
-    kind = torch.rand(n, generator=g)
-    stem, crown = kind < 0.25, (kind >= 0.25) & (kind < 0.85)
-    p = torch.empty(n, 3)
-    ang = torch.rand(n, generator=g) * 6.2832
-    rad = 0.1 + 0.15 * torch.rand(n, generator=g)
-    p[:, 0] = cx[which, 0] + torch.where(stem, rad * torch.cos(ang), torch.randn(n, generator=g) * 1.6)
-    p[:, 1] = cx[which, 1] + torch.where(stem, rad * torch.sin(ang), torch.randn(n, generator=g) * 1.6)
-    p[:, 2] = torch.where(stem, torch.rand(n, generator=g) * h[which] * 0.7,
-                          h[which] * (0.65 + 0.12 * torch.randn(n, generator=g)))
-    gr = ~(stem | crown)
-    p[gr, 0] = torch.rand(int(gr.sum()), generator=g) * side - side / 2
-    p[gr, 1] = torch.rand(int(gr.sum()), generator=g) * side - side / 2
-    p[gr, 2] = 0.05 * torch.randn(int(gr.sum()), generator=g)
-    refl = torch.rand(n, 1, generator=g) * 30 - 25
-    return torch.cat([p, refl], 1)
 
 
 def main():
