@@ -3,8 +3,11 @@
 
 ``compute_labels`` (:112-127) is restated statement by statement in numpy (the reference runs it through numba).
 The neighbour search is third-party there (pykdtree ``KDTree.query``, not vendored, not installed here): it is
-restated with scipy's cKDTree over float64 coordinates - "parity unpinned" for the neighbour sets themselves (no
-reference test or golden vector covers them), pinned only through this restatement of the arithmetic after them.
+restated with scipy's cKDTree over float64 coordinates.  PINNED: ``compute_labels`` and ``collect_predictions`` are
+checked against outputs of the reference's own ``PointCloudClassifier`` (imported with numba.jit -> identity and
+pykdtree -> the same scipy shim; tests/golden/make_golden_host.py -> tests/golden/host/vote.npz, collect.npz,
+segmentation.npz) by tests/test_host_golden.py.  What stays unpinned is only pykdtree's tie order among equidistant
+neighbours, which no published contract fixes.
 """
 import numpy as np
 

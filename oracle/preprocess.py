@@ -6,6 +6,9 @@ of writing ``voxel_*.pt`` files.  Third-party ``voxel_grid`` = ``oracle.ops.voxe
 EVERY column it is given - the reference passes x, y, z, reflectance, ..., n_z, so voxels are also split by
 height-above-ground and the single maximum-reflectance point gets its own cell).  Random capping uses the given
 generator (the reference uses the global RNG), so only voxels within the cap are comparable bit for bit.
+PINNED: tests/test_host_golden.py::test_voxeliser_matches_the_reference compares it (and the product's voxeliser) with
+voxel files written by the reference's own ``Voxelise.write_voxels`` (tests/golden/host/voxelise.npz; its hard-coded
+'cuda' device mapped to the CPU by the generating script).  Tied reflectance values are ranked by an unstable sort there.
 """
 import torch
 

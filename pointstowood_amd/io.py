@@ -58,22 +58,25 @@ def read_ply(path):
 
 
 def write_ply(path, columns, comments=()):
-    """Binary little-endian PLY: x, y, z float64, red/green/blue int, every other column float64 (io.py:49-83)."""
-    names = ["x", "y", "z"] + [c for c in ("red", "green", "blue") if c in columns and all(
-        k in columns for k in ("red", "green", "blue"))]
+    """Binary little-endian PLY, byte for byte what the reference's ``write_ply`` emits for the same columns
+    (io.py:49-83): x, y, z float64, red/green/blue ``int`` right after them when all three are present, every other
+    column float64 in input order; the header carries the reference's fixed comment / obj_info lines so that a file
+    written here is indistinguishable from one written there (checked against a reference-written fixture)."""
+    names = ["x", "y", "z"] + (["red", "green", "blue"] if "red" in columns else [])
     names += [c for c in columns if c not in names]
     n = len(columns["x"])
-    dt = np.dtype([(c, "<i4" if c in ("red", "green", "blue") else "<f8") for c in names])
+    dt = np.dtype([(c, "<i4" if c in ("red", "green", "blue") and "red" in columns else "<f8") for c in names])
     rec = np.empty(n, dtype=dt)
     for c in names:
         rec[c] = np.asarray(columns[c]).reshape(n)
     with open(path, "wb") as f:
-        f.write(b"ply\nformat binary_little_endian 1.0\n")
+        f.write(b"ply\nformat binary_little_endian 1.0\ncomment Author: Phil Wilkes\n")
         for c in comments:
             f.write(f"comment {c}\n".encode())
+        f.write(b"obj_info generated with pcd2ply.py\n")
         f.write(f"element vertex {n}\n".encode())
         for c in names:
-            f.write(f"property {'int' if c in ('red', 'green', 'blue') else 'float64'} {c}\n".encode())
+            f.write(f"property {'int' if dt[c] == np.dtype('<i4') else 'float64'} {c}\n".encode())
         f.write(b"end_header\n")
         rec.tofile(f)
 

@@ -15,6 +15,7 @@ records inputs and outputs:
   ply_*.ply, ply.npz write_ply bytes / read_ply arrays (io.py:11-83)
   columns.json       preprocess_point_cloud_data (predict.py:36-52)
   segmentation.npz   one CPU SemanticSegmentation run (:148-236) over a 4-voxel directory
+  voxelise.npz       Voxelise.write_voxels / preprocess (preprocessing.py:79-131) on a small plot, with and without reflectance
 
 The reference's source never enters this repo; only these data vectors do.
 
@@ -135,7 +136,7 @@ def gen_vote():
     g = np.random.default_rng(11)
     out = {}
     for k in (64, 32):
-        n = 400
+        n = 160
         nb = np.zeros((n, k, 5))
         nb[:, :, :3] = g.random((n, k, 3))
         nb[:, :, 4] = g.random((n, k))
@@ -285,11 +286,57 @@ def gen_segmentation():
     np.savez_compressed(os.path.join(OUT, "segmentation.npz"), **out)
 
 
+def gen_voxelise():
+    """Voxelise.write_voxels (preprocessing.py:79-127) + preprocess (:129-131).  The reference hard-codes device='cuda'
+    (:44-45,84,87); for this run ``Tensor.to`` / ``torch.arange`` are wrapped so that 'cuda' means the CPU - the
+    arithmetic is the same torch code either way.  max_pts is above every voxel's size so no random capping happens
+    (that part draws from the global torch RNG and is not comparable)."""
+    import glob
+    import src.preprocessing as ref_pp
+    from tests.test_host_cpu import _plot
+    real_to, real_arange = torch.Tensor.to, torch.arange
+
+    def to(self, *a, **kw):
+        a = tuple("cpu" if (isinstance(x, str) and x.startswith("cuda")) else x for x in a)
+        if isinstance(kw.get("device"), str) and kw["device"].startswith("cuda"):
+            kw["device"] = "cpu"
+        return real_to(self, *a, **kw)
+
+    def arange(*a, **kw):
+        if isinstance(kw.get("device"), str) and kw["device"].startswith("cuda"):
+            kw["device"] = "cpu"
+        return real_arange(*a, **kw)
+    out = {}
+    torch.Tensor.to, torch.arange = to, arange
+    ref_pp.torch.arange = arange
+    try:
+        for tag, refl in (("refl", True), ("norefl", False), ("refl_ties", True)):
+            pc = _plot(n=9000 if tag != "refl_ties" else 4000, seed=3 if refl else 4, refl=refl)
+            if tag == "refl":    # continuous reflectance: no ties, so the (unstable) sort of preprocessing.py:22 has one answer
+                pc[:, 3] = torch.randperm(pc.shape[0], generator=torch.Generator().manual_seed(12)).float() / pc.shape[0] * 40 - 30
+            cols = ["x", "y", "z", "reflectance", "dev"][: pc.shape[1]]
+            df = pd.DataFrame(pc.numpy().astype(np.float64), columns=cols)
+            with tempfile.TemporaryDirectory() as d:
+                args = types.SimpleNamespace(pc=df, vxfile=d, min_pts=64, max_pts=100000, resolution=0.01, grid_size=[2.0, 4.0])
+                ref_pp.preprocess(args)
+                files = sorted(glob.glob(os.path.join(d, "voxel_*.pt")), key=lambda f: int(os.path.basename(f)[6:-3]))
+                vox = [torch.load(f).numpy() for f in files]
+            out[f"{tag}.pc"] = pc.numpy()
+            out[f"{tag}.n_z"] = args.pc["n_z"].to_numpy()
+            out[f"{tag}.count"] = np.array(len(vox))
+            out[f"{tag}.sizes"] = np.array([v.shape[0] for v in vox])
+            out[f"{tag}.voxels"] = np.concatenate(vox, 0)
+    finally:
+        torch.Tensor.to, torch.arange = real_to, real_arange
+        ref_pp.torch.arange = real_arange
+    np.savez_compressed(os.path.join(OUT, "voxelise.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     only = set(sys.argv[1:])
     for name, fn in (("feed", gen_feed), ("sampler", gen_sampler), ("load_model", gen_load_model), ("vote", gen_vote),
-                     ("collect", gen_collect), ("ply", gen_ply), ("columns", gen_columns), ("segmentation", gen_segmentation)):
+                     ("collect", gen_collect), ("ply", gen_ply), ("columns", gen_columns), ("segmentation", gen_segmentation), ("voxelise", gen_voxelise)):
         if only and name not in only:
             continue
         fn()
