@@ -96,6 +96,11 @@ class Feed:
         return cls(**{k: b[k].to(device, non_blocking=non_blocking) for k in cls.FIELDS})
 
 
+def make_batch(rank: int, device, j: int = 0):
+    """Batch j of `rank`, resident on `device` (used by the tools/ scripts)."""
+    return Feed.to_device(host_batch(rank, j), device)
+
+
 def algorithmic_macs(geo):
     """SURVEY.md 8(d) / BASELINE.md 3: MACs of the reference forward for the level sizes actually produced."""
     N, (M1, M2, M3) = geo.N, [geo.levels[l].n for l in (1, 2, 3)]

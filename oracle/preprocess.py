@@ -34,9 +34,10 @@ def quantile_normalize_reflectance(refl):
     return 2 * (n - n.min()) / (n.max() - n.min()) - 1
 
 
-def voxelise(pc, grid_sizes=(2.0, 4.0), min_pts=128, max_pts=16384, generator=None):
-    """pc: [N, >=4] float32 (x, y, z, reflectance, ...) without n_z.  Returns (list of voxel tensors [n, cols+1], n_z)."""
-    pos = ground(pc.float())
+def voxelise(pc, grid_sizes=(2.0, 4.0), min_pts=128, max_pts=16384, generator=None, has_nz=False):
+    """pc: [N, >=4] float32 (x, y, z, reflectance, ...).  Returns (list of voxel tensors, n_z).  ``has_nz``: the input frame
+    has an 'n_z' column, so gpu_ground is skipped and the LAST column is returned as n_z (preprocessing.py:81-86,127)."""
+    pos = pc.float().clone() if has_nz else ground(pc.float())
     refl_on = not bool(torch.all(pos[:, 3] == 0))
     if refl_on:
         pos[:, 3] = quantile_normalize_reflectance(pos[:, 3].view(-1))

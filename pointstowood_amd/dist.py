@@ -11,9 +11,30 @@ from __future__ import annotations
 import torch
 
 
-def batch_cost(n_points: int) -> float:
-    """Relative cost of a voxel (the forward is dominated by per-point dense layers)."""
-    return float(n_points)
+# level grid resolutions (model.py:210-212) and the per-unit MACs of SURVEY.md 8(d)
+_RES = (0.04, 0.08, 0.16)
+_MAC_N, _MAC_M, _MAC_E = 803424, (1245184, 3440640, 12191232), (10496, 74496, 296448)
+
+
+def batch_cost(n_points: int, volume: float = 8.0, k: int = 32) -> float:
+    """Estimated MACs of the forward for one voxel of ``n_points`` points spread over ``volume`` m^3 (default: a 2 m
+    voxel): SURVEY.md 8(d)'s formula ``803424 N + 1245184 M1 + 3440640 M2 + 12191232 M3 + 10496 E1 + 74496 E2 + 296448 E3``
+    on level sizes estimated by cell occupancy (a level keeps one point per occupied cell: M_l = c_l (1 - exp(-M_{l-1} /
+    c_l)) with c_l = volume / res_l^3; for U(2 m, 16384) this gives 15349 / 9773 / 1940 against the measured 15366 /
+    10156 / 2185).  The cost is NOT proportional to the point count: small or sparse voxels keep relatively more level-2/3
+    points, where a point costs 3-12 M MACs instead of 0.8 M."""
+    import math
+    n = float(max(0, n_points))
+    if n == 0:
+        return 0.0
+    m, prev = [], n
+    for res in _RES:
+        cells = max(1.0, volume / res ** 3)
+        prev = min(prev, cells * (1.0 - math.exp(-prev / cells)))
+        m.append(prev)
+    ball = n * (4.0 / 3.0 * math.pi * (2 * _RES[0]) ** 3) / volume + 1.0       # expected points within r = 2 res (+ itself)
+    e = (m[0] * min(k, ball), m[1] * min(k, m[0]), m[2] * min(k, m[1]))
+    return _MAC_N * n + sum(a * b for a, b in zip(_MAC_M, m)) + sum(a * b for a, b in zip(_MAC_E, e))
 
 
 def partition_batches(costs, world: int):

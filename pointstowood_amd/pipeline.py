@@ -12,19 +12,20 @@ import time
 import torch
 
 from .backproject import collect_predictions
-from .dist import gather_rows, partition_batches, slice_for_rank
+from .dist import batch_cost, gather_rows, partition_batches, slice_for_rank
 from .predicter import PointBudgetSampler, collate_device
 from .preprocessing import voxelise
 
 
 def segment_plot(pc, model, grid_sizes=(2.0, 4.0), min_pts: int = 128, max_pts: int = 16384, is_wood: float = 0.5,
                  any_wood: float = 1.0, max_points: int = 524288, mode: str = "compat", generator=None, stats=None,
-                 dist=None, max_voxels: int = 512):
+                 dist=None, max_voxels: int = 512, ground: bool = True):
     """pc: [N, >= 4] float tensor on the GPU (x, y, z, reflectance, ...), plot-local coordinates (fp32-safe).
     Returns (n_z [N], label [N], pwood [N]) float32 on the device: the three columns the reference appends
     (``predicter.py:233``).  ``stats`` (dict, optional) receives stage timings and counts.  ``max_points`` /
     ``max_voxels``: budget of one forward (plots are mostly small voxels; 524288 points / 512 voxels classify 12 % faster
-    than 131072 / 128 and need ~12 GB).
+    than 131072 / 128 and need ~12 GB).  ``ground=False``: ``pc`` already has an n_z column (its last one), see
+    ``preprocessing.voxelise``.
 
     ``dist`` (an initialised ``torch.distributed``, one process per GPU, every rank holding the same ``pc`` and the same
     ``generator`` state): every rank voxelises (cheap, and it makes the voxel list identical everywhere without an
@@ -32,7 +33,7 @@ def segment_plot(pc, model, grid_sizes=(2.0, 4.0), min_pts: int = 128, max_pts: 
     back-projects a contiguous slice of the plot and the slices are all-gathered: two exchanges in total."""
     dev = pc.device
     t0 = time.perf_counter()
-    vox, n_z = voxelise(pc, tuple(grid_sizes), min_pts, max_pts, mode=mode, generator=generator)
+    vox, n_z = voxelise(pc, tuple(grid_sizes), min_pts, max_pts, mode=mode, generator=generator, ground=ground)
     if stats is not None:
         torch.cuda.synchronize(dev)
         stats["voxelise_s"], t0 = time.perf_counter() - t0, time.perf_counter()
@@ -44,7 +45,7 @@ def segment_plot(pc, model, grid_sizes=(2.0, 4.0), min_pts: int = 128, max_pts: 
     batches = list(PointBudgetSampler(lengths, max_points, max_voxels))
     world, rank = (dist.get_world_size(), dist.get_rank()) if dist is not None else (1, 0)
     if world > 1:
-        mine = partition_batches([sum(lengths[i] for i in b) for b in batches], world)[rank]
+        mine = partition_batches([sum(batch_cost(lengths[i]) for i in b) for b in batches], world)[rank]   # LPT on est. FLOPs
         batches = [batches[i] for i in mine]
     pending = collections.deque()
 

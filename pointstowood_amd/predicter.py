@@ -181,36 +181,33 @@ def classify(model, loader, is_wood: float = 0.5, device="cuda"):
 
 
 def classify_sharded(model, dataset, batches, is_wood, device, dist):
-    """``batches`` = list of voxel-index lists (identical on every rank).  Rank r classifies its share and
-    every rank receives all results, ordered by batch id, via one all-gather of a padded buffer."""
+    """``batches`` = list of voxel-index lists (identical on every rank).  Rank r classifies its share (LPT on the
+    estimated FLOPs of every batch) and every rank receives all results, ordered by batch id: one all-reduce of the
+    per-batch row counts (a voxel can lose rows to the NaN filter, which only its owner sees) and one all-gather of a
+    padded buffer.  No rank touches a voxel it does not own."""
     world, rank = dist.get_world_size(), dist.get_rank()
-    costs = [sum(batch_cost(dataset.lengths[i]) if hasattr(dataset, "lengths") else 1.0 for i in b) for b in batches]
+    lengths = getattr(dataset, "lengths", None)
+    costs = [sum(batch_cost(lengths[i]) if lengths is not None else 1.0 for i in b) for b in batches]
     plan = partition_batches(costs, world)
-    mine = []
+    mine, rows_of = [], torch.zeros(len(batches), dtype=torch.int64)
     for bid in plan[rank]:
         data = Batch.from_data_list([dataset[i] for i in batches[bid]])
         mine.append(classify_batch(model, data, is_wood, device))
+        rows_of[bid] = mine[-1].shape[0]
     local = torch.from_numpy(np.vstack(mine) if mine else np.zeros((0, 5), dtype=np.float32)).to(device)
-    counts = torch.zeros(world, dtype=torch.int64, device=device)
-    counts[rank] = local.shape[0]
-    dist.all_reduce(counts)
-    counts = [int(c) for c in counts.cpu()]
+    rows_of = rows_of.to(device)
+    dist.all_reduce(rows_of)                           # every batch has exactly one owner: the sum is its row count
+    rows_of = [int(c) for c in rows_of.cpu()]
+    counts = [sum(rows_of[b] for b in plan[r]) for r in range(world)]
     buf = torch.zeros((max(counts + [1]), 5), dtype=local.dtype, device=device)
     buf[: local.shape[0]] = local
     out = [torch.empty_like(buf) for _ in range(world)]
     dist.all_gather(out, buf)
-    parts = [o[:c] for o, c in zip(out, counts)]
-    # reorder: rank-major -> batch id order
-    sizes = {}
+    where = {}
     for r in range(world):
         off = 0
         for bid in plan[r]:
-            n = sum(_kept_len(dataset, i) for i in batches[bid])
-            sizes[bid] = (r, off, n)
-            off += n
-    ordered = [parts[sizes[b][0]][sizes[b][1]: sizes[b][1] + sizes[b][2]] for b in range(len(batches))]
+            where[bid] = (r, off, rows_of[bid])
+            off += rows_of[bid]
+    ordered = [out[where[b][0]][where[b][1]: where[b][1] + where[b][2]] for b in range(len(batches))]
     return torch.cat(ordered).cpu().numpy() if ordered else np.zeros((0, 5), dtype=np.float32)
-
-
-def _kept_len(dataset, i):
-    return dataset[i].pos.shape[0]

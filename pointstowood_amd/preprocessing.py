@@ -52,12 +52,17 @@ def _cells(P, size):
     return (((Pb - lo[None]) / S[None]).to(torch.long) * stride[None]).sum(dim=1)
 
 
-def voxelise(pc, grid_sizes=(2.0, 4.0), min_pts: int = 128, max_pts: int = 16384, mode: str = "compat", generator=None):
-    """pc: [N, >=4] (x, y, z, reflectance, ...) without n_z.  Returns (voxels, n_z): ``voxels`` is a list of
-    ``[n, cols+1]`` float32 tensors on ``pc.device`` in the reference's order (grid size major, ascending cell id)."""
+def voxelise(pc, grid_sizes=(2.0, 4.0), min_pts: int = 128, max_pts: int = 16384, mode: str = "compat", generator=None,
+             ground: bool = True):
+    """pc: [N, >=4] (x, y, z, reflectance, ...).  Returns (voxels, n_z): ``voxels`` is a list of ``[n, cols+1]`` float32
+    tensors on ``pc.device`` in the reference's order (grid size major, ascending cell id).
+
+    ``ground=False`` is the reference's branch for input that already carries an ``n_z`` column (any ``*_ours.ply``
+    written by this tool or the reference does): ``gpu_ground`` is skipped, the columns are binned as they come and the
+    LAST column is returned as n_z (preprocessing.py:81-86,127) - no second height column is appended."""
     if mode not in ("compat", "xyz"):
         raise ValueError("mode must be 'compat' or 'xyz'")
-    pos = ground_normalise(pc.to(torch.float32))
+    pos = ground_normalise(pc.to(torch.float32)) if ground else pc.to(torch.float32).clone()
     refl_on = not bool(torch.all(pos[:, 3] == 0))
     if refl_on:
         pos[:, 3] = quantile_normalize_reflectance(pos[:, 3].reshape(-1))

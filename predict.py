@@ -40,7 +40,9 @@ def build_parser():
     p.add_argument('--verbose', action='store_true', help="print stuff")
     # extensions of this build
     p.add_argument('--voxels', type=str, default=None, help='directory of voxel_*.pt files (skips preprocessing)')
-    p.add_argument('--precision', default='f16x3', choices=['f16x3', 'fp32'], help='MFMA mode of the forward')
+    p.add_argument('--precision', default='f16x3', choices=['f16x3', 'fp32', 'fp16', 'bf16'],
+                   help='MFMA mode of the forward: f16x3 (default) and fp32 meet the 1e-4 probability bar of the fp32 CPU path; '
+                        'fp16 / bf16 are the arithmetic of the reference autocast GPU path (about 1.7x faster, 1e-3..1e-2 off)')
     p.add_argument('--reference-sampler', action='store_true',
                    help='reproduce the reference BalancedBatchSampler exactly (drops the remainder, unseeded shuffles)')
     return p
@@ -86,8 +88,10 @@ def segment_file(path, args):
         print(f'Voxelising to {args.grid_size} grid sizes')
     stats = {}
     gen = torch.Generator(device=device).manual_seed(0) if world > 1 else None   # identical max_pts sampling on every rank
+    # input that already carries n_z (e.g. an *_ours.ply fed back in): the reference skips the height normalisation and
+    # takes the LAST column for n_z (preprocessing.py:81-86,127)
     n_z, label, pwood = segment_plot(pc, model, args.grid_size, args.min_pts, args.max_pts, args.is_wood, args.any_wood,
-                                     stats=stats, generator=gen, dist=dist)
+                                     stats=stats, generator=gen, dist=dist, ground='n_z' not in names)
     opath = os.path.join(os.path.dirname(path), os.path.splitext(os.path.basename(path))[0] + '_ours.ply')
     if rank != 0:
         return opath
@@ -120,8 +124,18 @@ def main(argv=None):
         raise SystemExit('predict.py needs an MI355X: the HIP path has no CPU fallback')
 
     from pointstowood_amd import DataLoader, Net
-    from pointstowood_amd.predicter import BalancedBatchSampler, VoxelDataset, classify_batch, load_model
-    device = torch.device('cuda')
+    from pointstowood_amd.predicter import (BalancedBatchSampler, VoxelDataset, classify_batch, classify_sharded, load_model)
+    # one process per GPU under `python -m torch.distributed.run --nproc-per-node N predict.py --voxels ...`: the voxel
+    # batches are sharded over the ranks (predicter.classify_sharded), rank 0 writes the result
+    world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        if not dist.is_initialized():
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    device = torch.device('cuda', local)
     model = Net(num_classes=1, precision=args.precision).to(device)
     try:
         load_model(args.model, model, device)
@@ -132,12 +146,18 @@ def main(argv=None):
     if len(ds) == 0:
         raise SystemExit(f'no voxel_*.pt files in {args.voxels}')
     sampler = BalancedBatchSampler(ds, args.batch_size, reference=args.reference_sampler)
-    loader = DataLoader(ds, batch_sampler=sampler, num_workers=0, pin_memory=True)
-    t0, outs, n = time.time(), [], 0
-    for data in loader:
-        outs.append(classify_batch(model, data, args.is_wood, device))
-        n += outs[-1].shape[0]
-    out = np.vstack(outs)
+    t0 = time.time()
+    if world > 1:
+        if args.reference_sampler:
+            np.random.seed(0)      # the reference's sampler draws from the global numpy RNG: every rank needs the same batches
+        out = classify_sharded(model, ds, [list(b) for b in sampler], args.is_wood, device, dist)
+    else:
+        loader = DataLoader(ds, batch_sampler=sampler, num_workers=0, pin_memory=True)
+        outs = [classify_batch(model, data, args.is_wood, device) for data in loader]
+        out = np.vstack(outs)
+    n = out.shape[0]
+    if rank != 0:
+        return out
     os.makedirs(args.odir, exist_ok=True)
     path = os.path.join(args.odir, 'classified_voxels.npy')
     np.save(path, out)

@@ -310,11 +310,15 @@ def gen_voxelise():
     torch.Tensor.to, torch.arange = to, arange
     ref_pp.torch.arange = arange
     try:
-        for tag, refl in (("refl", True), ("norefl", False), ("refl_ties", True)):
-            pc = _plot(n=9000 if tag != "refl_ties" else 4000, seed=3 if refl else 4, refl=refl)
+        for tag, refl in (("refl", True), ("norefl", False), ("refl_ties", True), ("has_nz", True)):
+            pc = _plot(n=9000 if tag in ("refl", "norefl") else 4000, seed=3 if refl else 4, refl=refl)
             if tag == "refl":    # continuous reflectance: no ties, so the (unstable) sort of preprocessing.py:22 has one answer
                 pc[:, 3] = torch.randperm(pc.shape[0], generator=torch.Generator().manual_seed(12)).float() / pc.shape[0] * 40 - 30
             cols = ["x", "y", "z", "reflectance", "dev"][: pc.shape[1]]
+            if tag == "has_nz":   # e.g. a *_ours.ply fed back in: gpu_ground is skipped, the last column is taken for n_z
+                pc[:, 3] = torch.randperm(pc.shape[0], generator=torch.Generator().manual_seed(13)).float() / pc.shape[0] * 40 - 30
+                pc[:, 4] = pc[:, 2] - pc[:, 2].min()
+                cols = ["x", "y", "z", "reflectance", "n_z"]
             df = pd.DataFrame(pc.numpy().astype(np.float64), columns=cols)
             with tempfile.TemporaryDirectory() as d:
                 args = types.SimpleNamespace(pc=df, vxfile=d, min_pts=64, max_pts=100000, resolution=0.01, grid_size=[2.0, 4.0])

@@ -153,6 +153,70 @@ def test_gather_logits_gloo_world2():
         assert ragged == expect and equal == [0.0] * 4 + [1.0] * 4
 
 
+def test_batch_cost_follows_the_flop_formula():
+    """dist.batch_cost = SURVEY 8(d)'s MAC formula on occupancy-estimated level sizes: exact coefficients, right
+    magnitude for the canonical voxel, and NOT proportional to the point count."""
+    from pointstowood_amd.dist import batch_cost
+    u16k = batch_cost(16384)
+    assert abs(u16k / 139.63e9 - 1.0) < 0.08                       # SURVEY 8(d): U2-16k = 139.63 GMAC
+    assert batch_cost(0) == 0.0 and batch_cost(2048) > 0
+    per_point_small, per_point_big = batch_cost(2048) / 2048, u16k / 16384
+    assert per_point_small > 1.5 * per_point_big                   # small voxels keep more level-2/3 points per input point
+    assert batch_cost(16384, volume=64.0) > u16k                   # a sparse 4 m voxel: almost every point survives sampling
+
+
+class _FakeModel:
+    """Stands in for Net on the CPU: logits = a fixed function of the positions."""
+    def __call__(self, data):
+        return data.pos.sum(dim=1) * 0.5 - 0.1 * data.batch.to(torch.float32)
+
+
+def _sharded_worker(rank, world, port, vdir, q):
+    import torch.distributed as dist
+    from pointstowood_amd.predicter import VoxelDataset, classify_sharded
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ds = VoxelDataset(vdir)
+    sampler = BalancedBatchSampler(ds, 2)           # deterministic (seeded) default mode: identical on every rank
+    loads = []
+    orig = ds.__class__.__getitem__
+
+    def spy(self, i):
+        loads.append(i)
+        return orig(self, i)
+    ds.__class__.__getitem__ = spy
+    out = classify_sharded(_FakeModel(), ds, [list(b) for b in sampler], 0.5, "cpu", dist)
+    q.put((rank, out.tolist(), sorted(loads)))
+    dist.destroy_process_group()
+
+
+def test_classify_sharded_gloo_world2(tmp_path):
+    """Two ranks classify disjoint shares of the voxel batches (one voxel has NaN-reflectance rows that only its owner
+    discovers), nobody loads a voxel it does not own, and every rank ends up with the single-process result."""
+    import torch.multiprocessing as mp
+    from pointstowood_amd.predicter import VoxelDataset, classify
+    g = torch.Generator().manual_seed(5)
+    for i, n in enumerate((300, 900, 150, 700, 500, 1100, 250)):
+        pc = torch.cat([torch.rand(n, 3, generator=g) * 2 + 10 * i, torch.rand(n, 1, generator=g)], 1)
+        if i == 3:
+            pc[[1, 50, 51], 3] = float("nan")
+        torch.save(pc, tmp_path / f"voxel_{i}.pt")
+    ds = VoxelDataset(str(tmp_path))
+    single = classify(_FakeModel(), DataLoader(ds, batch_sampler=BalancedBatchSampler(ds, 2), num_workers=0), 0.5, "cpu")
+    assert single.shape == (3900 - 3, 5)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + 7) % 1000
+    ps = [ctx.Process(target=_sharded_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=180) for _ in range(2))
+    [p.join(30) for p in ps]
+    loads = [set(r[2]) for r in res]
+    assert loads[0] and loads[1] and not (loads[0] & loads[1]) and loads[0] | loads[1] == set(range(7))
+    for _, out, _ in res:
+        assert np.array_equal(np.asarray(out, dtype=single.dtype), single)
+
+
 def test_predict_cli_keeps_the_reference_flag_surface():
     import importlib.util
     spec = importlib.util.spec_from_file_location("p2w_predict", os.path.join(ROOT, "predict.py"))

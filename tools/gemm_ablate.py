@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Time p2w_gemm_h2 on the network's GEMM shapes under the kernel's profiling ablations (P2W_GEMM_DBG)."""
+"""Time p2w_gemm_h2 on the network's GEMM shapes under the kernel's profiling ablations (flags bits 16..23, honoured by
+-DP2W_GEMM_ABLATE builds only).  PREC=0|1|2 (f16x3 / fp16 / bf16), GEMM_FLAGS=<P2W_GEMM_* bits>, ABLATE_MODES=0,1,..."""
 import ctypes as C
 import os
 os.environ.setdefault("P2W_EXTRA_CFLAGS", "-DP2W_GEMM_ABLATE")   # the ablation switches are compiled out of production builds
@@ -14,22 +15,25 @@ from pointstowood_amd._lib import Epilogue, check, lib, ptr, stream  # noqa: E40
 shapes = [(123046, 512, 512), (81683, 1024, 1024), (17506, 2048, 2048), (123046, 128, 512), (123046, 512, 128),
           (131072, 544, 512), (81683, 768, 640)]
 dev = torch.device("cuda")
+PREC, FLAGS = int(os.environ.get("PREC", "0")), int(os.environ.get("GEMM_FLAGS", "0"))
+planes, ka = (2, 32) if PREC == 0 else (1, 64)
+hdt = torch.bfloat16 if PREC == 2 else torch.float16
 for M, K, N in shapes:
-    Np, Kp = _lib.packed_dims(N, K)
-    A = (torch.randn(M, 2 * Kp, device=dev) * 0.5).half()
-    W = (torch.randn(2, Np, Kp, device=dev) * 0.5).half()
+    Np, Kp = _lib.packed_dims(N, K, PREC)
+    A = (torch.randn(M, planes * Kp, device=dev) * 0.5).to(hdt)
+    W = (torch.randn(planes, Np, Kp, device=dev) * 0.5).to(hdt)
     bias = torch.randn(N, device=dev)
     sc, sh = torch.randn(N, device=dev), torch.randn(N, device=dev)
-    oh = torch.empty(M, 2 * ((N + 31) // 32 * 32), dtype=torch.float16, device=dev)
+    ldh_o = (N + ka - 1) // ka * ka
+    oh = torch.empty(M, planes * ldh_o, dtype=hdt, device=dev)
     of = torch.empty(M, N, device=dev)
     ep = Epilogue(ptr(bias), ptr(sc), ptr(sh), None, None, None, 0, 1, 1, 0, 0)
     res = []
     for dbg in [int(v) for v in os.environ.get("ABLATE_MODES", "0,1,2,3,4,6").split(",")]:
-        os.environ["P2W_GEMM_DBG"] = str(dbg)
         for out_f, out_h in ((None, oh), (of, None)):
             def run():
-                check(lib().p2w_gemm_h2(ptr(A), Kp, ptr(W), 1.0, M, N, K, C.byref(ep), ptr(out_f), N, ptr(out_h),
-                                        (N + 31) // 32 * 32, stream()))
+                check(lib().p2w_gemm_h2(PREC, ptr(A), Kp, ptr(W), 1.0, M, N, K, C.byref(ep), ptr(out_f), N, ptr(out_h),
+                                        ldh_o, FLAGS | (dbg << 16), stream()))
             run(); torch.cuda.synchronize()
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()

@@ -8,7 +8,7 @@ from pointstowood_amd import synthetic_weights as weights
 from pointstowood_amd import Net
 from tests import golden_util as G
 
-for prec in ("f16x3", "fp32"):
+for prec in ("f16x3", "fp32", "fp16", "bf16"):
     worst = 0.0
     for name in G.CASES:
         g, inp, meta = G.load(name)

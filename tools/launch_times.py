@@ -8,7 +8,7 @@ from pointstowood_amd import synthetic_weights as weights
 from pointstowood_amd import Net
 
 dev = torch.device("cuda", 0)
-net = Net(num_classes=1, C=bench.C, k=bench.K_NBR).to(dev).eval()
+net = Net(num_classes=1, C=bench.C, k=bench.K_NBR, precision=os.environ.get("P2W_PRECISION", "f16x3")).to(dev).eval()
 net.load_state_dict(weights.synth_state_dict(1, bench.C, seed=0), strict=True)
 net = net.to(dev)
 data = bench.make_batch(0, dev)
