@@ -220,11 +220,14 @@ int32_t p2w_sa_conv(const float* P, int32_t ldp, const float* xyzr_src, const in
  *   P2W_PREC_BF16   one bf16 plane, v_mfma_f32_32x32x16_bf16.
  *   The single-plane modes are what the reference's own GPU path computes in (torch.cuda.amp.autocast,
  *   pointstowood/src/predicter.py:197); they do NOT meet the 1e-4 bar (tests report the measured error).
- * H tensor [M, F]: row m = planes x ldh 16-bit values ([hi(0..ldh) | lo(0..ldh)] for F16X3, [v(0..ldh)] otherwise),
- *   ldh >= F, ldh % 32 == 0 (F16X3) or % 64 == 0 (single plane) when the tensor feeds p2w_gemm_h2 (it is staged with
- *   16-byte direct-to-LDS copies in whole K slabs), pad columns zero.  F16X3 has the bytes of fp32, the others half.
- * H weights: Wh = [planes][N_pad][K_pad] of W * 2^e (e chosen at pack time so that the F16X3 lo plane stays a normal
- *   fp16; wscale = 2^-e is applied in the epilogue), dims from p2w_packed_dims_h. */
+ * H tensor [M, F]: row m holds planes x ldh 16-bit values, ldh >= F, pad columns zero.  Single plane: [v(0..ldh)],
+ *   ldh % 64 == 0 when the tensor feeds p2w_gemm_h2.  F16X3: ldh % 32 == 0 and the row is a sequence of blocks of 32
+ *   columns, each stored as [hi(32) | lo(32)] (column c: hi at 64*(c/32) + c%32, lo 32 values further; value = hi + lo).
+ *   Either way the 64 values a GEMM K-slab takes from a row are one 128-byte cache line, staged by 16-byte direct-to-LDS
+ *   copies (8 whole lines per wave-instruction).  F16X3 has the bytes of fp32, the others half.
+ * H weights: Wh = [N_pad][planes * K_pad] of W * 2^e, rows (= output channels) laid out like H tensor rows (e chosen at
+ *   pack time so that the F16X3 lo part stays a normal fp16; wscale = 2^-e is applied in the epilogue), dims from
+ *   p2w_packed_dims_h. */
 #define P2W_PREC_F16X3 0
 #define P2W_PREC_F16 1
 #define P2W_PREC_BF16 2

@@ -4,15 +4,19 @@
 // family keeps the instantiations out of each other's register allocation.  gfx950 only.
 //
 // An H tensor [M, F] is a row-major array of 16-bit planes (include/p2w.h):
-//   PREC 0 (f16x3): row m = [hi(0..ldh) | lo(0..ldh)], fp16, value = hi + lo (~22 bits), ldh % 32 == 0
-//   PREC 1 / 2    : row m = [v(0..ldh)], fp16 / bf16 (round to nearest), ldh % 64 == 0
-// pad columns are zero.  Weights are packed the same way: [planes][N_pad][K_pad] of W * 2^e.
+//   PREC 0 (f16x3): fp16 hi/lo pairs, value = hi + lo (~22 bits), ldh % 32 == 0; a row is a sequence of blocks of 32
+//                   columns, each stored as [hi(32) | lo(32)] = 128 contiguous bytes: column c -> hi at 64*(c/32) + c%32,
+//                   lo 32 halfs further (row pitch 2*ldh halfs)
+//   PREC 1 / 2    : row m = [v(0..ldh)], fp16 / bf16 (round to nearest), ldh % 64 == 0 (row pitch ldh halfs)
+// pad columns are zero.  Weights are packed the same way, one row per output channel: [N_pad][planes * K_pad] of W * 2^e.
+// Either way the 64 halfs a GEMM slab consumes of a row are ONE 128-byte cache line.
 //
 // The MFMA is v_mfma_f32_32x32x16_{f16,bf16}: lane l supplies A[row l&31][k = 8*(l>>5) + 0..7] (16 contiguous bytes),
 // B alike; C/D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).  f16x3 contracts a_lo*w_hi + a_hi*w_lo + a_hi*w_hi
 // (three MFMAs per product, fp32 accumulate); the single-plane modes issue one.
 #pragma once
 #include "p2w_common.h"
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -25,6 +29,16 @@ typedef __attribute__((address_space(3))) void* lds_vp;
 typedef const __attribute__((address_space(1))) void* glb_vp;
 
 constexpr int H_BK = 32;   // k per LDS row (64 bytes); a slab is two such row groups ("planes")
+
+#ifdef P2W_GEMM_STAMP   // diagnostic build (tools/gemm_stamps.py): in-kernel cycle stamps of the GEMM's phases
+__device__ __forceinline__ unsigned long long p2w_stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#endif
 
 template <int PREC> struct HCfg {
     static constexpr int planes = PREC == 0 ? 2 : 1;      // 16-bit planes per H row
@@ -70,9 +84,9 @@ __device__ __forceinline__ void h_store2(_Float16* __restrict__ base, unsigned l
     if constexpr (PREC == 0) {
         unsigned hw, lw;
         split_pair(a, b, hw, lw);
-        _Float16* p = base + (size_t)row * (2 * ldh) + col;
+        _Float16* p = base + (size_t)row * (2 * ldh) + 64 * (col >> 5) + (col & 31);   // block of 32 columns: [hi32 | lo32]
         *reinterpret_cast<unsigned*>(p) = hw;
-        *reinterpret_cast<unsigned*>(p + ldh) = lw;
+        *reinterpret_cast<unsigned*>(p + 32) = lw;
     } else {
         *reinterpret_cast<unsigned*>(base + (size_t)row * ldh + col) = pack_pair<PREC>(a, b);
     }
@@ -84,9 +98,9 @@ __device__ __forceinline__ void h_store4(_Float16* __restrict__ base, int ldh, s
         uint2 hi, lo;
         split_pair(v[0], v[1], hi.x, lo.x);
         split_pair(v[2], v[3], hi.y, lo.y);
-        _Float16* p = base + row * (size_t)(2 * ldh) + col;
+        _Float16* p = base + row * (size_t)(2 * ldh) + 64 * (col >> 5) + (col & 31);
         *reinterpret_cast<uint2*>(p) = hi;
-        *reinterpret_cast<uint2*>(p + ldh) = lo;
+        *reinterpret_cast<uint2*>(p + 32) = lo;
     } else {
         uint2 w;
         w.x = pack_pair<PREC>(v[0], v[1]);
@@ -288,58 +302,72 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void gemm_h2g_kernel(const _Float1
     constexpr int KS = HCfg<PREC>::kslab;
     constexpr int BM = 32 * RT * WR, BN = 32 * CT * WC, NW = WR * WC;
     constexpr int A_CH = 8 * BM, STAGE_CH = A_CH + 8 * BN;   // 16-byte chunks per stage (2 planes x rows x 4)
-    constexpr int NI = STAGE_CH / 64 / NW;                   // DMA instructions per wave per stage
-    static_assert(STAGE_CH % (64 * NW) == 0, "stage must split evenly over the waves");
+#ifndef P2W_GEMM_DMA_MODE
+#define P2W_GEMM_DMA_MODE 2
+#endif
+    // DMA issue (A/B switch P2W_GEMM_DMA_MODE): 0 = every wave issues its share as one burst behind the barrier;
+    // 1 = every wave spreads its share over the first half of its MFMAs; 2 (8-wave tiles) = waves 0..3 issue the whole
+    // stage behind the barrier while waves 4..7 - their SIMD partners, which the hardware's oldest-first arbitration makes
+    // the losers of every slab (in-kernel stamps: wave 0 waits 39 % of the loop at the barrier, wave 4 4 %) - start on the
+    // MFMAs at once: the issue time of one half is the other half's uncontested MFMA time.
+    constexpr int DMA_MODE = (P2W_GEMM_DMA_MODE == 2 && NW != 8) ? 1 : P2W_GEMM_DMA_MODE;
+    constexpr int NWI = DMA_MODE == 2 ? NW / 2 : NW;          // issuing waves
+    constexpr int NI = STAGE_CH / 64 / NWI;                  // DMA instructions per issuing wave per stage
+    static_assert(STAGE_CH % (64 * NWI) == 0, "stage must split evenly over the issuing waves");
     __shared__ __attribute__((aligned(16))) char S[2 * STAGE_CH * 16];
     int mt, nt;
     if (!tile_coords(nMt, nNt, &mt, &nt, tmode)) return;
     const int m0 = mt * BM, n0 = nt * BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wave / WC, wc = wave % WC;
-    const size_t a_pitch = PREC == 0 ? (size_t)2 * ldh_a : (size_t)ldh_a;   // halfs per A row
-    const size_t a_plane = PREC == 0 ? (size_t)ldh_a : (size_t)H_BK, w_plane = PREC == 0 ? plane : (size_t)H_BK;
+    // Global layout of one slab row: 64 halfs = 128 contiguous bytes (a whole cache line) - single-plane: k0..k0+63;
+    // f16x3 (interleaved H layout): [hi(k0..k0+31) | lo(k0..k0+31)].  So a slab advances 64 halfs in every precision.
+    const size_t a_pitch = (size_t)HCfg<PREC>::planes * ldh_a, w_pitch = (size_t)HCfg<PREC>::planes * Kpad;   // halfs per row
+    (void)plane;
 
-    // per-lane DMA sources (advance KS halfs per slab) and wave-uniform LDS chunk bases
+    // LDS image of a stage: rows of 128 B = 8 chunks of 16 B, A rows 0..BM-1 then B rows.  Chunk c of a row (c>>2 = plane:
+    // hi / lo, or the k half of a single-plane slab; c&3 = 8 k each) is stored at chunk position c ^ ((row >> 1) & 7), so a
+    // ds_read_b128 of one chunk index by 16 different rows spreads over all 16 slots of the 256-byte bank row: conflict-free.
+    // A DMA piece (one wave-instruction, 1 KiB) = 8 image rows: lane L -> row 8g + (L >> 3), stored chunk L & 7, reading the
+    // source chunk (L & 7) ^ swizzle: 8 rows x 128 contiguous bytes = 8 whole cache lines per piece.
     const _Float16* src[NI];
     int dstc[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-        const int g = wave + NW * i;
-        const int rloc = lane >> 2;
+        const int g = (wave % NWI) + NWI * i;
+        const int row = 8 * g + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
         if (g < BM / 8) {
-            const int p = g / (BM / 16), rb = g % (BM / 16);
-            const int row = 16 * rb + rloc, q = (lane & 3) ^ ((row >> 2) & 3);
             const int grow = (dbg & 32) ? row : min(m0 + row, M - 1);   // dbg 32: every workgroup reads row tile 0 (no A traffic)
-            src[i] = A + (size_t)grow * a_pitch + (size_t)p * a_plane + 8 * q;
-            dstc[i] = g * 64;
+            src[i] = A + (size_t)grow * a_pitch + 8 * c;
         } else {
-            const int g2 = g - BM / 8, p = g2 / (BN / 16), rb = g2 % (BN / 16);
-            const int row = 16 * rb + rloc, q = (lane & 3) ^ ((row >> 2) & 3);
-            src[i] = Wh + (size_t)p * w_plane + (size_t)(n0 + row) * Kpad + 8 * q;
-            dstc[i] = A_CH + g2 * 64;
+            src[i] = Wh + (size_t)(n0 + row - BM) * w_pitch + 8 * c;
         }
+        dstc[i] = g * 64;
     }
+    auto issue_piece = [&](int i, int stage, int k0) {
+        __builtin_amdgcn_global_load_lds((glb_vp)(src[i] + k0), (lds_vp)(S + ((size_t)stage * STAGE_CH + dstc[i]) * 16), 16, 0, 0);
+    };
+    const bool issuer = wave < NWI;   // wave-uniform
     auto issue = [&](int stage, int k0) {
+        if (issuer) {
 #pragma unroll
-        for (int i = 0; i < NI; ++i)
-            __builtin_amdgcn_global_load_lds((glb_vp)(src[i] + k0), (lds_vp)(S + ((size_t)stage * STAGE_CH + dstc[i]) * 16), 16, 0, 0);
+            for (int i = 0; i < NI; ++i) issue_piece(i, stage, k0);
+        }
     };
 
-    // fragment read offsets (bytes within a stage) for kk = 0; kk = 16 flips chunk bit 1 (q ^= 2)
+    // fragment read offsets (bytes within a stage) of plane 0, k step 0; plane 1 = ^ 64 (chunk bit 2), k step 1 = ^ 32 (bit 1)
     const int r = lane & 31, h = lane >> 5;
-    int offA[2][RT], offB[2][CT];  // [plane][tile]
+    int offA[RT], offB[CT];
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
+    for (int t = 0; t < RT; ++t) {
+        const int ra = wr * 32 * RT + 32 * t + r;
+        offA[t] = (ra * 8 + (h ^ ((ra >> 1) & 7))) * 16;
+    }
 #pragma unroll
-        for (int t = 0; t < RT; ++t) {
-            const int ra = wr * 32 * RT + 32 * t + r;
-            offA[p][t] = ((p * BM + ra) * 4 + (h ^ ((ra >> 2) & 3))) * 16;
-        }
-#pragma unroll
-        for (int t = 0; t < CT; ++t) {
-            const int rb = wc * 32 * CT + 32 * t + r;
-            offB[p][t] = (A_CH + (p * BN + rb) * 4 + (h ^ ((rb >> 2) & 3))) * 16;
-        }
+    for (int t = 0; t < CT; ++t) {
+        const int rb = BM + wc * 32 * CT + 32 * t + r;
+        offB[t] = (rb * 8 + (h ^ ((rb >> 1) & 7))) * 16;
     }
 
     f32x16 acc[RT][CT];
@@ -351,35 +379,61 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void gemm_h2g_kernel(const _Float1
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int nslab = Kpad / KS;
+#ifdef P2W_GEMM_STAMP
+    unsigned long long t_wait = 0, t_rd = 0;
+    const unsigned long long t_start = p2w_stamp();
+#endif
     issue(0, 0);
     h8 ah[RT], al[RT], bh[CT], bl[CT];   // plane 0 / plane 1 fragments
     if (dbg & 8) {   // diagnostic: fragments loaded once, the loop below is MFMA (+ optional barrier) only
         const char* st0 = S;
         __syncthreads();
 #pragma unroll
-        for (int t = 0; t < RT; ++t) { ah[t] = *reinterpret_cast<const h8*>(st0 + offA[0][t]); al[t] = *reinterpret_cast<const h8*>(st0 + offA[1][t]); }
+        for (int t = 0; t < RT; ++t) { ah[t] = *reinterpret_cast<const h8*>(st0 + offA[t]); al[t] = *reinterpret_cast<const h8*>(st0 + (offA[t] ^ 64)); }
 #pragma unroll
-        for (int t = 0; t < CT; ++t) { bh[t] = *reinterpret_cast<const h8*>(st0 + offB[0][t]); bl[t] = *reinterpret_cast<const h8*>(st0 + offB[1][t]); }
+        for (int t = 0; t < CT; ++t) { bh[t] = *reinterpret_cast<const h8*>(st0 + offB[t]); bl[t] = *reinterpret_cast<const h8*>(st0 + (offB[t] ^ 64)); }
     }
-    for (int s = 0; s < nslab; ++s) {
+    // One slab: barrier, the next slab's DMA, fragment reads + MFMAs of this slab.  The NI DMA pieces a wave issues are
+    // spread over the first half of the slab's MFMAs (sched_group_barrier) instead of going out as one burst behind the
+    // barrier: a piece costs ~60-180 issue cycles, and with every wave of the workgroup re-aligned by the barrier a burst
+    // leaves all four MFMA pipes idle for ~1000 cycles of a ~3000-cycle slab.
+    auto slab = [&](int s, auto more_c) {
+        constexpr bool MORE = decltype(more_c)::value;
+#ifdef P2W_GEMM_STAMP
+        const unsigned long long t_a = p2w_stamp();
+#endif
         if (!(dbg & 16)) __syncthreads();  // = s_waitcnt vmcnt(0) + barrier: slab s has landed for every wave, slab s-1's buffer is free
-        if (s + 1 < nslab && !(dbg & 2)) issue((s + 1) & 1, (s + 1) * KS);
+#ifdef P2W_GEMM_STAMP
+        const unsigned long long t_b = p2w_stamp();
+        t_wait += t_b - t_a;
+#endif
+        if (DMA_MODE != 1 && MORE && !(dbg & 2)) issue((s + 1) & 1, (s + 1) * 64);
         const char* st = S + (size_t)(s & 1) * STAGE_CH * 16;
-        if (dbg & 4) continue;
+        if (dbg & 4) return;
+        constexpr int NG = 2 * RT * CT;                                  // MFMA groups (one per tile pair and k step) of a slab
+        constexpr int GAP = (NG / (2 * NI)) > 0 ? NG / (2 * NI) : 1;     // groups between two pieces: all out in the first half
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             if (!(dbg & 8)) {
 #pragma unroll
             for (int t = 0; t < RT; ++t) {
-                ah[t] = *reinterpret_cast<const h8*>(st + (offA[0][t] ^ (kk << 5)));
-                al[t] = *reinterpret_cast<const h8*>(st + (offA[1][t] ^ (kk << 5)));
+                ah[t] = *reinterpret_cast<const h8*>(st + (offA[t] ^ (kk << 5)));
+                al[t] = *reinterpret_cast<const h8*>(st + (offA[t] ^ (kk << 5) ^ 64));
             }
 #pragma unroll
             for (int t = 0; t < CT; ++t) {
-                bh[t] = *reinterpret_cast<const h8*>(st + (offB[0][t] ^ (kk << 5)));
-                bl[t] = *reinterpret_cast<const h8*>(st + (offB[1][t] ^ (kk << 5)));
+                bh[t] = *reinterpret_cast<const h8*>(st + (offB[t] ^ (kk << 5)));
+                bl[t] = *reinterpret_cast<const h8*>(st + (offB[t] ^ (kk << 5) ^ 64));
             }
             }
+#if defined(P2W_GEMM_STAMP) && P2W_GEMM_STAMP > 1
+            {   // level 2: time until this half slab's fragments are in registers (drains the reads: perturbs the schedule)
+                const unsigned long long t_c = p2w_stamp();
+                asm volatile("" :: "v"(ah[0]), "v"(al[0]), "v"(bh[0]), "v"(bl[0]));
+                const unsigned long long t_d = p2w_stamp();
+                t_rd += t_d - t_c;
+            }
+#endif
 #pragma unroll
             for (int i = 0; i < RT; ++i)
 #pragma unroll
@@ -392,14 +446,39 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void gemm_h2g_kernel(const _Float1
                         acc[i][j] = h_mfma<PREC>(ah[i], bh[j], acc[i][j]);
                         acc[i][j] = h_mfma<PREC>(al[i], bl[j], acc[i][j]);
                     }
+                    if constexpr (DMA_MODE == 1) {
+                        const int g = (kk * RT + i) * CT + j;             // compile-time after unrolling
+                        if (MORE && !(dbg & 2) && (g % GAP) == GAP - 1 && g / GAP < NI) {
+                            issue_piece(g / GAP, (s + 1) & 1, (s + 1) * 64);
+                            __builtin_amdgcn_sched_barrier(0);            // keep the piece between its two MFMA groups
+                        }
+                    }
                 }
         }
-    }
+    };
+    for (int s = 0; s + 1 < nslab; ++s) slab(s, std::true_type{});
+    slab(nslab - 1, std::false_type{});
     if (dbg & 1) {
         if (acc[0][0][0] + acc[0][CT - 1][1] + acc[RT - 1][0][2] + acc[RT - 1][CT - 1][3] == 12345.678f && o.f32) o.f32[0] = 1.f;
         return;
     }
+#ifdef P2W_GEMM_STAMP
+    const unsigned long long t_loop = p2w_stamp();
+    const EpiArgs ep2 = {ep.bias, ep.sc0, ep.sh0, nullptr, nullptr, ep.residual, ep.ldr, ep.relu0, ep.relu1, ep.relu2, ep.relu_final};
+    gemm_epilogue_dispatch<PREC, RT, CT>(acc, ep2, wscale, m0 + wr * 32 * RT, n0 + wc * 32 * CT, lane, M, N, o, ef);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t_end = p2w_stamp();
+    // stamp buffer = ep.sh1 (the diagnostic launch passes it there; the sc1 stage is never applied in this build)
+    if (lane == 0 && (wave == 0 || wave == NW / 2) && blockIdx.x < 1024) {
+        unsigned long long* sb = reinterpret_cast<unsigned long long*>(const_cast<float*>(ep.sh1)) + (blockIdx.x * 2 + (wave ? 1 : 0)) * 8;
+        sb[0] = t_loop - t_start; sb[1] = t_wait; sb[2] = t_end - t_loop; sb[3] = t_rd; sb[4] = t_start; sb[5] = t_end;
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        sb[6] = xcc; sb[7] = (unsigned long long)nslab;
+    }
+#else
     gemm_epilogue_dispatch<PREC, RT, CT>(acc, ep, wscale, m0 + wr * 32 * RT, n0 + wc * 32 * CT, lane, M, N, o, ef);
+#endif
 }
 
 // host side of p2w_gemm_h2 for one precision (argument checks that do not depend on it are done by the caller)
@@ -425,7 +504,12 @@ static int32_t launch_gemm_h(const _Float16* Ah, int32_t ldh_a, const _Float16* 
     if (flags & P2W_GEMM_TILE_256) big = true;
     if (flags & P2W_GEMM_TILE_128) big = false;
     // epilogue class for the specialised interior-tile path (0 = generic); needs 32-bit element offsets
-    int ef = (ep.relu0 ? 1 : 0) | (ep.sc0 ? 2 : 0) | (ep.relu1 ? 4 : 0) | (ep.sc1 ? 8 : 0) | (ep.relu2 ? 16 : 0) |
+#ifdef P2W_GEMM_STAMP
+    const bool use_s1 = false;   // ep.sh1 carries the stamp buffer
+#else
+    const bool use_s1 = ep.sc1 != nullptr;
+#endif
+    int ef = (ep.relu0 ? 1 : 0) | (ep.sc0 ? 2 : 0) | (ep.relu1 ? 4 : 0) | (use_s1 ? 8 : 0) | (ep.relu2 ? 16 : 0) |
              (ep.residual ? 32 : 0) | (ep.relu_final ? 64 : 0) | (out_f32 ? 128 : 0) | (out_h2 ? 256 : 0);
     const size_t lim = (size_t)1 << 31;
     if ((size_t)M * (size_t)(ldo > 2 * ldh_o ? ldo : 2 * ldh_o) >= lim || (ep.residual && (size_t)M * ep.ldr >= lim) ||
@@ -551,22 +635,29 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
     auto item_mt = [&](int it) { return (first + it * stride) / nNt; };
     auto item_nt = [&](int it) { return (first + it * stride) % nNt; };
 
-    const int prow = tid >> 2, pq = tid & 3;   // rows prow + 128*u, u < NR ((row>>2)&3 is the same for all of them)
-    const int a_dst = (prow * 4 + (pq ^ ((prow >> 2) & 3))) * 16;
+    // LDS image of a stage.  f16x3: the GEMM kernel's (rows of 128 B = [hi 4 chunks | lo 4 chunks], chunk c stored at
+    // c ^ ((row >> 1) & 7), A rows then B rows); single plane: rows of 64 B, chunk q stored at q ^ ((row >> 2) & 3).
+    constexpr int RCH = 4 * NP;                                   // 16-byte chunks per image row
+    auto img = [](int row, int chunk) { return (row * RCH + (NP == 2 ? (chunk ^ ((row >> 1) & 7)) : (chunk ^ ((row >> 2) & 3)))) * 16; };
+    const int prow = tid >> 2, pq = tid & 3;   // rows prow + 128*u, u < NR (the swizzle term is the same for all of them)
+    const int a_dst = img(prow, pq);           // hi plane chunk; the lo chunk (f16x3) is at a_dst ^ 64
     // per-lane pieces of the B DMA source that do not depend on the item
     size_t boff[NI];
     int dstc[NI];
+    (void)plane;
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const int g2 = wave + NW * i, p = g2 / (BN / 16), rb = g2 % (BN / 16);
-        const int row = 16 * rb + (lane >> 2), q = (lane & 3) ^ ((row >> 2) & 3);
-        boff[i] = (size_t)p * plane + (size_t)row * C1pad + 8 * q;
+    for (int i = 0; i < NI; ++i) {   // a piece = 1 KiB of the B image: 8 rows x 128 B (f16x3: whole cache lines) / 16 rows x 64 B
+        const int g2 = wave + NW * i;
+        const int row = (NP == 2 ? 8 : 16) * g2 + (lane >> (NP == 2 ? 3 : 2));
+        const int c = NP == 2 ? ((lane & 7) ^ ((row >> 1) & 7)) : ((lane & 3) ^ ((row >> 2) & 3));
+        boff[i] = (size_t)row * (NP * C1pad) + 8 * c;
         dstc[i] = A_CH + g2 * 64;
     }
-    auto issue = [&](int stage, const _Float16* wbase, int k0) {   // wbase = W2h + nt * BN * C1pad (per item)
+    constexpr int KADV = NP == 2 ? 2 : 1;   // halfs a 32-k slab advances in a W2 row: 64 (hi + lo interleaved) or 32
+    auto issue = [&](int stage, const _Float16* wbase, int k0) {   // wbase = W2h + nt * BN * NP * C1pad (per item); k0 in k units
 #pragma unroll
         for (int i = 0; i < NI; ++i)
-            __builtin_amdgcn_global_load_lds((glb_vp)(wbase + boff[i] + k0),
+            __builtin_amdgcn_global_load_lds((glb_vp)(wbase + boff[i] + KADV * k0),
                                              (lds_vp)(S + ((size_t)stage * STAGE_CH + dstc[i]) * 16), 16, 0, 0);
     };
     // metadata of the producer's edge row (clamped: rows past the last target replay the last valid row)
@@ -627,27 +718,18 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
             }
         }
         char* st = S + (size_t)stage * STAGE_CH * 16;
-        *reinterpret_cast<uint4*>(st + a_dst + u * 128 * 64) = make_uint4(hiw[0], hiw[1], hiw[2], hiw[3]);
+        *reinterpret_cast<uint4*>(st + a_dst + u * 128 * RCH * 16) = make_uint4(hiw[0], hiw[1], hiw[2], hiw[3]);
         if constexpr (PREC == 0)
-            *reinterpret_cast<uint4*>(st + BM * 64 + a_dst + u * 128 * 64) = make_uint4(low[0], low[1], low[2], low[3]);
+            *reinterpret_cast<uint4*>(st + (a_dst ^ 64) + u * 128 * RCH * 16) = make_uint4(low[0], low[1], low[2], low[3]);
       }
     };
 
     const int r = lane & 31, h = lane >> 5;
-    int offA[NP][RT], offB[NP][2];
+    int offA[RT], offB[2];   // plane 0 (hi), k step 0; the lo plane is ^ 64, k step 1 is ^ 32
 #pragma unroll
-    for (int p = 0; p < NP; ++p) {
+    for (int t = 0; t < RT; ++t) offA[t] = img(wr * 32 * RT + 32 * t + r, h);
 #pragma unroll
-        for (int t = 0; t < RT; ++t) {
-            const int ra = wr * 32 * RT + 32 * t + r;
-            offA[p][t] = ((p * BM + ra) * 4 + (h ^ ((ra >> 2) & 3))) * 16;
-        }
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int rb = wc * 64 + 32 * t + r;
-            offB[p][t] = (A_CH + (p * BN + rb) * 4 + (h ^ ((rb >> 2) & 3))) * 16;
-        }
-    }
+    for (int t = 0; t < 2; ++t) offB[t] = A_CH * 16 + img(wc * 64 + 32 * t + r, h);
     f32x16 acc[RT][2];
 #pragma unroll
     for (int i = 0; i < RT; ++i)
@@ -691,7 +773,7 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
     SaEpiRegs<RT> e_cur, e_1;
     load_epi(item_mt(0), item_nt(0), e_cur);
     e_1 = e_cur;
-    const _Float16* wb1 = W2h + (size_t)item_nt(0) * BN * C1pad;   // W2 panel of the item in the produce stage
+    const _Float16* wb1 = W2h + (size_t)item_nt(0) * BN * NP * C1pad;   // W2 panel of the item in the produce stage
     int mt_cur = item_mt(0), nt_cur = item_nt(0);                   // item in the MFMA stage
     int mt_1 = mt_cur, nt_1 = nt_cur;                               // item in the produce stage
     __syncthreads();   // Wr staged
@@ -717,7 +799,7 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
             if (s1 == nslab) {
                 s1 = 0; it1 = it + 1;
                 mt_1 = item_mt(it1); nt_1 = item_nt(it1);
-                wb1 = W2h + (size_t)nt_1 * BN * C1pad;
+                wb1 = W2h + (size_t)nt_1 * BN * NP * C1pad;
                 load_epi(mt_1, nt_1, e_1);
             }
             if (!(dbg & 2)) issue((g + 1) & 1, wb1, s1 * H_BK);
@@ -742,9 +824,9 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
 #pragma unroll
-                for (int t = 0; t < RT; ++t) af[p][t] = *reinterpret_cast<const h8*>(st + (offA[p][t] ^ (kk << 5)));
+                for (int t = 0; t < RT; ++t) af[p][t] = *reinterpret_cast<const h8*>(st + (offA[t] ^ (kk << 5) ^ (p << 6)));
 #pragma unroll
-                for (int t = 0; t < 2; ++t) bf[p][t] = *reinterpret_cast<const h8*>(st + (offB[p][t] ^ (kk << 5)));
+                for (int t = 0; t < 2; ++t) bf[p][t] = *reinterpret_cast<const h8*>(st + (offB[t] ^ (kk << 5) ^ (p << 6)));
             }
             if (!(dbg & 4)) {
 #pragma unroll

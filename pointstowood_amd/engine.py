@@ -47,7 +47,7 @@ class Linear:
     relu1: int = 0
     relu2: int = 0
     relu_final: int = 0
-    w16: torch.Tensor | None = None   # H weights of W * 2^e: [2, N_pad, K_pad] fp16 hi / lo planes (f16x3),
+    w16: torch.Tensor | None = None   # H weights of W * 2^e: [N_pad, 2 K_pad] fp16, blocks of 32 k as [hi | lo] (f16x3),
                                       # [N_pad, K_pad] fp16 / bf16 (single-plane precisions)
     wscale: float = 1.0               # 2^-e
 
@@ -87,7 +87,9 @@ class PackedWeights:
             if prec == PREC_F16X3:
                 hi = Ws.to(torch.float32).to(torch.float16)
                 lo = (Ws - hi.double()).to(torch.float32).to(torch.float16)
-                w16 = torch.stack([hi, lo]).contiguous().to(device)
+                # H layout (include/p2w.h): per block of 32 k [hi(32) | lo(32)], one row per output channel
+                w16 = torch.stack([hi.view(Np, Kp // 32, 32), lo.view(Np, Kp // 32, 32)], dim=2).reshape(Np, 2 * Kp)
+                w16 = w16.contiguous().to(device)
             else:   # one plane, round to nearest
                 w16 = Ws.to(torch.float32).to(torch.float16 if precision == "fp16" else torch.bfloat16).contiguous().to(device)
             return Linear(w=None, N=N, K=K, w16=w16, wscale=2.0 ** (-e), **vec)

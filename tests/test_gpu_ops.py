@@ -125,10 +125,10 @@ def _pack_h(W, prec):
     Wp[:N, :K] = W.double()
     e = int(np.floor(np.log2(1024.0 / float(Wp.abs().max()))))
     Ws = Wp * 2.0 ** e
-    if prec == 0:
+    if prec == 0:     # H layout: blocks of 32 k stored as [hi(32) | lo(32)]
         hi = Ws.float().half()
         lo = (Ws - hi.double()).float().half()
-        w = torch.stack([hi, lo])
+        w = torch.stack([hi.view(Np, Kp // 32, 32), lo.view(Np, Kp // 32, 32)], dim=2).reshape(Np, 2 * Kp)
     else:
         w = Ws.float().to(torch.float16 if prec == 1 else torch.bfloat16)
     return w.contiguous().cuda(), 2.0 ** -e, Kp
@@ -145,6 +145,15 @@ def _to_h(x, prec, ldh):
     zeros = torch.zeros((m, 4), device="cuda")
     check(lib().p2w_concat_xyz_h2(prec, ptr(x.cuda().contiguous()), F, ptr(zeros), m, ptr(out), ldh, stream()))
     return out
+
+
+def _from_h(t, prec, ldh):
+    """Values [m, ldh] (float64, on the CPU) of an H tensor: f16x3 rows are blocks of 32 columns stored [hi(32) | lo(32)]."""
+    v = t.cpu().double()
+    if prec != 0:
+        return v[:, :ldh]
+    b = v.view(v.shape[0], ldh // 32, 2, 32)
+    return (b[:, :, 0] + b[:, :, 1]).reshape(v.shape[0], ldh)
 
 
 # relative error bound of a K-term dot product per precision (operand rounding 2^-22 / 2^-11 / 2^-8, fp32 accumulate)
@@ -186,8 +195,8 @@ def test_gemm_h_epilogue(prec, M, N, K, flags):
     scale = max(1.0, v.abs().max().item())
     err = (out.cpu().double() - v).abs().max().item()
     assert err <= H_TOL[prec] * scale, err
-    hv = outh.cpu().double()
-    got_h = hv[:, :N] + (hv[:, ldh_o:ldh_o + N] if prec == 0 else 0)
+    hv = _from_h(outh, prec, ldh_o)
+    got_h = hv[:, :N]
     assert (got_h - out.cpu().double()).abs().max().item() <= (2e-6 if prec == 0 else 1e-3 if prec == 1 else 8e-3) * scale
     assert float(hv[:, N:ldh_o].abs().max() if ldh_o > N else 0.0) == 0.0          # pad columns of an H row are zero
     # plain (no epilogue), fp32 output only, into a wider output
@@ -203,7 +212,7 @@ def test_gemm_h_rejects_bad_arguments():
     from pointstowood_amd._lib import lib, ptr, stream
     L = lib()
     A = torch.zeros((64, 128), dtype=torch.float16, device="cuda")
-    W = torch.zeros((2, 256, 64), dtype=torch.float16, device="cuda")
+    W = torch.zeros((256, 128), dtype=torch.float16, device="cuda")
     o = torch.zeros((64, 8), device="cuda")
     args = lambda prec, ldh, flags: (prec, ptr(A), ldh, ptr(W), 1.0, 64, 8, 64, None, ptr(o), 8, None, 0, flags, stream())
     assert L.p2w_gemm_h2(*args(0, 64, 0)) == 0

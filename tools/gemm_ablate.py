@@ -21,7 +21,7 @@ hdt = torch.bfloat16 if PREC == 2 else torch.float16
 for M, K, N in shapes:
     Np, Kp = _lib.packed_dims(N, K, PREC)
     A = (torch.randn(M, planes * Kp, device=dev) * 0.5).to(hdt)
-    W = (torch.randn(planes, Np, Kp, device=dev) * 0.5).to(hdt)
+    W = (torch.randn(Np, planes * Kp, device=dev) * 0.5).to(hdt)
     bias = torch.randn(N, device=dev)
     sc, sh = torch.randn(N, device=dev), torch.randn(N, device=dev)
     ldh_o = (N + ka - 1) // ka * ka
