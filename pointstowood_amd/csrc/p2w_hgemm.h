@@ -501,6 +501,9 @@ static int32_t launch_gemm_h(const _Float16* Ah, int32_t ldh_a, const _Float16* 
     const long rounds = (tiles256 + n_cu - 1) / n_cu;
     const bool fills = tiles256 * 100 >= rounds * n_cu * 78;
     bool big = N >= 256 && (N % 256) == 0 && tiles256 * 4 >= 3 * n_cu && fills;
+    // long-K layers with half a round of 256-tiles or more: the large tile's DMA economy outweighs the idle CUs
+    // (M = 17506, K = 2048, N = 512: 127 us vs 134 us for the best 128-tile order)
+    if (N >= 256 && (N % 256) == 0 && Kpad >= 1024 && tiles256 * 2 >= n_cu && tiles256 <= n_cu) big = true;
     if (flags & P2W_GEMM_TILE_256) big = true;
     if (flags & P2W_GEMM_TILE_128) big = false;
     // epilogue class for the specialised interior-tile path (0 = generic); needs 32-bit element offsets
@@ -522,7 +525,9 @@ static int32_t launch_gemm_h(const _Float16* Ah, int32_t ldh_a, const _Float16* 
         if (!ok) return 0;
         if (flags & P2W_GEMM_ORDER_ROWS) return 0;
         if (flags & P2W_GEMM_ORDER_COLS) return 1;
-        return w_bytes > (size_t)3 * 1024 * 1024 ? 1 : 0;
+        // column-slice order only pays when there are at least 8 column tiles (one or more per XCD); with fewer, several
+        // XCDs stream ALL of A for the same column tile (M = 17506, K = 2048, N = 512 at 128 x 128: 188 vs 134 us)
+        return (w_bytes > (size_t)3 * 1024 * 1024 && nNtx >= 8) ? 1 : 0;
     };
     if (big) {
         const int nMt = p2w_cdiv(M, 256), nNt2 = Npad / 256;
