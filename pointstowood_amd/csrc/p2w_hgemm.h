@@ -30,7 +30,7 @@ typedef const __attribute__((address_space(1))) void* glb_vp;
 
 constexpr int H_BK = 32;   // k per LDS row (64 bytes); a slab is two such row groups ("planes")
 
-#ifdef P2W_GEMM_STAMP   // diagnostic build (tools/gemm_stamps.py): in-kernel cycle stamps of the GEMM's phases
+#if defined(P2W_GEMM_STAMP) || defined(P2W_SA_STAMP)   // diagnostic builds (tools/gemm_stamps.py, tools/sa_stamps.py): in-kernel cycle stamps
 __device__ __forceinline__ unsigned long long p2w_stamp() {
     unsigned long long t;
     __builtin_amdgcn_sched_barrier(0);
@@ -614,8 +614,10 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
     constexpr int A_CH = 4 * NP * BM, STAGE_CH = A_CH + 4 * NP * BN;
     constexpr int NI = (4 * NP * BN) / 64 / NW;
     static_assert(NI >= 1, "every wave issues at least one W2 DMA piece per slab");
-    __shared__ __attribute__((aligned(16))) char S[2 * STAGE_CH * 16];
-    __shared__ __attribute__((aligned(16))) float Wr[4 * 512];   // layer-1 geometry weights (rx, ry, rz, refl rows), C1pad <= 512
+    // ONE __shared__ object: with a second one beside the DMA staging array hipcc cannot tell the LDS-DMA's destination from
+    // the other object and drains vmcnt(0) in front of the first ds_read of every slab (cdna_hip_programming.md, .s-level trap a)
+    __shared__ __attribute__((aligned(16))) char S[2 * STAGE_CH * 16 + 4 * 512 * 4];
+    float* const Wr = reinterpret_cast<float*>(S + 2 * STAGE_CH * 16);   // layer-1 geometry weights (rx, ry, rz, refl rows), C1pad <= 512
     const int tid = threadIdx.x, lane = tid & 63;
     for (int i = tid; i < 4 * C1pad; i += 512) Wr[i] = w1r4[i];
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wave / WCn, wc = wave % WCn;
@@ -678,18 +680,30 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
             m.g[u] = meta_g[row];
         }
     };
-    Vals pv;    // slab 0 only (prologue)
+    // Unconditional loads from clamped addresses (an empty slot reads row 0, a padded k re-reads the row's last chunk):
+    // a load behind a per-lane condition makes hipcc branch around it and drain vmcnt(0) at the join - with the W2 DMA
+    // and the gather itself in flight that exposed the whole gather latency in every slab.  The producer masks the values.
     auto gather = [&](const Meta& m, int k0, Vals& dst) {
         const int k = k0 + 8 * pq;
 #pragma unroll
         for (int u = 0; u < NR; ++u) {
-            const bool on = m.j[u] >= 0;
-            const float* p = P + (size_t)(on ? m.j[u] : 0) * ldp + 8 * pq + k0;
-            dst.v[u][0] = (on && k < C1) ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
-            dst.v[u][1] = (on && k + 4 < C1) ? *reinterpret_cast<const float4*>(p + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float* p = P + (size_t)max(m.j[u], 0) * ldp;
+            dst.v[u][0] = *reinterpret_cast<const float4*>(p + min(k, C1 - 4));
+            dst.v[u][1] = *reinterpret_cast<const float4*>(p + min(k + 4, C1 - 4));
         }
     };
-    auto produce = [&](int stage, const Meta& m, int k0, const Vals& src) {
+    // layer-1 geometry weights of the producer's 8 k values: read from LDS BEFORE the slab's DMA is issued (an LDS read
+    // behind a pending LDS-DMA makes hipcc wait for the DMA: it cannot tell the two LDS regions apart)
+    struct WRegs { float4 w[2][4]; };
+    auto load_w = [&](int k0, WRegs& wr_) {
+        const int k = k0 + 8 * pq;
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) wr_.w[half][c] = *reinterpret_cast<const float4*>(&Wr[c * C1pad + k + 4 * half]);
+    };
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_vp)S;   // LDS byte address of the staging array
+    auto produce = [&](int stage, const Meta& m, int k0, const Vals& src, const WRegs& wr_) {
         const int k = k0 + 8 * pq;
 #pragma unroll
       for (int u = 0; u < NR; ++u) {
@@ -701,11 +715,10 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
             const int kk = k + 4 * half;
             // branch-free (so the scheduler can interleave it with MFMAs): Wr is zero-padded to C1pad, P values of
             // empty slots / padded k are zero, and the geometry term is switched off with a select
-            const float4 wx = *reinterpret_cast<const float4*>(&Wr[0 * C1pad + kk]);
-            const float4 wy = *reinterpret_cast<const float4*>(&Wr[1 * C1pad + kk]);
-            const float4 wz = *reinterpret_cast<const float4*>(&Wr[2 * C1pad + kk]);
-            const float4 wf = *reinterpret_cast<const float4*>(&Wr[3 * C1pad + kk]);
-            const float4 p = src.v[u][half];
+            const float4 wx = wr_.w[half][0], wy = wr_.w[half][1], wz = wr_.w[half][2], wf = wr_.w[half][3];
+            const bool live = on && kk < C1;   // empty neighbour slot / padded k: the row chunk is zero
+            float4 p = src.v[u][half];
+            p.x = live ? p.x : 0.f; p.y = live ? p.y : 0.f; p.z = live ? p.z : 0.f; p.w = live ? p.w : 0.f;
             const float gx = on ? rg.x : 0.f, gy = on ? rg.y : 0.f, gz = on ? rg.z : 0.f, gw = on ? rg.w : 0.f;
             float v[4];
             v[0] = fmaxf(fmaf(gw, wf.x, fmaf(gz, wz.x, fmaf(gy, wy.x, fmaf(gx, wx.x, p.x)))), 0.f);
@@ -722,10 +735,20 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
                 hiw[2 * half] = pack_pair<PREC>(v[0], v[1]); hiw[2 * half + 1] = pack_pair<PREC>(v[2], v[3]);
             }
         }
-        char* st = S + (size_t)stage * STAGE_CH * 16;
-        *reinterpret_cast<uint4*>(st + a_dst + u * 128 * RCH * 16) = make_uint4(hiw[0], hiw[1], hiw[2], hiw[3]);
-        if constexpr (PREC == 0)
-            *reinterpret_cast<uint4*>(st + (a_dst ^ 64) + u * 128 * RCH * 16) = make_uint4(low[0], low[1], low[2], low[3]);
+        // The A rows go to LDS through inline asm: a store the compiler knows about, issued while the W2 DMA of the same
+        // stage is in flight, makes hipcc drain vmcnt(0) first (it cannot tell the A region from the DMA's B region) -
+        // in the middle of the slab.  The asm store is invisible to that bookkeeping; its own completion is waited for by
+        // the `s_waitcnt lgkmcnt(0)` in front of the loop's barrier.
+        const unsigned sa = lds_base + (unsigned)stage * (STAGE_CH * 16) + (unsigned)(a_dst + u * 128 * RCH * 16);
+        {
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 hv = {hiw[0], hiw[1], hiw[2], hiw[3]};
+            asm volatile("ds_write_b128 %0, %1" :: "v"(sa), "v"(hv) : "memory");
+            if constexpr (PREC == 0) {
+                const u32x4 lv = {low[0], low[1], low[2], low[3]};
+                asm volatile("ds_write_b128 %0, %1" :: "v"(sa ^ 64u), "v"(lv) : "memory");
+            }
+        }
       }
     };
 
@@ -743,85 +766,66 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    // Software pipeline over the flattened slab sequence g = 0..total-1 of this workgroup's items:
-    //   MFMA stage    : slab g        (reads LDS stage g&1)
-    //   produce stage : slab g+1      (A rows: VALU on P values gathered one slab EARLIER, written to stage (g+1)&1;
-    //                                  placed between the two MFMA groups of slab g so it co-issues with MFMAs in flight)
-    //   gather stage  : slab g+2      (global loads of P rows + W2 DMA of slab g+1 issued right after the barrier)
-    // Metadata (source row, normalised offset) of an item is prefetched one item ahead of the gather stage.
-    int it_q = 0, s_q = 0;                   // item / slab of the gather stage
-    Meta m_q, m_nxt;
-    load_meta(0, m_q);
-    m_nxt = m_q;
-    if (my_items > 1) load_meta(1, m_nxt);
-    auto advance_q = [&]() {                 // move the gather stage to the next slab (possibly the next item)
-        if (++s_q == nslab) {
-            s_q = 0; ++it_q;
-            m_q = m_nxt;
-            if (it_q + 1 < my_items) load_meta(it_q + 1, m_nxt);
-        }
-    };
-    // prologue: slab 0 produced synchronously, slab 1 gathered
-    auto load_epi = [&](int mt_, int nt_, SaEpiRegs<RT>& e) {   // parameters of an item's epilogue, fetched an item ahead
+    // Software pipeline over the flattened slab sequence g = 0..total-1 of this workgroup's items.  Iteration g:
+    //   top      : barrier (its vmcnt(0) retires everything issued in iteration g-1), W2 DMA of slab g+1
+    //   k step 0 : fragment reads + MFMAs of slab g, interleaved with the PRODUCER of slab g+1 (A rows: VALU on the
+    //              P values `va` gathered in iteration g-1 and metadata `ma`, written to stage (g+1)&1)
+    //   middle   : gather of slab g+2 (P rows, straight into `va`) using metadata `mb`; metadata load of slab g+3 -> `mc`
+    //   k step 1 : fragment reads + MFMAs
+    //   end      : epilogue if the item is complete; rotate ma <- mb <- mc (the copy of the just-loaded `mc` is where the
+    //              compiler waits for it: right in front of the next barrier)
+    // Every global load in the loop is unconditional, straight-line code behind the first MFMA block: hipcc drains
+    // vmcnt(0) at any join behind a branch that contains a load, and with the DMA in flight such a drain in front of the
+    // fragment reads serialises the DMA, the gather latency and the MFMAs (the previous form of this loop did that in
+    // every slab: 3.3x the MFMA time).  Slabs past the end replay the last slab's addresses and are never consumed.
+    struct Cur { int it, s; };
+    auto nxt = [&](Cur c) { if (++c.s == nslab) { c.s = 0; ++c.it; } return c; };
+    auto meta_of = [&](Cur c, Meta& m) { load_meta(min(c.it, my_items - 1), m); };
+    auto k_of = [&](Cur c) { return (c.it < my_items ? c.s : nslab - 1) * H_BK; };
+    Cur c0 = {0, 0}, c1 = nxt(c0), c2 = nxt(c1), c3 = nxt(c2);
+    Meta ma, mb, mc;
+    Vals va;
+    {   // prologue: slab 0 complete in stage 0, slab 1 gathered, metadata of slabs 2 and 3 on their way
+        Meta m0;
+        meta_of(c0, m0);
+        meta_of(c1, ma);
+        meta_of(c2, mb);
+        meta_of(c3, mc);
+        __syncthreads();   // Wr staged
+        issue(0, W2h + (size_t)item_nt(0) * BN * NP * C1pad, 0);
+        gather(m0, 0, va);
+        WRegs w0;
+        load_w(0, w0);
+        produce(0, m0, 0, va, w0);
+        gather(ma, k_of(c1), va);
+        // enter the loop with no register load pending (as every later iteration does, behind its barrier): otherwise the
+        // merged loop-head state makes hipcc wait vmcnt(0) - DMA included - at the producer's first use of `va` in EVERY slab
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = nt_ * BN + wc * 64 + j * 32 + (lane & 31);
-            const bool cv = col < C2;
-            e.bias[j] = cv ? b2[col] : 0.f; e.s[j] = cv ? bn_s[col] : 0.f; e.t[j] = cv ? bn_t[col] : 0.f;
-        }
+        for (int u = 0; u < NR; ++u)
 #pragma unroll
-        for (int i = 0; i < RT; ++i) {
-            const int tgt = mt_ * (BM / 32) + wr * RT + i;
-            e.d[i] = tgt < M ? min(deg[tgt], kw) : 0;
-        }
-    };
-    SaEpiRegs<RT> e_cur, e_1;
-    load_epi(item_mt(0), item_nt(0), e_cur);
-    e_1 = e_cur;
-    const _Float16* wb1 = W2h + (size_t)item_nt(0) * BN * NP * C1pad;   // W2 panel of the item in the produce stage
-    int mt_cur = item_mt(0), nt_cur = item_nt(0);                   // item in the MFMA stage
-    int mt_1 = mt_cur, nt_1 = nt_cur;                               // item in the produce stage
-    __syncthreads();   // Wr staged
-    issue(0, wb1, 0);
-    gather(m_q, 0, pv);
-    produce(0, m_q, 0, pv);
-    Vals pn = pv;          // gathered values of slab g+1
-    Meta m_n = m_q;
-    int k_n = 0;
-    if (total > 1) {
-        advance_q();
-        gather(m_q, s_q * H_BK, pn);
-        m_n = m_q; k_n = s_q * H_BK;
+            for (int hh = 0; hh < 2; ++hh)   // an opaque use: the compiler waits for the gather here, once
+                asm volatile("" : "+v"(va.v[u][hh].x), "+v"(va.v[u][hh].y), "+v"(va.v[u][hh].z), "+v"(va.v[u][hh].w));
     }
-    int it = 0, s = 0;                       // item / slab of the MFMA stage
-    int it1 = 0, s1 = 0;                     // item / slab of the produce stage (g+1)
+    int mt_cur = item_mt(0), nt_cur = item_nt(0);   // item in the MFMA stage
+#ifdef P2W_SA_STAMP
+    unsigned long long t_wait = 0, t_epi = 0, t_mma = 0;
+    const unsigned long long t_start = p2w_stamp();
+#endif
     for (int g = 0; g < total; ++g) {
-        __syncthreads();  // B(g) landed, A(g) written, stage (g+1)&1 free  (a counted vmcnt that leaves the gather in
-                          // flight across the barrier measured 2 % slower)
-        const bool more = g + 1 < total;
-        if (more) {
-            s1 = s + 1; it1 = it;
-            if (s1 == nslab) {
-                s1 = 0; it1 = it + 1;
-                mt_1 = item_mt(it1); nt_1 = item_nt(it1);
-                wb1 = W2h + (size_t)nt_1 * BN * NP * C1pad;
-                load_epi(mt_1, nt_1, e_1);
-            }
-            if (!(dbg & 2)) issue((g + 1) & 1, wb1, s1 * H_BK);
-        }
-        // values for the produce stage were gathered during the previous iteration
-        const Vals pu = pn;
-        const Meta m_u = m_n;
-        const int k_u = k_n;
-        // The gather of slab g+2 is issued here and lands in `pg` while this iteration's MFMAs run; it is only moved
-        // into the loop-carried registers at the END of the iteration (a register copy is a use: placed here, it
-        // would make the compiler wait for the loads before the first MFMA).
-        Vals pg = pn;
-        const bool fetch = g + 2 < total;
-        if (fetch) {
-            advance_q();
-            if (!(dbg & 16)) gather(m_q, s_q * H_BK, pg);
-        }
+#ifdef P2W_SA_STAMP
+        const unsigned long long t_a = p2w_stamp();
+#endif
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the producer's asm ds_writes of A(g) (see produce)
+        __syncthreads();  // B(g) landed, A(g) written, stage (g+1)&1 free, last iteration's gather / metadata in registers
+#ifdef P2W_SA_STAMP
+        const unsigned long long t_b = p2w_stamp();
+        t_wait += t_b - t_a;
+#endif
+        WRegs wk;
+        load_w(k_of(c1), wk);
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + 1 < total && !(dbg & 2))
+            issue((g + 1) & 1, W2h + (size_t)item_nt(c1.it) * BN * NP * C1pad, c1.s * H_BK);
         const char* st = S + (size_t)(g & 1) * STAGE_CH * 16;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -845,31 +849,64 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
                     acc[i][j] = h_mfma<PREC>(af[0][i], bf[0][j], acc[i][j]);
                 }
             }
-            if (kk == 0 && !(dbg & 8)) {  // producer VALU work is interleaved into the gaps of the MFMAs above
-                produce((g + 1) & 1, m_u, k_u, pu);   // unconditional: after the last slab it fills a stage nobody reads
-                constexpr int NM = 2 * RT * (PREC == 0 ? 3 : 1);   // MFMAs of this half slab
+            if (kk == 0) {
+                if (!(dbg & 8)) {   // producer VALU work is interleaved into the gaps of the MFMAs above
+                    produce((g + 1) & 1, ma, k_of(c1), va, wk);   // unconditional: after the last slab it fills a stage nobody reads
+                    constexpr int NM = 2 * RT * (PREC == 0 ? 3 : 1);   // MFMAs of this half slab
 #pragma unroll
-                for (int q = 0; q < NM; ++q) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x002, (PREC == 0 ? 16 : 40) * NR / RT, 0);   // VALU
+                    for (int q = 0; q < NM; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x002, (PREC == 0 ? 16 : 40) * NR / RT, 0);   // VALU
+                    }
                 }
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(dbg & 16)) gather(mb, k_of(c2), va);
+                meta_of(c3, mc);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (s == nslab - 1 && !(dbg & 1)) {  // item finished: reduce over neighbour slots and store, then start the next accumulation
-            sa_epilogue_regs<PREC, RT>(acc, wscale, mt_cur * (BM / 32), nt_cur * BN, wr, wc, lane, M, e_cur, C2, out, ldo, out_h2, ldh);
+#ifdef P2W_SA_STAMP
+        const unsigned long long t_c = p2w_stamp();
+        t_mma += t_c - t_b;            // DMA issue + fragment reads + MFMAs + producer + gather issue
+#endif
+        if (c0.s == nslab - 1) {  // item finished: reduce over neighbour slots and store, then start the next accumulation
+            if (!(dbg & 1)) {
+                SaEpiRegs<RT> e;   // loaded here, once per item: a wait in front of the epilogue is harmless
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int col = nt_cur * BN + wc * 64 + j * 32 + (lane & 31);
+                    const bool cv = col < C2;
+                    e.bias[j] = cv ? b2[col] : 0.f; e.s[j] = cv ? bn_s[col] : 0.f; e.t[j] = cv ? bn_t[col] : 0.f;
+                }
+#pragma unroll
+                for (int i = 0; i < RT; ++i) {
+                    const int tgt = mt_cur * (BM / 32) + wr * RT + i;
+                    e.d[i] = tgt < M ? min(deg[tgt], kw) : 0;
+                }
+                sa_epilogue_regs<PREC, RT>(acc, wscale, mt_cur * (BM / 32), nt_cur * BN, wr, wc, lane, M, e, C2, out, ldo, out_h2, ldh);
+            }
 #pragma unroll
             for (int i = 0; i < RT; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+                    for (int e2 = 0; e2 < 16; ++e2) acc[i][j][e2] = 0.f;
+            const int itn = min(c0.it + 1, my_items - 1);
+            mt_cur = item_mt(itn); nt_cur = item_nt(itn);
         }
-        if (s == nslab - 1) e_cur = e_1;
-        s = s1; it = it1; mt_cur = mt_1; nt_cur = nt_1;
+#ifdef P2W_SA_STAMP
+        t_epi += p2w_stamp() - t_c;
+#endif
         __builtin_amdgcn_sched_barrier(0);
-        if (fetch) { pn = pg; m_n = m_q; k_n = s_q * H_BK; }
+        ma = mb; mb = mc;
+        c0 = c1; c1 = c2; c2 = c3; c3 = nxt(c3);
     }
+#ifdef P2W_SA_STAMP
+    if (lane == 0 && (wave == 0 || wave == 4) && blockIdx.x < 256) {   // stamp buffer: the 64 KiB behind the edge metadata
+        unsigned long long* sb = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(const_cast<int*>(meta_j) + (size_t)M * 32) + 64) + (blockIdx.x * 2 + (wave ? 1 : 0)) * 8;
+        sb[0] = p2w_stamp() - t_start; sb[1] = t_wait; sb[2] = t_epi; sb[3] = t_mma; sb[4] = (unsigned long long)total; sb[5] = (unsigned long long)my_items;
+    }
+#endif
 }
 
 __global__ __launch_bounds__(256) void sa_edge_meta_kernel(const float4* __restrict__ xyzr, const int* __restrict__ idx, const int* __restrict__ batch_dst,

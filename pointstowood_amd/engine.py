@@ -430,7 +430,9 @@ class Engine:
             P = new(src.n, C1)
             self._gemm_h2("gemm_hoist", xh[l - 1], pad8(p["F_in"]), src.n, p["hoist"], out_f32=P, ldo=C1)
             conv, convh = new(M, C2), newh(M, C2)
-            meta = torch.empty(M * 32 * 20, dtype=torch.uint8, device=dev)   # per-edge (j, normalised offset) scratch
+            meta = torch.empty(M * 32 * 20 + 65536, dtype=torch.uint8, device=dev)   # per-edge (j, normalised offset) scratch (+ room for diagnostics)
+            if keep is not None:
+                keep[f"sa{l}_module.ws"] = meta
             self._call("sa_conv", L.p2w_sa_conv_h, prec, ptr(P), C1, ptr(src.xyzr), ptr(dst.idx), ptr(dst.batch),
                        ptr(geo.sf), ptr(dst.nbr), ptr(dst.deg), geo.k, M, ptr(p["w1r4"]), ptr(p["W2"].w16),
                        p["W2"].wscale, C1, C2, ptr(p["b2"]), ptr(p["bn_s"]), ptr(p["bn_t"]), ptr(conv), C2, ptr(convh),
