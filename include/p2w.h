@@ -247,10 +247,12 @@ int32_t p2w_packed_dims_h(int32_t prec, int32_t N, int32_t K, int32_t* N_pad, in
 int32_t p2w_gemm_h2(int32_t prec, const void* A_h, int32_t ldh_a, const void* Wh, float wscale, int32_t M, int32_t N,
                     int32_t K, const p2w_epilogue* epi, float* out_f32, int32_t ldo, void* out_h, int32_t ldh_o,
                     int32_t flags, p2w_stream_t stream);
-/* p2w_sa_conv with H weights W2h and fp32 and/or H outputs.  P (the hoisted layer-1 product) stays fp32.
+/* p2w_sa_conv with H weights W2h and fp32 and/or H outputs.  P (the hoisted layer-1 product, fp32) has n_src + 1 rows of
+ * ldp >= round_up(C1, K granularity) floats: rows 0..n_src-1 = x_src * W1x^T + b1 with ZERO pad columns, row n_src all
+ * zero (the row empty neighbour slots read; the kernel's loads are unconditional).
  * ws: 16-byte aligned scratch of >= M*32*20 bytes for the per-edge metadata (P2W_EWORKSPACE otherwise);
  * kw <= 32 (one 32-row MFMA tile per target) and round_up(C1, K granularity) <= 512 (P2W_EUNSUPPORTED otherwise). */
-int32_t p2w_sa_conv_h(int32_t prec, const float* P, int32_t ldp, const float* xyzr_src, const int32_t* idx,
+int32_t p2w_sa_conv_h(int32_t prec, const float* P, int32_t ldp, int32_t n_src, const float* xyzr_src, const int32_t* idx,
                       const int32_t* batch_dst, const float* sf, const int32_t* nbr, const int32_t* deg, int32_t kw,
                       int32_t M, const float* w1r4, const void* W2h, float wscale, int32_t C1, int32_t C2,
                       const float* b2, const float* bn_s, const float* bn_t, float* out, int32_t ldo, void* out_h,

@@ -365,7 +365,7 @@ extern "C" int32_t p2w_gemm_h2(int32_t prec, const void* A_h, int32_t ldh_a, con
 __global__ __launch_bounds__(256) void sa_edge_meta_kernel(const float4* __restrict__ xyzr, const int* __restrict__ idx,
                                                            const int* __restrict__ batch_dst, const float* __restrict__ sf,
                                                            const int* __restrict__ nbr, const int* __restrict__ deg, int kw,
-                                                           int M, int* __restrict__ meta_j, float4* __restrict__ meta_g) {
+                                                           int M, int n_src, int* __restrict__ meta_j, float4* __restrict__ meta_g) {
     const long g = (long)blockIdx.x * 256 + threadIdx.x;
     const int tgt = (int)(g >> 5), slot = (int)(g & 31);
     int j = 0;
@@ -391,12 +391,12 @@ __global__ __launch_bounds__(256) void sa_edge_meta_kernel(const float4* __restr
     const float den = dmax + 1e-8f;
     if (tgt < M) {
         const bool valid = slot < deg[tgt] && slot < kw;
-        meta_j[g] = valid ? j : -1;     // empty slot: the producer writes a zero row, the epilogue masks it
+        meta_j[g] = valid ? j : n_src;  // empty slot: P's all-zero row + a zero offset give a zero A row; the epilogue masks it
         meta_g[g] = make_float4(rx / den, ry / den, rz / den, rf);
     }
 }
 
-extern "C" int32_t p2w_sa_conv_h(int32_t prec, const float* P, int32_t ldp, const float* xyzr_src, const int32_t* idx,
+extern "C" int32_t p2w_sa_conv_h(int32_t prec, const float* P, int32_t ldp, int32_t n_src, const float* xyzr_src, const int32_t* idx,
                                  const int32_t* batch_dst, const float* sf, const int32_t* nbr, const int32_t* deg,
                                  int32_t kw, int32_t M, const float* w1r4, const void* W2h, float wscale, int32_t C1,
                                  int32_t C2, const float* b2, const float* bn_s, const float* bn_t, float* out,
@@ -409,14 +409,14 @@ extern "C" int32_t p2w_sa_conv_h(int32_t prec, const float* P, int32_t ldp, cons
     P2W_CHECK_PTR(bn_s); P2W_CHECK_PTR(bn_t);
     if (!out && !out_h) return P2W_ENULL;
     P2W_CHECK_ALIGN16(P); P2W_CHECK_ALIGN16(xyzr_src); P2W_CHECK_ALIGN16(w1r4); P2W_CHECK_ALIGN16(W2h);
-    if (M < 0 || kw <= 0 || kw > 32 || C1 <= 0 || C2 <= 0 || (C1 & 3) || (ldp & 3) || ldp < C1 || (out && ldo < C2) ||
+    if (M < 0 || n_src < 0 || kw <= 0 || kw > 32 || C1 <= 0 || C2 <= 0 || (C1 & 3) || (ldp & 3) || ldp < C1 || (out && ldo < C2) ||
         (out_h && (ldh < C2 || (ldh & 7))) || !(wscale > 0.f))
         return P2W_EINVAL;
     const _Float16* W2 = static_cast<const _Float16*>(W2h);
     if (prec == P2W_PREC_F16X3)
-        return launch_sa_conv_h<0>(P, ldp, xyzr_src, idx, batch_dst, sf, nbr, deg, kw, M, w1r4, W2, wscale, C1, C2, b2, bn_s, bn_t,
+        return launch_sa_conv_h<0>(P, ldp, n_src, xyzr_src, idx, batch_dst, sf, nbr, deg, kw, M, w1r4, W2, wscale, C1, C2, b2, bn_s, bn_t,
                                    out, ldo, static_cast<_Float16*>(out_h), ldh, ws, ws_bytes, flags, p2w_s(stream));
-    return p2w_sa_conv_h1_impl(prec, P, ldp, xyzr_src, idx, batch_dst, sf, nbr, deg, kw, M, w1r4, W2, wscale, C1, C2, b2, bn_s,
+    return p2w_sa_conv_h1_impl(prec, P, ldp, n_src, xyzr_src, idx, batch_dst, sf, nbr, deg, kw, M, w1r4, W2, wscale, C1, C2, b2, bn_s,
                                bn_t, out, ldo, static_cast<_Float16*>(out_h), ldh, ws, ws_bytes, flags, p2w_s(stream));
 }
 

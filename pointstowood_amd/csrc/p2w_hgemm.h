@@ -556,7 +556,11 @@ static int32_t launch_gemm_h(const _Float16* Ah, int32_t ldh_a, const _Float16* 
 //     the [E, C] edge tensors of the reference never exist in HBM.
 // ------------------------------------------------------------------------------------------------
 template <int RT> struct SaEpiRegs { float bias[2], s[2], t[2]; int d[RT]; };
-// layer-2 bias + ReLU + BN affine, then max over the target's valid neighbour slots (rows of the 32-row MFMA tile)
+// layer-2 bias + ReLU + BN affine, then max over the target's valid neighbour slots (rows of the 32-row MFMA tile).
+// bias + ReLU + BN are monotone in the accumulator (wscale > 0: non-decreasing for s >= 0, non-increasing for s < 0) and
+// every rounding step keeps (weak) monotonicity, so the maximum over the slots of the transformed values IS the transform
+// of the maximum (s >= 0) or minimum (s < 0) of the raw accumulators, bit for bit: 2 VALU per value instead of 5 and
+// the transform once per column.
 template <int PREC, int RT>   // RT 32-row tiles (= targets) per wave
 __device__ __forceinline__ void sa_epilogue_regs(const f32x16 (&acc)[RT][2], float wscale, int t0, int n0, int wr, int wc,
                                                  int lane, int M, const SaEpiRegs<RT>& e, int C2, float* __restrict__ out, int ldo,
@@ -571,15 +575,16 @@ __device__ __forceinline__ void sa_epilogue_regs(const f32x16 (&acc)[RT][2], flo
         for (int j = 0; j < 2; ++j) {
             const int col = n0 + wc * 64 + j * 32 + (lane & 31);
             const bool cv = col < C2;
-            float vmax = -INFINITY;
+            const float sgn = e.s[j] < 0.f ? -1.f : 1.f;
+            float ext = -INFINITY;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int slot = (r & 3) + 8 * (r >> 2) + 4 * h;
-                const float v = fmaf(fmaxf(fmaf(acc[i][j][r], wscale, e.bias[j]), 0.f), e.s[j], e.t[j]);
-                if (slot < d) vmax = fmaxf(vmax, v);
+                if (slot < d) ext = fmaxf(ext, sgn * acc[i][j][r]);
             }
-            vmax = fmaxf(vmax, __shfl_xor(vmax, 32));
-            if (d == 0) vmax = 0.f;
+            ext = fmaxf(ext, __shfl_xor(ext, 32));
+            float vmax = fmaf(fmaxf(fmaf(sgn * ext, wscale, e.bias[j]), 0.f), e.s[j], e.t[j]);
+            if (d == 0 || !cv) vmax = 0.f;   // rows without neighbours; pad columns of an H row stay zero
             if (cv && h == 0 && out) out[(size_t)tgt * ldo + col] = vmax;
             if (out_h2) {  // lanes (2p, 2p+1) hold adjacent columns: the even lane stores both as one word per plane
                 const float nb = __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(vmax), 0xB1, 0xf, 0xf, false));
@@ -676,20 +681,21 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
             long row = (long)item_mt(it) * BM + prow + 128 * u;
             const long last = (long)M * 32 - 1;
             row = row < last ? row : last;
-            m.j[u] = meta_j[row];      // < 0: empty neighbour slot (its row is masked in the epilogue)
+            m.j[u] = meta_j[row];      // n_src (P's zero row) for an empty neighbour slot (masked in the epilogue as well)
             m.g[u] = meta_g[row];
         }
     };
-    // Unconditional loads from clamped addresses (an empty slot reads row 0, a padded k re-reads the row's last chunk):
-    // a load behind a per-lane condition makes hipcc branch around it and drain vmcnt(0) at the join - with the W2 DMA
-    // and the gather itself in flight that exposed the whole gather latency in every slab.  The producer masks the values.
+    // Unconditional loads (a load behind a per-lane condition makes hipcc branch around it and drain vmcnt(0) at the join -
+    // with the W2 DMA and the gather itself in flight that exposed the whole gather latency in every slab).  No masks
+    // either: an empty neighbour slot points at P's all-zero row n_src and carries a zero offset (sa_edge_meta_kernel),
+    // and P's pad columns up to C1pad are zero, so relu(0 + 0) = 0 falls out of the arithmetic.
     auto gather = [&](const Meta& m, int k0, Vals& dst) {
         const int k = k0 + 8 * pq;
 #pragma unroll
         for (int u = 0; u < NR; ++u) {
-            const float* p = P + (size_t)max(m.j[u], 0) * ldp;
-            dst.v[u][0] = *reinterpret_cast<const float4*>(p + min(k, C1 - 4));
-            dst.v[u][1] = *reinterpret_cast<const float4*>(p + min(k + 4, C1 - 4));
+            const float* p = P + (size_t)m.j[u] * ldp + k;
+            dst.v[u][0] = *reinterpret_cast<const float4*>(p);
+            dst.v[u][1] = *reinterpret_cast<const float4*>(p + 4);
         }
     };
     // layer-1 geometry weights of the producer's 8 k values: read from LDS BEFORE the slab's DMA is issued (an LDS read
@@ -708,18 +714,14 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
 #pragma unroll
       for (int u = 0; u < NR; ++u) {
         const float4 rg = m.g[u];
-        const bool on = m.j[u] >= 0;
         unsigned hiw[4], low[4];
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const int kk = k + 4 * half;
-            // branch-free (so the scheduler can interleave it with MFMAs): Wr is zero-padded to C1pad, P values of
-            // empty slots / padded k are zero, and the geometry term is switched off with a select
+            // branch-free (so the scheduler can interleave it with MFMAs): Wr is zero-padded to C1pad
             const float4 wx = wr_.w[half][0], wy = wr_.w[half][1], wz = wr_.w[half][2], wf = wr_.w[half][3];
-            const bool live = on && kk < C1;   // empty neighbour slot / padded k: the row chunk is zero
-            float4 p = src.v[u][half];
-            p.x = live ? p.x : 0.f; p.y = live ? p.y : 0.f; p.z = live ? p.z : 0.f; p.w = live ? p.w : 0.f;
-            const float gx = on ? rg.x : 0.f, gy = on ? rg.y : 0.f, gz = on ? rg.z : 0.f, gw = on ? rg.w : 0.f;
+            const float4 p = src.v[u][half];
+            const float gx = rg.x, gy = rg.y, gz = rg.z, gw = rg.w;
             float v[4];
             v[0] = fmaxf(fmaf(gw, wf.x, fmaf(gz, wz.x, fmaf(gy, wy.x, fmaf(gx, wx.x, p.x)))), 0.f);
             v[1] = fmaxf(fmaf(gw, wf.y, fmaf(gz, wz.y, fmaf(gy, wy.y, fmaf(gx, wx.y, p.y)))), 0.f);
@@ -767,14 +769,14 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     // Software pipeline over the flattened slab sequence g = 0..total-1 of this workgroup's items.  Iteration g:
-    //   top      : barrier (its vmcnt(0) retires everything issued in iteration g-1), W2 DMA of slab g+1
+    //   top      : barrier; register loads: gather of slab g+2 (P rows -> `vb`, addresses from metadata `mb`), metadata of
+    //              slab g+3 -> `mc`, epilogue parameters of slab g+1's item -> `ep_n`; then the W2 DMA of slab g+1
     //   k step 0 : fragment reads + MFMAs of slab g, interleaved with the PRODUCER of slab g+1 (A rows: VALU on the
     //              P values `va` gathered in iteration g-1 and metadata `ma`, written to stage (g+1)&1)
-    //   middle   : gather of slab g+2 (P rows, straight into `va`) using metadata `mb`; metadata load of slab g+3 -> `mc`
     //   k step 1 : fragment reads + MFMAs
-    //   end      : epilogue if the item is complete; rotate ma <- mb <- mc (the copy of the just-loaded `mc` is where the
-    //              compiler waits for it: right in front of the next barrier)
-    // Every global load in the loop is unconditional, straight-line code behind the first MFMA block: hipcc drains
+    //   end      : epilogue if the item is complete; rotate va <- vb, ma <- mb <- mc, ep_ <- ep_n (these copies are where
+    //              the compiler waits for this iteration's loads: right in front of the next barrier)
+    // Every global load in the loop is unconditional, straight-line code issued before the slab's DMA: hipcc drains
     // vmcnt(0) at any join behind a branch that contains a load, and with the DMA in flight such a drain in front of the
     // fragment reads serialises the DMA, the gather latency and the MFMAs (the previous form of this loop did that in
     // every slab: 3.3x the MFMA time).  Slabs past the end replay the last slab's addresses and are never consumed.
@@ -807,6 +809,18 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
                 asm volatile("" : "+v"(va.v[u][hh].x), "+v"(va.v[u][hh].y), "+v"(va.v[u][hh].z), "+v"(va.v[u][hh].w));
     }
     int mt_cur = item_mt(0), nt_cur = item_nt(0);   // item in the MFMA stage
+    // epilogue parameters (clamped addresses, no conditions: see the loop's rule about loads)
+    auto load_epi = [&](int mt_, int nt_, SaEpiRegs<RT>& e) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = min(nt_ * BN + wc * 64 + j * 32 + (lane & 31), C2 - 1);
+            e.bias[j] = b2[col]; e.s[j] = bn_s[col]; e.t[j] = bn_t[col];
+        }
+#pragma unroll
+        for (int i = 0; i < RT; ++i) e.d[i] = min(deg[min(mt_ * (BM / 32) + wr * RT + i, M - 1)], kw);
+    };
+    SaEpiRegs<RT> ep_;
+    load_epi(mt_cur, nt_cur, ep_);   // item 0; later items' parameters arrive one iteration ahead (ep_n)
 #ifdef P2W_SA_STAMP
     unsigned long long t_wait = 0, t_epi = 0, t_mma = 0;
     const unsigned long long t_start = p2w_stamp();
@@ -821,6 +835,17 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
         const unsigned long long t_b = p2w_stamp();
         t_wait += t_b - t_a;
 #endif
+        // All register loads of the iteration go out HERE, before the DMA: the gather of slab g+2 (into `vb`: the producer
+        // still needs `va`), the metadata of slab g+3 and the epilogue parameters of slab g+1's item.  Nothing reads them
+        // before the rotation at the end of the iteration, so the only wait on them sits in front of the next barrier.
+        Vals vb;
+        if (!(dbg & 16)) gather(mb, k_of(c2), vb); else vb = va;
+        meta_of(c3, mc);
+        SaEpiRegs<RT> ep_n;
+        {
+            const int it1 = min(c1.it, my_items - 1);
+            load_epi(item_mt(it1), item_nt(it1), ep_n);
+        }
         WRegs wk;
         load_w(k_of(c1), wk);
         __builtin_amdgcn_sched_barrier(0);
@@ -860,9 +885,6 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (!(dbg & 16)) gather(mb, k_of(c2), va);
-                meta_of(c3, mc);
-                __builtin_amdgcn_sched_barrier(0);
             }
         }
 #ifdef P2W_SA_STAMP
@@ -871,18 +893,10 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
 #endif
         if (c0.s == nslab - 1) {  // item finished: reduce over neighbour slots and store, then start the next accumulation
             if (!(dbg & 1)) {
-                SaEpiRegs<RT> e;   // loaded here, once per item: a wait in front of the epilogue is harmless
+                SaEpiRegs<RT> e = ep_;
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int col = nt_cur * BN + wc * 64 + j * 32 + (lane & 31);
-                    const bool cv = col < C2;
-                    e.bias[j] = cv ? b2[col] : 0.f; e.s[j] = cv ? bn_s[col] : 0.f; e.t[j] = cv ? bn_t[col] : 0.f;
-                }
-#pragma unroll
-                for (int i = 0; i < RT; ++i) {
-                    const int tgt = mt_cur * (BM / 32) + wr * RT + i;
-                    e.d[i] = tgt < M ? min(deg[tgt], kw) : 0;
-                }
+                for (int i = 0; i < RT; ++i)
+                    if (mt_cur * (BM / 32) + wr * RT + i >= M) e.d[i] = 0;
                 sa_epilogue_regs<PREC, RT>(acc, wscale, mt_cur * (BM / 32), nt_cur * BN, wr, wc, lane, M, e, C2, out, ldo, out_h2, ldh);
             }
 #pragma unroll
@@ -898,7 +912,7 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
         t_epi += p2w_stamp() - t_c;
 #endif
         __builtin_amdgcn_sched_barrier(0);
-        ma = mb; mb = mc;
+        va = vb; ma = mb; mb = mc; ep_ = ep_n;
         c0 = c1; c1 = c2; c2 = c3; c3 = nxt(c3);
     }
 #ifdef P2W_SA_STAMP
@@ -911,11 +925,11 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
 
 __global__ __launch_bounds__(256) void sa_edge_meta_kernel(const float4* __restrict__ xyzr, const int* __restrict__ idx, const int* __restrict__ batch_dst,
                                     const float* __restrict__ sf, const int* __restrict__ nbr, const int* __restrict__ deg, int kw,
-                                    int M, int* __restrict__ meta_j, float4* __restrict__ meta_g);
+                                    int M, int n_src, int* __restrict__ meta_j, float4* __restrict__ meta_g);
 
 // host side of p2w_sa_conv_h for one precision (pointer / size checks are done by the caller)
 template <int PREC>
-static int32_t launch_sa_conv_h(const float* P, int32_t ldp, const float* xyzr_src, const int32_t* idx, const int32_t* batch_dst,
+static int32_t launch_sa_conv_h(const float* P, int32_t ldp, int32_t n_src, const float* xyzr_src, const int32_t* idx, const int32_t* batch_dst,
                                 const float* sf, const int32_t* nbr, const int32_t* deg, int32_t kw, int32_t M,
                                 const float* w1r4, const _Float16* W2h, float wscale, int32_t C1, int32_t C2, const float* b2,
                                 const float* bn_s, const float* bn_t, float* out, int32_t ldo, _Float16* out_h2, int32_t ldh,
@@ -923,12 +937,13 @@ static int32_t launch_sa_conv_h(const float* P, int32_t ldp, const float* xyzr_s
     constexpr int KA = HCfg<PREC>::kalign;
     const int C2pad = (C2 + 255) / 256 * 256, C1pad = (C1 + KA - 1) / KA * KA;
     if (C1pad > 512) return P2W_EUNSUPPORTED;
+    if (ldp < C1pad) return P2W_EINVAL;   // P rows are read in whole K slabs: pad columns (zero) must exist
     if (ws == nullptr || ws_bytes < (size_t)M * 32 * 20) return P2W_EWORKSPACE;
     if (reinterpret_cast<uintptr_t>(ws) & 15u) return P2W_EALIGN;
     float4* meta_g = static_cast<float4*>(ws);
     int* meta_j = reinterpret_cast<int*>(meta_g + (size_t)M * 32);
     sa_edge_meta_kernel<<<p2w_cdiv((long)M * 32, 256), 256, 0, stream>>>(
-        reinterpret_cast<const float4*>(xyzr_src), idx, batch_dst, sf, nbr, deg, kw, M, meta_j, meta_g);
+        reinterpret_cast<const float4*>(xyzr_src), idx, batch_dst, sf, nbr, deg, kw, M, n_src, meta_j, meta_g);
     const int n_cu = p2w_cu_count();
     const bool wide = C2 > 128;
     const int sadbg = (flags >> 16) & 0xff;
@@ -951,7 +966,7 @@ static int32_t launch_sa_conv_h(const float* P, int32_t ldp, const float* xyzr_s
 int32_t p2w_gemm_h1_impl(int32_t prec, const _Float16* Ah, int32_t ldh_a, const _Float16* Wp, float wscale, int32_t M, int32_t N,
                          int32_t K, const EpiArgs& ep, float* out_f32, int32_t ldo, _Float16* out_h2, int32_t ldh_o,
                          int32_t flags, hipStream_t stream);
-int32_t p2w_sa_conv_h1_impl(int32_t prec, const float* P, int32_t ldp, const float* xyzr_src, const int32_t* idx,
+int32_t p2w_sa_conv_h1_impl(int32_t prec, const float* P, int32_t ldp, int32_t n_src, const float* xyzr_src, const int32_t* idx,
                             const int32_t* batch_dst, const float* sf, const int32_t* nbr, const int32_t* deg, int32_t kw,
                             int32_t M, const float* w1r4, const _Float16* W2h, float wscale, int32_t C1, int32_t C2,
                             const float* b2, const float* bn_s, const float* bn_t, float* out, int32_t ldo, _Float16* out_h2,

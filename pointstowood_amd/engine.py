@@ -427,13 +427,19 @@ class Engine:
         for l in (1, 2, 3):
             p, src, dst = w.sa[l - 1], lv[l - 1], lv[l]
             M, C1, C2, E = dst.n, p["C1"], p["C2"], 4 * p["C2"]
-            P = new(src.n, C1)
-            self._gemm_h2("gemm_hoist", xh[l - 1], pad8(p["F_in"]), src.n, p["hoist"], out_f32=P, ldo=C1)
+            # hoisted layer-1 product P = x_src W1x^T + b1: src.n rows + one all-zero row (read by empty neighbour slots), row
+            # pitch padded to whole K slabs with zero columns (p2w_sa_conv_h reads it with unconditional loads)
+            C1p = pad8(C1)
+            P = new(src.n + 1, C1p)
+            P[src.n].zero_()
+            if C1p != C1:
+                P[:, C1:].zero_()
+            self._gemm_h2("gemm_hoist", xh[l - 1], pad8(p["F_in"]), src.n, p["hoist"], out_f32=P, ldo=C1p)
             conv, convh = new(M, C2), newh(M, C2)
             meta = torch.empty(M * 32 * 20 + 65536, dtype=torch.uint8, device=dev)   # per-edge (j, normalised offset) scratch (+ room for diagnostics)
             if keep is not None:
                 keep[f"sa{l}_module.ws"] = meta
-            self._call("sa_conv", L.p2w_sa_conv_h, prec, ptr(P), C1, ptr(src.xyzr), ptr(dst.idx), ptr(dst.batch),
+            self._call("sa_conv", L.p2w_sa_conv_h, prec, ptr(P), C1p, src.n, ptr(src.xyzr), ptr(dst.idx), ptr(dst.batch),
                        ptr(geo.sf), ptr(dst.nbr), ptr(dst.deg), geo.k, M, ptr(p["w1r4"]), ptr(p["W2"].w16),
                        p["W2"].wscale, C1, C2, ptr(p["b2"]), ptr(p["bn_s"]), ptr(p["bn_t"]), ptr(conv), C2, ptr(convh),
                        pad8(C2), ptr(meta), meta.numel(), 0)
