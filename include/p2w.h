@@ -239,6 +239,9 @@ int32_t p2w_packed_dims_h(int32_t prec, int32_t N, int32_t K, int32_t* N_pad, in
 #define P2W_GEMM_GENERIC_EPI 4   /* run the runtime-flag epilogue instead of the specialised one */
 #define P2W_GEMM_ORDER_ROWS 8    /* tile order: an XCD owns whole row tiles (W re-read from its L2) */
 #define P2W_GEMM_ORDER_COLS 16   /* tile order: an XCD owns a slice of column tiles (A streamed per slice) */
+/* flags of p2w_sa_conv_h (0 = let the library choose the work-item shape by C2) */
+#define P2W_SA_ITEM_256 1        /* 4 targets x 256 output columns per work item */
+#define P2W_SA_ITEM_128 2        /* 8 targets x 128 output columns per work item */
 /* bits 16..23 of `flags` of p2w_gemm_h2 / p2w_sa_conv_h: profiling ablations, honoured only by diagnostic builds
  * (-DP2W_GEMM_ABLATE / -DP2W_SA_ABLATE); production builds ignore them. */
 

@@ -945,7 +945,8 @@ static int32_t launch_sa_conv_h(const float* P, int32_t ldp, int32_t n_src, cons
     sa_edge_meta_kernel<<<p2w_cdiv((long)M * 32, 256), 256, 0, stream>>>(
         reinterpret_cast<const float4*>(xyzr_src), idx, batch_dst, sf, nbr, deg, kw, M, n_src, meta_j, meta_g);
     const int n_cu = p2w_cu_count();
-    const bool wide = C2 > 128;
+    // 256-column items halve the A production per output column; measured on levels 2 / 3 (C2 = 256 / 512): 2.73 vs 2.82-2.97 ms
+    const bool wide = (flags & (P2W_SA_ITEM_256 | P2W_SA_ITEM_128)) ? (flags & P2W_SA_ITEM_256) != 0 : C2 > 128;
     const int sadbg = (flags >> 16) & 0xff;
     const int nMt3 = p2w_cdiv(M, wide ? 4 : 8), nNt3 = p2w_cdiv(C2, wide ? 256 : 128);
     const long items = (long)nMt3 * nNt3;

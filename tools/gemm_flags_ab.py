@@ -31,7 +31,8 @@ shapes = [(131072, 32, 64, "f"), (123046, 128, 192, "f"), (81683, 256, 384, "f")
 g = torch.Generator(device="cuda").manual_seed(0)
 for M, K, N, kind in shapes:
     Np, Kp = _lib.packed_dims(N, K, PREC)
-    A = torch.zeros(M, planes * Kp, device=dev, dtype=hdt)
+    lda = Kp + int(os.environ.get("LDA_EXTRA", "0"))        # row pitch experiment: ldh_a may exceed K_pad
+    A = torch.zeros(M, planes * lda, device=dev, dtype=hdt)
     A[:, : planes * K] = (torch.randn(M, planes * K, device=dev, generator=g) * 0.5).to(hdt)
     W = torch.zeros(Np, planes * Kp, device=dev, dtype=hdt)     # H rows: timing only, any finite content will do
     W[:N, : planes * K] = (torch.randn(N, planes * K, device=dev, generator=g) * 0.5).to(hdt)
@@ -46,7 +47,7 @@ for M, K, N, kind in shapes:
 
     def run(fl):
         o = outs[fl]
-        check(lib().p2w_gemm_h2(PREC, ptr(A), Kp, ptr(W), 1.0, M, N, K, C.byref(ep), ptr(o) if kind == "f" else None, N,
+        check(lib().p2w_gemm_h2(PREC, ptr(A), lda, ptr(W), 1.0, M, N, K, C.byref(ep), ptr(o) if kind == "f" else None, N,
                                 ptr(o) if kind == "h" else None, ldh_o, fl, stream()))
     for fl in flagsets:
         run(fl)
