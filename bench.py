@@ -22,7 +22,7 @@ collective: an RCCL all-gather of the per-point logits.  Rank 0 prints ONE JSON 
 ``roofline`` is measured live: after the timed regions one extra, sequential step is run with HIP
 events around every run of consecutive launches of one kernel class (on the launch stream) and the
 dominant kernel's algorithmic FLOPs are divided by its measured time; ``traffic`` comes from the
-committed rocprofv3 PMC summary of the same command (``profiles/r2_hbm_traffic.json``).
+committed rocprofv3 PMC summary of the same command (``profiles/r2_<precision>_hbm_traffic.json``).
 ``hbm_kernels`` gives the memory-bound kernels' algorithmic bytes / measured time
 against the 8 TB/s HBM peak.  ``cpu_baseline`` times the CPU oracle (``oracle/net.py``, a port of
 the reference forward pinned to the reference's own outputs) on a bounded sample of batch 0.
@@ -45,7 +45,7 @@ sys.path.insert(0, ROOT)
 PEAK_TFLOPS = {"fp32": 157.3, "f16x3": 2500.0, "fp16": 2500.0, "bf16": 2500.0}
 PEAK_HBM_GBPS = 8000.0
 C, K_NBR, BATCH, NPTS = 32, 32, 8, 16384
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r2_hbm_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r2_{precision}_hbm_traffic.json")   # written by tools/profile_r2.sh
 
 
 def parse_args(argv=None):
@@ -298,11 +298,12 @@ def main():
                  "sa_conv_kernel": (f"sa_conv16p_kernel<{args.precision}> (+ sa_edge_meta_kernel)" if h else "sa_conv_kernel")}
         traffic, traffic_src = None, None
         try:
-            t = json.load(open(TRAFFIC_FILE))
+            tfile = TRAFFIC_FILE.format(precision=args.precision)
+            t = json.load(open(tfile))
             if t.get("precision") == args.precision and dom in t.get("kernels", {}):
                 k = t["kernels"][dom]
                 traffic = (k["fetch_bytes_per_step"] + k["write_bytes_per_step"]) / max(1, k["launches_per_step"])
-                traffic_src = os.path.relpath(TRAFFIC_FILE, ROOT)
+                traffic_src = os.path.relpath(tfile, ROOT)
         except (OSError, ValueError, KeyError):
             pass
         abytes = algorithmic_bytes(geo)
