@@ -82,6 +82,20 @@ int32_t p2w_voxel_sample(const float* xyzr, const int32_t* ptr, int32_t B, int32
                          uint64_t* sorted_keys_out, uint64_t* cell_keys_out, p2w_grid* grid_out, int32_t* inv_out,
                          int32_t* rank_sorted_out, void* ws, size_t ws_bytes, p2w_stream_t stream);
 
+/* The same sub-sampling WITHOUT a sort, for batches whose cell grid fits a direct table of `table_cells` entries (the
+ * per-voxel forward: a few voxels of a few metres): a cell's key is its table index; representatives by atomic max, ranks by
+ * a scan of the occupancy flags, the optional sorted order by a counting-sort scatter (the order of points INSIDE a cell is
+ * unspecified - every consumer orders candidates by the index they carry).  Outputs as p2w_voxel_sample.  Whether the grid
+ * fits is only known on the device: if it does not, *status_out (device int32) is set to 1 and an EMPTY level is returned
+ * (ptr_out = 0, so work already queued behind the call finds nothing to do) - the caller checks it (with the level sizes it reads back anyway) and repeats the level with p2w_voxel_sample.
+ * ws: p2w_voxel_sample_table_ws_bytes(n_bound, table_cells) bytes (20 B per table entry). */
+size_t p2w_voxel_sample_table_ws_bytes(int32_t n_bound, int64_t table_cells);
+int32_t p2w_voxel_sample_table(const float* xyzr, const int32_t* ptr, int32_t B, int32_t n_bound, float res,
+                               int32_t* idx_out, int32_t* ptr_out, int32_t* batch_out, int32_t* order_out,
+                               uint64_t* sorted_keys_out, uint64_t* cell_keys_out, p2w_grid* grid_out, int32_t* inv_out,
+                               int32_t* rank_sorted_out, int32_t* status_out, int64_t table_cells, void* ws, size_t ws_bytes,
+                               p2w_stream_t stream);
+
 /* out[i] = (x, y, z, bit pattern of order[i]) of xyzr[order[i]] for i < ptr[B]: the records of a level in another
  * (e.g. cell-sorted) order, each carrying its own index - input for the P2W_SEARCH_*_IN_W modes below. */
 int32_t p2w_index_records(const float* xyzr, const int32_t* order, const int32_t* ptr, int32_t B, int32_t n_bound,

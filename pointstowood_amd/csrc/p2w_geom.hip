@@ -289,6 +289,277 @@ extern "C" int32_t p2w_consecutive_cluster(const int64_t* cell, int32_t n, int32
 }
 
 // ------------------------------------------------------------------------------------------------
+// Table sampler: the same outputs as p2w_voxel_sample WITHOUT a sort, for batches whose cell grid is small enough to be
+// held as a direct table (the per-voxel forward: B voxels of a few metres at 4 / 8 / 16 cm cells).  A cell's key
+// ((b - b_lo) * c2 + z) * c1 + y) * c0 + x IS its table index, so
+//   insert : tab_max[key] = max point index (atomicMax: the representative the reference's scatter leaves), cnt[key]++
+//   scan   : exclusive scan of the occupancy flags (rank of every cell = its position in the output level) and of the
+//            counts (start of every cell in the cell-sorted order), hand-written two-level scan
+//   compact: representatives, batch, keys, CSR in ascending key order;  points: rank of every point's cell, and - when
+//            the sorted order is asked for - a counting-sort scatter (order inside a cell is unspecified; every consumer
+//            orders candidates by their carried index, never by storage position)
+// Whether the table fits is only known on the device (the grid's extent is data): the kernels then set *status_out = 1
+// and hand out an EMPTY level (ptr_out = 0: work already queued behind the call finds nothing to do); the caller reads the
+// status with the level sizes it fetches anyway and repeats the level with p2w_voxel_sample.
+// ------------------------------------------------------------------------------------------------
+constexpr int TK_ITEMS = 4, TK_BLOCK = 1024, TK_TILE = TK_ITEMS * TK_BLOCK;
+
+struct TkGeom { long long c0, c1, c2, cells, T; int b_lo; float lo0, lo1, lo2; };
+__device__ __forceinline__ TkGeom tk_geom(const VsHeader* h, const int* ptr, int B, float res) {
+    TkGeom g;
+    g.b_lo = 0;
+    while (g.b_lo < B - 1 && ptr[g.b_lo + 1] == ptr[g.b_lo]) ++g.b_lo;
+    int b_hi = B - 1;
+    while (b_hi > g.b_lo && ptr[b_hi + 1] == ptr[b_hi]) --b_hi;
+    g.lo0 = ord2f(h->lo[0]); g.lo1 = ord2f(h->lo[1]); g.lo2 = ord2f(h->lo[2]);
+    g.c0 = (long long)((ord2f(h->hi[0]) - g.lo0) / res) + 1;
+    g.c1 = (long long)((ord2f(h->hi[1]) - g.lo1) / res) + 1;
+    g.c2 = (long long)((ord2f(h->hi[2]) - g.lo2) / res) + 1;
+    g.cells = g.c0 * g.c1 * g.c2;
+    g.T = (g.c0 > (1 << 20) || g.c1 > (1 << 20) || g.c2 > (1 << 20)) ? (1ll << 62) : g.cells * (long long)(b_hi - g.b_lo + 1);
+    return g;
+}
+
+__global__ __launch_bounds__(256) void tk_insert_kernel(const float4* __restrict__ xyzr, const int* __restrict__ ptr, int B,
+                                                        int n_bound, float res, const VsHeader* __restrict__ h, long long T_cap,
+                                                        int* __restrict__ tab_max, int* __restrict__ cnt, int* __restrict__ key32,
+                                                        int* __restrict__ status) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int n = ptr[B];
+    if (n == 0) return;
+    const TkGeom g = tk_geom(h, ptr, B, res);
+    if (g.T > T_cap) {
+        if (i == 0) *status = 1;
+        return;
+    }
+    if (i >= n || i >= n_bound) return;
+    const float4 p = xyzr[i];
+    const int b = p2w_find_segment(ptr, B, i);
+    const long long k0 = (long long)((p.x - g.lo0) / res);     // the arithmetic of vs_keys_kernel (oracle/ops.py voxel_grid)
+    const long long k1 = (long long)((p.y - g.lo1) / res);
+    const long long k2 = (long long)((p.z - g.lo2) / res);
+    const long long kb = (long long)(((float)b - (float)g.b_lo) / 1.0f);
+    const int t = (int)(k0 + k1 * g.c0 + k2 * (g.c0 * g.c1) + kb * g.cells);
+    key32[i] = t;
+    atomicMax(&tab_max[t], i);
+    if (cnt) atomicAdd(&cnt[t], 1);
+}
+
+// block-local exclusive scans of the occupancy flags (-> rank) and, optionally, of the counts (-> off); block totals
+__global__ __launch_bounds__(TK_BLOCK) void tk_scan1_kernel(const int* __restrict__ tab_max, const int* __restrict__ cnt, long long T_cap,
+                                                           int* __restrict__ rank, int* __restrict__ off, int* __restrict__ bs_occ,
+                                                           int* __restrict__ bs_cnt, const int* __restrict__ status) {
+    __shared__ int wsum[2][TK_BLOCK / 64];
+    if (*status) return;
+    const long long t0 = (long long)blockIdx.x * TK_TILE + (long long)threadIdx.x * TK_ITEMS;
+    int f[TK_ITEMS], c[TK_ITEMS], sf = 0, sc = 0;
+#pragma unroll
+    for (int e = 0; e < TK_ITEMS; ++e) {
+        const long long t = t0 + e;
+        f[e] = (t < T_cap && tab_max[t] >= 0) ? 1 : 0;
+        c[e] = (cnt && t < T_cap) ? cnt[t] : 0;
+        sf += f[e]; sc += c[e];
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int xf = sf, xc = sc;   // inclusive wave scans
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int of = __shfl_up(xf, d), oc = __shfl_up(xc, d);
+        if (lane >= d) { xf += of; xc += oc; }
+    }
+    if (lane == 63) { wsum[0][wave] = xf; wsum[1][wave] = xc; }
+    __syncthreads();
+    int bf = 0, bc = 0, tf = 0, tc = 0;
+    for (int w = 0; w < TK_BLOCK / 64; ++w) {
+        if (w < wave) { bf += wsum[0][w]; bc += wsum[1][w]; }
+        tf += wsum[0][w]; tc += wsum[1][w];
+    }
+    int rf = bf + xf - sf, rc = bc + xc - sc;   // exclusive prefix of this thread's first item within the block
+#pragma unroll
+    for (int e = 0; e < TK_ITEMS; ++e) {
+        const long long t = t0 + e;
+        if (t < T_cap) { rank[t] = rf; if (cnt) off[t] = rc; }
+        rf += f[e]; rc += c[e];
+    }
+    if (threadIdx.x == 0) { bs_occ[blockIdx.x] = tf; bs_cnt[blockIdx.x] = tc; }
+}
+
+// exclusive scan of the block totals, in place, by one workgroup
+__global__ __launch_bounds__(1024) void tk_scan2_kernel(int* __restrict__ bs_occ, int* __restrict__ bs_cnt, int nblk, int* __restrict__ total_out,
+                                                        const int* __restrict__ status) {
+    __shared__ int wsum[2][16];
+    __shared__ int carry[2];
+    if (*status) return;
+    if (threadIdx.x == 0) { carry[0] = 0; carry[1] = 0; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int base = 0; base < nblk; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int vf = i < nblk ? bs_occ[i] : 0, vc = i < nblk ? bs_cnt[i] : 0;
+        int xf = vf, xc = vc;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int of = __shfl_up(xf, d), oc = __shfl_up(xc, d);
+            if (lane >= d) { xf += of; xc += oc; }
+        }
+        if (lane == 63) { wsum[0][wave] = xf; wsum[1][wave] = xc; }
+        __syncthreads();
+        int bf = carry[0], bc = carry[1], tf = 0, tc = 0;
+        for (int w = 0; w < 16; ++w) {
+            if (w < wave) { bf += wsum[0][w]; bc += wsum[1][w]; }
+            tf += wsum[0][w]; tc += wsum[1][w];
+        }
+        if (i < nblk) { bs_occ[i] = bf + xf - vf; bs_cnt[i] = bc + xc - vc; }
+        __syncthreads();
+        if (threadIdx.x == 0) { carry[0] += tf; carry[1] += tc; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total_out = carry[0];
+}
+
+__global__ __launch_bounds__(256) void tk_compact_kernel(const int* __restrict__ tab_max, const int* __restrict__ rank,
+                                                         const int* __restrict__ bs_occ, const int* __restrict__ total, long long T_cap,
+                                                         const int* __restrict__ ptr, int B, float res, const VsHeader* __restrict__ h,
+                                                         int* __restrict__ idx_out, int* __restrict__ ptr_out, int* __restrict__ batch_out,
+                                                         unsigned long long* __restrict__ cell_keys_out, p2w_grid* __restrict__ grid_out,
+                                                         const int* __restrict__ status) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int n = ptr[B];
+    if (*status || n == 0) {   // overflow: hand out an EMPTY level, so that whatever the caller has already queued behind this
+        if (t <= B) ptr_out[t] = 0;   // call (searches, the next level's sampling) sees zero points instead of undefined sizes
+        if (t == 0 && grid_out) {     // ... and a well-formed one-cell grid (searches of a valid level INTO this one read it)
+            p2w_grid gg;
+            for (int d = 0; d < 3; ++d) { gg.lo[d] = 0.f; gg.hi[d] = 0.f; gg.dims[d] = 1; }
+            gg.res = res; gg.b_lo = 0;
+            *grid_out = gg;
+        }
+        return;
+    }
+    const TkGeom g = tk_geom(h, ptr, B, res);
+    if (t == 0 && grid_out) {
+        p2w_grid gg;
+        gg.lo[0] = g.lo0; gg.lo[1] = g.lo1; gg.lo[2] = g.lo2;
+        for (int d = 0; d < 3; ++d) gg.hi[d] = ord2f(h->hi[d]);
+        gg.dims[0] = g.c0; gg.dims[1] = g.c1; gg.dims[2] = g.c2;
+        gg.res = res; gg.b_lo = g.b_lo;
+        *grid_out = gg;
+    }
+    if (t <= B) {   // CSR of the sampled level: cells of the voxels before b
+        const long long first = ((long long)t - g.b_lo) * g.cells;
+        ptr_out[t] = (t <= g.b_lo) ? 0 : (first < g.T ? rank[first] + bs_occ[first / TK_TILE] : *total);
+    }
+    if (t >= g.T || t >= T_cap) return;
+    const int rep = tab_max[t];
+    if (rep < 0) return;
+    const int o = rank[t] + bs_occ[t / TK_TILE];
+    idx_out[o] = rep;
+    if (batch_out) batch_out[o] = g.b_lo + (int)(t / g.cells);
+    if (cell_keys_out) cell_keys_out[o] = (unsigned long long)t;
+}
+
+__global__ __launch_bounds__(256) void tk_points_kernel(const int* __restrict__ key32, const int* __restrict__ rank, const int* __restrict__ bs_occ,
+                                                        const int* __restrict__ off, const int* __restrict__ bs_cnt, int* __restrict__ fill,
+                                                        const int* __restrict__ ptr, int B, int n_bound, int* __restrict__ inv_out,
+                                                        int* __restrict__ order_out, unsigned long long* __restrict__ sorted_keys_out,
+                                                        int* __restrict__ rank_sorted_out, const int* __restrict__ status) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= ptr[B] || i >= n_bound) return;
+    if (*status) {   // overflow: harmless per-point outputs (rank 0, identity order) for whatever is already queued behind us
+        if (inv_out) inv_out[i] = 0;
+        if (order_out) order_out[i] = i;
+        if (sorted_keys_out) sorted_keys_out[i] = 0ull;
+        if (rank_sorted_out) rank_sorted_out[i] = 0;
+        return;
+    }
+    const int t = key32[i];
+    const int r = rank[t] + bs_occ[t / TK_TILE];
+    if (inv_out) inv_out[i] = r;
+    if (order_out) {
+        const int pos = off[t] + bs_cnt[t / TK_TILE] + atomicAdd(&fill[t], 1);
+        order_out[pos] = i;
+        if (sorted_keys_out) sorted_keys_out[pos] = (unsigned long long)t;
+        if (rank_sorted_out) rank_sorted_out[pos] = r;
+    }
+}
+
+struct TkLayout { size_t hdr, key32, bs_occ, bs_cnt, total, tab_max, rank, cnt, off, fill, bytes; long long T_cap; int nblk; };
+static void tk_layout(int n_bound, long long T_cap, TkLayout* L) {
+    auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
+    L->T_cap = T_cap;
+    L->nblk = (int)((T_cap + TK_TILE - 1) / TK_TILE);
+    size_t o = 0;
+    L->hdr = o; o += up(sizeof(VsHeader));
+    L->total = o; o += 256;
+    L->key32 = o; o += up(sizeof(int) * (size_t)n_bound);
+    L->bs_occ = o; o += up(sizeof(int) * (size_t)L->nblk);
+    L->bs_cnt = o; o += up(sizeof(int) * (size_t)L->nblk);
+    L->tab_max = o; o += up(sizeof(int) * (size_t)T_cap);
+    L->cnt = o; o += up(sizeof(int) * (size_t)T_cap);
+    L->fill = o; o += up(sizeof(int) * (size_t)T_cap);
+    L->rank = o; o += up(sizeof(int) * (size_t)T_cap);
+    L->off = o; o += up(sizeof(int) * (size_t)T_cap);
+    L->bytes = o;
+}
+
+extern "C" size_t p2w_voxel_sample_table_ws_bytes(int32_t n_bound, int64_t table_cells) {
+    if (n_bound < 0 || table_cells <= 0 || table_cells > ((int64_t)1 << 30)) return 0;
+    TkLayout L;
+    tk_layout(n_bound > 0 ? n_bound : 1, table_cells, &L);
+    return L.bytes;
+}
+
+extern "C" int32_t p2w_voxel_sample_table(const float* xyzr, const int32_t* ptr, int32_t B, int32_t n_bound, float res,
+                                          int32_t* idx_out, int32_t* ptr_out, int32_t* batch_out, int32_t* order_out,
+                                          uint64_t* sorted_keys_out, uint64_t* cell_keys_out, p2w_grid* grid_out,
+                                          int32_t* inv_out, int32_t* rank_sorted_out, int32_t* status_out, int64_t table_cells,
+                                          void* ws, size_t ws_bytes, p2w_stream_t stream) {
+    P2W_CHECK_PTR(ptr); P2W_CHECK_PTR(ptr_out); P2W_CHECK_PTR(status_out);
+    if (B <= 0 || n_bound < 0 || !(res > 0.0f) || table_cells <= 0 || table_cells > ((int64_t)1 << 30)) return P2W_EINVAL;
+    hipStream_t s = p2w_s(stream);
+    hipError_t e = hipMemsetAsync(status_out, 0, sizeof(int), s);
+    if (e != hipSuccess) return (int32_t)e;
+    if (n_bound == 0) return (int32_t)hipMemsetAsync(ptr_out, 0, sizeof(int) * (B + 1), s);
+    P2W_CHECK_PTR(xyzr); P2W_CHECK_PTR(idx_out); P2W_CHECK_PTR(batch_out); P2W_CHECK_PTR(ws);
+    P2W_CHECK_ALIGN16(xyzr); P2W_CHECK_ALIGN16(ws);
+    if ((sorted_keys_out || rank_sorted_out) && !order_out) return P2W_ENULL;
+    TkLayout L;
+    tk_layout(n_bound, table_cells, &L);
+    if (ws_bytes < L.bytes) return P2W_EWORKSPACE;
+    char* w = static_cast<char*>(ws);
+    auto* hdr = reinterpret_cast<VsHeader*>(w + L.hdr);
+    int* tab_max = reinterpret_cast<int*>(w + L.tab_max);
+    int* cnt = order_out ? reinterpret_cast<int*>(w + L.cnt) : nullptr;
+    int* fill = reinterpret_cast<int*>(w + L.fill);
+    int* rank = reinterpret_cast<int*>(w + L.rank);
+    int* off = reinterpret_cast<int*>(w + L.off);
+    int* key32 = reinterpret_cast<int*>(w + L.key32);
+    int* bs_occ = reinterpret_cast<int*>(w + L.bs_occ);
+    int* bs_cnt = reinterpret_cast<int*>(w + L.bs_cnt);
+    int* total = reinterpret_cast<int*>(w + L.total);
+    const auto* x4 = reinterpret_cast<const float4*>(xyzr);
+    const int nblk_pts = p2w_cdiv(n_bound, 256);
+    e = hipMemsetAsync(tab_max, 0xff, sizeof(int) * (size_t)table_cells, s);   // -1 = empty cell
+    if (e != hipSuccess) return (int32_t)e;
+    if (order_out) {   // cnt and fill are adjacent
+        e = hipMemsetAsync(cnt, 0, (L.fill - L.cnt) + sizeof(int) * (size_t)table_cells, s);
+        if (e != hipSuccess) return (int32_t)e;
+    }
+    vs_init_kernel<<<1, 64, 0, s>>>(hdr);
+    vs_minmax_kernel<<<nblk_pts < 256 ? nblk_pts : 256, 256, 0, s>>>(x4, ptr, B, hdr);
+    tk_insert_kernel<<<nblk_pts, 256, 0, s>>>(x4, ptr, B, n_bound, res, hdr, (long long)table_cells, tab_max, cnt, key32, status_out);
+    tk_scan1_kernel<<<L.nblk, TK_BLOCK, 0, s>>>(tab_max, cnt, (long long)table_cells, rank, off, bs_occ, bs_cnt, status_out);
+    tk_scan2_kernel<<<1, 1024, 0, s>>>(bs_occ, bs_cnt, L.nblk, total, status_out);
+    const long long cgrid = (table_cells > B + 1 ? table_cells : B + 1);
+    tk_compact_kernel<<<p2w_cdiv(cgrid, 256), 256, 0, s>>>(tab_max, rank, bs_occ, total, (long long)table_cells, ptr, B, res, hdr, idx_out,
+                                                            ptr_out, batch_out, reinterpret_cast<unsigned long long*>(cell_keys_out),
+                                                            grid_out, status_out);
+    if (inv_out || order_out)
+        tk_points_kernel<<<nblk_pts, 256, 0, s>>>(key32, rank, bs_occ, off, bs_cnt, fill, ptr, B, n_bound, inv_out, order_out,
+                                                  reinterpret_cast<unsigned long long*>(sorted_keys_out), rank_sorted_out, status_out);
+    return P2W_LAUNCH_STATUS();
+}
+
+// ------------------------------------------------------------------------------------------------
 // level gather with the (p / sf) * sf round trip
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void level_gather_kernel(const float4* __restrict__ src, const int* __restrict__ idx,

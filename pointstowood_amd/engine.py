@@ -237,6 +237,10 @@ class Engine:
         self.res_streams = int(os.environ.get("P2W_RES_STREAMS", "1"))      # residual-block chunk chains in flight (2: +0.6 %, measured)
         self.res_chunk_rows = int(os.environ.get("P2W_RES_CHUNK", "65536"))   # rows (at 4F=512) per residual-block chunk; 0 = whole level
         self.gemm_flags = int(os.environ.get("P2W_GEMM_FLAGS", "0"))          # P2W_GEMM_* bits of include/p2w.h (A/B runs)
+        # grid sub-sampling: "table" = direct cell table (no sort; falls back per batch when the grid does not fit), "sort"
+        self.sampler = os.environ.get("P2W_SAMPLER", "table")
+        self._table_scale = [1, 1, 1]   # per level: grows by 8 after an overflow, 0 = table given up for this level
+        self._ws_t = None
         self.events = None  # set to a list to record (name, start, end) events per launch
         self.events_grouped = False   # True: (name, start, end, launches) per run of consecutive same-name launches
         self._open = None
@@ -282,6 +286,25 @@ class Engine:
                       lin.relu0, lin.relu1, lin.relu2, lin.relu_final)
         self._call(name, lib().p2w_gemm, ptr(A), lda, ptr(lin.w), M, lin.N, lin.K, C.byref(ep), ptr(out), ldo)
 
+    TABLE_CELLS_MAX = 1 << 26          # 64 M entries x 20 B = 1.3 GB of workspace at most
+
+    def _table_cells(self, level, B):
+        """Table entries for the sampler of `level`: B voxels x the cells of a 2.3 m cube at that resolution (+ margin), times
+        the level's growth factor.  0: use the sort."""
+        if self.sampler != "table" or self._table_scale[level] == 0:
+            return 0
+        per_voxel = (int(2.3 / SA_RES[level]) + 3) ** 3
+        cells = B * per_voxel * self._table_scale[level]
+        return cells if cells <= self.TABLE_CELLS_MAX else 0
+
+    def _table_workspace(self, n, cells, device):
+        need = int(lib().p2w_voxel_sample_table_ws_bytes(n, cells))
+        if need == 0:
+            raise RuntimeError("p2w_voxel_sample_table_ws_bytes failed")
+        if self._ws_t is None or self._ws_t.numel() < need or self._ws_t.device != device:
+            self._ws_t = torch.empty(need, dtype=torch.uint8, device=device)
+        return self._ws_t
+
     def _workspace(self, n, device):
         need = int(lib().p2w_voxel_sample_ws_bytes(n))
         if need == 0:
@@ -291,13 +314,17 @@ class Engine:
         return self._ws
 
     # -- phase 1 ------------------------------------------------------------------------------
-    def _geometry_async(self, pos, reflectance, ptr0, sf) -> Geometry:
+    def _geometry_async(self, pos, reflectance, ptr0, sf, force_sort: bool = False) -> Geometry:
         L = lib()
         dev = pos.device
         N, B, k = pos.shape[0], sf.numel(), self.k
         i32 = dict(dtype=torch.int32, device=dev)
         f32 = dict(dtype=torch.float32, device=dev)
         geo = Geometry(B=B, N=N, k=k, sf=sf)
+        geo.args = (pos, reflectance, ptr0, sf)
+        geo.stream = torch.cuda.current_stream()
+        status = torch.zeros(3, **i32)    # per level: 1 = the table sampler's grid did not fit (results undefined)
+        geo.table_levels = []
         xyzr0, batch0 = torch.empty((N, 4), **f32), torch.empty(N, **i32)
         self._call("pack_xyzr", L.p2w_pack_xyzr, ptr(pos), pos.stride(0), ptr(reflectance), ptr(ptr0), B, N,
                    ptr(xyzr0), ptr(batch0))
@@ -327,9 +354,18 @@ class Engine:
             # rank of every source point's cell among the sampled level (= index of its representative): seeds the
             # interpolation searches (level 0 takes part in its sorted order, so it needs the rank per sorted position)
             ranks[l] = torch.empty(N, **i32) if (grid_search and self.fp_hints) else None
-            self._call("voxel_sample", L.p2w_voxel_sample, ptr(src.xyzr), ptr(src.ptr), B, N, res, ptr(lv.idx),
-                       ptr(lv.ptr), ptr(lv.batch), ptr(order), ptr(skeys), ptr(ckeys[l + 1]), ptr(grids[l + 1]),
-                       ptr(ranks[l]) if l > 0 else None, ptr(ranks[l]) if l == 0 else None, ptr(ws), ws.numel())
+            cells = 0 if force_sort else self._table_cells(l, B)
+            if cells:
+                ws_t = self._table_workspace(N, cells, dev)
+                geo.table_levels.append(l)
+                self._call("voxel_sample", L.p2w_voxel_sample_table, ptr(src.xyzr), ptr(src.ptr), B, N, res, ptr(lv.idx),
+                           ptr(lv.ptr), ptr(lv.batch), ptr(order), ptr(skeys), ptr(ckeys[l + 1]), ptr(grids[l + 1]),
+                           ptr(ranks[l]) if l > 0 else None, ptr(ranks[l]) if l == 0 else None, ptr(status[l:]), cells,
+                           ptr(ws_t), ws_t.numel())
+            else:
+                self._call("voxel_sample", L.p2w_voxel_sample, ptr(src.xyzr), ptr(src.ptr), B, N, res, ptr(lv.idx),
+                           ptr(lv.ptr), ptr(lv.batch), ptr(order), ptr(skeys), ptr(ckeys[l + 1]), ptr(grids[l + 1]),
+                           ptr(ranks[l]) if l > 0 else None, ptr(ranks[l]) if l == 0 else None, ptr(ws), ws.numel())
             if l == 0:   # model.py:117-118: the 0.04 level uses radius(r = 2*resolution)
                 # The input points arrive in arbitrary order; the searches that touch level 0 (this ball query as
                 # candidates, the last interpolation as queries) run over the cell-sorted copy so that a workgroup's
@@ -376,8 +412,8 @@ class Engine:
             geo.fp_nbr[f] = (nbr, deg)
         aux0 += list(ckeys.values()) + list(grids.values()) + [t for t in ranks.values() if t is not None]
         geo.aux = list(bbox.values()) + aux0
-        geo.counts_dev = torch.stack([geo.levels[l].ptr[B] for l in (1, 2, 3)])
-        geo.counts_host = torch.empty(3, dtype=torch.int32, pin_memory=True)
+        geo.counts_dev = torch.cat([torch.stack([geo.levels[l].ptr[B] for l in (1, 2, 3)]), status])
+        geo.counts_host = torch.empty(6, dtype=torch.int32, pin_memory=True)
         geo.counts_host.copy_(geo.counts_dev, non_blocking=True)
         geo.done = torch.cuda.Event()
         geo.done.record()
@@ -386,6 +422,18 @@ class Engine:
     def _geometry_finish(self, geo):
         """The only host sync of the forward: wait for the three level sizes."""
         geo.done.synchronize()
+        overflow = [l for l in range(3) if int(geo.counts_host[3 + l])]
+        if overflow:
+            # the batch's cell grid did not fit the sampler's table at these levels (device-side knowledge): everything
+            # downstream of the first of them is undefined.  Repeat the geometry with the sort (rare: voxels much larger than
+            # 2 m), and give the table 8 x the room next time.
+            for l in overflow:
+                grown = self._table_scale[l] * 8
+                self._table_scale[l] = grown if geo.B * (int(2.3 / SA_RES[l]) + 3) ** 3 * grown <= self.TABLE_CELLS_MAX else 0
+            with torch.cuda.stream(geo.stream):
+                redo = self._geometry_async(*geo.args, force_sort=True)
+            redo.done.synchronize()
+            geo.__dict__.update(redo.__dict__)
         for l in (1, 2, 3):
             geo.levels[l].n = int(geo.counts_host[l - 1])
         return geo

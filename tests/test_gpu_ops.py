@@ -293,6 +293,69 @@ def _sorted_level(b, res):
                 skeys=skeys, ckeys=ckeys[:m], grid=grid)
 
 
+@pytest.mark.parametrize("sizes,res,surface", [([5000], 0.04, False), ([1500, 40, 2600], 0.08, True), ([16384, 3000, 1, 700], 0.04, False),
+                                               ([9000, 0, 4000], 0.16, False)])
+def test_table_sampler_equals_sort_sampler(sizes, res, surface):
+    """p2w_voxel_sample_table (direct cell table, no sort) against p2w_voxel_sample on the same batch: representatives,
+    CSR, batch, cell keys, grid and ranks identical; the sorted order is a permutation in ascending cell order (the
+    order inside a cell is free).  A table that is too small must say so."""
+    import ctypes as C
+    from pointstowood_amd._lib import lib, ptr, stream
+    vox = [synth.uniform_voxel(2.0, max(n, 1), 77 + i, True) if not surface else synth.surface_voxel(2.0, max(n, 1), 77 + i, True)
+           for i, n in enumerate(sizes)]
+    b = synth.collate([v for v, n in zip(vox, sizes)])
+    keep = torch.cat([torch.ones(max(n, 1), dtype=torch.bool) if n > 0 else torch.zeros(1, dtype=torch.bool) for n in sizes])
+    pos = b["pos"][keep].cuda()
+    n, B = pos.shape[0], len(sizes)
+    L = lib()
+    xyzr = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
+    xyzr[:, :3] = pos
+    csr = torch.zeros(B + 1, dtype=torch.int32)
+    csr[1:] = torch.cumsum(torch.tensor(sizes), 0).int()
+    csr = csr.cuda()
+    i32 = dict(dtype=torch.int32, device="cuda")
+    i64 = dict(dtype=torch.int64, device="cuda")
+
+    def outputs():
+        return dict(idx=torch.full((n,), -7, **i32), ptr=torch.full((B + 1,), -7, **i32), batch=torch.full((n,), -7, **i32),
+                    order=torch.full((n,), -7, **i32), skeys=torch.full((n,), -7, **i64), ckeys=torch.full((n,), -7, **i64),
+                    grid=torch.zeros(8, **i64), inv=torch.full((n,), -7, **i32), rsort=torch.full((n,), -7, **i32))
+    a, t = outputs(), outputs()
+    ws = torch.empty(int(L.p2w_voxel_sample_ws_bytes(n)), dtype=torch.uint8, device="cuda")
+    assert L.p2w_voxel_sample(ptr(xyzr), ptr(csr), B, n, res, ptr(a["idx"]), ptr(a["ptr"]), ptr(a["batch"]), ptr(a["order"]),
+                              ptr(a["skeys"]), ptr(a["ckeys"]), ptr(a["grid"]), ptr(a["inv"]), ptr(a["rsort"]), ptr(ws), ws.numel(),
+                              stream()) == 0
+    cells = B * (int(2.3 / res) + 3) ** 3
+    wt = torch.empty(int(L.p2w_voxel_sample_table_ws_bytes(n, cells)), dtype=torch.uint8, device="cuda")
+    status = torch.full((1,), 9, **i32)
+    assert L.p2w_voxel_sample_table(ptr(xyzr), ptr(csr), B, n, res, ptr(t["idx"]), ptr(t["ptr"]), ptr(t["batch"]), ptr(t["order"]),
+                                    ptr(t["skeys"]), ptr(t["ckeys"]), ptr(t["grid"]), ptr(t["inv"]), ptr(t["rsort"]), ptr(status),
+                                    cells, ptr(wt), wt.numel(), stream()) == 0
+    torch.cuda.synchronize()
+    assert int(status) == 0
+    m = int(a["ptr"][B])
+    assert torch.equal(t["ptr"], a["ptr"]) and m > 0
+    for k in ("idx", "batch", "ckeys"):
+        assert torch.equal(t[k][:m], a[k][:m]), k
+    assert torch.equal(t["grid"], a["grid"]) and torch.equal(t["inv"], a["inv"])
+    assert torch.equal(t["skeys"], a["skeys"])                                   # the multiset of keys in ascending order
+    assert torch.equal(torch.sort(t["order"].long()).values, torch.arange(n, device="cuda"))
+    assert torch.equal(t["skeys"], torch.gather(a["skeys"], 0, torch.argsort(a["order"].long())[t["order"].long()]))   # each point keeps its key
+    assert torch.equal(t["rsort"], t["inv"][t["order"].long()])
+    # without the optional outputs
+    t2 = outputs()
+    assert L.p2w_voxel_sample_table(ptr(xyzr), ptr(csr), B, n, res, ptr(t2["idx"]), ptr(t2["ptr"]), ptr(t2["batch"]), None, None,
+                                    ptr(t2["ckeys"]), None, ptr(t2["inv"]), None, ptr(status), cells, ptr(wt), wt.numel(), stream()) == 0
+    assert torch.equal(t2["idx"][:m], a["idx"][:m]) and torch.equal(t2["inv"], a["inv"]) and int(status) == 0
+    # a table that cannot hold the grid reports it instead of writing out of bounds
+    small = 1000
+    assert L.p2w_voxel_sample_table(ptr(xyzr), ptr(csr), B, n, res, ptr(t2["idx"]), ptr(t2["ptr"]), ptr(t2["batch"]), None, None,
+                                    None, None, None, None, ptr(status), small, ptr(wt), wt.numel(), stream()) == 0
+    assert int(status) == 1 and int(t2["ptr"].abs().max()) == 0          # ... and hands out an empty level
+    assert L.p2w_voxel_sample_table(ptr(xyzr), ptr(csr), B, n, res, ptr(t2["idx"]), ptr(t2["ptr"]), ptr(t2["batch"]), None, None,
+                                    None, None, None, None, ptr(status), cells, ptr(wt), 1024, stream()) == -4      # workspace
+
+
 @pytest.mark.parametrize("sizes,surface", [([5000], False), ([1500, 40, 2600], True), ([16384, 3000], False)])
 def test_voxel_sample_order_is_cell_sorted_permutation(sizes, surface):
     b = _batch(sizes, seed=21, surface=surface)
