@@ -28,7 +28,8 @@ typedef float fpair __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void* lds_vp;
 typedef const __attribute__((address_space(1))) void* glb_vp;
 
-constexpr int H_BK = 32;   // k per LDS row (64 bytes); a slab is two such row groups ("planes")
+constexpr int H_BK = 32;   // k per plane of a PointNetConv slab
+
 
 #if defined(P2W_GEMM_STAMP) || defined(P2W_SA_STAMP)   // diagnostic builds (tools/gemm_stamps.py, tools/sa_stamps.py): in-kernel cycle stamps
 __device__ __forceinline__ unsigned long long p2w_stamp() {
@@ -152,106 +153,126 @@ struct EpiArgs {
     const float *bias, *sc0, *sh0, *sc1, *sh1, *residual;
     int ldr, relu0, relu1, relu2, relu_final;
 };
-// epilogue value -> optional fp32 store + optional H store.  H: lanes (2p, 2p+1) own adjacent columns of the same
-// rows; they swap one register of each (r, r+1) pair so that every lane stores two adjacent columns as one 32-bit
-// word per plane (even lane: row(r), odd lane: row(r+1)).
+// Outputs of a GEMM launch: optional fp32 [M, ldo] and / or optional H [M, ldh].
 struct OutArgs { float* f32; int ldo; _Float16* h2; int ldh; };
 
-__device__ __forceinline__ float epi_value(float a, float wscale, float bias, const EpiArgs& ep, float s0, float t0, float s1,
-                                           float t1, size_t row, int col, bool ok) {
-    float v = fmaf(a, wscale, bias);
-    if (ep.relu0) v = fmaxf(v, 0.f);
-    if (ep.sc0) { v = fmaf(v, s0, t0); }
-    if (ep.relu1) v = fmaxf(v, 0.f);
-    if (ep.sc1) { v = fmaf(v, s1, t1); }
-    if (ep.relu2) v = fmaxf(v, 0.f);
-    if (ep.residual && ok) v += ep.residual[row * ep.ldr + col];
-    if (ep.relu_final) v = fmaxf(v, 0.f);
-    return v;
+// Column ownership.  The W rows of a stage are staged PERMUTED (w_stage_row below): LDS row 32 t + r of a wave's column
+// range holds output channel 64 (t >> 1) + 2 r + (t & 1), so lane r of accumulator tiles 2 jp and 2 jp + 1 holds the two
+// ADJACENT columns c = col0 + 64 jp + 2 r and c + 1 of the same rows: an H word (two fp16) or a float2 per lane and row
+// without any cross-lane exchange, per-column parameters as float2 loads.
+__device__ __forceinline__ int w_stage_row(int rho) {   // LDS W row (within the workgroup's BN rows) -> W row (output channel)
+    const int t = rho >> 5, r = rho & 31;
+    return 64 * (t >> 1) + 2 * r + (t & 1);
 }
 
-template <int PREC, int RT, int CT>
-__device__ __forceinline__ void gemm_epilogue2(const f32x16 (&acc)[RT][CT], const EpiArgs& ep, float wscale, int row0, int col0,
-                                               int lane, int M, int N, const OutArgs& o) {
-    const int h = lane >> 5, odd = lane & 1;
+// EF >= 0: compile-time flags (1 relu0, 2 sc0, 4 relu1, 8 sc1, 16 relu2, 32 residual, 64 relu_final, 128 fp32 out, 256 H out)
+// for interior tiles (every row < M, every column < N, even N / ldo / ldr, 8-byte aligned parameter vectors): no guards,
+// float2 parameter / residual / fp32 accesses, the residual of the next row in flight while a row is finished and stored
+// (on gfx950 loads and stores retire through one counter: a load waited for right behind its issue drains every store).
+// EF < 0: runtime flags, every access guarded (edge tiles, odd sizes); pad columns [N, ldh) of the H rows are written as zeros.
+template <int PREC, int RT, int CT, int EF>
+__device__ __forceinline__ void gemm_epilogue_il(const f32x16 (&acc)[RT][CT], const EpiArgs& ep, float wscale, int row0, int col0,
+                                                 int lane, int M, int N, const OutArgs& o) {
+    static_assert(CT % 2 == 0, "column tiles come in interleaved pairs");
+    constexpr bool GEN = EF < 0;
+    constexpr int JP = CT / 2, NSTEP = RT * 16;
+    const bool R0 = GEN ? ep.relu0 != 0 : (EF & 1) != 0, S0 = GEN ? ep.sc0 != nullptr : (EF & 2) != 0;
+    const bool R1 = GEN ? ep.relu1 != 0 : (EF & 4) != 0, S1 = GEN ? ep.sc1 != nullptr : (EF & 8) != 0;
+    const bool R2 = GEN ? ep.relu2 != 0 : (EF & 16) != 0, RES = GEN ? ep.residual != nullptr : (EF & 32) != 0;
+    const bool RF = GEN ? ep.relu_final != 0 : (EF & 64) != 0, OF = GEN ? o.f32 != nullptr : (EF & 128) != 0;
+    const bool OH = GEN ? o.h2 != nullptr : (EF & 256) != 0;
+    const int r = lane & 31, h = lane >> 5;
+    const int cb = col0 + 2 * r;   // even column of pair 0; pair jp: + 64 jp
+    fpair bias[JP], s0[JP], t0[JP], s1[JP], t1[JP];
 #pragma unroll
-    for (int j = 0; j < CT; ++j) {
-        const int col = col0 + j * 32 + (lane & 31);
-        const bool cv = col < N;
-        const float bias = (cv && ep.bias) ? ep.bias[col] : 0.f;
-        const float s0 = (cv && ep.sc0) ? ep.sc0[col] : 1.f, t0 = (cv && ep.sc0) ? ep.sh0[col] : 0.f;
-        const float s1 = (cv && ep.sc1) ? ep.sc1[col] : 1.f, t1 = (cv && ep.sc1) ? ep.sh1[col] : 0.f;
+    for (int jp = 0; jp < JP; ++jp) {
+        const int c = cb + 64 * jp;
+        bias[jp] = fpair{0.f, 0.f}; s0[jp] = fpair{1.f, 1.f}; t0[jp] = fpair{0.f, 0.f}; s1[jp] = fpair{1.f, 1.f}; t1[jp] = fpair{0.f, 0.f};
+        if constexpr (GEN) {
 #pragma unroll
-        for (int i = 0; i < RT; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const int rowa = row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;  // row of register r; r+1 is rowa + 1
-                float va = epi_value(acc[i][j][r], wscale, bias, ep, s0, t0, s1, t1, (size_t)rowa, col, cv && rowa < M);
-                float vb = epi_value(acc[i][j][r + 1], wscale, bias, ep, s0, t0, s1, t1, (size_t)rowa + 1, col,
-                                     cv && rowa + 1 < M);
-                if (!cv) { va = 0.f; vb = 0.f; }  // pad columns of an H row must be zero
-                if (o.f32 && cv) {
-                    if (rowa < M) o.f32[(size_t)rowa * o.ldo + col] = va;
-                    if (rowa + 1 < M) o.f32[(size_t)(rowa + 1) * o.ldo + col] = vb;
+            for (int e = 0; e < 2; ++e)
+                if (c + e < N) {
+                    if (ep.bias) bias[jp][e] = ep.bias[c + e];
+                    if (S0) { s0[jp][e] = ep.sc0[c + e]; t0[jp][e] = ep.sh0[c + e]; }
+                    if (S1) { s1[jp][e] = ep.sc1[c + e]; t1[jp][e] = ep.sh1[c + e]; }
                 }
-                if (o.h2) {
-                    const float send = odd ? va : vb;
-                    const float recv = __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(send), 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, false));
-                    const float c0v = odd ? recv : va, c1v = odd ? vb : recv;  // columns (col & ~1), (col | 1)
-                    const int roww = rowa + odd, colw = col & ~1;
-                    if (roww < M && colw < o.ldh) h_store2<PREC>(o.h2, o.ldh, roww, colw, c0v, c1v);
-                }
-            }
+        } else {
+            if (ep.bias) bias[jp] = *reinterpret_cast<const fpair*>(ep.bias + c);
+            if (S0) { s0[jp] = *reinterpret_cast<const fpair*>(ep.sc0 + c); t0[jp] = *reinterpret_cast<const fpair*>(ep.sh0 + c); }
+            if (S1) { s1[jp] = *reinterpret_cast<const fpair*>(ep.sc1 + c); t1[jp] = *reinterpret_cast<const fpair*>(ep.sh1 + c); }
         }
     }
-}
-
-// Compile-time specialised epilogue for interior tiles (every row < M, every column < N): no per-element guards,
-// no flag selects, 32-bit offsets.  EF bits: 1 relu0, 2 sc0, 4 relu1, 8 sc1, 16 relu2, 32 residual, 64 relu_final,
-// 128 fp32 out, 256 H out.  Edge tiles and unlisted combinations use gemm_epilogue2 (runtime flags).
-template <int PREC, int RT, int CT, int EF>
-__device__ __forceinline__ void gemm_epilogue3(const f32x16 (&acc)[RT][CT], const EpiArgs& ep, float wscale, int row0, int col0,
-                                               int lane, const OutArgs& o) {
-    constexpr bool R0 = EF & 1, S0 = EF & 2, R1 = EF & 4, S1 = EF & 8, R2 = EF & 16, RES = EF & 32, RF = EF & 64,
-                   OF = EF & 128, OH = EF & 256;
-    const int h = lane >> 5, odd = lane & 1;
+    auto row_of = [&](int st) { const int i = st >> 4, reg = st & 15; return row0 + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * h; };
+    auto value = [&](float a, float b, float s0v, float t0v, float s1v, float t1v, float res) {
+        float v = fmaf(a, wscale, b);
+        if (R0) v = fmaxf(v, 0.f);
+        if (S0) v = fmaf(v, s0v, t0v);
+        if (R1) v = fmaxf(v, 0.f);
+        if (S1) v = fmaf(v, s1v, t1v);
+        if (R2) v = fmaxf(v, 0.f);
+        if (RES) v += res;
+        if (RF) v = fmaxf(v, 0.f);
+        return v;
+    };
+    fpair rcur[JP], rnxt[JP];
+    auto load_res = [&](fpair (&dst)[JP], int st) {   // specialised path only
+        const float* rp = ep.residual + ((unsigned)row_of(st) * (unsigned)ep.ldr + (unsigned)cb);
 #pragma unroll
-    for (int j = 0; j < CT; ++j) {
-        const int col = col0 + j * 32 + (lane & 31);
-        const float bias = ep.bias ? ep.bias[col] : 0.f;
-        float s0 = 1.f, t0 = 0.f, s1 = 1.f, t1 = 0.f;
-        if (S0) { s0 = ep.sc0[col]; t0 = ep.sh0[col]; }
-        if (S1) { s1 = ep.sc1[col]; t1 = ep.sh1[col]; }
-        auto f = [&](float a, unsigned roff) {
-            float v = fmaf(a, wscale, bias);
-            if (R0) v = fmaxf(v, 0.f);
-            if (S0) v = fmaf(v, s0, t0);
-            if (R1) v = fmaxf(v, 0.f);
-            if (S1) v = fmaf(v, s1, t1);
-            if (R2) v = fmaxf(v, 0.f);
-            if (RES) v += ep.residual[roff];
-            if (RF) v = fmaxf(v, 0.f);
-            return v;
-        };
+        for (int jp = 0; jp < JP; ++jp) dst[jp] = *reinterpret_cast<const fpair*>(rp + 64 * jp);
+    };
 #pragma unroll
-        for (int i = 0; i < RT; ++i) {
-            const unsigned rbase = (unsigned)(row0 + i * 32 + 4 * h);
-            __builtin_amdgcn_sched_barrier(0);  // keep the scheduler from hoisting every tile's loads at once (spills)
+    for (int jp = 0; jp < JP; ++jp) { rcur[jp] = fpair{0.f, 0.f}; rnxt[jp] = fpair{0.f, 0.f}; }
+    if constexpr (!GEN) {
+        if (RES) load_res(rcur, 0);
+    }
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                if ((r & 7) == 0) __builtin_amdgcn_sched_barrier(0);
-                const unsigned rowa = rbase + (r & 3) + 8 * (r >> 2);
-                const float va = f(acc[i][j][r], RES ? rowa * (unsigned)ep.ldr + col : 0u);
-                const float vb = f(acc[i][j][r + 1], RES ? (rowa + 1) * (unsigned)ep.ldr + col : 0u);
-                if (OF) {
-                    o.f32[rowa * (unsigned)o.ldo + col] = va;
-                    o.f32[(rowa + 1) * (unsigned)o.ldo + col] = vb;
-                }
+    for (int st = 0; st < NSTEP; ++st) {
+        const int i = st >> 4, reg = st & 15;
+        const int row = row_of(st);
+        if constexpr (!GEN) {
+            if (RES && st + 1 < NSTEP) load_res(rnxt, st + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            float* fp = OF ? o.f32 + ((unsigned)row * (unsigned)o.ldo + (unsigned)cb) : nullptr;
+            _Float16* hp = nullptr;
+            if (OH) {
+                if constexpr (PREC == 0) hp = o.h2 + ((unsigned)row * (unsigned)(2 * o.ldh) + (unsigned)(64 * (cb >> 5) + (cb & 31)));
+                else hp = o.h2 + ((unsigned)row * (unsigned)o.ldh + (unsigned)cb);
+            }
+#pragma unroll
+            for (int jp = 0; jp < JP; ++jp) {
+                const float va = value(acc[i][2 * jp][reg], bias[jp][0], s0[jp][0], t0[jp][0], s1[jp][0], t1[jp][0], rcur[jp][0]);
+                const float vb = value(acc[i][2 * jp + 1][reg], bias[jp][1], s0[jp][1], t0[jp][1], s1[jp][1], t1[jp][1], rcur[jp][1]);
+                if (OF) *reinterpret_cast<fpair*>(fp + 64 * jp) = fpair{va, vb};
                 if (OH) {
-                    const float send = odd ? va : vb;
-                    const float recv = __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(send), 0xB1, 0xf, 0xf, false));
-                    const float c0v = odd ? recv : va, c1v = odd ? vb : recv;
-                    h_store2<PREC>(o.h2, (unsigned)o.ldh, rowa + odd, (unsigned)(col & ~1), c0v, c1v);
+                    if constexpr (PREC == 0) {
+                        unsigned hw, lw;
+                        split_pair(va, vb, hw, lw);
+                        *reinterpret_cast<unsigned*>(hp + 128 * jp) = hw;        // 64 columns further = two [hi32 | lo32] blocks
+                        *reinterpret_cast<unsigned*>(hp + 128 * jp + 32) = lw;
+                    } else {
+                        *reinterpret_cast<unsigned*>(hp + 64 * jp) = pack_pair<PREC>(va, vb);
+                    }
+                }
+            }
+            if (RES) {
+#pragma unroll
+                for (int jp = 0; jp < JP; ++jp) rcur[jp] = rnxt[jp];
+            }
+        } else {
+            if (row < M) {
+#pragma unroll
+                for (int jp = 0; jp < JP; ++jp) {
+                    const int c = cb + 64 * jp;
+                    float v[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const bool cv = c + e < N;
+                        const float res = (RES && cv) ? ep.residual[(size_t)row * ep.ldr + c + e] : 0.f;
+                        v[e] = value(acc[i][2 * jp + e][reg], bias[jp][e], s0[jp][e], t0[jp][e], s1[jp][e], t1[jp][e], res);
+                        if (!cv) v[e] = 0.f;                       // pad columns of an H row must be zero
+                        if (OF && cv) o.f32[(size_t)row * o.ldo + c + e] = v[e];
+                    }
+                    if (OH && c < o.ldh) h_store2<PREC>(o.h2, o.ldh, row, c, v[0], v[1]);
                 }
             }
         }
@@ -264,25 +285,24 @@ __device__ __forceinline__ void gemm_epilogue_dispatch(const f32x16 (&acc)[RT][C
     const bool full = (row0 + 32 * RT <= M) && (col0 + 32 * CT <= N) && ef != 0;
     if (full) {
         switch (ef) {
-#define P2W_EPI_CASE(E) case E: gemm_epilogue3<PREC, RT, CT, E>(acc, ep, wscale, row0, col0, lane, o); return;
+#define P2W_EPI_CASE(E) case E: gemm_epilogue_il<PREC, RT, CT, E>(acc, ep, wscale, row0, col0, lane, M, N, o); return;
             P2W_EPI_CASE(128) P2W_EPI_CASE(257) P2W_EPI_CASE(263) P2W_EPI_CASE(287) P2W_EPI_CASE(480) P2W_EPI_CASE(224)
             P2W_EPI_CASE(131) P2W_EPI_CASE(259) P2W_EPI_CASE(387) P2W_EPI_CASE(129)
 #undef P2W_EPI_CASE
             default: break;
         }
     }
-    gemm_epilogue2<PREC, RT, CT>(acc, ep, wscale, row0, col0, lane, M, N, o);
+    gemm_epilogue_il<PREC, RT, CT, -1>(acc, ep, wscale, row0, col0, lane, M, N, o);
 }
 
 // ------------------------------------------------------------------------------------------------
 // GEMM over H operands: both operands are 16-bit planes in HBM, so a K-slab is staged with direct-to-LDS loads
 // (global_load_lds_dwordx4: no VGPR round trip, no ds_write) into a 2-stage ring; one barrier per slab, the next
 // slab's DMA is in flight during the whole MFMA phase of the current one.
-// LDS image of a stage (16-byte chunks): A plane p, row r, chunk q -> ((p*BM + r)*4 + (q ^ ((r>>2)&3)));  B after A.
-// f16x3: plane p = hi / lo of k0..k0+31.  Single-plane modes: plane p = k0+32p..k0+32p+31 of a 64-wide slab, so the
-// image, the DMA pattern and the fragment reads are the same and only the MFMA pairing differs.
-// Rows are 64 B unpadded (the DMA writes 1 KiB linearly per wave-instruction: lane L -> chunk base+L), so the XOR
-// swizzle is applied on the per-lane SOURCE address and again on the ds_read address: conflict-free ds_read_b128.
+// A slab takes 64 halfs = ONE 128-byte cache line of every A / W row (f16x3: [hi(32 k) | lo(32 k)]; single-plane: 64 k),
+// stored as a 128-byte LDS row of 8 chunks with an XOR swizzle (details at the DMA setup below): conflict-free
+// ds_read_b128 fragments, and the image, the DMA pattern and the fragment reads are the same in every precision - only
+// the MFMA pairing differs.  W rows are staged permuted (w_stage_row) so that a lane owns adjacent output columns.
 // Out-of-range A rows are clamped to M-1 (their results are never stored); K padding is zero in both operands.
 // ------------------------------------------------------------------------------------------------
 template <int PREC, int WR, int WC, int RT, int CT>   // waves WR x WC, wave tile (32*RT) x (32*CT)
@@ -341,7 +361,7 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void gemm_h2g_kernel(const _Float1
             const int grow = (dbg & 32) ? row : min(m0 + row, M - 1);   // dbg 32: every workgroup reads row tile 0 (no A traffic)
             src[i] = A + (size_t)grow * a_pitch + 8 * c;
         } else {
-            src[i] = Wh + (size_t)(n0 + row - BM) * w_pitch + 8 * c;
+            src[i] = Wh + (size_t)(n0 + w_stage_row(row - BM)) * w_pitch + 8 * c;
         }
         dstc[i] = g * 64;
     }
@@ -517,6 +537,11 @@ static int32_t launch_gemm_h(const _Float16* Ah, int32_t ldh_a, const _Float16* 
     const size_t lim = (size_t)1 << 31;
     if ((size_t)M * (size_t)(ldo > 2 * ldh_o ? ldo : 2 * ldh_o) >= lim || (ep.residual && (size_t)M * ep.ldr >= lim) ||
         (N & 1) || (flags & P2W_GEMM_GENERIC_EPI))
+        ef = 0;
+    // the specialised epilogue moves column PAIRS (float2 / one H word per lane): even pitches, 8-byte aligned vectors
+    auto odd8 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 7) != 0; };
+    if ((out_f32 && ((ldo & 1) || odd8(out_f32))) || (ep.residual && ((ep.ldr & 1) || odd8(ep.residual))) || odd8(ep.bias) ||
+        odd8(ep.sc0) || odd8(ep.sh0) || odd8(ep.sc1) || odd8(ep.sh1))
         ef = 0;
     // tile order: keep W L2-resident per XCD when it does not fit an XCD's L2 (see tile_coords)
     const size_t w_bytes = (size_t)N * Kpad * 2 * HCfg<PREC>::planes;
