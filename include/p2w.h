@@ -268,7 +268,8 @@ int32_t p2w_gemm_h2(int32_t prec, const void* A_h, int32_t ldh_a, const void* Wh
  * ldp >= round_up(C1, K granularity) floats: rows 0..n_src-1 = x_src * W1x^T + b1 with ZERO pad columns, row n_src all
  * zero (the row empty neighbour slots read; the kernel's loads are unconditional).
  * ws: 16-byte aligned scratch of >= M*32*20 bytes for the per-edge metadata (P2W_EWORKSPACE otherwise);
- * kw <= 32 (one 32-row MFMA tile per target) and round_up(C1, K granularity) <= 512 (P2W_EUNSUPPORTED otherwise). */
+ * kw <= 32 (one 32-row MFMA tile per target); round_up(C1, K granularity) <= 512, C2 <= 1024 (LDS tables), M < 2^26 and
+ * (n_src + 1) * ldp < 2^33 (32-bit offsets) - P2W_EUNSUPPORTED otherwise. */
 int32_t p2w_sa_conv_h(int32_t prec, const float* P, int32_t ldp, int32_t n_src, const float* xyzr_src, const int32_t* idx,
                       const int32_t* batch_dst, const float* sf, const int32_t* nbr, const int32_t* deg, int32_t kw,
                       int32_t M, const float* w1r4, const void* W2h, float wscale, int32_t C1, int32_t C2,

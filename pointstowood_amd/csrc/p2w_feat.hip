@@ -365,7 +365,7 @@ extern "C" int32_t p2w_gemm_h2(int32_t prec, const void* A_h, int32_t ldh_a, con
 __global__ __launch_bounds__(256) void sa_edge_meta_kernel(const float4* __restrict__ xyzr, const int* __restrict__ idx,
                                                            const int* __restrict__ batch_dst, const float* __restrict__ sf,
                                                            const int* __restrict__ nbr, const int* __restrict__ deg, int kw,
-                                                           int M, int n_src, int* __restrict__ meta_j, float4* __restrict__ meta_g) {
+                                                           int M, int n_src, int ldp4, int* __restrict__ meta_j, float4* __restrict__ meta_g) {
     const long g = (long)blockIdx.x * 256 + threadIdx.x;
     const int tgt = (int)(g >> 5), slot = (int)(g & 31);
     int j = 0;
@@ -391,7 +391,8 @@ __global__ __launch_bounds__(256) void sa_edge_meta_kernel(const float4* __restr
     const float den = dmax + 1e-8f;
     if (tgt < M) {
         const bool valid = slot < deg[tgt] && slot < kw;
-        meta_j[g] = valid ? j : n_src;  // empty slot: P's all-zero row + a zero offset give a zero A row; the epilogue masks it
+        // offset of the source's P row in float4 units; empty slot: P's all-zero row + a zero offset give a zero A row (the epilogue masks it)
+        meta_j[g] = (valid ? j : n_src) * ldp4;
         meta_g[g] = make_float4(rx / den, ry / den, rz / den, rf);
     }
 }

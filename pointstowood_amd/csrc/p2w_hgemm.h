@@ -29,6 +29,7 @@ typedef __attribute__((address_space(3))) void* lds_vp;
 typedef const __attribute__((address_space(1))) void* glb_vp;
 
 constexpr int H_BK = 32;   // k per plane of a PointNetConv slab
+constexpr int SA_EPI_COLS = 1024;   // capacity of the fused PointNetConv's LDS table of per-column epilogue parameters (C2 limit)
 
 
 #if defined(P2W_GEMM_STAMP) || defined(P2W_SA_STAMP)   // diagnostic builds (tools/gemm_stamps.py, tools/sa_stamps.py): in-kernel cycle stamps
@@ -646,10 +647,13 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
     static_assert(NI >= 1, "every wave issues at least one W2 DMA piece per slab");
     // ONE __shared__ object: with a second one beside the DMA staging array hipcc cannot tell the LDS-DMA's destination from
     // the other object and drains vmcnt(0) in front of the first ds_read of every slab (cdna_hip_programming.md, .s-level trap a)
-    __shared__ __attribute__((aligned(16))) char S[2 * STAGE_CH * 16 + 4 * 512 * 4];
+    __shared__ __attribute__((aligned(16))) char S[2 * STAGE_CH * 16 + 4 * 512 * 4 + 3 * SA_EPI_COLS * 4];
     float* const Wr = reinterpret_cast<float*>(S + 2 * STAGE_CH * 16);   // layer-1 geometry weights (rx, ry, rz, refl rows), C1pad <= 512
+    float* const Ep = Wr + 4 * 512;   // the epilogue's per-column parameters [bias | BN scale | BN shift][C2 <= SA_EPI_COLS]: read when an
+                                      // item is finished instead of being prefetched (6 loads + their addresses) in every slab
     const int tid = threadIdx.x, lane = tid & 63;
     for (int i = tid; i < 4 * C1pad; i += 512) Wr[i] = w1r4[i];
+    for (int i = tid; i < C2; i += 512) { Ep[i] = b2[i]; Ep[SA_EPI_COLS + i] = bn_s[i]; Ep[2 * SA_EPI_COLS + i] = bn_t[i]; }
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wave / WCn, wc = wave % WCn;
     const int nitems = nMt * nNt, nslab = C1pad / H_BK;
     // XCD-aware work assignment: workgroups b, b+8, b+16.. share an XCD (round-robin dispatch) and therefore an L2.
@@ -668,7 +672,8 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
     const int my_items = (limit - first + stride - 1) / stride;
     const int total = my_items * nslab;
 
-    // item -> (row tile, column tile): column tiles of one row tile are adjacent work items
+    // item -> (row tile, column tile): column tiles of one row tile are adjacent work items.  The division runs once per item
+    // (in nxt(), when a slab counter wraps), not in every slab.
     auto item_mt = [&](int it) { return (first + it * stride) / nNt; };
     auto item_nt = [&](int it) { return (first + it * stride) % nNt; };
 
@@ -700,13 +705,12 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
     // metadata of the producer's edge row (clamped: rows past the last target replay the last valid row)
     struct Meta { int j[NR]; float4 g[NR]; };
     struct Vals { float4 v[NR][2]; };
-    auto load_meta = [&](int it, Meta& m) {
+    const int last_row = M * 32 - 1;   // < 2^31 (launcher)
+    auto load_meta = [&](int mt_, Meta& m) {
 #pragma unroll
         for (int u = 0; u < NR; ++u) {
-            long row = (long)item_mt(it) * BM + prow + 128 * u;
-            const long last = (long)M * 32 - 1;
-            row = row < last ? row : last;
-            m.j[u] = meta_j[row];      // n_src (P's zero row) for an empty neighbour slot (masked in the epilogue as well)
+            const int row = min(mt_ * BM + prow + 128 * u, last_row);
+            m.j[u] = meta_j[row];      // offset of the source's P row in float4 units (P's zero row for an empty neighbour slot)
             m.g[u] = meta_g[row];
         }
     };
@@ -715,12 +719,12 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
     // either: an empty neighbour slot points at P's all-zero row n_src and carries a zero offset (sa_edge_meta_kernel),
     // and P's pad columns up to C1pad are zero, so relu(0 + 0) = 0 falls out of the arithmetic.
     auto gather = [&](const Meta& m, int k0, Vals& dst) {
-        const int k = k0 + 8 * pq;
+        const unsigned k4 = (unsigned)(k0 >> 2) + 2u * pq;
 #pragma unroll
         for (int u = 0; u < NR; ++u) {
-            const float* p = P + (size_t)m.j[u] * ldp + k;
-            dst.v[u][0] = *reinterpret_cast<const float4*>(p);
-            dst.v[u][1] = *reinterpret_cast<const float4*>(p + 4);
+            const float4* p = reinterpret_cast<const float4*>(P) + ((unsigned)m.j[u] + k4);
+            dst.v[u][0] = p[0];
+            dst.v[u][1] = p[1];
         }
     };
     // layer-1 geometry weights of the producer's 8 k values: read from LDS BEFORE the slab's DMA is issued (an LDS read
@@ -805,11 +809,18 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
     // vmcnt(0) at any join behind a branch that contains a load, and with the DMA in flight such a drain in front of the
     // fragment reads serialises the DMA, the gather latency and the MFMAs (the previous form of this loop did that in
     // every slab: 3.3x the MFMA time).  Slabs past the end replay the last slab's addresses and are never consumed.
-    struct Cur { int it, s; };
-    auto nxt = [&](Cur c) { if (++c.s == nslab) { c.s = 0; ++c.it; } return c; };
-    auto meta_of = [&](Cur c, Meta& m) { load_meta(min(c.it, my_items - 1), m); };
+    struct Cur { int it, s, mt, nt; };   // item, slab, the item's row / column tile (items past the end replay the last one)
+    auto nxt = [&](Cur c) {
+        if (++c.s == nslab) {
+            c.s = 0; ++c.it;
+            const int itc = min(c.it, my_items - 1);
+            c.mt = item_mt(itc); c.nt = item_nt(itc);
+        }
+        return c;
+    };
+    auto meta_of = [&](Cur c, Meta& m) { load_meta(c.mt, m); };
     auto k_of = [&](Cur c) { return (c.it < my_items ? c.s : nslab - 1) * H_BK; };
-    Cur c0 = {0, 0}, c1 = nxt(c0), c2 = nxt(c1), c3 = nxt(c2);
+    Cur c0 = {0, 0, item_mt(0), item_nt(0)}, c1 = nxt(c0), c2 = nxt(c1), c3 = nxt(c2);
     Meta ma, mb, mc;
     Vals va;
     {   // prologue: slab 0 complete in stage 0, slab 1 gathered, metadata of slabs 2 and 3 on their way
@@ -819,7 +830,7 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
         meta_of(c2, mb);
         meta_of(c3, mc);
         __syncthreads();   // Wr staged
-        issue(0, W2h + (size_t)item_nt(0) * BN * NP * C1pad, 0);
+        issue(0, W2h + (size_t)c0.nt * BN * NP * C1pad, 0);
         gather(m0, 0, va);
         WRegs w0;
         load_w(0, w0);
@@ -833,19 +844,15 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
             for (int hh = 0; hh < 2; ++hh)   // an opaque use: the compiler waits for the gather here, once
                 asm volatile("" : "+v"(va.v[u][hh].x), "+v"(va.v[u][hh].y), "+v"(va.v[u][hh].z), "+v"(va.v[u][hh].w));
     }
-    int mt_cur = item_mt(0), nt_cur = item_nt(0);   // item in the MFMA stage
-    // epilogue parameters (clamped addresses, no conditions: see the loop's rule about loads)
-    auto load_epi = [&](int mt_, int nt_, SaEpiRegs<RT>& e) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = min(nt_ * BN + wc * 64 + j * 32 + (lane & 31), C2 - 1);
-            e.bias[j] = b2[col]; e.s[j] = bn_s[col]; e.t[j] = bn_t[col];
-        }
+    // neighbour counts of the wave's targets (clamped addresses, no conditions: see the loop's rule about loads); the
+    // per-column parameters come from the LDS table when the item is finished
+    struct Degs { int d[RT]; };
+    auto load_deg = [&](int mt_, Degs& e) {
 #pragma unroll
         for (int i = 0; i < RT; ++i) e.d[i] = min(deg[min(mt_ * (BM / 32) + wr * RT + i, M - 1)], kw);
     };
-    SaEpiRegs<RT> ep_;
-    load_epi(mt_cur, nt_cur, ep_);   // item 0; later items' parameters arrive one iteration ahead (ep_n)
+    Degs dg_;
+    load_deg(c0.mt, dg_);   // item 0; later items' counts arrive one iteration ahead (dg_n)
 #ifdef P2W_SA_STAMP
     unsigned long long t_wait = 0, t_epi = 0, t_mma = 0;
     const unsigned long long t_start = p2w_stamp();
@@ -866,16 +873,13 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
         Vals vb;
         if (!(dbg & 16)) gather(mb, k_of(c2), vb); else vb = va;
         meta_of(c3, mc);
-        SaEpiRegs<RT> ep_n;
-        {
-            const int it1 = min(c1.it, my_items - 1);
-            load_epi(item_mt(it1), item_nt(it1), ep_n);
-        }
+        Degs dg_n;
+        load_deg(c1.mt, dg_n);
         WRegs wk;
         load_w(k_of(c1), wk);
         __builtin_amdgcn_sched_barrier(0);
         if (g + 1 < total && !(dbg & 2))
-            issue((g + 1) & 1, W2h + (size_t)item_nt(c1.it) * BN * NP * C1pad, c1.s * H_BK);
+            issue((g + 1) & 1, W2h + (size_t)c1.nt * BN * NP * C1pad, c1.s * H_BK);
         const char* st = S + (size_t)(g & 1) * STAGE_CH * 16;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -918,11 +922,15 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
 #endif
         if (c0.s == nslab - 1) {  // item finished: reduce over neighbour slots and store, then start the next accumulation
             if (!(dbg & 1)) {
-                SaEpiRegs<RT> e = ep_;
+                SaEpiRegs<RT> e;
 #pragma unroll
-                for (int i = 0; i < RT; ++i)
-                    if (mt_cur * (BM / 32) + wr * RT + i >= M) e.d[i] = 0;
-                sa_epilogue_regs<PREC, RT>(acc, wscale, mt_cur * (BM / 32), nt_cur * BN, wr, wc, lane, M, e, C2, out, ldo, out_h2, ldh);
+                for (int j = 0; j < 2; ++j) {
+                    const int col = min(c0.nt * BN + wc * 64 + j * 32 + (lane & 31), C2 - 1);
+                    e.bias[j] = Ep[col]; e.s[j] = Ep[SA_EPI_COLS + col]; e.t[j] = Ep[2 * SA_EPI_COLS + col];
+                }
+#pragma unroll
+                for (int i = 0; i < RT; ++i) e.d[i] = (c0.mt * (BM / 32) + wr * RT + i >= M) ? 0 : dg_.d[i];
+                sa_epilogue_regs<PREC, RT>(acc, wscale, c0.mt * (BM / 32), c0.nt * BN, wr, wc, lane, M, e, C2, out, ldo, out_h2, ldh);
             }
 #pragma unroll
             for (int i = 0; i < RT; ++i)
@@ -930,14 +938,12 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int e2 = 0; e2 < 16; ++e2) acc[i][j][e2] = 0.f;
-            const int itn = min(c0.it + 1, my_items - 1);
-            mt_cur = item_mt(itn); nt_cur = item_nt(itn);
         }
 #ifdef P2W_SA_STAMP
         t_epi += p2w_stamp() - t_c;
 #endif
         __builtin_amdgcn_sched_barrier(0);
-        va = vb; ma = mb; mb = mc; ep_ = ep_n;
+        va = vb; ma = mb; mb = mc; dg_ = dg_n;
         c0 = c1; c1 = c2; c2 = c3; c3 = nxt(c3);
     }
 #ifdef P2W_SA_STAMP
@@ -950,7 +956,7 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
 
 __global__ __launch_bounds__(256) void sa_edge_meta_kernel(const float4* __restrict__ xyzr, const int* __restrict__ idx, const int* __restrict__ batch_dst,
                                     const float* __restrict__ sf, const int* __restrict__ nbr, const int* __restrict__ deg, int kw,
-                                    int M, int n_src, int* __restrict__ meta_j, float4* __restrict__ meta_g);
+                                    int M, int n_src, int ldp4, int* __restrict__ meta_j, float4* __restrict__ meta_g);
 
 // host side of p2w_sa_conv_h for one precision (pointer / size checks are done by the caller)
 template <int PREC>
@@ -961,14 +967,15 @@ static int32_t launch_sa_conv_h(const float* P, int32_t ldp, int32_t n_src, cons
                                 void* ws, size_t ws_bytes, int32_t flags, hipStream_t stream) {
     constexpr int KA = HCfg<PREC>::kalign;
     const int C2pad = (C2 + 255) / 256 * 256, C1pad = (C1 + KA - 1) / KA * KA;
-    if (C1pad > 512) return P2W_EUNSUPPORTED;
+    // LDS tables (layer-1 geometry weights, per-column epilogue parameters) and 32-bit offsets: edge rows, P rows in float4 units
+    if (C1pad > 512 || C2 > SA_EPI_COLS || (long)M * 32 >= (1L << 31) || ((long)n_src + 1) * (ldp / 4) >= (1L << 31)) return P2W_EUNSUPPORTED;
     if (ldp < C1pad) return P2W_EINVAL;   // P rows are read in whole K slabs: pad columns (zero) must exist
     if (ws == nullptr || ws_bytes < (size_t)M * 32 * 20) return P2W_EWORKSPACE;
     if (reinterpret_cast<uintptr_t>(ws) & 15u) return P2W_EALIGN;
     float4* meta_g = static_cast<float4*>(ws);
     int* meta_j = reinterpret_cast<int*>(meta_g + (size_t)M * 32);
     sa_edge_meta_kernel<<<p2w_cdiv((long)M * 32, 256), 256, 0, stream>>>(
-        reinterpret_cast<const float4*>(xyzr_src), idx, batch_dst, sf, nbr, deg, kw, M, n_src, meta_j, meta_g);
+        reinterpret_cast<const float4*>(xyzr_src), idx, batch_dst, sf, nbr, deg, kw, M, n_src, ldp / 4, meta_j, meta_g);
     const int n_cu = p2w_cu_count();
     // 256-column items halve the A production per output column; measured on levels 2 / 3 (C2 = 256 / 512): 2.73 vs 2.82-2.97 ms
     const bool wide = (flags & (P2W_SA_ITEM_256 | P2W_SA_ITEM_128)) ? (flags & P2W_SA_ITEM_256) != 0 : C2 > 128;
