@@ -596,19 +596,37 @@ __device__ __forceinline__ void sa_epilogue_regs(const f32x16 (&acc)[RT][2], flo
     for (int i = 0; i < RT; ++i) {
         const int tgt = t0 + wr * RT + i;
         if (tgt >= M) continue;
-        const int d = e.d[i];
+        const int d = __builtin_amdgcn_readfirstlane(e.d[i]);   // the same for every lane (one target per 32-row tile)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int col = n0 + wc * 64 + j * 32 + (lane & 31);
             const bool cv = col < C2;
             const float sgn = e.s[j] < 0.f ? -1.f : 1.f;
-            float ext = -INFINITY;
+            const fpair sg2 = {sgn, sgn};
+            float ext;
+            if (d >= 32) {   // every slot valid (the kNN levels): packed sign multiply, three-input maxima, no masks
+                fpair p[8];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int slot = (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (slot < d) ext = fmaxf(ext, sgn * acc[i][j][r]);
+                for (int q = 0; q < 8; ++q) p[q] = fpair{acc[i][j][2 * q], acc[i][j][2 * q + 1]} * sg2;
+                float m0 = fmaxf(fmaxf(p[0][0], p[0][1]), p[1][0]);
+                float m1 = fmaxf(fmaxf(p[1][1], p[2][0]), p[2][1]);
+                float m2 = fmaxf(fmaxf(p[3][0], p[3][1]), p[4][0]);
+                float m3 = fmaxf(fmaxf(p[4][1], p[5][0]), p[5][1]);
+                m0 = fmaxf(fmaxf(m0, p[6][0]), p[6][1]);
+                m1 = fmaxf(fmaxf(m1, p[7][0]), p[7][1]);
+                ext = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+            } else {
+                ext = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int slot = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (slot < d) ext = fmaxf(ext, sgn * acc[i][j][r]);
+                }
             }
-            ext = fmaxf(ext, __shfl_xor(ext, 32));
+            {   // the other half of the tile's rows lives in lane ^ 32: one v_permlane32_swap instead of an LDS round trip
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ext), __float_as_uint(ext), false, false);
+                ext = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+            }
             float vmax = fmaf(fmaxf(fmaf(sgn * ext, wscale, e.bias[j]), 0.f), e.s[j], e.t[j]);
             if (d == 0 || !cv) vmax = 0.f;   // rows without neighbours; pad columns of an H row stay zero
             if (cv && h == 0 && out) out[(size_t)tgt * ldo + col] = vmax;
