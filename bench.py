@@ -293,7 +293,7 @@ def main():
         achieved = 2.0 * kmacs[dom] / (dom_ms * 1e-3) / 1e12
         pts = world * args.steps * BATCH * NPTS
         h = args.precision != "fp32"
-        kname = {"gemm_kernel": (f"gemm_h2g_kernel<{args.precision}> (256x256 and 128x128 tile instantiations, all launches)"
+        kname = {"gemm_kernel": (f"gemm_hp_kernel<{args.precision}> (persistent; 256x256 and 128x128 tile instantiations, all launches)"
                                  if h else "gemm_kernel"),
                  "sa_conv_kernel": (f"sa_conv16p_kernel<{args.precision}> (+ sa_edge_meta_kernel)" if h else "sa_conv_kernel")}
         traffic, traffic_src = None, None

@@ -116,8 +116,7 @@ __device__ __forceinline__ void h_store4(_Float16* __restrict__ base, int ldh, s
 //          fetched once, W is always an L2 hit.
 //  mode 1 (W larger than L2, few rows): an XCD owns a slice of column tiles (its W slice stays L2-resident) and sweeps
 //          ALL row tiles; A is streamed once per XCD slice instead of W once per row tile.
-__device__ __forceinline__ bool tile_coords(int nMt, int nNt, int* mt, int* nt, int mode = 0) {
-    const int L = blockIdx.x;
+__device__ __forceinline__ bool tile_coords_at(int L, int nMt, int nNt, int* mt, int* nt, int mode = 0) {
     const int xcd = L & 7, w = L >> 3;
     if (mode == 0) {
         *mt = xcd + 8 * (w / nNt);
@@ -134,6 +133,9 @@ __device__ __forceinline__ bool tile_coords(int nMt, int nNt, int* mt, int* nt, 
     *nt = xcd % nNt;
     *mt = xcd / nNt + r * w;
     return *mt < nMt;
+}
+__device__ __forceinline__ bool tile_coords(int nMt, int nNt, int* mt, int* nt, int mode = 0) {
+    return tile_coords_at(blockIdx.x, nMt, nNt, mt, nt, mode);
 }
 static inline int tile_grid(int nMt, int nNt, int mode = 0) {
     if (mode == 0) return 8 * ((nMt + 7) / 8) * nNt;
@@ -280,13 +282,25 @@ __device__ __forceinline__ void gemm_epilogue_il(const f32x16 (&acc)[RT][CT], co
     }
 }
 
-template <int PREC, int RT, int CT>
+// s_waitcnt immediate of gfx9: vmcnt[3:0] | expcnt << 4 | lgkmcnt << 8 | vmcnt[5:4] << 14 (expcnt / lgkmcnt left at their maxima)
+constexpr int p2w_vmcnt_imm(int n) { return (n & 15) | (7 << 4) | (15 << 8) | ((n >> 4) << 14); }
+
+// WAIT_OLDER (persistent kernel): behind the epilogue, wait until everything this wave issued BEFORE the epilogue has
+// retired (the next tile's first-slab DMA) without waiting for the epilogue's own stores: loads, stores and LDS-DMA retire
+// in order through one counter, so "at most n outstanding" with n = the number of stores the epilogue just issued (capped at
+// the counter's 63) is exactly that.  The wait sits here, in the branch that knows n at compile time, through the builtin:
+// the compiler's scoreboard then knows on every path that no load is pending (the guarded path drains completely).
+template <int PREC, int RT, int CT, bool WAIT_OLDER = false>
 __device__ __forceinline__ void gemm_epilogue_dispatch(const f32x16 (&acc)[RT][CT], const EpiArgs& ep, float wscale, int row0,
                                                        int col0, int lane, int M, int N, const OutArgs& o, int ef) {
     const bool full = (row0 + 32 * RT <= M) && (col0 + 32 * CT <= N) && ef != 0;
     if (full) {
         switch (ef) {
-#define P2W_EPI_CASE(E) case E: gemm_epilogue_il<PREC, RT, CT, E>(acc, ep, wscale, row0, col0, lane, M, N, o); return;
+#define P2W_EPI_CASE(E) case E: { \
+            gemm_epilogue_il<PREC, RT, CT, E>(acc, ep, wscale, row0, col0, lane, M, N, o); \
+            constexpr int n_st = RT * 16 * (CT / 2) * (((E) & 128 ? 1 : 0) + ((E) & 256 ? (PREC == 0 ? 2 : 1) : 0)); \
+            if constexpr (WAIT_OLDER) __builtin_amdgcn_s_waitcnt(p2w_vmcnt_imm(n_st < 63 ? n_st : 63)); \
+            return; }
             P2W_EPI_CASE(128) P2W_EPI_CASE(257) P2W_EPI_CASE(263) P2W_EPI_CASE(287) P2W_EPI_CASE(480) P2W_EPI_CASE(224)
             P2W_EPI_CASE(131) P2W_EPI_CASE(259) P2W_EPI_CASE(387) P2W_EPI_CASE(129)
 #undef P2W_EPI_CASE
@@ -294,6 +308,7 @@ __device__ __forceinline__ void gemm_epilogue_dispatch(const f32x16 (&acc)[RT][C
         }
     }
     gemm_epilogue_il<PREC, RT, CT, -1>(acc, ep, wscale, row0, col0, lane, M, N, o);
+    if constexpr (WAIT_OLDER) __builtin_amdgcn_s_waitcnt(p2w_vmcnt_imm(0));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -502,6 +517,167 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void gemm_h2g_kernel(const _Float1
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------
+// gemm_hp_kernel: the production form of the GEMM above - the same stage image, DMA pieces, fragment reads, MFMAs and
+// epilogue, run by PERSISTENT workgroups.  Workgroup b walks the virtual blocks b, b + gridDim, ... of the XCD-aware tile
+// order (gridDim is a multiple of 8, so a workgroup stays on its XCD's tiles), and the K slabs of consecutive tiles form
+// one software pipeline: the first slab of the next tile is issued at the top of the last slab of the current one, so it
+// lands during that slab's MFMAs and the epilogue.  A workgroup per tile paid the first slab's whole latency (~2 us) and a
+// workgroup launch for every tile - 3 % of a 64-slab tile, 25 % of the 4-slab tiles of the expand layers.
+// The epilogue's stores must not be waited for at the next tile's first barrier (loads, stores and LDS-DMA retire through
+// ONE in-order counter on gfx950): that barrier waits with a COUNTED vmcnt - the DMA is older than every store of the
+// epilogue, so "at most n outstanding" with n <= the number of stores behind it means the DMA has landed.
+// ------------------------------------------------------------------------------------------------
+template <int PREC, int WR, int WC, int RT, int CT>
+__global__ __launch_bounds__(64 * WR * WC, 2) void gemm_hp_kernel(const _Float16* __restrict__ A, int ldh_a,
+                                                               const _Float16* __restrict__ Wh, float wscale, int M, int N,
+                                                               int Kpad, int nMt, int nNt, int nvb, EpiArgs ep, OutArgs o, int ef,
+                                                               int tmode) {
+    constexpr int KS = HCfg<PREC>::kslab;
+    constexpr int BM = 32 * RT * WR, BN = 32 * CT * WC, NW = WR * WC;
+    constexpr int A_CH = 8 * BM, STAGE_CH = A_CH + 8 * BN;
+    constexpr bool HALF = NW == 8;                        // 8-wave tile: waves 0..3 issue the whole stage (see gemm_h2g_kernel)
+    constexpr int NWI = HALF ? NW / 2 : NW;
+    constexpr int NI = STAGE_CH / 64 / NWI;
+    static_assert(STAGE_CH % (64 * NWI) == 0, "stage must split evenly over the issuing waves");
+    __shared__ __attribute__((aligned(16))) char S[2 * STAGE_CH * 16];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wave / WC, wc = wave % WC;
+    const size_t a_pitch = (size_t)HCfg<PREC>::planes * ldh_a, w_pitch = (size_t)HCfg<PREC>::planes * Kpad;
+    auto next_tile = [&](int& L, int& mt_, int& nt_) {   // first valid virtual block at or after L (stepping by the grid)
+        while (L < nvb) {
+            if (tile_coords_at(L, nMt, nNt, &mt_, &nt_, tmode)) return true;
+            L += gridDim.x;
+        }
+        return false;
+    };
+    int L = blockIdx.x, mt, nt;
+    if (!next_tile(L, mt, nt)) return;
+
+    const _Float16* src[NI];
+    auto setup_src = [&](int mt_, int nt_) {   // per-lane DMA sources of a tile (LDS image: gemm_h2g_kernel)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int g = (wave % NWI) + NWI * i;
+            const int row = 8 * g + (lane >> 3);
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            if (g < BM / 8) src[i] = A + (size_t)min(mt_ * BM + row, M - 1) * a_pitch + 8 * c;
+            else src[i] = Wh + (size_t)(nt_ * BN + w_stage_row(row - BM)) * w_pitch + 8 * c;
+        }
+    };
+    // The DMA is issued through inline asm: hipcc never emits a COUNTED vmcnt while a global_load_lds it knows about is
+    // pending - it drains to vmcnt(0) at the first use of any loaded value and in front of LDS reads it cannot tell apart
+    // from the DMA's destination - which would put the epilogue's stores (and the next tile's first slab) on every wait.
+    // Hidden from its bookkeeping, the compiler's own waits can only become stricter than needed, never weaker (the
+    // counter retires in order); the slab protocol below waits for the DMA by hand.
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_vp)S;
+    auto issue_piece = [&](int i, int stage, int k0) {
+        const int g = (wave % NWI) + NWI * i;
+        const unsigned dst = lds_base + (unsigned)(stage * STAGE_CH + g * 64) * 16u;
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                     :: "v"(src[i] + k0), "s"(dst) : "m0", "memory");
+    };
+    const bool issuer = wave < NWI;   // wave-uniform
+    const int r = lane & 31, h = lane >> 5;
+    int offA[RT], offB[CT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        const int ra = wr * 32 * RT + 32 * t + r;
+        offA[t] = (ra * 8 + (h ^ ((ra >> 1) & 7))) * 16;
+    }
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+        const int rb = BM + wc * 32 * CT + 32 * t + r;
+        offB[t] = (rb * 8 + (h ^ ((rb >> 1) & 7))) * 16;
+    }
+    const int nslab = Kpad / KS;
+    setup_src(mt, nt);
+    if (issuer) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) issue_piece(i, 0, 0);
+    }
+    int gs = 0;        // slabs done by this workgroup: stage of the current slab = gs & 1
+    bool landed = false;   // the DMA of the slab about to start has been waited for already (behind the previous tile's epilogue)
+    f32x16 acc[RT][CT];
+    h8 ah[RT], al[RT], bh[CT], bl[CT];
+    // one slab.  LAST: the slab behind it belongs to the next tile (mtn, ntn) - or, past the last tile, is a replay nobody reads
+    auto slab = [&](int s, auto last_c, int mtn, int ntn) {
+        constexpr bool LAST = decltype(last_c)::value;
+        // s_waitcnt through the builtin (simm16: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt << 8 | vmcnt[5:4] << 14): unlike an asm
+        // statement it also updates the compiler's own scoreboard, so it does not re-wait later for loads that are done
+        // s_waitcnt through the builtin: unlike an asm statement it also updates the compiler's own scoreboard
+        asm volatile("" ::: "memory");
+        if (landed) __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) only: this slab's DMA was waited for behind the epilogue
+        else __builtin_amdgcn_s_waitcnt(0x0070);          // vmcnt(0) lgkmcnt(0)
+        landed = false;
+        __builtin_amdgcn_s_barrier();   // slab gs has landed for every wave, the other stage is free
+        asm volatile("" ::: "memory");
+        if constexpr (LAST) setup_src(mtn, ntn);
+        constexpr int NG = 2 * RT * CT;
+        constexpr int GAP = (NG / (2 * NI)) > 0 ? NG / (2 * NI) : 1;
+        const int k_next = LAST ? 0 : (s + 1) * 64;
+        if constexpr (HALF) {
+            if (issuer) {
+#pragma unroll
+                for (int i = 0; i < NI; ++i) issue_piece(i, (gs + 1) & 1, k_next);
+            }
+        }
+        const char* st = S + (size_t)(gs & 1) * STAGE_CH * 16;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {
+                ah[t] = *reinterpret_cast<const h8*>(st + (offA[t] ^ (kk << 5)));
+                al[t] = *reinterpret_cast<const h8*>(st + (offA[t] ^ (kk << 5) ^ 64));
+            }
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+                bh[t] = *reinterpret_cast<const h8*>(st + (offB[t] ^ (kk << 5)));
+                bl[t] = *reinterpret_cast<const h8*>(st + (offB[t] ^ (kk << 5) ^ 64));
+            }
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int j = 0; j < CT; ++j) {
+                    if constexpr (PREC == 0) {
+                        acc[i][j] = h_mfma<PREC>(al[i], bh[j], acc[i][j]);
+                        acc[i][j] = h_mfma<PREC>(ah[i], bl[j], acc[i][j]);
+                        acc[i][j] = h_mfma<PREC>(ah[i], bh[j], acc[i][j]);
+                    } else {
+                        acc[i][j] = h_mfma<PREC>(ah[i], bh[j], acc[i][j]);
+                        acc[i][j] = h_mfma<PREC>(al[i], bl[j], acc[i][j]);
+                    }
+                    if constexpr (!HALF) {   // 4-wave tile: every wave spreads its pieces over the first half of its MFMAs
+                        const int g = (kk * RT + i) * CT + j;
+                        if ((g % GAP) == GAP - 1 && g / GAP < NI) {
+                            issue_piece(g / GAP, (gs + 1) & 1, k_next);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
+        }
+        ++gs;
+    };
+    while (true) {
+        int Ln = L + gridDim.x, mtn = mt, ntn = nt;
+        const bool more = next_tile(Ln, mtn, ntn);
+        if (!more) { mtn = mt; ntn = nt; }
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int j = 0; j < CT; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        for (int s = 0; s + 1 < nslab; ++s) slab(s, std::false_type{}, 0, 0);
+        slab(nslab - 1, std::true_type{}, mtn, ntn);
+        gemm_epilogue_dispatch<PREC, RT, CT, true>(acc, ep, wscale, mt * BM + wr * 32 * RT, nt * BN + wc * 32 * CT, lane, M, N, o, ef);
+        landed = true;
+        if (!more) break;
+        L = Ln; mt = mtn; nt = ntn;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the replayed stage behind the last tile
+}
+
 // host side of p2w_gemm_h2 for one precision (argument checks that do not depend on it are done by the caller)
 template <int PREC>
 static int32_t launch_gemm_h(const _Float16* Ah, int32_t ldh_a, const _Float16* Wp, float wscale, int32_t M, int32_t N, int32_t K,
@@ -555,6 +731,7 @@ static int32_t launch_gemm_h(const _Float16* Ah, int32_t ldh_a, const _Float16* 
         // XCDs stream ALL of A for the same column tile (M = 17506, K = 2048, N = 512 at 128 x 128: 188 vs 134 us)
         return (w_bytes > (size_t)3 * 1024 * 1024 && nNtx >= 8) ? 1 : 0;
     };
+#if defined(P2W_GEMM_STAMP) || defined(P2W_GEMM_ABLATE)   // diagnostic builds: one workgroup per tile, with the probes
     if (big) {
         const int nMt = p2w_cdiv(M, 256), nNt2 = Npad / 256;
         const int tm = pick_mode(nNt2);
@@ -566,6 +743,23 @@ static int32_t launch_gemm_h(const _Float16* Ah, int32_t ldh_a, const _Float16* 
         gemm_h2g_kernel<PREC, 2, 2, 2, 2><<<tile_grid(nMt, nNt1, tm), 256, 0, stream>>>(
             Ah, ldh_a, Wp, (size_t)Npad * Kpad, wscale, M, N, Kpad, nMt, nNt1, ep, o, dbg, ef, tm);
     }
+#else
+    (void)dbg;
+    auto pgrid = [&](int nvb, int per_cu) {   // persistent grid: whole XCD rounds, at most per_cu workgroups per CU
+        int g = nvb < n_cu * per_cu ? nvb : n_cu * per_cu;
+        if (g >= 8) g &= ~7;
+        return g;
+    };
+    if (big) {
+        const int nMt = p2w_cdiv(M, 256), nNt2 = Npad / 256;
+        const int tm = pick_mode(nNt2), nvb = tile_grid(nMt, nNt2, tm);
+        gemm_hp_kernel<PREC, 2, 4, 4, 2><<<pgrid(nvb, 1), 512, 0, stream>>>(Ah, ldh_a, Wp, wscale, M, N, Kpad, nMt, nNt2, nvb, ep, o, ef, tm);
+    } else {
+        const int nMt = p2w_cdiv(M, 128), nNt1 = p2w_cdiv(N, 128);
+        const int tm = pick_mode(nNt1), nvb = tile_grid(nMt, nNt1, tm);
+        gemm_hp_kernel<PREC, 2, 2, 2, 2><<<pgrid(nvb, 2), 256, 0, stream>>>(Ah, ldh_a, Wp, wscale, M, N, Kpad, nMt, nNt1, nvb, ep, o, ef, tm);
+    }
+#endif
     return P2W_LAUNCH_STATUS();
 }
 

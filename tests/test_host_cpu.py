@@ -430,11 +430,11 @@ def test_hot_kernels_stay_off_the_register_cliff():
         assert len(hits) == 1, (substr, [k for k in usage if substr in k])
         return hits[0]
     for prec in (0, 1, 2):   # f16x3 (p2w_feat.hip), fp16 / bf16 (p2w_feat_h1.hip)
-        big = one(f"gemm_h2g_kernelILi{prec}ELi2ELi4ELi4ELi2E")
-        assert big["ScratchSize [bytes/lane]"] <= 400, big          # 348 today: interior-epilogue spills only
-        assert one(f"gemm_h2g_kernelILi{prec}ELi2ELi2ELi2ELi2E")["ScratchSize [bytes/lane]"] == 0
+        for tile in ("Li2ELi4ELi4ELi2E", "Li2ELi2ELi2ELi2E"):   # the persistent GEMM, 256 x 256 and 128 x 128 tiles
+            g = one(f"gemm_hp_kernelILi{prec}E{tile}")
+            assert g["ScratchSize [bytes/lane]"] == 0 and g["VGPRs Spill"] == 0, g
         for k in (f"sa_conv16p_kernelILi{prec}ELi256ELi2E", f"sa_conv16p_kernelILi{prec}ELi128ELi2E"):
-            assert one(k)["VGPRs Spill"] == 0 and one(k)["LDS Size [bytes/block]"] <= 112 * 1024
+            assert one(k)["VGPRs Spill"] == 0 and one(k)["LDS Size [bytes/block]"] <= 120 * 1024
     for k, v in usage.items():
         if "slab_search_kernel" in k or k.startswith("_Z10knn_kernel") or k.startswith("_Z11ball_kernel"):
             assert v["VGPRs Spill"] == 0, (k, v)

@@ -19,16 +19,16 @@ root, prec, forwards = sys.argv[1], sys.argv[2], float(sys.argv[3])
 def short(name):
     n = re.sub(r"\(.*", "", name).replace("void ", "")
     n = re.sub(r"rocprim::ROCPRIM_\d+_NS::detail::", "rocprim::", n)
-    m = re.match(r"_Z\d+(gemm_h2g_kernel|sa_conv16p_kernel)ILi(\d)ELi(\d+)ELi(\d+)E(?:Li(\d+)ELi(\d+)E)?", n)
+    m = re.match(r"_Z\d+(gemm_h2g_kernel|gemm_hp_kernel|sa_conv16p_kernel)ILi(\d)ELi(\d+)ELi(\d+)E(?:Li(\d+)ELi(\d+)E)?", n)
     if m:
-        if m.group(1) == "gemm_h2g_kernel":
-            return f"gemm_h2g_kernel<prec{m.group(2)},{m.group(3)},{m.group(4)},{m.group(5)},{m.group(6)}>"
+        if m.group(1) in ("gemm_h2g_kernel", "gemm_hp_kernel"):
+            return f"{m.group(1)}<prec{m.group(2)},{m.group(3)},{m.group(4)},{m.group(5)},{m.group(6)}>"
         return f"sa_conv16p_kernel<prec{m.group(2)},{m.group(3)},{m.group(4)}>"
     return n[:90]
 
 
 def klass(name):
-    if "gemm_h2g_kernel" in name or name.startswith("gemm_kernel"):
+    if "gemm_h2g_kernel" in name or "gemm_hp_kernel" in name or name.startswith("gemm_kernel"):
         return "gemm_kernel"
     if "sa_conv16p_kernel" in name or "sa_edge_meta" in name or name.startswith("sa_conv_kernel"):
         return "sa_conv_kernel"
