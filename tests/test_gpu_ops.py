@@ -230,6 +230,33 @@ def test_gemm_h_rejects_bad_arguments():
     assert L.p2w_packed_dims_h(7, 1, 1, C.byref(a), C.byref(b)) == -1
 
 
+def test_sa_conv_h_reports_its_limits():
+    """The fused PointNetConv keeps two tables in LDS and uses 32-bit offsets: sizes beyond them are P2W_EUNSUPPORTED (-5),
+    never a wrong answer (include/p2w.h)."""
+    from pointstowood_amd._lib import lib, ptr, stream
+    L = lib()
+    dev = "cuda"
+    M, n_src, C1 = 8, 8, 64
+    z = lambda *sh, dt=torch.float32: torch.zeros(sh, dtype=dt, device=dev)
+    xyzr, idx, bd, sf = z(n_src, 4), z(M, dt=torch.int32), z(M, dt=torch.int32), torch.ones(1, device=dev)
+    nbr, deg, w1r4 = z(M, 32, dt=torch.int32), z(M, dt=torch.int32), z(4, 64)
+    ws = torch.zeros(M * 32 * 20 + 65536, dtype=torch.uint8, device=dev)
+
+    def call(C2, ldp=64, C1_=C1):
+        P = z(n_src + 1, ldp)
+        W2 = z(max(256, (C2 + 255) // 256 * 256), 2 * ((C1_ + 31) // 32 * 32), dt=torch.float16)
+        v = z(C2)
+        out = z(M, C2)
+        return L.p2w_sa_conv_h(0, ptr(P), ldp, n_src, ptr(xyzr), ptr(idx), ptr(bd), ptr(sf), ptr(nbr), ptr(deg), 32, M, ptr(w1r4),
+                               ptr(W2), 1.0, C1_, C2, ptr(v), ptr(v), ptr(v), ptr(out), C2, None, 0, ptr(ws), ws.numel(), 0, stream())
+    assert call(256) == 0
+    assert call(1024) == 0
+    assert call(1028) == -5                         # per-column epilogue table: C2 <= 1024
+    w1r4 = z(4, 576)
+    assert call(256, ldp=576, C1_=544) == -5        # layer-1 geometry weights table: round_up(C1) <= 512
+    torch.cuda.synchronize()
+
+
 def test_c_abi_rejects_bad_arguments():
     from pointstowood_amd._lib import lib, ptr, stream
     x = torch.zeros(16, 4, device="cuda")
