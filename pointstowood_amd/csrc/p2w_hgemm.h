@@ -56,6 +56,18 @@ __device__ __forceinline__ f32x16 h_mfma(h8 a, h8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
+// The production GEMM uses the 16x16x32 shape: lane l supplies A[row l&15][k = 8*(l>>4) + 0..7] (one 16-byte chunk: a whole
+// 32-k plane row per instruction), B alike; C/D: col = l&15, row = 4*(l>>4) + reg.  Same FLOPs per cycle as 32x32x16, but
+// MI355X holds a higher clock on it (MI355X_MICROARCH.md, DVFS item 7): GEMM class -15 % in a same-box A/B.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int PREC>
+__device__ __forceinline__ f32x4 h_mfma16(h8 a, h8 b, f32x4 c) {
+    if constexpr (PREC == 2)
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
 // fp16 hi/lo split of two values at once: hi = round-toward-zero fp16 of v (v_cvt_pkrtz_f16_f32 converts a PAIR per
 // instruction and, rounding toward zero, saturates at +-65504 instead of overflowing to inf), lo = round-to-nearest
 // fp16 of the exact fp32 remainder v - hi (v_cvt_pk_f16_f32, also a pair per instruction; nearest keeps the split
@@ -311,6 +323,143 @@ __device__ __forceinline__ void gemm_epilogue_dispatch(const f32x16 (&acc)[RT][C
     if constexpr (WAIT_OLDER) __builtin_amdgcn_s_waitcnt(p2w_vmcnt_imm(0));
 }
 
+// ---- the same epilogue for 16 x 16 accumulator tiles (gemm_hp_kernel) ----
+// W rows are staged by w_stage_row16: LDS row 16 t + c of a wave's column range holds output channel 32 (t >> 1) + 2 c + (t & 1),
+// so lane c of tiles 2 jq, 2 jq + 1 holds the adjacent columns col0 + 32 jq + 2 c (+1) of rows 16 it + 4 (lane >> 4) + reg.
+__device__ __forceinline__ int w_stage_row16(int rho) {
+    const int t = rho >> 4, c = rho & 15;
+    return 32 * (t >> 1) + 2 * c + (t & 1);
+}
+template <int PREC, int RT16, int CT16, int EF>
+__device__ __forceinline__ void gemm_epilogue_16(const f32x4 (&acc)[RT16][CT16], const EpiArgs& ep, float wscale, int row0, int col0,
+                                                 int lane, int M, int N, const OutArgs& o) {
+    static_assert(CT16 % 2 == 0, "column tiles come in interleaved pairs");
+    constexpr bool GEN = EF < 0;
+    constexpr int JQ = CT16 / 2, NSTEP = RT16 * 4;
+    const bool R0 = GEN ? ep.relu0 != 0 : (EF & 1) != 0, S0 = GEN ? ep.sc0 != nullptr : (EF & 2) != 0;
+    const bool R1 = GEN ? ep.relu1 != 0 : (EF & 4) != 0, S1 = GEN ? ep.sc1 != nullptr : (EF & 8) != 0;
+    const bool R2 = GEN ? ep.relu2 != 0 : (EF & 16) != 0, RES = GEN ? ep.residual != nullptr : (EF & 32) != 0;
+    const bool RF = GEN ? ep.relu_final != 0 : (EF & 64) != 0, OF = GEN ? o.f32 != nullptr : (EF & 128) != 0;
+    const bool OH = GEN ? o.h2 != nullptr : (EF & 256) != 0;
+    const int c16 = lane & 15, kg = lane >> 4;
+    const int cb = col0 + 2 * c16;   // even column of pair 0; pair jq: + 32 jq
+    fpair bias[JQ], s0[JQ], t0[JQ], s1[JQ], t1[JQ];
+#pragma unroll
+    for (int jq = 0; jq < JQ; ++jq) {
+        const int c = cb + 32 * jq;
+        bias[jq] = fpair{0.f, 0.f}; s0[jq] = fpair{1.f, 1.f}; t0[jq] = fpair{0.f, 0.f}; s1[jq] = fpair{1.f, 1.f}; t1[jq] = fpair{0.f, 0.f};
+        if constexpr (GEN) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                if (c + e < N) {
+                    if (ep.bias) bias[jq][e] = ep.bias[c + e];
+                    if (S0) { s0[jq][e] = ep.sc0[c + e]; t0[jq][e] = ep.sh0[c + e]; }
+                    if (S1) { s1[jq][e] = ep.sc1[c + e]; t1[jq][e] = ep.sh1[c + e]; }
+                }
+        } else {
+            if (ep.bias) bias[jq] = *reinterpret_cast<const fpair*>(ep.bias + c);
+            if (S0) { s0[jq] = *reinterpret_cast<const fpair*>(ep.sc0 + c); t0[jq] = *reinterpret_cast<const fpair*>(ep.sh0 + c); }
+            if (S1) { s1[jq] = *reinterpret_cast<const fpair*>(ep.sc1 + c); t1[jq] = *reinterpret_cast<const fpair*>(ep.sh1 + c); }
+        }
+    }
+    auto row_of = [&](int st) { return row0 + 16 * (st >> 2) + 4 * kg + (st & 3); };
+    auto value = [&](float a, float b, float s0v, float t0v, float s1v, float t1v, float res) {
+        float v = fmaf(a, wscale, b);
+        if (R0) v = fmaxf(v, 0.f);
+        if (S0) v = fmaf(v, s0v, t0v);
+        if (R1) v = fmaxf(v, 0.f);
+        if (S1) v = fmaf(v, s1v, t1v);
+        if (R2) v = fmaxf(v, 0.f);
+        if (RES) v += res;
+        if (RF) v = fmaxf(v, 0.f);
+        return v;
+    };
+    fpair rcur[JQ], rnxt[JQ];
+    auto load_res = [&](fpair (&dst)[JQ], int st) {   // specialised path only
+        const float* rp = ep.residual + ((unsigned)row_of(st) * (unsigned)ep.ldr + (unsigned)cb);
+#pragma unroll
+        for (int jq = 0; jq < JQ; ++jq) dst[jq] = *reinterpret_cast<const fpair*>(rp + 32 * jq);
+    };
+#pragma unroll
+    for (int jq = 0; jq < JQ; ++jq) { rcur[jq] = fpair{0.f, 0.f}; rnxt[jq] = fpair{0.f, 0.f}; }
+    if constexpr (!GEN) {
+        if (RES) load_res(rcur, 0);
+    }
+#pragma unroll
+    for (int st = 0; st < NSTEP; ++st) {
+        const int it = st >> 2, reg = st & 3;
+        const int row = row_of(st);
+        if constexpr (!GEN) {
+            if (RES && st + 1 < NSTEP) load_res(rnxt, st + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            float* fp = OF ? o.f32 + ((unsigned)row * (unsigned)o.ldo + (unsigned)cb) : nullptr;
+            _Float16* hp = nullptr;
+            if (OH) {
+                if constexpr (PREC == 0) hp = o.h2 + ((unsigned)row * (unsigned)(2 * o.ldh) + (unsigned)(64 * (cb >> 5) + (cb & 31)));
+                else hp = o.h2 + ((unsigned)row * (unsigned)o.ldh + (unsigned)cb);
+            }
+#pragma unroll
+            for (int jq = 0; jq < JQ; ++jq) {
+                const float va = value(acc[it][2 * jq][reg], bias[jq][0], s0[jq][0], t0[jq][0], s1[jq][0], t1[jq][0], rcur[jq][0]);
+                const float vb = value(acc[it][2 * jq + 1][reg], bias[jq][1], s0[jq][1], t0[jq][1], s1[jq][1], t1[jq][1], rcur[jq][1]);
+                if (OF) *reinterpret_cast<fpair*>(fp + 32 * jq) = fpair{va, vb};
+                if (OH) {
+                    if constexpr (PREC == 0) {
+                        unsigned hw, lw;
+                        split_pair(va, vb, hw, lw);
+                        *reinterpret_cast<unsigned*>(hp + 64 * jq) = hw;        // 32 columns further = the next [hi32 | lo32] block
+                        *reinterpret_cast<unsigned*>(hp + 64 * jq + 32) = lw;
+                    } else {
+                        *reinterpret_cast<unsigned*>(hp + 32 * jq) = pack_pair<PREC>(va, vb);
+                    }
+                }
+            }
+            if (RES) {
+#pragma unroll
+                for (int jq = 0; jq < JQ; ++jq) rcur[jq] = rnxt[jq];
+            }
+        } else {
+            if (row < M) {
+#pragma unroll
+                for (int jq = 0; jq < JQ; ++jq) {
+                    const int c = cb + 32 * jq;
+                    float v[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const bool cv = c + e < N;
+                        const float res = (RES && cv) ? ep.residual[(size_t)row * ep.ldr + c + e] : 0.f;
+                        v[e] = value(acc[it][2 * jq + e][reg], bias[jq][e], s0[jq][e], t0[jq][e], s1[jq][e], t1[jq][e], res);
+                        if (!cv) v[e] = 0.f;                       // pad columns of an H row must be zero
+                        if (OF && cv) o.f32[(size_t)row * o.ldo + c + e] = v[e];
+                    }
+                    if (OH && c < o.ldh) h_store2<PREC>(o.h2, o.ldh, row, c, v[0], v[1]);
+                }
+            }
+        }
+    }
+}
+
+template <int PREC, int RT16, int CT16, bool WAIT_OLDER = false>
+__device__ __forceinline__ void gemm_epilogue_dispatch16(const f32x4 (&acc)[RT16][CT16], const EpiArgs& ep, float wscale, int row0,
+                                                         int col0, int lane, int M, int N, const OutArgs& o, int ef) {
+    const bool full = (row0 + 16 * RT16 <= M) && (col0 + 16 * CT16 <= N) && ef != 0;
+    if (full) {
+        switch (ef) {
+#define P2W_EPI_CASE(E) case E: { \
+            gemm_epilogue_16<PREC, RT16, CT16, E>(acc, ep, wscale, row0, col0, lane, M, N, o); \
+            constexpr int n_st = RT16 * 4 * (CT16 / 2) * (((E) & 128 ? 1 : 0) + ((E) & 256 ? (PREC == 0 ? 2 : 1) : 0)); \
+            if constexpr (WAIT_OLDER) __builtin_amdgcn_s_waitcnt(p2w_vmcnt_imm(n_st < 63 ? n_st : 63)); \
+            return; }
+            P2W_EPI_CASE(128) P2W_EPI_CASE(257) P2W_EPI_CASE(263) P2W_EPI_CASE(287) P2W_EPI_CASE(480) P2W_EPI_CASE(224)
+            P2W_EPI_CASE(131) P2W_EPI_CASE(259) P2W_EPI_CASE(387) P2W_EPI_CASE(129)
+#undef P2W_EPI_CASE
+            default: break;
+        }
+    }
+    gemm_epilogue_16<PREC, RT16, CT16, -1>(acc, ep, wscale, row0, col0, lane, M, N, o);
+    if constexpr (WAIT_OLDER) __builtin_amdgcn_s_waitcnt(p2w_vmcnt_imm(0));
+}
+
 // ------------------------------------------------------------------------------------------------
 // GEMM over H operands: both operands are 16-bit planes in HBM, so a K-slab is staged with direct-to-LDS loads
 // (global_load_lds_dwordx4: no VGPR round trip, no ds_write) into a 2-stage ring; one barrier per slab, the next
@@ -562,7 +711,7 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void gemm_hp_kernel(const _Float16
             const int row = 8 * g + (lane >> 3);
             const int c = (lane & 7) ^ ((row >> 1) & 7);
             if (g < BM / 8) src[i] = A + (size_t)min(mt_ * BM + row, M - 1) * a_pitch + 8 * c;
-            else src[i] = Wh + (size_t)(nt_ * BN + w_stage_row(row - BM)) * w_pitch + 8 * c;
+            else src[i] = Wh + (size_t)(nt_ * BN + w_stage_row16(row - BM)) * w_pitch + 8 * c;
         }
     };
     // The DMA is issued through inline asm: hipcc never emits a COUNTED vmcnt while a global_load_lds it knows about is
@@ -578,17 +727,20 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void gemm_hp_kernel(const _Float16
                      :: "v"(src[i] + k0), "s"(dst) : "m0", "memory");
     };
     const bool issuer = wave < NWI;   // wave-uniform
-    const int r = lane & 31, h = lane >> 5;
-    int offA[RT], offB[CT];
+    // fragment read offsets (bytes within a stage) of plane 0: lane (row l & 15 of a 16-row tile, k octet l >> 4) reads the
+    // chunk of its octet; plane 1 (f16x3: lo; single plane: k 32..63) = ^ 64
+    constexpr int RT16 = 2 * RT, CT16 = 2 * CT;
+    const int r16 = lane & 15, kg = lane >> 4;
+    int offA[RT16], offB[CT16];
 #pragma unroll
-    for (int t = 0; t < RT; ++t) {
-        const int ra = wr * 32 * RT + 32 * t + r;
-        offA[t] = (ra * 8 + (h ^ ((ra >> 1) & 7))) * 16;
+    for (int t = 0; t < RT16; ++t) {
+        const int ra = wr * 32 * RT + 16 * t + r16;
+        offA[t] = (ra * 8 + (kg ^ ((ra >> 1) & 7))) * 16;
     }
 #pragma unroll
-    for (int t = 0; t < CT; ++t) {
-        const int rb = BM + wc * 32 * CT + 32 * t + r;
-        offB[t] = (rb * 8 + (h ^ ((rb >> 1) & 7))) * 16;
+    for (int t = 0; t < CT16; ++t) {
+        const int rb = BM + wc * 32 * CT + 16 * t + r16;
+        offB[t] = (rb * 8 + (kg ^ ((rb >> 1) & 7))) * 16;
     }
     const int nslab = Kpad / KS;
     setup_src(mt, nt);
@@ -598,8 +750,8 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void gemm_hp_kernel(const _Float16
     }
     int gs = 0;        // slabs done by this workgroup: stage of the current slab = gs & 1
     bool landed = false;   // the DMA of the slab about to start has been waited for already (behind the previous tile's epilogue)
-    f32x16 acc[RT][CT];
-    h8 ah[RT], al[RT], bh[CT], bl[CT];
+    f32x4 acc[RT16][CT16];
+    h8 ah[RT16 / 2], al[RT16 / 2], bh[CT16], bl[CT16];   // A fragments of one half of the wave's row tiles, B of all column tiles
     // one slab.  LAST: the slab behind it belongs to the next tile (mtn, ntn) - or, past the last tile, is a replay nobody reads
     auto slab = [&](int s, auto last_c, int mtn, int ntn) {
         constexpr bool LAST = decltype(last_c)::value;
@@ -613,7 +765,8 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void gemm_hp_kernel(const _Float16
         __builtin_amdgcn_s_barrier();   // slab gs has landed for every wave, the other stage is free
         asm volatile("" ::: "memory");
         if constexpr (LAST) setup_src(mtn, ntn);
-        constexpr int NG = 2 * RT * CT;
+        constexpr int HR = RT16 / 2;                 // row tiles per half
+        constexpr int NG = 2 * HR * CT16;            // tile pairs (MFMA groups) of a slab
         constexpr int GAP = (NG / (2 * NI)) > 0 ? NG / (2 * NI) : 1;
         const int k_next = LAST ? 0 : (s + 1) * 64;
         if constexpr (HALF) {
@@ -624,31 +777,32 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void gemm_hp_kernel(const _Float16
         }
         const char* st = S + (size_t)(gs & 1) * STAGE_CH * 16;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int t = 0; t < CT16; ++t) {
+            bh[t] = *reinterpret_cast<const h8*>(st + offB[t]);
+            bl[t] = *reinterpret_cast<const h8*>(st + (offB[t] ^ 64));
+        }
 #pragma unroll
-            for (int t = 0; t < RT; ++t) {
-                ah[t] = *reinterpret_cast<const h8*>(st + (offA[t] ^ (kk << 5)));
-                al[t] = *reinterpret_cast<const h8*>(st + (offA[t] ^ (kk << 5) ^ 64));
+        for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+            for (int t = 0; t < HR; ++t) {
+                ah[t] = *reinterpret_cast<const h8*>(st + offA[hh * HR + t]);
+                al[t] = *reinterpret_cast<const h8*>(st + (offA[hh * HR + t] ^ 64));
             }
 #pragma unroll
-            for (int t = 0; t < CT; ++t) {
-                bh[t] = *reinterpret_cast<const h8*>(st + (offB[t] ^ (kk << 5)));
-                bl[t] = *reinterpret_cast<const h8*>(st + (offB[t] ^ (kk << 5) ^ 64));
-            }
+            for (int i = 0; i < HR; ++i)
 #pragma unroll
-            for (int i = 0; i < RT; ++i)
-#pragma unroll
-                for (int j = 0; j < CT; ++j) {
+                for (int j = 0; j < CT16; ++j) {
+                    f32x4& c = acc[hh * HR + i][j];
                     if constexpr (PREC == 0) {
-                        acc[i][j] = h_mfma<PREC>(al[i], bh[j], acc[i][j]);
-                        acc[i][j] = h_mfma<PREC>(ah[i], bl[j], acc[i][j]);
-                        acc[i][j] = h_mfma<PREC>(ah[i], bh[j], acc[i][j]);
+                        c = h_mfma16<PREC>(al[i], bh[j], c);
+                        c = h_mfma16<PREC>(ah[i], bl[j], c);
+                        c = h_mfma16<PREC>(ah[i], bh[j], c);
                     } else {
-                        acc[i][j] = h_mfma<PREC>(ah[i], bh[j], acc[i][j]);
-                        acc[i][j] = h_mfma<PREC>(al[i], bl[j], acc[i][j]);
+                        c = h_mfma16<PREC>(ah[i], bh[j], c);
+                        c = h_mfma16<PREC>(al[i], bl[j], c);
                     }
                     if constexpr (!HALF) {   // 4-wave tile: every wave spreads its pieces over the first half of its MFMAs
-                        const int g = (kk * RT + i) * CT + j;
+                        const int g = (hh * HR + i) * CT16 + j;
                         if ((g % GAP) == GAP - 1 && g / GAP < NI) {
                             issue_piece(g / GAP, (gs + 1) & 1, k_next);
                             __builtin_amdgcn_sched_barrier(0);
@@ -663,14 +817,12 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void gemm_hp_kernel(const _Float16
         const bool more = next_tile(Ln, mtn, ntn);
         if (!more) { mtn = mt; ntn = nt; }
 #pragma unroll
-        for (int i = 0; i < RT; ++i)
+        for (int i = 0; i < RT16; ++i)
 #pragma unroll
-            for (int j = 0; j < CT; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            for (int j = 0; j < CT16; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int s = 0; s + 1 < nslab; ++s) slab(s, std::false_type{}, 0, 0);
         slab(nslab - 1, std::true_type{}, mtn, ntn);
-        gemm_epilogue_dispatch<PREC, RT, CT, true>(acc, ep, wscale, mt * BM + wr * 32 * RT, nt * BN + wc * 32 * CT, lane, M, N, o, ef);
+        gemm_epilogue_dispatch16<PREC, RT16, CT16, true>(acc, ep, wscale, mt * BM + wr * 32 * RT, nt * BN + wc * 32 * CT, lane, M, N, o, ef);
         landed = true;
         if (!more) break;
         L = Ln; mt = mtn; nt = ntn;
