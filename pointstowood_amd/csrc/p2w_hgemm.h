@@ -850,9 +850,9 @@ static int32_t launch_gemm_h(const _Float16* Ah, int32_t ldh_a, const _Float16* 
     const long rounds = (tiles256 + n_cu - 1) / n_cu;
     const bool fills = tiles256 * 100 >= rounds * n_cu * 78;
     bool big = N >= 256 && (N % 256) == 0 && tiles256 * 4 >= 3 * n_cu && fills;
-    // long-K layers with half a round of 256-tiles or more: the large tile's DMA economy outweighs the idle CUs
-    // (M = 17506, K = 2048, N = 512: 127 us vs 134 us for the best 128-tile order)
-    if (N >= 256 && (N % 256) == 0 && Kpad >= 1024 && tiles256 * 2 >= n_cu && tiles256 <= n_cu) big = true;
+    // (a rule that also took long-K layers with only half a round of 256-tiles to the large tile paid off with one workgroup
+    // per tile and 32x32x16 MFMAs; with persistent workgroups on 16x16x32 the small tile wins there: M = 32768, K = 1024,
+    // N = 256: 48 vs 68 us; M = 17506, K = 2048, N = 512: 113 vs 130 us)
     if (flags & P2W_GEMM_TILE_256) big = true;
     if (flags & P2W_GEMM_TILE_128) big = false;
     // epilogue class for the specialised interior-tile path (0 = generic); needs 32-bit element offsets
