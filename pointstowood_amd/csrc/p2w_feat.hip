@@ -685,7 +685,7 @@ extern "C" int32_t p2w_rowdot(const float* x, int32_t ldx, int32_t F, const floa
 }
 
 // ------------------------------------------------------------------------------------------------
-extern "C" int32_t p2w_version(void) { return 200; }
+extern "C" int32_t p2w_version(void) { return 210; }
 
 extern "C" const char* p2w_strerror(int32_t code) {
     switch (code) {
