@@ -1007,8 +1007,11 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
     constexpr int NP = HCfg<PREC>::planes;
     constexpr int WCn = BN / 64, BM = 32 * RT * (8 / WCn), NW = 8, NR = BM / 128;   // NR producer rows per thread
     constexpr int A_CH = 4 * NP * BM, STAGE_CH = A_CH + 4 * NP * BN;
-    constexpr int NI = (4 * NP * BN) / 64 / NW;
-    static_assert(NI >= 1, "every wave issues at least one W2 DMA piece per slab");
+    // the W2 DMA of a slab is issued by waves 0..3 only: in-kernel stamps show them 26 % of the loop at the barrier while
+    // their SIMD partners (waves 4..7, the losers of the oldest-first arbitration) wait 4 % - the same asymmetry as in the GEMM
+    constexpr int NWI = 4;
+    constexpr int NI = (4 * NP * BN) / 64 / NWI;
+    static_assert(NI >= 1, "every issuing wave has at least one W2 DMA piece per slab");
     // ONE __shared__ object: with a second one beside the DMA staging array hipcc cannot tell the LDS-DMA's destination from
     // the other object and drains vmcnt(0) in front of the first ds_read of every slab (cdna_hip_programming.md, .s-level trap a)
     __shared__ __attribute__((aligned(16))) char S[2 * STAGE_CH * 16 + 4 * 512 * 4 + 3 * SA_EPI_COLS * 4];
@@ -1053,7 +1056,7 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
     (void)plane;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {   // a piece = 1 KiB of the B image: 8 rows x 128 B (f16x3: whole cache lines) / 16 rows x 64 B
-        const int g2 = wave + NW * i;
+        const int g2 = (wave % NWI) + NWI * i;
         const int row = (NP == 2 ? 8 : 16) * g2 + (lane >> (NP == 2 ? 3 : 2));
         const int c = NP == 2 ? ((lane & 7) ^ ((row >> 1) & 7)) : ((lane & 3) ^ ((row >> 2) & 3));
         boff[i] = (size_t)row * (NP * C1pad) + 8 * c;
@@ -1061,6 +1064,7 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
     }
     constexpr int KADV = NP == 2 ? 2 : 1;   // halfs a 32-k slab advances in a W2 row: 64 (hi + lo interleaved) or 32
     auto issue = [&](int stage, const _Float16* wbase, int k0) {   // wbase = W2h + nt * BN * NP * C1pad (per item); k0 in k units
+        if (wave >= NWI) return;
 #pragma unroll
         for (int i = 0; i < NI; ++i)
             __builtin_amdgcn_global_load_lds((glb_vp)(wbase + boff[i] + KADV * k0),
