@@ -235,7 +235,7 @@ class Engine:
         self.chunk_pick = int(os.environ.get("P2W_CHUNK_PICK", "1"))       # fill-aware chunk sizes (pick_chunk); 0: plain budget
         self.fp_hints = os.environ.get("P2W_FP_HINTS", "1") != "0"           # seed the interpolation searches from the sampler
         self.res_streams = int(os.environ.get("P2W_RES_STREAMS", "1"))      # residual-block chunk chains in flight (2: +0.6 %, measured)
-        self.res_chunk_rows = int(os.environ.get("P2W_RES_CHUNK", "65536"))   # rows (at 4F=512) per residual-block chunk; 0 = whole level
+        self.res_chunk_rows = int(os.environ.get("P2W_RES_CHUNK", "131072"))  # rows (at 4F=512) per residual-block chunk; 0 = whole level (swept: tools/chunk_sweep.sh)
         self.gemm_flags = int(os.environ.get("P2W_GEMM_FLAGS", "0"))          # P2W_GEMM_* bits of include/p2w.h (A/B runs)
         # grid sub-sampling: "table" = direct cell table (no sort; falls back per batch when the grid does not fit), "sort"
         self.sampler = os.environ.get("P2W_SAMPLER", "table")
