@@ -17,5 +17,5 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- p
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $BENCH --pipeline 0 > $OUT/write.json 2> $OUT/write.err
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/mfma -- python3 $BENCH --pipeline 0 > $OUT/mfma.json 2> $OUT/mfma.err
 cd $ROOT
-python3 tools/profile_summary.py $OUT $PREC 13
+python3 tools/profile_summary.py $OUT $PREC 21   # forwards per process: 8 allocator-sizing + 2 warmup + 10 steps + 1 profiled
 ls -la $OUT | head -30
