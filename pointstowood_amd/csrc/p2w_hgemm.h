@@ -1229,8 +1229,12 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
 #ifdef P2W_SA_STAMP
         const unsigned long long t_a = p2w_stamp();
 #endif
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the producer's asm ds_writes of A(g) (see produce)
-        __syncthreads();  // B(g) landed, A(g) written, stage (g+1)&1 free, last iteration's gather / metadata in registers
+        // B(g) landed (waited for in front of the previous iteration's epilogue, see there), A(g) written, stage (g+1)&1 free.
+        // No __syncthreads(): its fence would wait (vmcnt(0)) for the stores of an epilogue issued a moment ago.
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the producer's asm ds_writes of A(g) (see produce)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
 #ifdef P2W_SA_STAMP
         const unsigned long long t_b = p2w_stamp();
         t_wait += t_b - t_a;
@@ -1288,6 +1292,19 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
         const unsigned long long t_c = p2w_stamp();
         t_mma += t_c - t_b;            // DMA issue + fragment reads + MFMAs + producer + gather issue
 #endif
+        // Everything this iteration loaded (gather of slab g+2, metadata of slab g+3, next item's degrees) and the W2 DMA of slab
+        // g+1 is waited for HERE, by an opaque use of the loaded registers: in front of the epilogue's stores, which then stay in
+        // flight across the next barrier (loads, stores and LDS-DMA retire through one counter: a wait placed behind the
+        // stores would wait for them too, 1-2 us per item).
+#pragma unroll
+        for (int u = 0; u < NR; ++u) {
+            asm volatile("" : "+v"(vb.v[u][0].x), "+v"(vb.v[u][0].y), "+v"(vb.v[u][0].z), "+v"(vb.v[u][0].w),
+                              "+v"(vb.v[u][1].x), "+v"(vb.v[u][1].y), "+v"(vb.v[u][1].z), "+v"(vb.v[u][1].w));
+            asm volatile("" : "+v"(mc.j[u]), "+v"(mc.g[u].x), "+v"(mc.g[u].y), "+v"(mc.g[u].z), "+v"(mc.g[u].w));
+        }
+#pragma unroll
+        for (int i = 0; i < RT; ++i) asm volatile("" : "+v"(dg_n.d[i]));
+        __builtin_amdgcn_s_waitcnt(p2w_vmcnt_imm(0));   // ... and the DMA (the compiler's own wait above normally is vmcnt(0) already)
         if (c0.s == nslab - 1) {  // item finished: reduce over neighbour slots and store, then start the next accumulation
             if (!(dbg & 1)) {
                 SaEpiRegs<RT> e;
