@@ -1,5 +1,7 @@
 """Operator-level parity on the GPU: every HIP operator (through the C ABI) against oracle/ops.py
 on seeded inputs.  Index results must be bit-exact."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -205,6 +207,17 @@ def test_gemm_h_epilogue(prec, M, N, K, flags):
     v2 = A[:, :K].double() @ W.double().t()
     assert (out2[:, :N].cpu().double() - v2).abs().max().item() <= H_TOL[prec] * max(1.0, v2.abs().max().item())
     assert float(out2[:, N:].abs().max()) == 0.0
+
+
+def test_gemm_h_random_shapes():
+    """80 random (shape, precision, epilogue, tile flag) cases of p2w_gemm_h2 against fp64 (tools/stress_gemm.py: edge tiles of both
+    tile sizes, single-slab K, one-row / one-column problems, odd N through the guarded epilogue, every output combination)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_gemm.py"), "80", "5"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "80 cases ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
 
 
 def test_gemm_h_rejects_bad_arguments():
