@@ -256,6 +256,7 @@ int32_t p2w_packed_dims_h(int32_t prec, int32_t N, int32_t K, int32_t* N_pad, in
 /* flags of p2w_sa_conv_h (0 = let the library choose the work-item shape by C2) */
 #define P2W_SA_ITEM_256 1        /* 4 targets x 256 output columns per work item */
 #define P2W_SA_ITEM_128 2        /* 8 targets x 128 output columns per work item */
+#define P2W_SA_PACK8 4           /* targets with <= 8 neighbours share a 32-row MFMA tile four at a time (sparse ball-query levels) */
 /* bits 16..23 of `flags` of p2w_gemm_h2 / p2w_sa_conv_h: profiling ablations, honoured only by diagnostic builds
  * (-DP2W_GEMM_ABLATE / -DP2W_SA_ABLATE); production builds ignore them. */
 
@@ -267,9 +268,10 @@ int32_t p2w_gemm_h2(int32_t prec, const void* A_h, int32_t ldh_a, const void* Wh
 /* p2w_sa_conv with H weights W2h and fp32 and/or H outputs.  P (the hoisted layer-1 product, fp32) has n_src + 1 rows of
  * ldp >= round_up(C1, K granularity) floats: rows 0..n_src-1 = x_src * W1x^T + b1 with ZERO pad columns, row n_src all
  * zero (the row empty neighbour slots read; the kernel's loads are unconditional).
- * ws: 16-byte aligned scratch of >= M*32*20 bytes for the per-edge metadata (P2W_EWORKSPACE otherwise);
- * kw <= 32 (one 32-row MFMA tile per target); round_up(C1, K granularity) <= 512, C2 <= 1024 (LDS tables), M < 2^26 and
+ * ws: 16-byte aligned scratch of >= p2w_sa_conv_h_ws_bytes(M, flags) bytes for the per-edge metadata (P2W_EWORKSPACE otherwise);
+ * kw <= 32 (one 32-row MFMA tile per target); round_up(C1, K granularity) <= 512, C2 <= 1024 (LDS tables), M < 2^25 and
  * (n_src + 1) * ldp < 2^33 (32-bit offsets) - P2W_EUNSUPPORTED otherwise. */
+size_t p2w_sa_conv_h_ws_bytes(int32_t M, int32_t flags);
 int32_t p2w_sa_conv_h(int32_t prec, const float* P, int32_t ldp, int32_t n_src, const float* xyzr_src, const int32_t* idx,
                       const int32_t* batch_dst, const float* sf, const int32_t* nbr, const int32_t* deg, int32_t kw,
                       int32_t M, const float* w1r4, const void* W2h, float wscale, int32_t C1, int32_t C2,

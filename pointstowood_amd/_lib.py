@@ -26,6 +26,7 @@ SEARCH_X_INDEX_IN_W, SEARCH_Q_ROW_IN_W, SEARCH_BOX = 1, 2, 4   # include/p2w.h P
 PREC_F16X3, PREC_F16, PREC_BF16 = 0, 1, 2                      # include/p2w.h P2W_PREC_*
 PREC_OF = {"f16x3": PREC_F16X3, "fp16": PREC_F16, "bf16": PREC_BF16}
 GEMM_TILE_128, GEMM_TILE_256, GEMM_GENERIC_EPI, GEMM_ORDER_ROWS, GEMM_ORDER_COLS = 1, 2, 4, 8, 16   # P2W_GEMM_*
+SA_ITEM_256, SA_ITEM_128, SA_PACK8 = 1, 2, 4                                                       # P2W_SA_*
 
 SIGNATURES = {
     "p2w_version": (_i32, []),
@@ -57,6 +58,7 @@ SIGNATURES = {
                            _vp, _i32, _vp]),
     "p2w_packed_dims_h": (_i32, [_i32, _i32, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
     "p2w_gemm_h2": (_i32, [_i32, _vp, _i32, _vp, _f32, _i32, _i32, _i32, C.POINTER(Epilogue), _vp, _i32, _vp, _i32, _i32, _vp]),
+    "p2w_sa_conv_h_ws_bytes": (_sz, [_i32, _i32]),
     "p2w_sa_conv_h": (_i32, [_i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _f32, _i32, _i32, _vp, _vp,
                              _vp, _vp, _i32, _vp, _i32, _vp, _sz, _i32, _vp]),
     "p2w_stem_h2": (_i32, [_i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp]),

@@ -362,20 +362,32 @@ extern "C" int32_t p2w_gemm_h2(int32_t prec, const void* A_h, int32_t ldh_a, con
                             p2w_s(stream));
 }
 
+// Rows of the fused PointNetConv's GEMM, 32 per MFMA tile, G per target (G = 32: a tile per target; G = 8: four targets per
+// tile).  Target of slot group gi: list[gi] (gi < *n_list_dev) or gi itself.  Writes per row the source's P row offset and
+// the normalised offset g = (rel / (dmax + 1e-8), refl_j) (pointnet.py:119-129), per group the descriptor
+// (target << 6) | neighbour count, -1 for a group without a target.
 __global__ __launch_bounds__(256) void sa_edge_meta_kernel(const float4* __restrict__ xyzr, const int* __restrict__ idx,
                                                            const int* __restrict__ batch_dst, const float* __restrict__ sf,
                                                            const int* __restrict__ nbr, const int* __restrict__ deg, int kw,
-                                                           int M, int n_src, int ldp4, int* __restrict__ meta_j, float4* __restrict__ meta_g) {
+                                                           int M, int n_src, int ldp4, int G, const int* __restrict__ list,
+                                                           const int* __restrict__ n_list_dev, int* __restrict__ meta_j,
+                                                           float4* __restrict__ meta_g, int* __restrict__ desc) {
     const long g = (long)blockIdx.x * 256 + threadIdx.x;
-    const int tgt = (int)(g >> 5), slot = (int)(g & 31);
-    int j = 0;
+    const int n_groups = list ? *n_list_dev : M;                 // slot groups that have a target
+    const int gpt = 32 / G;
+    const long n_tiles = ((long)n_groups + gpt - 1) / gpt;
+    if (g >= n_tiles * 32) return;                               // whole 64-lane waves leave together (32 | 64)
+    const int gi = (int)(g / G), slot = (int)(g % G);
+    const int tgt = gi < n_groups ? (list ? list[gi] : gi) : -1;
+    int j = 0, d = 0;
     float rx = 0.f, ry = 0.f, rz = 0.f, rf = 0.f, nrm = 0.f;
-    if (tgt < M) {
-        const int d = deg[tgt];
+    bool valid = false;
+    if (tgt >= 0) {
+        d = min(deg[tgt], kw);
         const int self = idx[tgt];
         const float s = sf[batch_dst[tgt]];
         const float4 pi = xyzr[self];
-        const bool valid = slot < d && slot < kw;
+        valid = slot < d;
         j = valid ? nbr[(size_t)tgt * kw + slot] : self;
         if (j < 0) j = self;
         const float4 pj = xyzr[j];
@@ -386,16 +398,59 @@ __global__ __launch_bounds__(256) void sa_edge_meta_kernel(const float4* __restr
         }
     }
     float dmax = nrm;
-#pragma unroll
-    for (int off = 16; off >= 1; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off));  // 32 lanes = one target
+    for (int off = G >> 1; off >= 1; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off));  // G lanes = one target
     const float den = dmax + 1e-8f;
-    if (tgt < M) {
-        const bool valid = slot < deg[tgt] && slot < kw;
-        // offset of the source's P row in float4 units; empty slot: P's all-zero row + a zero offset give a zero A row (the epilogue masks it)
-        meta_j[g] = (valid ? j : n_src) * ldp4;
-        meta_g[g] = make_float4(rx / den, ry / den, rz / den, rf);
+    // offset of the source's P row in float4 units; empty slot: P's all-zero row + a zero offset give a zero A row (the epilogue masks it)
+    meta_j[g] = (valid ? j : n_src) * ldp4;
+    meta_g[g] = make_float4(rx / den, ry / den, rz / den, rf);
+    if (slot == 0) desc[gi] = tgt >= 0 ? ((tgt << 6) | d) : -1;
+}
+
+// P2W_SA_PACK8: stable partition of the targets by neighbour count (<= 8: four to a tile) - block counts, one-block scan, scatter
+__global__ __launch_bounds__(SA_PART_BLOCK) void sa_part_count_kernel(const int* __restrict__ deg, int kw, int M, int* __restrict__ blk_small) {
+    const int t = blockIdx.x * SA_PART_BLOCK + threadIdx.x;
+    const bool small = t < M && min(deg[t], kw) <= 8;
+    const int c = __syncthreads_count(small);
+    if (threadIdx.x == 0) blk_small[blockIdx.x] = c;
+}
+__global__ __launch_bounds__(1024) void sa_part_scan_kernel(int* __restrict__ blk_small, int nblk, int M, int* __restrict__ counts) {
+    __shared__ int part[1024];
+    const int per = (nblk + 1023) / 1024, b0 = threadIdx.x * per, b1 = min(b0 + per, nblk);
+    int sum = 0;
+    for (int b = b0; b < b1; ++b) sum += blk_small[b];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {   // inclusive scan of the per-thread sums
+        const int v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = part[threadIdx.x] - sum;            // exclusive prefix of this thread's blocks
+    for (int b = b0; b < b1; ++b) { const int c = blk_small[b]; blk_small[b] = run; run += c; }
+    if (threadIdx.x == 1023) {
+        const int ns = part[1023], nl = M - ns;
+        counts[0] = ns; counts[1] = nl; counts[2] = (ns + 3) / 4; counts[3] = nl;
     }
 }
+__global__ __launch_bounds__(SA_PART_BLOCK) void sa_part_scatter_kernel(const int* __restrict__ deg, int kw, int M, const int* __restrict__ blk_small,
+                                                                     int* __restrict__ list_small, int* __restrict__ list_large) {
+    __shared__ int wsum[SA_PART_BLOCK / 64];
+    const int t = blockIdx.x * SA_PART_BLOCK + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool in = t < M, small = in && min(deg[t], kw) <= 8;
+    const unsigned long long bal = __ballot(small);
+    const int r_in_wave = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wave] = __popcll(bal);
+    __syncthreads();
+    int before = 0;                                   // small targets of this block in earlier waves
+    for (int w = 0; w < wave; ++w) before += wsum[w];
+    const int off_s = blk_small[blockIdx.x];          // small targets in earlier blocks
+    const int rank_s = before + r_in_wave;            // this target's rank among the block's small ones (if small)
+    if (small) list_small[off_s + rank_s] = t;
+    else if (in) list_large[(blockIdx.x * SA_PART_BLOCK - off_s) + (threadIdx.x - rank_s)] = t;   // stable: earlier large targets
+}
+
+extern "C" size_t p2w_sa_conv_h_ws_bytes(int32_t M, int32_t flags) { return sa_conv_ws_bytes(M < 0 ? 0 : M, flags); }
 
 extern "C" int32_t p2w_sa_conv_h(int32_t prec, const float* P, int32_t ldp, int32_t n_src, const float* xyzr_src, const int32_t* idx,
                                  const int32_t* batch_dst, const float* sf, const int32_t* nbr, const int32_t* deg,

@@ -927,58 +927,75 @@ static int32_t launch_gemm_h(const _Float16* Ah, int32_t ldh_a, const _Float16* 
 //     so the max over neighbours is a max over the accumulator tile's rows (16 registers + one lane^32 exchange) and
 //     the [E, C] edge tensors of the reference never exist in HBM.
 // ------------------------------------------------------------------------------------------------
-template <int RT> struct SaEpiRegs { float bias[2], s[2], t[2]; int d[RT]; };
-// layer-2 bias + ReLU + BN affine, then max over the target's valid neighbour slots (rows of the 32-row MFMA tile).
+// Tile descriptors.  The metadata pre-pass lays the GEMM's rows out in 32-row MFMA tiles of 32 / G targets with G neighbour
+// slots each (G = 32: one target per tile; G = 8: four low-degree targets per tile, see p2w_sa_conv_h's P2W_SA_PACK8) and
+// writes one descriptor per target slot group: (target row << 6) | neighbour count, or -1 for an unused group.
+template <int RT, int GPT> struct SaEpiRegs { float bias[2], s[2], t[2]; int dsc[RT][GPT]; };
+// layer-2 bias + ReLU + BN affine, then max over the target's valid neighbour slots (rows of its group in the MFMA tile).
 // bias + ReLU + BN are monotone in the accumulator (wscale > 0: non-decreasing for s >= 0, non-increasing for s < 0) and
 // every rounding step keeps (weak) monotonicity, so the maximum over the slots of the transformed values IS the transform
 // of the maximum (s >= 0) or minimum (s < 0) of the raw accumulators, bit for bit: 2 VALU per value instead of 5 and
 // the transform once per column.
-template <int PREC, int RT>   // RT 32-row tiles (= targets) per wave
-__device__ __forceinline__ void sa_epilogue_regs(const f32x16 (&acc)[RT][2], float wscale, int t0, int n0, int wr, int wc,
-                                                 int lane, int M, const SaEpiRegs<RT>& e, int C2, float* __restrict__ out, int ldo,
+template <int PREC, int RT, int G>   // RT 32-row tiles per wave, G rows (neighbour slots) per target
+__device__ __forceinline__ void sa_epilogue_regs(const f32x16 (&acc)[RT][2], float wscale, int n0, int wc, int lane,
+                                                 const SaEpiRegs<RT, 32 / G>& e, int C2, float* __restrict__ out, int ldo,
                                                  _Float16* __restrict__ out_h2, int ldh) {
+    static_assert(G == 32 || G == 8, "one or four targets per 32-row tile");
+    constexpr int GPT = 32 / G;
     const int h = lane >> 5;
 #pragma unroll
     for (int i = 0; i < RT; ++i) {
-        const int tgt = t0 + wr * RT + i;
-        if (tgt >= M) continue;
-        const int d = __builtin_amdgcn_readfirstlane(e.d[i]);   // the same for every lane (one target per 32-row tile)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wc * 64 + j * 32 + (lane & 31);
-            const bool cv = col < C2;
-            const float sgn = e.s[j] < 0.f ? -1.f : 1.f;
-            const fpair sg2 = {sgn, sgn};
-            float ext;
-            if (d >= 32) {   // every slot valid (the kNN levels): packed sign multiply, three-input maxima, no masks
-                fpair p[8];
+        for (int q = 0; q < GPT; ++q) {
+            const int dsc = __builtin_amdgcn_readfirstlane(e.dsc[i][q]);   // the same for every lane
+            if (dsc < 0) continue;
+            const int tgt = dsc >> 6, d = dsc & 63;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) p[q] = fpair{acc[i][j][2 * q], acc[i][j][2 * q + 1]} * sg2;
-                float m0 = fmaxf(fmaxf(p[0][0], p[0][1]), p[1][0]);
-                float m1 = fmaxf(fmaxf(p[1][1], p[2][0]), p[2][1]);
-                float m2 = fmaxf(fmaxf(p[3][0], p[3][1]), p[4][0]);
-                float m3 = fmaxf(fmaxf(p[4][1], p[5][0]), p[5][1]);
-                m0 = fmaxf(fmaxf(m0, p[6][0]), p[6][1]);
-                m1 = fmaxf(fmaxf(m1, p[7][0]), p[7][1]);
-                ext = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
-            } else {
-                ext = -INFINITY;
+            for (int j = 0; j < 2; ++j) {
+                const int col = n0 + wc * 64 + j * 32 + (lane & 31);
+                const bool cv = col < C2;
+                const float sgn = e.s[j] < 0.f ? -1.f : 1.f;
+                const fpair sg2 = {sgn, sgn};
+                float ext;
+                if constexpr (G == 32) {
+                    if (d >= 32) {   // every slot valid (the kNN levels): packed sign multiply, three-input maxima, no masks
+                        fpair p[8];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int slot = (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (slot < d) ext = fmaxf(ext, sgn * acc[i][j][r]);
+                        for (int u = 0; u < 8; ++u) p[u] = fpair{acc[i][j][2 * u], acc[i][j][2 * u + 1]} * sg2;
+                        float m0 = fmaxf(fmaxf(p[0][0], p[0][1]), p[1][0]);
+                        float m1 = fmaxf(fmaxf(p[1][1], p[2][0]), p[2][1]);
+                        float m2 = fmaxf(fmaxf(p[3][0], p[3][1]), p[4][0]);
+                        float m3 = fmaxf(fmaxf(p[4][1], p[5][0]), p[5][1]);
+                        m0 = fmaxf(fmaxf(m0, p[6][0]), p[6][1]);
+                        m1 = fmaxf(fmaxf(m1, p[7][0]), p[7][1]);
+                        ext = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+                    } else {
+                        ext = -INFINITY;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int slot = (r & 3) + 8 * (r >> 2) + 4 * h;
+                            if (slot < d) ext = fmaxf(ext, sgn * acc[i][j][r]);
+                        }
+                    }
+                } else {   // rows 8 q .. 8 q + 7 of the tile: registers 4 q .. 4 q + 3 of both half-waves
+                    ext = -INFINITY;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int slot = r + 4 * h;
+                        if (slot < d) ext = fmaxf(ext, sgn * acc[i][j][4 * q + r]);
+                    }
                 }
-            }
-            {   // the other half of the tile's rows lives in lane ^ 32: one v_permlane32_swap instead of an LDS round trip
-                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ext), __float_as_uint(ext), false, false);
-                ext = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-            }
-            float vmax = fmaf(fmaxf(fmaf(sgn * ext, wscale, e.bias[j]), 0.f), e.s[j], e.t[j]);
-            if (d == 0 || !cv) vmax = 0.f;   // rows without neighbours; pad columns of an H row stay zero
-            if (cv && h == 0 && out) out[(size_t)tgt * ldo + col] = vmax;
-            if (out_h2) {  // lanes (2p, 2p+1) hold adjacent columns: the even lane stores both as one word per plane
-                const float nb = __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(vmax), 0xB1, 0xf, 0xf, false));
-                if (h == 0 && (lane & 1) == 0 && col < ldh) h_store2<PREC>(out_h2, ldh, tgt, col, vmax, nb);
+                {   // the other half of the group's rows lives in lane ^ 32: one v_permlane32_swap instead of an LDS round trip
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ext), __float_as_uint(ext), false, false);
+                    ext = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+                }
+                float vmax = fmaf(fmaxf(fmaf(sgn * ext, wscale, e.bias[j]), 0.f), e.s[j], e.t[j]);
+                if (d == 0 || !cv) vmax = 0.f;   // rows without neighbours; pad columns of an H row stay zero
+                if (cv && h == 0 && out) out[(size_t)tgt * ldo + col] = vmax;
+                if (out_h2) {  // lanes (2p, 2p+1) hold adjacent columns: the even lane stores both as one word per plane
+                    const float nb = __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(vmax), 0xB1, 0xf, 0xf, false));
+                    if (h == 0 && (lane & 1) == 0 && col < ldh) h_store2<PREC>(out_h2, ldh, tgt, col, vmax, nb);
+                }
             }
         }
     }
@@ -987,12 +1004,13 @@ __device__ __forceinline__ void sa_epilogue_regs(const f32x16 (&acc)[RT][2], flo
 // <BN, RT>: <256, 2>: 4 targets x 256 columns (waves 2 x 4, wave tile 64 x 64);  <128, 2>: 8 targets x 128 columns (waves 4 x 2)
 // (one workgroup per CU either way: LDS).  The A operand is produced on the VALU; in the single-plane modes a slab is
 // 32 k of ONE plane (half the LDS image and DMA, one MFMA per tile pair and k step).
-template <int PREC, int BN, int RT>
+// M = number of 32-row tiles (read from tiles_dev when given: the packed pre-pass only knows it on the device); desc: see SaEpiRegs.
+template <int PREC, int BN, int RT, int G>
 __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restrict__ P, int ldp, const int* __restrict__ meta_j,
-                                                            const float4* __restrict__ meta_g, const int* __restrict__ deg,
-                                                            int kw, int M, const float* __restrict__ w1r4, int C1, int C1pad,
+                                                            const float4* __restrict__ meta_g, const int* __restrict__ desc,
+                                                            const int* __restrict__ tiles_dev, int M, const float* __restrict__ w1r4, int C1, int C1pad,
                                                             const _Float16* __restrict__ W2h, size_t plane, float wscale, int C2,
-                                                            int nMt, int nNt, const float* __restrict__ b2,
+                                                            int nMt_, int nNt, const float* __restrict__ b2,
                                                             const float* __restrict__ bn_s, const float* __restrict__ bn_t,
                                                             float* __restrict__ out, int ldo, _Float16* __restrict__ out_h2,
                                                             int ldh, int dbg_) {
@@ -1006,6 +1024,10 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
 #endif
     constexpr int NP = HCfg<PREC>::planes;
     constexpr int WCn = BN / 64, BM = 32 * RT * (8 / WCn), NW = 8, NR = BM / 128;   // NR producer rows per thread
+    constexpr int GPT = 32 / G;                                                     // targets per 32-row tile
+    if (tiles_dev) M = *tiles_dev;
+    const int nMt = tiles_dev ? (M + BM / 32 - 1) / (BM / 32) : nMt_;
+    if (M <= 0) return;
     constexpr int A_CH = 4 * NP * BM, STAGE_CH = A_CH + 4 * NP * BN;
     // the W2 DMA of a slab is issued by waves 0..3 only: in-kernel stamps show them 26 % of the loop at the barrier while
     // their SIMD partners (waves 4..7, the losers of the oldest-first arbitration) wait 4 % - the same asymmetry as in the GEMM
@@ -1214,10 +1236,12 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
     }
     // neighbour counts of the wave's targets (clamped addresses, no conditions: see the loop's rule about loads); the
     // per-column parameters come from the LDS table when the item is finished
-    struct Degs { int d[RT]; };
+    struct Degs { int d[RT][GPT]; };   // descriptors of the wave's tiles (tiles past the end read the last tile's, masked below)
     auto load_deg = [&](int mt_, Degs& e) {
 #pragma unroll
-        for (int i = 0; i < RT; ++i) e.d[i] = min(deg[min(mt_ * (BM / 32) + wr * RT + i, M - 1)], kw);
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int q = 0; q < GPT; ++q) e.d[i][q] = desc[min(mt_ * (BM / 32) + wr * RT + i, M - 1) * GPT + q];
     };
     Degs dg_;
     load_deg(c0.mt, dg_);   // item 0; later items' counts arrive one iteration ahead (dg_n)
@@ -1303,19 +1327,23 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
             asm volatile("" : "+v"(mc.j[u]), "+v"(mc.g[u].x), "+v"(mc.g[u].y), "+v"(mc.g[u].z), "+v"(mc.g[u].w));
         }
 #pragma unroll
-        for (int i = 0; i < RT; ++i) asm volatile("" : "+v"(dg_n.d[i]));
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int q = 0; q < GPT; ++q) asm volatile("" : "+v"(dg_n.d[i][q]));
         __builtin_amdgcn_s_waitcnt(p2w_vmcnt_imm(0));   // ... and the DMA (the compiler's own wait above normally is vmcnt(0) already)
         if (c0.s == nslab - 1) {  // item finished: reduce over neighbour slots and store, then start the next accumulation
             if (!(dbg & 1)) {
-                SaEpiRegs<RT> e;
+                SaEpiRegs<RT, GPT> e;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int col = min(c0.nt * BN + wc * 64 + j * 32 + (lane & 31), C2 - 1);
                     e.bias[j] = Ep[col]; e.s[j] = Ep[SA_EPI_COLS + col]; e.t[j] = Ep[2 * SA_EPI_COLS + col];
                 }
 #pragma unroll
-                for (int i = 0; i < RT; ++i) e.d[i] = (c0.mt * (BM / 32) + wr * RT + i >= M) ? 0 : dg_.d[i];
-                sa_epilogue_regs<PREC, RT>(acc, wscale, c0.mt * (BM / 32), c0.nt * BN, wr, wc, lane, M, e, C2, out, ldo, out_h2, ldh);
+                for (int i = 0; i < RT; ++i)
+#pragma unroll
+                    for (int q = 0; q < GPT; ++q) e.dsc[i][q] = (c0.mt * (BM / 32) + wr * RT + i >= M) ? -1 : dg_.d[i][q];
+                sa_epilogue_regs<PREC, RT, G>(acc, wscale, c0.nt * BN, wc, lane, e, C2, out, ldo, out_h2, ldh);
             }
 #pragma unroll
             for (int i = 0; i < RT; ++i)
@@ -1332,16 +1360,32 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
         c0 = c1; c1 = c2; c2 = c3; c3 = nxt(c3);
     }
 #ifdef P2W_SA_STAMP
-    if (lane == 0 && (wave == 0 || wave == 4) && blockIdx.x < 256) {   // stamp buffer: the 64 KiB behind the edge metadata
-        unsigned long long* sb = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(const_cast<int*>(meta_j) + (size_t)M * 32) + 64) + (blockIdx.x * 2 + (wave ? 1 : 0)) * 8;
+    if (lane == 0 && (wave == 0 || wave == 4) && blockIdx.x < 256) {   // stamp buffer: the 64 KiB behind the tile descriptors
+        unsigned long long* sb = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(const_cast<int*>(desc) + (size_t)M * GPT) + 64) + (blockIdx.x * 2 + (wave ? 1 : 0)) * 8;
         sb[0] = p2w_stamp() - t_start; sb[1] = t_wait; sb[2] = t_epi; sb[3] = t_mma; sb[4] = (unsigned long long)total; sb[5] = (unsigned long long)my_items;
     }
 #endif
 }
 
+// pre-pass kernels (p2w_feat.hip)
 __global__ __launch_bounds__(256) void sa_edge_meta_kernel(const float4* __restrict__ xyzr, const int* __restrict__ idx, const int* __restrict__ batch_dst,
                                     const float* __restrict__ sf, const int* __restrict__ nbr, const int* __restrict__ deg, int kw,
-                                    int M, int n_src, int ldp4, int* __restrict__ meta_j, float4* __restrict__ meta_g);
+                                    int M, int n_src, int ldp4, int G, const int* __restrict__ list, const int* __restrict__ n_list_dev,
+                                    int* __restrict__ meta_j, float4* __restrict__ meta_g, int* __restrict__ desc);
+constexpr int SA_PART_BLOCK = 1024;
+__global__ __launch_bounds__(SA_PART_BLOCK) void sa_part_count_kernel(const int* __restrict__ deg, int kw, int M, int* __restrict__ blk_small);
+__global__ __launch_bounds__(1024) void sa_part_scan_kernel(int* __restrict__ blk_small, int nblk, int M, int* __restrict__ counts);
+__global__ __launch_bounds__(SA_PART_BLOCK) void sa_part_scatter_kernel(const int* __restrict__ deg, int kw, int M, const int* __restrict__ blk_small,
+                                                                     int* __restrict__ list_small, int* __restrict__ list_large);
+
+// workspace of p2w_sa_conv_h: per-row metadata (20 B per row of a 32-row tile) + tile descriptors; with P2W_SA_PACK8 both
+// target classes have their own rows (worst case: every target in either class), the two target lists and the partition's counters
+static inline size_t sa_conv_ws_bytes(long M, int flags) {
+    const long tiles32 = M, tiles8 = (M + 3) / 4;
+    if (!(flags & P2W_SA_PACK8)) return (size_t)(tiles32 * 32 * 20 + tiles32 * 4 + 256);
+    const long nblk = (M + SA_PART_BLOCK - 1) / SA_PART_BLOCK;
+    return (size_t)((tiles32 + tiles8) * 32 * 20 + (tiles32 + tiles8 * 4) * 4 + 2 * M * 4 + nblk * 4 + 64 + 1024);
+}
 
 // host side of p2w_sa_conv_h for one precision (pointer / size checks are done by the caller)
 template <int PREC>
@@ -1353,30 +1397,63 @@ static int32_t launch_sa_conv_h(const float* P, int32_t ldp, int32_t n_src, cons
     constexpr int KA = HCfg<PREC>::kalign;
     const int C2pad = (C2 + 255) / 256 * 256, C1pad = (C1 + KA - 1) / KA * KA;
     // LDS tables (layer-1 geometry weights, per-column epilogue parameters) and 32-bit offsets: edge rows, P rows in float4 units
-    if (C1pad > 512 || C2 > SA_EPI_COLS || (long)M * 32 >= (1L << 31) || ((long)n_src + 1) * (ldp / 4) >= (1L << 31)) return P2W_EUNSUPPORTED;
+    if (C1pad > 512 || C2 > SA_EPI_COLS || (long)M >= (1L << 25) || ((long)n_src + 1) * (ldp / 4) >= (1L << 31)) return P2W_EUNSUPPORTED;   // (descriptors hold target << 6)
     if (ldp < C1pad) return P2W_EINVAL;   // P rows are read in whole K slabs: pad columns (zero) must exist
-    if (ws == nullptr || ws_bytes < (size_t)M * 32 * 20) return P2W_EWORKSPACE;
+    if (ws == nullptr || ws_bytes < sa_conv_ws_bytes(M, flags)) return P2W_EWORKSPACE;
     if (reinterpret_cast<uintptr_t>(ws) & 15u) return P2W_EALIGN;
-    float4* meta_g = static_cast<float4*>(ws);
-    int* meta_j = reinterpret_cast<int*>(meta_g + (size_t)M * 32);
-    sa_edge_meta_kernel<<<p2w_cdiv((long)M * 32, 256), 256, 0, stream>>>(
-        reinterpret_cast<const float4*>(xyzr_src), idx, batch_dst, sf, nbr, deg, kw, M, n_src, ldp / 4, meta_j, meta_g);
     const int n_cu = p2w_cu_count();
     // 256-column items halve the A production per output column; measured on levels 2 / 3 (C2 = 256 / 512): 2.73 vs 2.82-2.97 ms
     const bool wide = (flags & (P2W_SA_ITEM_256 | P2W_SA_ITEM_128)) ? (flags & P2W_SA_ITEM_256) != 0 : C2 > 128;
     const int sadbg = (flags >> 16) & 0xff;
-    const int nMt3 = p2w_cdiv(M, wide ? 4 : 8), nNt3 = p2w_cdiv(C2, wide ? 256 : 128);
-    const long items = (long)nMt3 * nNt3;
-    int grid = (int)(items < n_cu ? items : n_cu);
-    if (grid >= 8) grid &= ~7;   // whole XCD rounds (see the kernel's work assignment)
-    if (wide)
-        sa_conv16p_kernel<PREC, 256, 2><<<grid, 512, 0, stream>>>(
-            P, ldp, meta_j, meta_g, deg, kw, M, w1r4, C1, C1pad, W2h, (size_t)C2pad * C1pad, wscale, C2, nMt3, nNt3, b2, bn_s,
-            bn_t, out, ldo, out_h2, ldh, sadbg);
-    else
-        sa_conv16p_kernel<PREC, 128, 2><<<grid, 512, 0, stream>>>(
-            P, ldp, meta_j, meta_g, deg, kw, M, w1r4, C1, C1pad, W2h, (size_t)C2pad * C1pad, wscale, C2, nMt3, nNt3, b2, bn_s,
-            bn_t, out, ldo, out_h2, ldh, sadbg);
+    const int tpi = wide ? 4 : 8, nNt3 = p2w_cdiv(C2, wide ? 256 : 128);   // tiles per work item, column tiles
+    const float4* x4 = reinterpret_cast<const float4*>(xyzr_src);
+    // one class of targets: metadata pre-pass over `rows_max` rows + the persistent kernel over at most `tiles_max` tiles
+    auto run = [&](auto g_c, const int* list, const int* n_list_dev, const int* tiles_dev, long tiles_max, float4* meta_g, int* meta_j,
+                   int* desc) {
+        constexpr int G = decltype(g_c)::value;
+        const long rows_max = tiles_max * 32;
+        sa_edge_meta_kernel<<<p2w_cdiv(rows_max, 256), 256, 0, stream>>>(x4, idx, batch_dst, sf, nbr, deg, kw, M, n_src, ldp / 4, G,
+                                                                       list, n_list_dev, meta_j, meta_g, desc);
+        const long items = p2w_cdiv(tiles_max, tpi) * nNt3;
+        int grid = (int)(items < n_cu ? items : n_cu);
+        if (grid >= 8) grid &= ~7;   // whole XCD rounds (see the kernel's work assignment)
+        const int nMt3 = (int)p2w_cdiv(tiles_max, tpi);
+        if (wide)
+            sa_conv16p_kernel<PREC, 256, 2, G><<<grid, 512, 0, stream>>>(
+                P, ldp, meta_j, meta_g, desc, tiles_dev, (int)tiles_max, w1r4, C1, C1pad, W2h, (size_t)C2pad * C1pad, wscale, C2, nMt3,
+                nNt3, b2, bn_s, bn_t, out, ldo, out_h2, ldh, sadbg);
+        else
+            sa_conv16p_kernel<PREC, 128, 2, G><<<grid, 512, 0, stream>>>(
+                P, ldp, meta_j, meta_g, desc, tiles_dev, (int)tiles_max, w1r4, C1, C1pad, W2h, (size_t)C2pad * C1pad, wscale, C2, nMt3,
+                nNt3, b2, bn_s, bn_t, out, ldo, out_h2, ldh, sadbg);
+    };
+    char* w = static_cast<char*>(ws);
+    if (!(flags & P2W_SA_PACK8)) {
+        float4* meta_g = reinterpret_cast<float4*>(w);
+        int* meta_j = reinterpret_cast<int*>(meta_g + (size_t)M * 32);
+        int* desc = meta_j + (size_t)M * 32;
+        run(std::integral_constant<int, 32>{}, nullptr, nullptr, nullptr, M, meta_g, meta_j, desc);
+        return P2W_LAUNCH_STATUS();
+    }
+    // P2W_SA_PACK8: targets with at most 8 neighbours (the sparse ball-query level) share a 32-row MFMA tile four at a time,
+    // the others keep a tile each.  Stable partition on the device (no host synchronisation: the kernels read their tile
+    // counts from `counts`), then one pre-pass + persistent kernel per class.
+    const long t32 = M, t8 = (M + 3) / 4, nblk = p2w_cdiv(M, SA_PART_BLOCK);
+    float4* mg_l = reinterpret_cast<float4*>(w);            w += t32 * 32 * 16;
+    float4* mg_s = reinterpret_cast<float4*>(w);            w += t8 * 32 * 16;
+    int* mj_l = reinterpret_cast<int*>(w);                  w += t32 * 32 * 4;
+    int* mj_s = reinterpret_cast<int*>(w);                  w += t8 * 32 * 4;
+    int* desc_l = reinterpret_cast<int*>(w);                w += t32 * 4;
+    int* desc_s = reinterpret_cast<int*>(w);                w += t8 * 4 * 4;
+    int* list_s = reinterpret_cast<int*>(w);                w += (size_t)M * 4;
+    int* list_l = reinterpret_cast<int*>(w);                w += (size_t)M * 4;
+    int* blk = reinterpret_cast<int*>(w);                   w += nblk * 4;
+    int* counts = reinterpret_cast<int*>(w);   // [0] small targets, [1] large targets, [2] tiles of small targets, [3] tiles of large targets
+    sa_part_count_kernel<<<(int)nblk, SA_PART_BLOCK, 0, stream>>>(deg, kw, M, blk);
+    sa_part_scan_kernel<<<1, 1024, 0, stream>>>(blk, (int)nblk, M, counts);
+    sa_part_scatter_kernel<<<(int)nblk, SA_PART_BLOCK, 0, stream>>>(deg, kw, M, blk, list_s, list_l);
+    run(std::integral_constant<int, 8>{}, list_s, counts + 0, counts + 2, t8, mg_s, mj_s, desc_s);
+    run(std::integral_constant<int, 32>{}, list_l, counts + 1, counts + 3, t32, mg_l, mj_l, desc_l);
     return P2W_LAUNCH_STATUS();
 }
 

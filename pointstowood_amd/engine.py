@@ -25,7 +25,7 @@ from dataclasses import dataclass, field
 import torch
 
 from . import _lib
-from ._lib import PREC_F16X3, PREC_OF, SEARCH_Q_ROW_IN_W, SEARCH_X_INDEX_IN_W, Epilogue, check, lib, ptr
+from ._lib import PREC_F16X3, PREC_OF, SA_PACK8, SEARCH_Q_ROW_IN_W, SEARCH_X_INDEX_IN_W, Epilogue, check, lib, ptr
 
 BN_EPS = 1e-5
 SA_RES = (0.04, 0.08, 0.16)  # model.py:210-212
@@ -237,6 +237,8 @@ class Engine:
         self.res_streams = int(os.environ.get("P2W_RES_STREAMS", "1"))      # residual-block chunk chains in flight (2: +0.6 %, measured)
         self.res_chunk_rows = int(os.environ.get("P2W_RES_CHUNK", "131072"))  # rows (at 4F=512) per residual-block chunk; 0 = whole level (swept: tools/chunk_sweep.sh)
         self.gemm_flags = int(os.environ.get("P2W_GEMM_FLAGS", "0"))          # P2W_GEMM_* bits of include/p2w.h (A/B runs)
+        self.sa_flags = int(os.environ.get("P2W_SA_FLAGS", "0"))              # P2W_SA_ITEM_* bits (A/B runs)
+        self.sa_pack = os.environ.get("P2W_SA_PACK", "1") != "0"              # P2W_SA_PACK8 on the ball-query level
         # grid sub-sampling: "table" = direct cell table (no sort; falls back per batch when the grid does not fit), "sort"
         self.sampler = os.environ.get("P2W_SAMPLER", "table")
         self._table_scale = [1, 1, 1]   # per level: grows by 8 after an overflow, 0 = table given up for this level
@@ -484,13 +486,16 @@ class Engine:
                 P[:, C1:].zero_()
             self._gemm_h2("gemm_hoist", xh[l - 1], pad8(p["F_in"]), src.n, p["hoist"], out_f32=P, ldo=C1p)
             conv, convh = new(M, C2), newh(M, C2)
-            meta = torch.empty(M * 32 * 20 + 65536, dtype=torch.uint8, device=dev)   # per-edge (j, normalised offset) scratch (+ room for diagnostics)
+            # level 1 is the ball query: on sparse input most targets have few neighbours, and those with <= 8 share an MFMA
+            # tile four at a time (P2W_SA_PACK8); the kNN levels always fill their 32 slots
+            sa_flags = self.sa_flags | (SA_PACK8 if (l == 1 and self.sa_pack) else 0)
+            meta = torch.empty(int(L.p2w_sa_conv_h_ws_bytes(M, sa_flags)) + 65536, dtype=torch.uint8, device=dev)   # per-edge (j, normalised offset) scratch (+ room for diagnostics)
             if keep is not None:
                 keep[f"sa{l}_module.ws"] = meta
             self._call("sa_conv", L.p2w_sa_conv_h, prec, ptr(P), C1p, src.n, ptr(src.xyzr), ptr(dst.idx), ptr(dst.batch),
                        ptr(geo.sf), ptr(dst.nbr), ptr(dst.deg), geo.k, M, ptr(p["w1r4"]), ptr(p["W2"].w16),
                        p["W2"].wscale, C1, C2, ptr(p["b2"]), ptr(p["bn_s"]), ptr(p["bn_t"]), ptr(conv), C2, ptr(convh),
-                       pad8(C2), ptr(meta), meta.numel(), 0)
+                       pad8(C2), ptr(meta), meta.numel(), sa_flags)
             out = new(M, C2)
             outh = newh(M, C2) if l < 3 else None
             # residual block in row chunks: the two 4F-wide intermediates of a chunk (2 x chunk x 4F x 4 B) are written

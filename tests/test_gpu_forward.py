@@ -142,6 +142,34 @@ def test_forward_is_deterministic_and_batch_order_is_voxel_major():
     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("precision", ["f16x3", "fp16"])
+def test_packed_pointnetconv_is_bit_identical(precision):
+    """P2W_SA_PACK8 (targets with <= 8 neighbours share an MFMA tile four at a time, the others keep their own tile) only
+    re-arranges the rows of the fused PointNetConv's GEMM: logits must be bit-identical with and without it - on sparse voxels
+    (most targets small), on a dense one (ball query at its cap: every target large) and on a mixed batch with tiny voxels."""
+    from pointstowood_amd import Net
+    batches = [synth.collate([synth.uniform_voxel(2.0, 6000, 81, True), synth.uniform_voxel(2.0, 900, 82, False)]),
+               synth.collate([synth.uniform_voxel(0.3, 5000, 83, True)]),                      # dense: ~32 neighbours everywhere
+               synth.collate([synth.uniform_voxel(2.0, 3, 84, True), synth.uniform_voxel(1.0, 4000, 85, True),
+                              synth.uniform_voxel(4.0, 2000, 86, False)])]
+    net = Net(num_classes=1, C=8, k=32, precision=precision)
+    net.load_state_dict(weights.synth_state_dict(1, 8, seed=9), strict=True)
+    net = net.cuda().eval()
+
+    def mk(b):
+        d = _D()
+        d.pos, d.batch, d.reflectance, d.sf = b["pos"].cuda(), b["batch"].cuda(), b["reflectance"].cuda(), b["sf"].cuda()
+        return d
+    outs = {}
+    for pack in (True, False):
+        net(mk(batches[0]))                    # builds the engine
+        net._engine.sa_pack = pack
+        outs[pack] = [net(mk(b)).clone() for b in batches]
+    torch.cuda.synchronize()
+    for a, b in zip(outs[True], outs[False]):
+        assert bool(torch.isfinite(a).all()) and torch.equal(a, b)
+
+
 def test_stream_pipeline_equals_sequential_forward():
     """Net.stream (geometry of batch i+1 overlapped with features of batch i on a second HIP stream) must return
     bit-identical logits to one forward per batch, in order."""

@@ -253,7 +253,7 @@ def test_sa_conv_h_reports_its_limits():
     z = lambda *sh, dt=torch.float32: torch.zeros(sh, dtype=dt, device=dev)
     xyzr, idx, bd, sf = z(n_src, 4), z(M, dt=torch.int32), z(M, dt=torch.int32), torch.ones(1, device=dev)
     nbr, deg, w1r4 = z(M, 32, dt=torch.int32), z(M, dt=torch.int32), z(4, 64)
-    ws = torch.zeros(M * 32 * 20 + 65536, dtype=torch.uint8, device=dev)
+    ws = torch.zeros(int(L.p2w_sa_conv_h_ws_bytes(M, 4)) + 65536, dtype=torch.uint8, device=dev)
 
     def call(C2, ldp=64, C1_=C1):
         P = z(n_src + 1, ldp)

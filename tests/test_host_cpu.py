@@ -433,7 +433,8 @@ def test_hot_kernels_stay_off_the_register_cliff():
         for tile in ("Li2ELi4ELi4ELi2E", "Li2ELi2ELi2ELi2E"):   # the persistent GEMM, 256 x 256 and 128 x 128 tiles
             g = one(f"gemm_hp_kernelILi{prec}E{tile}")
             assert g["ScratchSize [bytes/lane]"] <= 16, g          # 8 today: one value parked across the tile loop, not in the slab loop
-        for k in (f"sa_conv16p_kernelILi{prec}ELi256ELi2E", f"sa_conv16p_kernelILi{prec}ELi128ELi2E"):
+        for k in (f"sa_conv16p_kernelILi{prec}ELi256ELi2ELi32E", f"sa_conv16p_kernelILi{prec}ELi128ELi2ELi32E",
+                  f"sa_conv16p_kernelILi{prec}ELi256ELi2ELi8E", f"sa_conv16p_kernelILi{prec}ELi128ELi2ELi8E"):
             assert one(k)["VGPRs Spill"] == 0 and one(k)["LDS Size [bytes/block]"] <= 120 * 1024
     for k, v in usage.items():
         if "slab_search_kernel" in k or k.startswith("_Z10knn_kernel") or k.startswith("_Z11ball_kernel"):

@@ -19,11 +19,11 @@ root, prec, forwards = sys.argv[1], sys.argv[2], float(sys.argv[3])
 def short(name):
     n = re.sub(r"\(.*", "", name).replace("void ", "")
     n = re.sub(r"rocprim::ROCPRIM_\d+_NS::detail::", "rocprim::", n)
-    m = re.match(r"_Z\d+(gemm_h2g_kernel|gemm_hp_kernel|sa_conv16p_kernel)ILi(\d)ELi(\d+)ELi(\d+)E(?:Li(\d+)ELi(\d+)E)?", n)
+    m = re.match(r"_Z\d+(gemm_h2g_kernel|gemm_hp_kernel|sa_conv16p_kernel)ILi(\d)ELi(\d+)ELi(\d+)E(?:Li(\d+)E)?(?:Li(\d+)E)?", n)
     if m:
         if m.group(1) in ("gemm_h2g_kernel", "gemm_hp_kernel"):
             return f"{m.group(1)}<prec{m.group(2)},{m.group(3)},{m.group(4)},{m.group(5)},{m.group(6)}>"
-        return f"sa_conv16p_kernel<prec{m.group(2)},{m.group(3)},{m.group(4)}>"
+        return f"sa_conv16p_kernel<prec{m.group(2)},{m.group(3)},{m.group(4)},G{m.group(5)}>"
     return n[:90]
 
 

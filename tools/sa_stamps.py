@@ -6,6 +6,7 @@ import os
 import statistics
 import sys
 os.environ.setdefault("P2W_EXTRA_CFLAGS", "-DP2W_SA_STAMP")
+os.environ["P2W_SA_PACK"] = "0"   # one class of targets per level: the stamp buffer sits behind its descriptors
 
 import torch
 
@@ -27,7 +28,7 @@ geo = keep["geometry"]
 for l in (1, 2, 3):
     M = geo.levels[l].n
     ws = keep[f"sa{l}_module.ws"]
-    off = M * 32 * 20 + 64
+    off = M * 32 * 20 + M * 4 + 64
     st = ws[off: off + 256 * 2 * 8 * 8].view(torch.int64).view(256, 2, 8).cpu()
     used = st[:, 0, 0] > 0
     med = lambda t: statistics.median(t.tolist())
