@@ -30,7 +30,7 @@ def short(name):
 def klass(name):
     if "gemm_h2g_kernel" in name or "gemm_hp_kernel" in name or name.startswith("gemm_kernel"):
         return "gemm_kernel"
-    if "sa_conv16p_kernel" in name or "sa_edge_meta" in name or name.startswith("sa_conv_kernel"):
+    if "sa_conv16p_kernel" in name or "sa_edge_meta" in name or "sa_part_" in name or name.startswith("sa_conv_kernel"):
         return "sa_conv_kernel"
     for k in ("interp_concat", "segment_max", "level_gather", "rowdot", "stem_kernel", "concat_xyz", "slab_search", "knn_hint"):
         if k in name:
