@@ -11,9 +11,10 @@
 // pad columns are zero.  Weights are packed the same way, one row per output channel: [N_pad][planes * K_pad] of W * 2^e.
 // Either way the 64 halfs a GEMM slab consumes of a row are ONE 128-byte cache line.
 //
-// The MFMA is v_mfma_f32_32x32x16_{f16,bf16}: lane l supplies A[row l&31][k = 8*(l>>5) + 0..7] (16 contiguous bytes),
-// B alike; C/D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).  f16x3 contracts a_lo*w_hi + a_hi*w_lo + a_hi*w_hi
-// (three MFMAs per product, fp32 accumulate); the single-plane modes issue one.
+// MFMAs: the production GEMM (gemm_hp_kernel) uses v_mfma_f32_16x16x32_{f16,bf16} (layout at h_mfma16 below); the fused
+// PointNetConv and the diagnostic one-workgroup-per-tile GEMM use v_mfma_f32_32x32x16_{f16,bf16}: lane l supplies
+// A[row l&31][k = 8*(l>>5) + 0..7] (16 contiguous bytes), B alike; C/D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
+// f16x3 contracts a_lo*w_hi + a_hi*w_lo + a_hi*w_hi (three MFMAs per product, fp32 accumulate); the single-plane modes issue one.
 #pragma once
 #include "p2w_common.h"
 #include <type_traits>
