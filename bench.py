@@ -51,7 +51,7 @@ TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r2_{precision}_hbm_traffic.json")
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--steps", type=int, default=48)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batches", type=int, default=8, help="distinct seeded voxel batches the steps rotate over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
