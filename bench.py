@@ -22,7 +22,7 @@ collective: an RCCL all-gather of the per-point logits.  Rank 0 prints ONE JSON 
 ``roofline`` is measured live: after the timed regions one extra, sequential step is run with HIP
 events around every run of consecutive launches of one kernel class (on the launch stream) and the
 dominant kernel's algorithmic FLOPs are divided by its measured time; ``traffic`` comes from the
-committed rocprofv3 PMC summary of the same command (``profiles/r2_<precision>_hbm_traffic.json``).
+committed rocprofv3 PMC summary of the same command (``profiles/r3_<precision>_hbm_traffic.json``).
 ``hbm_kernels`` gives the memory-bound kernels' algorithmic bytes / measured time
 against the 8 TB/s HBM peak.  ``cpu_baseline`` times the CPU oracle (``oracle/net.py``, a port of
 the reference forward pinned to the reference's own outputs) on a bounded sample of batch 0.
@@ -45,7 +45,7 @@ sys.path.insert(0, ROOT)
 PEAK_TFLOPS = {"fp32": 157.3, "f16x3": 2500.0, "fp16": 2500.0, "bf16": 2500.0}
 PEAK_HBM_GBPS = 8000.0
 C, K_NBR, BATCH, NPTS = 32, 32, 8, 16384
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r2_{precision}_hbm_traffic.json")   # written by tools/profile_r2.sh
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r3_{precision}_hbm_traffic.json")   # written by tools/profile_r3.sh
 
 
 def parse_args(argv=None):
@@ -55,13 +55,35 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batches", type=int, default=8, help="distinct seeded voxel batches the steps rotate over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-full", action="store_true",
+                    help="BASELINE.md section 4 in full: the whole batch 0 (8 voxels), 5 timed passes, thread counts {16, 64, all} swept "
+                         "(minutes of CPU time); default: a bounded sample (3 voxels, 3 timed passes, 16 threads)")
+    ap.add_argument("--no-workloads", action="store_true",
+                    help="skip the extra `workloads` object (configs[2], configs[4] in f16x3 and fp16, a surface-like batch)")
+    ap.add_argument("--workload", default="voxels", choices=["voxels", "plot"],
+                    help="voxels (default): BASELINE configs[1], one voxel batch per GPU per step (weak scaling); plot: BASELINE "
+                         "configs[3], ONE synthetic plot voxelised, classified and back-projected by all ranks together (strong scaling)")
+    ap.add_argument("--plot-points", type=int, default=10_000_000, help="--workload plot: points of the synthetic plot")
     ap.add_argument("--no-pcie", action="store_true", help="skip the second (H2D/D2H-inclusive) timed region")
     ap.add_argument("--pipeline", type=int, default=1,
                     help="1: two-stream pipeline over the step sequence (default); 0: strictly sequential forwards")
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "fp16", "bf16", "fp32"],
                     help="f16x3: split-fp16 MFMA (3 MFMAs per product, fp32-class accuracy; the parity default); fp16 / bf16: one "
                          "MFMA per product (the reference's autocast arithmetic; outside the 1e-4 bar); fp32: fp32 MFMA")
+    ap.add_argument("--engine-opt", action="append", default=[], metavar="KEY=VALUE",
+                    help="EngineOptions field for the benched Net (A/B runs), e.g. --engine-opt res_streams=2 --engine-opt sampler=sort")
     return ap.parse_args(argv)
+
+
+def engine_options(pairs):
+    """--engine-opt KEY=VALUE ... -> keyword arguments of Net (values typed like the EngineOptions defaults)."""
+    from pointstowood_amd.engine import EngineOptions
+    defaults, out = EngineOptions(), {}
+    for kv in pairs:
+        key, _, val = kv.partition("=")
+        cur = getattr(defaults, key)   # AttributeError names an unknown option
+        out[key] = (val.lower() not in ("0", "false", "no")) if isinstance(cur, bool) else type(cur)(val)
+    return out
 
 
 def self_launch(args) -> int:
@@ -164,27 +186,165 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(batch0):
-    """CPU oracle on the FIRST voxel of batch 0 of this benchmark (same batch definition, bounded sample)."""
+def cpu_baseline(batch0, full=False):
+    """CPU oracle (oracle/net.py, a port pinned to the reference's own outputs) on a bounded sample of batch 0 of this
+    benchmark, as ONE batch like the GPU runs it (same batch definition, same k, C, weights): median of the timed passes.
+    default: the first 3 voxels, 1 warm-up + 3 timed passes, 16 torch threads (more only add contention on this path);
+    full: all 8 voxels, 5 timed passes, thread counts {16, 64, all} swept once, the best reported."""
     import torch
     from oracle import net as onet
     from pointstowood_amd import synthetic_weights as weights
-    threads = min(os.cpu_count() or 1, 16)   # more threads only add contention on this path
-    torch.set_num_threads(threads)
     sd = weights.synth_state_dict(1, C, seed=0)
-    n = int(batch0["ptr"][1])
+    nvox = BATCH if full else 3
+    n = int(batch0["ptr"][nvox])
     pos, refl = batch0["pos"][:n].clone(), batch0["reflectance"][:n].clone()
-    bidx, sf = torch.zeros(n, dtype=torch.long), batch0["sf"][:1].clone()
+    bidx, sf = batch0["batch"][:n].clone(), batch0["sf"][:nvox].clone()
     run = lambda: onet.forward(sd, pos, bidx, refl, sf, k=K_NBR)
-    run()  # warm-up
-    reps, t0 = 2, time.perf_counter()
-    for _ in range(reps):
-        run()
+    cores = os.cpu_count() or 1
+    sweep = sorted({min(cores, t) for t in ((16, 64, cores) if full else (16,))})
+    reps, best, tried = (5 if full else 3), None, {}
+    for threads in sweep:
+        torch.set_num_threads(threads)
+        run()  # warm-up
+        ts = []
+        for _ in range(reps if threads == sweep[0] or not full else 2):   # the sweep's other settings: 2 passes each
+            t0 = time.perf_counter()
+            run()
+            ts.append(time.perf_counter() - t0)
+        tried[threads] = statistics.median(ts)
+        if best is None or tried[threads] < tried[best]:
+            best = threads
+    if full and best != sweep[0]:   # the winner gets its full number of passes
+        torch.set_num_threads(best)
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            run()
+            ts.append(time.perf_counter() - t0)
+        tried[best] = statistics.median(ts)
+    dt = tried[best]
+    return {"value": n / dt, "unit": "points/s", "cores": best, "kind": "port", "cpu_model": cpu_model(), "host_cores": cores,
+            "ms_per_batch": dt * 1e3, "voxels": nvox,
+            "threads_tried": {str(t): round(v, 3) for t, v in tried.items()},
+            "sample": f"voxels 0..{nvox - 1} of batch 0 as one batch ({n} pts, U2-16k seeds 123..{122 + nvox}), k={K_NBR}, C={C}, fp32, "
+                      f"median of {reps} timed passes after 1 warm-up, {dt:.2f} s per pass, {best} torch threads"}
+
+
+def device_feed(vox, device):
+    from pointstowood_amd import synthetic_voxels as synth
+    return Feed.to_device(synth.collate(vox), device)
+
+
+def measure_workload(net, data, reps=3):
+    """One extra workload: setup forward (sizes the allocator), `reps` pipelined steps over the same batch, then one
+    sequential profiled step for the per-kernel times and the algorithmic FLOPs of the level sizes actually produced."""
+    import torch
+    net(data)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in net.stream(data for _ in range(reps)):
+        pass
+    torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
-    return {"value": n / dt, "unit": "points/s", "cores": threads, "kind": "port", "cpu_model": cpu_model(),
-            "host_cores": os.cpu_count(),
-            "sample": f"voxel 0 of batch 0 ({n} pts, U2-16k seed 123), k={K_NBR}, C={C}, fp32, {reps} timed passes after 1 "
-                      f"warm-up, {dt:.2f} s per pass, {threads} torch threads"}
+    per, geo = profile_step(net, data)
+    total_macs, kmacs, sizes = algorithmic_macs(geo)
+    n = int(data.pos.shape[0])
+    top = sorted(per.items(), key=lambda kv: -kv[1][0])[:3]
+    out = {"points": n, "voxels": int(data.sf.numel()), "steps": reps, "ms_per_batch": round(dt * 1e3, 3),
+           "points_per_s": round(n / dt, 1), "end_to_end_tflops_algorithmic": round(2.0 * total_macs / dt / 1e12, 2),
+           "level_sizes": sizes, "kernel_ms_top3": {k: round(v[0], 3) for k, v in top}}
+    for kname, macs in kmacs.items():
+        if kname in per and per[kname][0] > 0:
+            out[kname + "_tflops_algorithmic"] = round(2.0 * macs / (per[kname][0] * 1e-3) / 1e12, 1)
+    return out
+
+
+def extra_workloads(net, args, device):
+    """The other BASELINE.json workloads and a surface-like batch, measured in the same run as the bench line (a few steps
+    each): driver-observable numbers for configs[2], configs[4] (f16x3 and, as the config says fp16, fp16) and for input
+    that saturates the ball-query cap the way real TLS surfaces do (model.py:118; SURVEY.md 8d's second generator)."""
+    import torch
+    from pointstowood_amd import Net
+    from pointstowood_amd import synthetic_voxels as synth
+    from pointstowood_amd import synthetic_weights as weights
+    out = {}
+    cases = [
+        ("configs[2] B=64 x 16384 xyz+reflectance", lambda: [synth.uniform_voxel(2.0, NPTS, 200 + i, True) for i in range(64)]),
+        ("configs[4] B=128 mixed 512..16384", lambda: [synth.uniform_voxel(2.0, n, 400 + i, True) for i, n in enumerate(synth.mixed_sizes())]),
+        ("surface B=8 x 16384 xyz-only (cylinders + blobs: ball-query cap saturated)",
+         lambda: [synth.surface_voxel(2.0, NPTS, 300 + i, False) for i in range(BATCH)]),
+    ]
+    for name, make in cases:
+        d = device_feed(make(), device)
+        out[name] = dict(measure_workload(net, d), dtype=args.precision)
+        if name.startswith("configs[4]") and args.precision == "f16x3":
+            net16 = Net(num_classes=1, C=C, k=K_NBR, precision="fp16", **engine_options(args.engine_opt))
+            net16.load_state_dict(weights.synth_state_dict(1, C, seed=0), strict=True)
+            net16 = net16.to(device).eval()
+            out[name + " [fp16]"] = dict(measure_workload(net16, d), dtype="fp16",
+                                         note="one fp16 MFMA per product: the reference's autocast arithmetic, outside the 1e-4 bar")
+            del net16
+        del d
+        torch.cuda.empty_cache()
+    return out
+
+
+def plot_main(args, world, rank, device, dist):
+    """--workload plot: BASELINE configs[3] - ONE synthetic plot, voxelised (2 m + 4 m grids, min 128 / max 16384 points),
+    classified (LPT-sharded voxel batches) and back-projected (contiguous slices of the plot) by all ranks together:
+    strong scaling.  A step = the whole plot once; value = plot points / s."""
+    import torch
+    from pointstowood_amd import Net
+    from pointstowood_amd import synthetic_weights as weights
+    from pointstowood_amd.pipeline import segment_plot
+    from pointstowood_amd.synthetic_voxels import forest_plot
+    net = Net(num_classes=1, C=C, k=K_NBR, precision=args.precision, **engine_options(args.engine_opt))
+    net.load_state_dict(weights.synth_state_dict(1, C, seed=0), strict=True)
+    net = net.to(device).eval()
+    n = args.plot_points
+    side = max(10.0, 100.0 * (n / 10_000_000) ** 0.5)
+    pc = forest_plot(n, side=side).to(device)
+    gen = lambda: torch.Generator(device=device).manual_seed(0)
+    steps, warm = max(1, min(args.steps, 3)), max(1, min(args.warmup, 1))
+    for _ in range(warm):
+        segment_plot(pc, net, generator=gen(), dist=dist)
+    times, stats = [], {}
+    for _ in range(steps):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        stats = {}
+        t0 = time.perf_counter()
+        n_z, label, pwood = segment_plot(pc, net, generator=gen(), stats=stats, dist=dist)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t)
+        times.append(dt)
+    assert bool(torch.isfinite(pwood).all())
+    if rank == 0:
+        dt = sum(times) / len(times)
+        print(json.dumps({
+            "metric": "plot points/sec (voxelise + classify + back-project)", "value": n / dt, "unit": "points/s", "n_gpus": world,
+            "steps": steps, "warmup": warm, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[3]: {n}-point synthetic forest plot ({side:.0f} m square), grid_size 2.0/4.0, min_pts 128, "
+                                   "max_pts 16384, voxel batches of <= 524288 points / 512 voxels LPT-sharded over the ranks, one all-gather "
+                                   "of the classified points, back-projection (k=64 median vote) on contiguous plot slices, one all-gather",
+                       "voxels": stats.get("voxels"), "classified_points": stats.get("classified_points"), "C": C,
+                       "parallelism": f"voxel-batch sharding x{world} + plot-slice sharding x{world}, 2 RCCL all-gathers"},
+            "stages_s_rank0_last_step": {k: round(v, 4) for k, v in stats.items() if k.endswith("_s")},
+            "classified_points_per_s": stats.get("classified_points", 0) / max(stats.get("classify_s", 1e-9), 1e-9),
+        }), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
@@ -210,10 +370,13 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=device)
 
+    if args.workload == "plot":
+        return plot_main(args, world, rank, device, dist)
+
     from pointstowood_amd import synthetic_weights as weights
     from pointstowood_amd import Net
     from pointstowood_amd.dist import gather_logits
-    net = Net(num_classes=1, C=C, k=K_NBR, precision=args.precision)
+    net = Net(num_classes=1, C=C, k=K_NBR, precision=args.precision, **engine_options(args.engine_opt))
     net.load_state_dict(weights.synth_state_dict(1, C, seed=0), strict=True)
     net = net.to(device).eval()
     nb = max(1, args.batches)
@@ -222,6 +385,8 @@ def main():
     pinned = [{k: b[k].pin_memory() for k in Feed.FIELDS} for b in host]
     out_host = [torch.empty(BATCH * NPTS, dtype=torch.float32).pin_memory() for _ in range(nb)]
     peak = PEAK_TFLOPS[args.precision]
+
+    gather_marks = []
 
     def run(n, pcie=False, stamps=None):
         """n steps = n full forwards (geometry + features) of one voxel batch each, rotating over the distinct batches.
@@ -234,7 +399,14 @@ def main():
                 yield Feed.to_device(pinned[i % nb], device, non_blocking=True) if pcie else resident[i % nb]
 
         def finish(i, logits):
-            o = gather_logits(logits, dist) if world > 1 else logits
+            if world > 1:   # the path's only collective, bracketed by events on the launch stream (its own time per step)
+                g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                g0.record()
+                o = gather_logits(logits, dist)
+                g1.record()
+                gather_marks.append((g0, g1))
+            else:
+                o = logits
             if pcie:
                 out_host[i % nb].copy_(logits, non_blocking=True)
             if stamps is not None:
@@ -265,25 +437,34 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        ranks = None
         if world > 1:
-            t = torch.tensor([dt], device=device, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t)
+            # every rank's own wall time and the time its gathers took (diagnosis of a scaling curve: a slow rank, or the
+            # collective, shows up here); `dt` = the maximum over ranks, as the contract says
+            gather_ms = sum(a.elapsed_time(b) for a, b in gather_marks[-n:]) / n
+            mine = torch.tensor([dt, gather_ms], device=device, dtype=torch.float64)
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            dts = [float(t[0]) for t in allr]
+            ranks = {"ms_per_step_min": min(dts) / n * 1e3, "ms_per_step_max": max(dts) / n * 1e3,
+                     "ms_per_step_by_rank": [round(v / n * 1e3, 4) for v in dts],
+                     "gather_ms_per_step_by_rank": [round(float(t[1]), 4) for t in allr]}
+            dt = max(dts)
         marks = [s0] + stamps
         per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(n)]   # completion-to-completion, ms
-        return dt, per_step, out
+        return dt, per_step, out, ranks
 
     # setup, not warmup: one untimed forward per distinct batch so that the caching allocator has seen every workspace size
     # (level sizes are data-dependent; a first-time hipMalloc inside the timed region costs milliseconds); then W warmup steps
     for d in resident:
         net(d)
     run(args.warmup)
-    dt, per_step, out = timed(args.steps, False)
+    dt, per_step, out, rank_stats = timed(args.steps, False)
     assert bool(torch.isfinite(out).all())
     pcie = None
     if not args.no_pcie:
         run(min(2, args.warmup), pcie=True)
-        dt_p, per_p, _ = timed(args.steps, True)
+        dt_p, per_p, _, _ = timed(args.steps, True)
         pcie = {"value": world * args.steps * BATCH * NPTS / dt_p, "unit": "points/s", "ms_per_step": dt_p / args.steps * 1e3,
                 "ms_per_step_median": statistics.median(per_p),
                 "what": "same steps with the inputs (pos, batch, reflectance, sf, ptr: 2.7 MB) copied from pinned host memory and "
@@ -340,8 +521,12 @@ def main():
             "hbm_kernels": hbm,
             "kernel_ms_per_step": {kname: round(v[0], 4) for kname, v in sorted(per.items(), key=lambda kv: -kv[1][0])},
         }
+        if rank_stats is not None:
+            line["ranks"] = rank_stats
+        if world == 1 and not args.no_workloads:
+            line["workloads"] = extra_workloads(net, args, device)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(host[0])
+            line["cpu_baseline"] = cpu_baseline(host[0], full=args.cpu_baseline_full)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

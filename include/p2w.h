@@ -258,7 +258,9 @@ int32_t p2w_packed_dims_h(int32_t prec, int32_t N, int32_t K, int32_t* N_pad, in
 #define P2W_SA_ITEM_128 2        /* 8 targets x 128 output columns per work item */
 #define P2W_SA_PACK8 4           /* targets with <= 8 neighbours share a 32-row MFMA tile four at a time (sparse ball-query levels) */
 /* bits 16..23 of `flags` of p2w_gemm_h2 / p2w_sa_conv_h: profiling ablations, honoured only by diagnostic builds
- * (-DP2W_GEMM_ABLATE / -DP2W_SA_ABLATE); production builds ignore them. */
+ * (-DP2W_GEMM_ABLATE / -DP2W_SA_ABLATE); production builds ignore them.
+ * bits 8..15 of `flags` of p2w_gemm_h2: scheduling experiments (tools/gemm_desync.py; results unchanged): bits 8..13 = start
+ * stagger of every other workgroup of an XCD in units of 2 us, bit 14 / 15 = persistent grid on 1/2 / 1/4 of the CUs. */
 
 /* p2w_gemm with an H A operand, H weights and fp32 and/or H outputs (either pointer may be NULL):
  * Linear / 1x1 Conv1d + folded BatchNorm / depthwise affines + ReLU + residual - model.py:75-85, :198-202, :241-242. */

@@ -17,8 +17,10 @@ from __future__ import annotations
 import torch
 import torch.nn.functional as F
 
-from . import ops
+from . import ops as _oracle_ops
 from .weights import BN_EPS, fp_channels, sa_channels  # noqa: F401
+
+ops = _oracle_ops   # the operator module the functions below call; ``forward(..., ops=module)`` swaps it for one call
 
 
 def _bn(sd, p, x):
@@ -65,13 +67,15 @@ def _pointnet_conv(sd, p, x, pos_src, pos_dst, src, dst):
     pos_j, pos_i = pos_src[src], pos_dst[dst]
     rel = pos_j[:, :3] - pos_i[:, :3]
     nrm = torch.norm(rel, dim=1, keepdim=True)
-    dmax, _ = ops.scatter_max(nrm, dst, dim=0)
-    msg = torch.zeros((pos_j.shape[0], pos_j.shape[1]))
+    dmax, _ = ops.scatter_max(nrm, dst, dim=0, dim_size=pos_dst.shape[0])
+    msg = torch.zeros((pos_j.shape[0], pos_j.shape[1]), device=pos_j.device)
     msg[:, :3] = rel / (dmax[dst] + 1e-8)
     msg[:, 3] = pos_j[:, 3]
     msg = torch.cat([x[src], msg], dim=1)
     msg = _mlp(sd, p + ".local_nn", msg, 2)
-    return ops.segment_max_rows(msg, dst, pos_dst.shape[0])
+    if hasattr(ops, "segment_max_rows"):
+        return ops.segment_max_rows(msg, dst, pos_dst.shape[0])
+    return ops.scatter_max(msg, dst, dim=0, dim_size=pos_dst.shape[0])[0]   # = MessagePassing.propagate's aggr='max'
 
 
 def _sa(sd, p, resolution, k, x, pos, batch, reflectance, sf, cap):
@@ -107,8 +111,17 @@ def _fp(sd, p, k, x, pos, batch, x_skip, pos_skip, batch_skip, cap):
 
 
 @torch.no_grad()
-def forward(sd, pos, batch, reflectance, sf, k: int = 32, capture: dict | None = None):
-    """logits [sum N] fp32.  ``k`` overrides ``SAModule.k`` (hard-coded 32 at model.py:210-212)."""
+def forward(sd, pos, batch, reflectance, sf, k: int = 32, capture: dict | None = None, ops=None):
+    """logits [sum N] fp32.  ``k`` overrides ``SAModule.k`` (hard-coded 32 at model.py:210-212).
+    ``ops``: another module with the operators' call signatures (``pointstowood_amd.ops`` on GPU tensors: the composition
+    test of INTEGRATION.md's route B); default = ``oracle.ops``."""
+    if ops is not None:
+        global_ops = globals()["ops"]
+        globals()["ops"] = ops
+        try:
+            return forward(sd, pos, batch, reflectance, sf, k=k, capture=capture)
+        finally:
+            globals()["ops"] = global_ops
     cap = capture
     x0 = _mlp(sd, "stem_mlp", pos[:, :3], 1)
     sa0 = (x0, pos, batch, reflectance, sf)
@@ -116,9 +129,9 @@ def forward(sd, pos, batch, reflectance, sf, k: int = 32, capture: dict | None =
     sa2 = _sa(sd, "sa2_module", 0.08, k, *sa1, cap)
     sa3 = _sa(sd, "sa3_module", 0.16, k, *sa2, cap)
     # GlobalSAModule.forward (model.py:134-140)
-    x4 = ops.global_max_pool(_mlp(sd, "sa4_module.NN", torch.cat([sa3[0], sa3[1]], dim=1), 2), sa3[2])
+    x4 = globals()["ops"].global_max_pool(_mlp(sd, "sa4_module.NN", torch.cat([sa3[0], sa3[1]], dim=1), 2), sa3[2])
     nb = x4.shape[0]
-    sa4 = (x4, torch.zeros((nb, 3)), torch.arange(nb))
+    sa4 = (x4, torch.zeros((nb, 3), device=pos.device), torch.arange(nb, device=pos.device))
     if cap is not None:
         cap["stem"] = x0
         cap["sa4_module.out"] = x4

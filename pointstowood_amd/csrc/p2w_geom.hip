@@ -339,7 +339,16 @@ __global__ __launch_bounds__(256) void tk_insert_kernel(const float4* __restrict
     const long long k1 = (long long)((p.y - g.lo1) / res);
     const long long k2 = (long long)((p.z - g.lo2) / res);
     const long long kb = (long long)(((float)b - (float)g.b_lo) / 1.0f);
-    const int t = (int)(k0 + k1 * g.c0 + k2 * (g.c0 * g.c1) + kb * g.cells);
+    const long long tl = k0 + k1 * g.c0 + k2 * (g.c0 * g.c1) + kb * g.cells;
+    // a non-finite coordinate (fminf / fmaxf of the bounding-box pass ignore NaN; the float -> int64 cast of one is undefined)
+    // must not become a table index: report it like a grid that does not fit - the caller repeats the level with the sort
+    // sampler, which only ever forms a (garbage) key from it
+    if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) || tl < 0 || tl >= g.T || k0 < 0 || k0 >= g.c0 || k1 < 0 || k1 >= g.c1 || k2 < 0 || k2 >= g.c2) {
+        *status = 1;
+        key32[i] = 0;
+        return;
+    }
+    const int t = (int)tl;
     key32[i] = t;
     atomicMax(&tab_max[t], i);
     if (cnt) atomicAdd(&cnt[t], 1);

@@ -682,10 +682,14 @@ template <int PREC, int WR, int WC, int RT, int CT>
 __global__ __launch_bounds__(64 * WR * WC, 2) void gemm_hp_kernel(const _Float16* __restrict__ A, int ldh_a,
                                                                const _Float16* __restrict__ Wh, float wscale, int M, int N,
                                                                int Kpad, int nMt, int nNt, int nvb, EpiArgs ep, OutArgs o, int ef,
-                                                               int tmode) {
+                                                               int tmode, int stagger) {
     constexpr int KS = HCfg<PREC>::kslab;
     constexpr int BM = 32 * RT * WR, BN = 32 * CT * WC, NW = WR * WC;
     constexpr int A_CH = 8 * BM, STAGE_CH = A_CH + 8 * BN;
+    if (stagger > 0 && ((blockIdx.x >> 3) & 1)) {   // start stagger (100 MHz ticks): every other workgroup of an XCD starts late
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)stagger) __builtin_amdgcn_s_sleep(16);
+    }
     constexpr bool HALF = NW == 8;                        // 8-wave tile: waves 0..3 issue the whole stage (see gemm_h2g_kernel)
     constexpr int NWI = HALF ? NW / 2 : NW;
     constexpr int NI = STAGE_CH / 64 / NWI;
@@ -898,19 +902,22 @@ static int32_t launch_gemm_h(const _Float16* Ah, int32_t ldh_a, const _Float16* 
     }
 #else
     (void)dbg;
+    const int stagger = ((flags >> 8) & 63) * 200;             // diagnostic: start stagger in units of 2 us
+    const int gdiv = (flags & (1 << 14)) ? 2 : (flags & (1 << 15)) ? 4 : 1;   // diagnostic: persistent grid on 1/2, 1/4 of the CUs
     auto pgrid = [&](int nvb, int per_cu) {   // persistent grid: whole XCD rounds, at most per_cu workgroups per CU
-        int g = nvb < n_cu * per_cu ? nvb : n_cu * per_cu;
+        const int cap = n_cu * per_cu / gdiv;
+        int g = nvb < cap ? nvb : cap;
         if (g >= 8) g &= ~7;
         return g;
     };
     if (big) {
         const int nMt = p2w_cdiv(M, 256), nNt2 = Npad / 256;
         const int tm = pick_mode(nNt2), nvb = tile_grid(nMt, nNt2, tm);
-        gemm_hp_kernel<PREC, 2, 4, 4, 2><<<pgrid(nvb, 1), 512, 0, stream>>>(Ah, ldh_a, Wp, wscale, M, N, Kpad, nMt, nNt2, nvb, ep, o, ef, tm);
+        gemm_hp_kernel<PREC, 2, 4, 4, 2><<<pgrid(nvb, 1), 512, 0, stream>>>(Ah, ldh_a, Wp, wscale, M, N, Kpad, nMt, nNt2, nvb, ep, o, ef, tm, stagger);
     } else {
         const int nMt = p2w_cdiv(M, 128), nNt1 = p2w_cdiv(N, 128);
         const int tm = pick_mode(nNt1), nvb = tile_grid(nMt, nNt1, tm);
-        gemm_hp_kernel<PREC, 2, 2, 2, 2><<<pgrid(nvb, 2), 256, 0, stream>>>(Ah, ldh_a, Wp, wscale, M, N, Kpad, nMt, nNt1, nvb, ep, o, ef, tm);
+        gemm_hp_kernel<PREC, 2, 2, 2, 2><<<pgrid(nvb, 2), 256, 0, stream>>>(Ah, ldh_a, Wp, wscale, M, N, Kpad, nMt, nNt1, nvb, ep, o, ef, tm, stagger);
     }
 #endif
     return P2W_LAUNCH_STATUS();

@@ -19,8 +19,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
-import os
-from dataclasses import dataclass, field
+from dataclasses import dataclass, field, fields
 
 import torch
 
@@ -216,8 +215,38 @@ def pick_chunk(m: int, budget: int, col_tiles: int, n_cu: int = 256) -> int:
     return best
 
 
+@dataclass
+class EngineOptions:
+    """Behaviour switches of the forward.  They are keyword arguments of ``Net(...)`` / ``Engine(...)`` - the product reads
+    no environment variables (nor does the C ABI behind it).  Every combination gives the same results; the defaults are
+    the measured-fastest ones on MI355X, the others exist for A/B runs, tests and odd inputs."""
+    sampler: str = "table"        # grid sub-sampling: "table" = direct cell table (no sort; per-batch fallback to the sort), "sort"
+    search: str = "grid"          # neighbour searches: "grid" = cell-indexed (p2w_*_grid), "brute" = whole-voxel streaming kernels
+    table_cells_per_point: float = 32.0   # the table sampler is taken while its table has at most this many entries per point
+    fp_hints: bool = True         # seed the k = 2 interpolation searches from the sampler's ranks (p2w_knn_hint2)
+    sa_pack: bool = True          # P2W_SA_PACK8 on the ball-query level (targets with <= 8 neighbours share an MFMA tile)
+    chunk_pick: bool = True       # fill-aware row-chunk sizes (pick_chunk); False: the plain budget
+    res_chunk_rows: int = 131072  # rows (at 4F = 512) per residual-block / FP chunk; 0 = whole level (swept: tools/chunk_sweep.sh)
+    res_streams: int = 1          # residual-block chunk chains in flight (2: +0.6 %, measured)
+    feature_streams: int = 1      # Net.stream(): feature phases in flight
+    geo_priority: int = 0         # HIP stream priorities of the two-stream pipeline (features are the critical path)
+    feat_priority: int = -1
+    gemm_flags: int = 0           # P2W_GEMM_* bits of include/p2w.h passed to every p2w_gemm_h2 call (A/B runs)
+    sa_flags: int = 0             # P2W_SA_ITEM_* bits passed to p2w_sa_conv_h (A/B runs)
+
+    def __post_init__(self):
+        if self.sampler not in ("table", "sort"):
+            raise ValueError("sampler must be 'table' or 'sort'")
+        if self.search not in ("grid", "brute"):
+            raise ValueError("search must be 'grid' or 'brute'")
+
+    @classmethod
+    def names(cls):
+        return tuple(f.name for f in fields(cls))
+
+
 class Engine:
-    def __init__(self, weights: PackedWeights, k: int = 32, precision: str = "f16x3"):
+    def __init__(self, weights: PackedWeights, k: int = 32, precision: str = "f16x3", options: EngineOptions | None = None, **kw):
         self.w = weights
         self.k = int(k)
         if precision not in ("f16x3", "fp32", "fp16", "bf16"):
@@ -231,17 +260,12 @@ class Engine:
         if not 1 <= self.k <= 32:
             raise ValueError("k must be in 1..32: the fused PointNetConv maps a target's neighbour slots onto one 32-row MFMA "
                              "tile (P2W_MAX_K_CONV in include/p2w.h); the reference hard-codes k = 32 (model.py:210-212)")
-        self.feature_streams = int(os.environ.get("P2W_FEATURE_STREAMS", "1"))  # Net.stream(): feature phases in flight
-        self.chunk_pick = int(os.environ.get("P2W_CHUNK_PICK", "1"))       # fill-aware chunk sizes (pick_chunk); 0: plain budget
-        self.fp_hints = os.environ.get("P2W_FP_HINTS", "1") != "0"           # seed the interpolation searches from the sampler
-        self.res_streams = int(os.environ.get("P2W_RES_STREAMS", "1"))      # residual-block chunk chains in flight (2: +0.6 %, measured)
-        self.res_chunk_rows = int(os.environ.get("P2W_RES_CHUNK", "131072"))  # rows (at 4F=512) per residual-block chunk; 0 = whole level (swept: tools/chunk_sweep.sh)
-        self.gemm_flags = int(os.environ.get("P2W_GEMM_FLAGS", "0"))          # P2W_GEMM_* bits of include/p2w.h (A/B runs)
-        self.sa_flags = int(os.environ.get("P2W_SA_FLAGS", "0"))              # P2W_SA_ITEM_* bits (A/B runs)
-        self.sa_pack = os.environ.get("P2W_SA_PACK", "1") != "0"              # P2W_SA_PACK8 on the ball-query level
-        # grid sub-sampling: "table" = direct cell table (no sort; falls back per batch when the grid does not fit), "sort"
-        self.sampler = os.environ.get("P2W_SAMPLER", "table")
-        self._table_scale = [1, 1, 1]   # per level: grows by 8 after an overflow, 0 = table given up for this level
+        if options is not None and kw:
+            raise TypeError("pass either options= or individual EngineOptions fields")
+        self.options = options if options is not None else EngineOptions(**kw)
+        for name in EngineOptions.names():      # the switches live on the engine (tools flip them between runs)
+            setattr(self, name, getattr(self.options, name))
+        self._table_scale = [1, 1, 1]   # per level: grows by 8 (up to TABLE_SCALE_MAX) after an overflow
         self._ws_t = None
         self.events = None  # set to a list to record (name, start, end) events per launch
         self.events_grouped = False   # True: (name, start, end, launches) per run of consecutive same-name launches
@@ -289,15 +313,25 @@ class Engine:
         self._call(name, lib().p2w_gemm, ptr(A), lda, ptr(lin.w), M, lin.N, lin.K, C.byref(ep), ptr(out), ldo)
 
     TABLE_CELLS_MAX = 1 << 26          # 64 M entries x 20 B = 1.3 GB of workspace at most
+    TABLE_SCALE_MAX = 64               # growth factor cap of a level's table after overflows
 
-    def _table_cells(self, level, B):
+    def _table_cells(self, level, B, N):
         """Table entries for the sampler of `level`: B voxels x the cells of a 2.3 m cube at that resolution (+ margin), times
-        the level's growth factor.  0: use the sort."""
-        if self.sampler != "table" or self._table_scale[level] == 0:
+        the level's growth factor.  0: use the sort.  The table's cost grows with its CELLS (12 B of memset per entry, two scan
+        passes, a compaction), the sort's with the POINTS: many small voxels (B in the hundreds, a few hundred points each) give
+        tens of millions of cells for half a million points, so the table is only taken while it has at most
+        ``table_cells_per_point`` entries per point (and fits TABLE_CELLS_MAX) - decided per batch, nothing is remembered."""
+        if self.sampler != "table":
             return 0
         per_voxel = (int(2.3 / SA_RES[level]) + 3) ** 3
+        limit = min(self.TABLE_CELLS_MAX, self.table_cells_per_point * max(N, 1))
         cells = B * per_voxel * self._table_scale[level]
-        return cells if cells <= self.TABLE_CELLS_MAX else 0
+        if cells > limit and B * per_voxel <= limit:
+            # the room earlier (larger) voxels asked for no longer pays, the plain 2.3 m provision would: start over with it
+            # (a batch of large voxels then costs one repeated geometry pass, as the first one did)
+            self._table_scale[level] = 1
+            cells = B * per_voxel
+        return cells if cells <= limit else 0
 
     def _table_workspace(self, n, cells, device):
         need = int(lib().p2w_voxel_sample_table_ws_bytes(n, cells))
@@ -342,7 +376,7 @@ class Engine:
                 self._call("tile_bbox", L.p2w_tile_bbox, ptr(lv_.xyzr), ptr(lv_.ptr), B, N, ptr(t))
                 bbox[level] = t
             return bbox[level]
-        grid_search = os.environ.get("P2W_SEARCH", "grid") != "brute"   # brute: whole-voxel streaming kernels (A/B, tests)
+        grid_search = self.search != "brute"   # brute: whole-voxel streaming kernels (A/B, tests)
         i64 = dict(dtype=torch.int64, device=dev)
         sorted0 = skeys0 = None   # level 0 in cell order (the level-1 sampler's sort), each record carrying its own index
         ckeys, grids, ranks = {}, {}, {}     # level -> cell key of every record (ascending) / p2w_grid of the sampling call
@@ -356,7 +390,7 @@ class Engine:
             # rank of every source point's cell among the sampled level (= index of its representative): seeds the
             # interpolation searches (level 0 takes part in its sorted order, so it needs the rank per sorted position)
             ranks[l] = torch.empty(N, **i32) if (grid_search and self.fp_hints) else None
-            cells = 0 if force_sort else self._table_cells(l, B)
+            cells = 0 if force_sort else self._table_cells(l, B, N)
             if cells:
                 ws_t = self._table_workspace(N, cells, dev)
                 geo.table_levels.append(l)
@@ -429,9 +463,8 @@ class Engine:
             # the batch's cell grid did not fit the sampler's table at these levels (device-side knowledge): everything
             # downstream of the first of them is undefined.  Repeat the geometry with the sort (rare: voxels much larger than
             # 2 m), and give the table 8 x the room next time.
-            for l in overflow:
-                grown = self._table_scale[l] * 8
-                self._table_scale[l] = grown if geo.B * (int(2.3 / SA_RES[l]) + 3) ** 3 * grown <= self.TABLE_CELLS_MAX else 0
+            for l in overflow:   # more room next time (capped); whether a batch's table is worth taking is _table_cells' decision
+                self._table_scale[l] = min(self._table_scale[l] * 8, self.TABLE_SCALE_MAX)
             with torch.cuda.stream(geo.stream):
                 redo = self._geometry_async(*geo.args, force_sort=True)
             redo.done.synchronize()
@@ -684,8 +717,8 @@ class Engine:
             # else, so IT gets the high-priority stream and the geometry of the next batch fills what is left (next to
             # the PointNetConv kernels, at kernel tails): measured 10.09 vs 10.23 ms per step against the opposite
             # assignment, 10.26 with both high, 10.23 with both normal.
-            self._s_geo = torch.cuda.Stream(priority=int(os.environ.get("P2W_GEO_PRIORITY", "0")))
-            self._s_feat = [torch.cuda.Stream(priority=int(os.environ.get("P2W_FEAT_PRIORITY", "-1")))
+            self._s_geo = torch.cuda.Stream(priority=int(self.geo_priority))
+            self._s_feat = [torch.cuda.Stream(priority=int(self.feat_priority))
                             for _ in range(max(1, self.feature_streams))]
         s_geo = self._s_geo
         f_streams = self._s_feat[: max(1, self.feature_streams)]

@@ -63,12 +63,20 @@ def write_ply(path, columns, comments=()):
     column float64 in input order; the header carries the reference's fixed comment / obj_info lines so that a file
     written here is indistinguishable from one written there (checked against a reference-written fixture)."""
     names = ["x", "y", "z"] + (["red", "green", "blue"] if "red" in columns else [])
-    names += [c for c in columns if c not in names]
     n = len(columns["x"])
+    data = {c: np.asarray(columns[c]).reshape(n) for c in names}
+    for c in columns:
+        if c in data:
+            continue
+        try:   # the reference drops, silently, every extra column that does not convert to float64 (io.py:72-78)
+            data[c] = np.asarray(columns[c]).reshape(n).astype(np.float64)
+            names.append(c)
+        except (TypeError, ValueError):
+            pass
     dt = np.dtype([(c, "<i4" if c in ("red", "green", "blue") and "red" in columns else "<f8") for c in names])
     rec = np.empty(n, dtype=dt)
     for c in names:
-        rec[c] = np.asarray(columns[c]).reshape(n)
+        rec[c] = data[c]
     with open(path, "wb") as f:
         f.write(b"ply\nformat binary_little_endian 1.0\ncomment Author: Phil Wilkes\n")
         for c in comments:

@@ -16,7 +16,7 @@ import math
 import torch
 
 from . import _lib
-from .engine import Engine, PackedWeights
+from .engine import Engine, EngineOptions, PackedWeights
 
 
 def _bn(prefix, c):
@@ -73,9 +73,13 @@ class _Node(torch.nn.Module):
 
 
 class Net(torch.nn.Module):
-    def __init__(self, num_classes: int, C: int = 32, k: int = 32, precision: str = "f16x3"):
+    def __init__(self, num_classes: int, C: int = 32, k: int = 32, precision: str = "f16x3", **engine_options):
+        """``num_classes`` / ``C`` as the reference's ``Net``; ``k`` = neighbours per SA level (the reference hard-codes 32);
+        ``precision`` see below; ``engine_options``: fields of ``engine.EngineOptions`` (sampler=, search=, sa_pack=, ...),
+        the behaviour switches of the forward - keyword arguments, not environment variables."""
         super().__init__()
         self.num_classes, self.C, self.k = int(num_classes), int(C), int(k)
+        self.engine_options = EngineOptions(**engine_options)
         # "f16x3": split-fp16 MFMA, fp32 accumulate (parity default); "fp32": fp32 MFMA; "fp16" / "bf16": one MFMA per
         # product like the reference's torch.cuda.amp.autocast path (predicter.py:197) - faster, NOT within 1e-4
         self.precision = precision
@@ -127,9 +131,9 @@ class Net(torch.nn.Module):
     def _ensure_packed(self, device):
         if self._packed is None or self._packed.device != device or self._packed.precision != self.precision:
             self._packed = PackedWeights(self.state_dict(), self.C, self.num_classes, device, self.precision)
-            self._engine = Engine(self._packed, k=self.k, precision=self.precision)
-        if self._engine.k != self.k or self._engine.precision != self.precision:
-            self._engine = Engine(self._packed, k=self.k, precision=self.precision)
+            self._engine = Engine(self._packed, k=self.k, precision=self.precision, options=self.engine_options)
+        if self._engine.k != self.k or self._engine.precision != self.precision or self._engine.options is not self.engine_options:
+            self._engine = Engine(self._packed, k=self.k, precision=self.precision, options=self.engine_options)
         return self._engine
 
     # -- forward --------------------------------------------------------------------------------

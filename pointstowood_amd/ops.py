@@ -9,7 +9,8 @@ module instead of torch-geometric / torch-cluster / torch-scatter):
     scatter_max(src, index, dim=0)                     pointnet.py:122
     global_max_pool(x, batch)                          model.py:136
     knn_interpolate(x, pos_x, pos_y, batch_x, batch_y, k)  model.py:149
-    pointnet_conv(...)                                 pointnet.py:86-132 (fused: see engine.py)
+    MessagePassing.propagate(edge_index, x=, pos=)  (aggr=max)   pointnet.py:108 -> ``MessagePassing`` below
+    PointNetConv(local_nn, ...)(x, (pos, pos[idx]), edge_index)   pointnet.py:19-132, called at model.py:123 (fused kernel)
 
 Every function requires CUDA (MI355X) tensors and libp2w_gfx950.so; there is no fallback.
 Index results are int64 like the reference's; the kernels work in int32 internally.
@@ -143,14 +144,155 @@ def scatter_max(src, index, dim=0, out=None, dim_size=None):
 
 
 def knn_interpolate(x, pos_x, pos_y, batch_x=None, batch_y=None, k=3, num_workers=1):
+    """PyG's signature and default (k = 3); any 1 <= k <= 64 and any feature width (rows are padded to a multiple of 4
+    floats for the kernel's 16-byte accesses)."""
     _lib.require_cuda(x, pos_x, pos_y)
-    if k > 2 or x.shape[1] % 4:
-        raise RuntimeError("knn_interpolate: k <= 2 and a feature width that is a multiple of 4 are supported")
+    if not 1 <= k <= 64:
+        raise RuntimeError("knn_interpolate: k must be in 1..64")
     nbr, deg = _search("knn", pos_x, pos_y, None, batch_x, batch_y, int(k))
-    m, F = pos_y.shape[0], x.shape[1]
+    m, F0 = pos_y.shape[0], x.shape[1]
+    F = (F0 + 3) // 4 * 4
+    xc = x.to(torch.float32)
+    if F != F0:
+        xc = torch.nn.functional.pad(xc, (0, F - F0))
+    xc = xc.contiguous()
     out = torch.empty((m, F), dtype=torch.float32, device=x.device)
-    xc = x.to(torch.float32).contiguous()
     rc, rf = _xyzr(pos_x), _xyzr(pos_y)   # keep both alive until the launch is enqueued
     check(lib().p2w_interp_concat(ptr(xc), F, ptr(rc), ptr(rf), ptr(nbr), ptr(deg), int(k), None, 0, m,
                                   ptr(out), F, stream()), "knn_interpolate")
-    return out
+    return out if F == F0 else out[:, :F0].contiguous()
+
+
+# --------------------------------------------------------------------------- the 8th operator
+class MessagePassing(torch.nn.Module):
+    """The part of PyG's ``MessagePassing`` the reference uses (``pointnet.py:19,71,108``): ``propagate(edge_index, **kw)``
+    with ``flow='source_to_target'`` and ``aggr='max'``.  ``edge_index[0]`` = source j, ``edge_index[1]`` = target i,
+    grouped by target (as ``radius`` / ``knn`` return them).  ``message``'s parameters are collected the PyG way:
+    ``<name>_j`` = ``kw[name]`` (its first element if a pair) gathered by source, ``<name>_i`` = (second element) by
+    target, ``edge_index_i`` / ``edge_index_j`` the index rows; the messages are max-aggregated per target
+    (``scatter_max``, HIP), targets without edges get 0.  The reference's own ``PointNetConv`` subclass runs on this
+    base unchanged; ``PointNetConv`` below is the fused replacement of the whole layer."""
+
+    def __init__(self, aggr="max", flow="source_to_target", **kw):
+        super().__init__()
+        if aggr != "max" or flow != "source_to_target":
+            raise NotImplementedError("only aggr='max', flow='source_to_target' (what the reference uses)")
+        self.aggr, self.flow = aggr, flow
+
+    def reset_parameters(self):
+        pass
+
+    def propagate(self, edge_index, size=None, **kw):
+        import inspect
+        j, i = edge_index[0], edge_index[1]
+        args = {}
+        for name in inspect.signature(self.message).parameters:
+            if name == "edge_index_i":
+                args[name] = i
+            elif name == "edge_index_j":
+                args[name] = j
+            elif name.endswith("_j") or name.endswith("_i"):
+                v = kw[name[:-2]]
+                side = 0 if name.endswith("_j") else 1
+                v = v[side] if isinstance(v, (tuple, list)) else v
+                args[name] = None if v is None else v[j if side == 0 else i]
+            else:
+                args[name] = kw[name]
+        msg = self.message(**args)
+        if size is not None:
+            n_dst = size[1] if isinstance(size, (tuple, list)) else size
+        else:
+            n_dst = None
+            for v in kw.values():   # number of targets = rows of the second element of any pair argument
+                if isinstance(v, (tuple, list)) and v[1] is not None:
+                    n_dst = v[1].shape[0]
+                    break
+                if torch.is_tensor(v):
+                    n_dst = v.shape[0]
+            if n_dst is None:
+                n_dst = int(i.max()) + 1
+        return scatter_max(msg, i, dim=0, dim_size=n_dst)[0]
+
+
+def _local_nn_weights(local_nn):
+    """(W1, b1, W2, b2, bn_scale, bn_shift) of ``MLP([F_in + 4, C1, C2])`` (model.py:198-202): Lin + ReLU, Lin + ReLU + BN."""
+    try:
+        lin1, lin2, bn = local_nn[0][0], local_nn[1][0], local_nn[1][2]
+    except (TypeError, IndexError) as e:
+        raise NotImplementedError("the fused PointNetConv supports local_nn = MLP([F_in + 4, C1, C2]) as the reference builds it") from e
+    if bn.training:
+        raise RuntimeError("pointstowood_amd.ops.PointNetConv is inference-only: call .eval()")
+    s = (bn.weight.double() / torch.sqrt(bn.running_var.double() + bn.eps))
+    t = bn.bias.double() - bn.running_mean.double() * s
+    return lin1.weight, lin1.bias, lin2.weight, lin2.bias, s.float(), t.float()
+
+
+class PointNetConv(MessagePassing):
+    """Drop-in for the reference's ``src.pointnet.PointNetConv`` (``pointnet.py:19-132``; built at ``model.py:94``, called
+    at ``:123``) in eval mode: same constructor, same parameter names (``local_nn.*``), same
+    ``forward(x, (pos_src, pos_dst), edge_index)`` with ``pos`` = [n, 4] (sf-scaled xyz, reflectance) - message MLP +
+    max aggregation by ONE fused HIP kernel (``p2w_sa_conv``, fp32 MFMA: the [E, C] edge tensors are never formed) after a
+    hoisted layer-1 GEMM (``p2w_gemm``).  Edges must be grouped by target with at most ``P2W_MAX_K_CONV`` = 32 per target
+    (``radius(max_num_neighbors=32)`` / ``knn(k=32)`` as the reference calls them); ``global_nn`` is applied afterwards as
+    in the reference; ``add_self_loops`` must be False (the reference passes False)."""
+
+    def __init__(self, local_nn=None, global_nn=None, add_self_loops=True, **kw):
+        self.radius = kw.pop("radius", None)
+        kw.setdefault("aggr", "max")
+        super().__init__(**kw)
+        self.local_nn, self.global_nn, self.add_self_loops = local_nn, global_nn, add_self_loops
+
+    @torch.no_grad()
+    def forward(self, x, pos, edge_index):
+        import ctypes as C
+        if self.add_self_loops:
+            raise NotImplementedError("add_self_loops=True is not supported (the reference builds the layer with False)")
+        x_src = x[0] if isinstance(x, (tuple, list)) else x
+        pos_src, pos_dst = pos if isinstance(pos, (tuple, list)) else (pos, pos)
+        _lib.require_cuda(x_src, pos_src, pos_dst, edge_index)
+        dev = pos_src.device
+        W1, b1, W2, b2, bn_s, bn_t = _local_nn_weights(self.local_nn)
+        n_src, M, F_in = pos_src.shape[0], pos_dst.shape[0], x_src.shape[1]
+        C1, C2 = W1.shape[0], W2.shape[0]
+        if W1.shape[1] != F_in + 4 or pos_src.shape[1] != 4 or C1 % 4:
+            raise RuntimeError("PointNetConv: local_nn must take F_in + 4 inputs, pos must be [n, 4], C1 a multiple of 4")
+        j, i = edge_index[0].to(torch.int64), edge_index[1].to(torch.int64)
+        E = j.numel()
+        deg = torch.bincount(i, minlength=M)
+        if E and (int(deg.max()) > 32 or bool((i[1:] < i[:-1]).any())):
+            raise RuntimeError("PointNetConv: edges must be grouped by target, at most 32 per target")
+        start = torch.cumsum(deg, 0) - deg
+        nbr = torch.full((M, 32), -1, dtype=torch.int32, device=dev)
+        if E:
+            nbr[i, torch.arange(E, device=dev) - start[i]] = j.to(torch.int32)
+        deg = deg.to(torch.int32)
+        f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
+        # hoisted layer 1: P = x_src W1x^T + b1 once per source point
+        Np, Kp = _lib.packed_dims(C1, F_in)
+        Wx = torch.zeros((Np, Kp), dtype=torch.float32, device=dev)
+        Wx[:C1, :F_in] = f32(W1[:, :F_in])
+        xs = f32(x_src)
+        if F_in % 4:
+            xs = torch.nn.functional.pad(xs, (0, 4 - F_in % 4)).contiguous()
+        # (+ M zero rows: an empty neighbour slot is addressed through the target's own record, which follows the sources)
+        P = torch.zeros((n_src + M, C1), dtype=torch.float32, device=dev)
+        b1d = f32(b1)
+        ep = _lib.Epilogue(ptr(b1d), None, None, None, None, None, 0, 0, 0, 0, 0)
+        check(lib().p2w_gemm(ptr(xs), xs.shape[1], ptr(Wx), n_src, C1, F_in, C.byref(ep), ptr(P), C1, stream()), "PointNetConv hoist")
+        _, C1p = _lib.packed_dims(C2, C1)
+        w1r4 = torch.zeros((4, C1p), dtype=torch.float32, device=dev)
+        w1r4[:, :C1] = f32(W1[:, F_in:F_in + 4]).t()
+        N2p, _ = _lib.packed_dims(C2, C1)
+        W2p = torch.zeros((N2p, C1p), dtype=torch.float32, device=dev)
+        W2p[:C2, :C1] = f32(W2)
+        # sources and targets in one record array (the kernel addresses a target through an index into the sources)
+        rec = torch.cat([f32(pos_src), f32(pos_dst)], 0)
+        idx = torch.arange(n_src, n_src + M, dtype=torch.int32, device=dev)
+        one, zb = torch.ones(1, dtype=torch.float32, device=dev), torch.zeros(M, dtype=torch.int32, device=dev)
+        b2d, sd, td = f32(b2), f32(bn_s), f32(bn_t)
+        out = torch.empty((M, C2), dtype=torch.float32, device=dev)
+        check(lib().p2w_sa_conv(ptr(P), C1, ptr(rec), ptr(idx), ptr(zb), ptr(one), ptr(nbr), ptr(deg), 32, M, ptr(w1r4),
+                                ptr(W2p), C1, C2, ptr(b2d), ptr(sd), ptr(td), ptr(out), C2, stream()), "PointNetConv")
+        if self.global_nn is not None:
+            out = self.global_nn(out)
+        return out

@@ -17,6 +17,11 @@ from .predicter import PointBudgetSampler, collate_device
 from .preprocessing import voxelise
 
 
+def _sync(dev):
+    if dev.type == "cuda":   # (the sharding logic is also exercised on the CPU with stand-in stages: tests/test_host_cpu.py)
+        torch.cuda.synchronize(dev)
+
+
 def segment_plot(pc, model, grid_sizes=(2.0, 4.0), min_pts: int = 128, max_pts: int = 16384, is_wood: float = 0.5,
                  any_wood: float = 1.0, max_points: int = 524288, mode: str = "compat", generator=None, stats=None,
                  dist=None, max_voxels: int = 512, ground: bool = True):
@@ -35,7 +40,7 @@ def segment_plot(pc, model, grid_sizes=(2.0, 4.0), min_pts: int = 128, max_pts: 
     t0 = time.perf_counter()
     vox, n_z = voxelise(pc, tuple(grid_sizes), min_pts, max_pts, mode=mode, generator=generator, ground=ground)
     if stats is not None:
-        torch.cuda.synchronize(dev)
+        _sync(dev)
         stats["voxelise_s"], t0 = time.perf_counter() - t0, time.perf_counter()
         stats["voxels"] = len(vox)
     n = pc.shape[0]
@@ -69,7 +74,7 @@ def segment_plot(pc, model, grid_sizes=(2.0, 4.0), min_pts: int = 128, max_pts: 
     cls_xyz, cls_prob = cls[:, :3].contiguous(), cls[:, 3].contiguous()
     cls_pred = (cls_prob >= is_wood).to(torch.float32)                                       # predicter.py:200
     if stats is not None:
-        torch.cuda.synchronize(dev)
+        _sync(dev)
         stats["classify_s"], t0 = time.perf_counter() - t0, time.perf_counter()
         stats["classified_points"] = int(cls_prob.numel())
     q0, q1 = slice_for_rank(n, rank, world)
@@ -78,6 +83,6 @@ def segment_plot(pc, model, grid_sizes=(2.0, 4.0), min_pts: int = 128, max_pts: 
         both = gather_rows(torch.stack([label, pwood], 1), dist)
         label, pwood = both[:, 0].contiguous(), both[:, 1].contiguous()
     if stats is not None:
-        torch.cuda.synchronize(dev)
+        _sync(dev)
         stats["backproject_s"] = time.perf_counter() - t0
     return n_z, label, pwood

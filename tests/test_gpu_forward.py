@@ -271,3 +271,55 @@ def test_bench_contract_line():
         assert key in rf, key
     assert rf["bound"] in ("hbm", "mfma") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     assert abs(d["value"] - 8 * 16384 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+
+
+# ---- INTEGRATION.md route B as a composition: the reference forward's statements over pointstowood_amd.ops -----------------
+@pytest.mark.parametrize("name", ["u2_2k_k16_c32", "ragged_b2_refl_c8", "surface_cap_c4"])
+def test_reference_forward_over_the_operator_module_matches_reference_vectors(name):
+    """oracle/net.py restates Net.forward statement by statement over an operator module; with ops = pointstowood_amd.ops
+    (voxel_grid, consecutive_cluster, radius, knn, scatter_max, global_max_pool, knn_interpolate on the GPU, the dense
+    layers by PyTorch on the same device) the composition must reproduce the vectors the reference's own model produced:
+    what a maintainer gets from swapping the imports of src/model.py (route B)."""
+    from pointstowood_amd import ops as H
+    g, inp, meta = G.load(name)
+    sd = {k: v.cuda() for k, v in weights.synth_state_dict(1, meta["C"], seed=meta["wseed"]).items()}
+    cap = {}
+    logits = onet.forward(sd, inp["pos"].cuda(), inp["batch"].cuda(), inp["reflectance"].cuda(), inp["sf"].cuda(),
+                          k=meta["k"], capture=cap, ops=H)
+    assert onet.ops.__name__ == "oracle.ops"     # the swap is scoped to the call
+    for l in (1, 2, 3):
+        G.check(g, f"idx{l}", cap[f"sa{l}_module.idx"], what="route B ")
+        G.check(g, f"edge{l}.q", cap[f"sa{l}_module.edge_q"], what="route B ")
+        G.check(g, f"edge{l}.c", cap[f"sa{l}_module.edge_c"], what="route B ")
+    for n in ("sa1_module.conv", "sa2_module.out", "sa3_module.out", "sa4_module.out", "fp4_module.out", "fp1_module.out"):
+        G.check(g, n, cap[n], rtol=2e-4, atol=2e-4, what="route B ")
+    G.check(g, "logits", logits, rtol=1e-4, atol=4e-4)
+    G.check(g, "probs", torch.sigmoid(logits), atol=1e-4)
+
+
+def test_engine_switches_are_keyword_arguments_and_do_not_change_results():
+    """EngineOptions through Net(...): every combination gives bit-identical logits (sort sampler, whole-voxel searches,
+    no packing of low-degree targets, no search hints), and nothing is read from the environment."""
+    import os
+    from pointstowood_amd import Net
+    from pointstowood_amd.engine import EngineOptions
+    inp = synth.collate([synth.uniform_voxel(2.0, 6000, 61, True), synth.surface_voxel(2.0, 3000, 62, True)])
+    sd = weights.synth_state_dict(1, 8, seed=4)
+    d = _D()
+    d.pos, d.batch, d.reflectance, d.sf = (inp[k].cuda() for k in ("pos", "batch", "reflectance", "sf"))
+    outs = []
+    os.environ["P2W_SAMPLER"], os.environ["P2W_SEARCH"] = "nonsense", "nonsense"     # would have been read (and broken) before
+    try:
+        for kw in ({}, dict(sampler="sort"), dict(search="brute"), dict(sa_pack=False, fp_hints=False), dict(table_cells_per_point=0.0)):
+            net = Net(num_classes=1, C=8, k=32, **kw)
+            net.load_state_dict(sd, strict=True)
+            outs.append(net.cuda().eval()(d).clone())
+            assert net._engine.options == EngineOptions(**kw)
+    finally:
+        del os.environ["P2W_SAMPLER"], os.environ["P2W_SEARCH"]
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    with pytest.raises(TypeError):
+        Net(num_classes=1, C=8, no_such_option=1)
+    with pytest.raises(ValueError):
+        Net(num_classes=1, C=8, sampler="hash")

@@ -702,3 +702,105 @@ def test_knn_grid_with_sampler_hints_and_with_bogus_hints(sizes, surface):
     d2nd = ((q[ok] - coarse.cpu()[nb[ok][:, 1], :3]) ** 2).sum(1)
     hq = torch.empty(n); hq[order.cpu().long()] = hint.cpu()
     assert bool((d2nd <= hq[ok] * (1 + 1e-5) + 1e-12).all())
+
+
+# ---- the 8th operator (MessagePassing.propagate, aggr = max) and the fused PointNetConv layer ----------------------------
+def _sa_level_inputs(sizes, res, k, seed, surface=False, F_in=8):
+    """One SA level's inputs as SAModule.forward builds them (model.py:109-123): sources, sampled targets, edges."""
+    b = _batch(sizes, seed=seed, surface=surface)
+    pos4 = torch.cat([b["pos"], b["reflectance"][:, None]], 1)
+    idx = O.consecutive_cluster(O.voxel_grid(b["pos"], res, b["batch"]))[1]
+    if res == 0.04:
+        row, col = O.radius(b["pos"], b["pos"][idx], res * 2, b["batch"], b["batch"][idx], max_num_neighbors=k)
+    else:
+        row, col = O.knn(b["pos"], b["pos"][idx], k, b["batch"], b["batch"][idx])
+    pos4 = pos4.clone()
+    pos4[:, :3] = pos4[:, :3] / b["sf"][b["batch"]][:, None]
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(pos4.shape[0], F_in, generator=g)
+    return x, pos4, idx, torch.stack([col, row], 0)
+
+
+def _local_nn(F_in, C1, C2, seed):
+    """MLP([F_in + 4, C1, C2]) as model.py:198-202 builds it, with non-trivial BN statistics (negative scales included)."""
+    from torch.nn import BatchNorm1d as BN, Linear as Lin, ReLU, Sequential as Seq
+    torch.manual_seed(seed)
+    nn = Seq(Seq(Lin(F_in + 4, C1), ReLU()), Seq(Lin(C1, C2), ReLU(), BN(C2)))
+    bn = nn[1][2]
+    with torch.no_grad():
+        bn.weight.copy_(torch.randn(C2)); bn.bias.copy_(torch.randn(C2) * 0.3)
+        bn.running_mean.copy_(torch.randn(C2) * 0.2); bn.running_var.copy_(torch.rand(C2) + 0.5)
+    return nn.eval()
+
+
+def _message_reference(nn, x, pos_src, pos_dst, edge_index):
+    """PointNetConv.message + max aggregation (pointnet.py:111-132) in plain PyTorch on the CPU."""
+    j, i = edge_index
+    rel = pos_src[j, :3] - pos_dst[i, :3]
+    nrm = torch.norm(rel, dim=1, keepdim=True)
+    dmax = O.scatter_max(nrm, i, dim=0, dim_size=pos_dst.shape[0])[0]
+    msg = torch.zeros(j.numel(), 4)
+    msg[:, :3] = rel / (dmax[i] + 1e-8)
+    msg[:, 3] = pos_src[j, 3]
+    with torch.no_grad():
+        out = nn(torch.cat([x[j], msg], 1))
+    return O.segment_max_rows(out, i, pos_dst.shape[0])
+
+
+@pytest.mark.parametrize("sizes,res,k,surface", [([2000], 0.08, 32, False), ([1500, 300], 0.04, 32, True), ([900, 40], 0.16, 16, False)])
+def test_pointnet_conv_operator_matches_the_message_passing_definition(H, sizes, res, k, surface):
+    """ops.PointNetConv (fused p2w_gemm + p2w_sa_conv) == gather -> local_nn -> max, the layer of pointnet.py:86-132,
+    called the way model.py:123 calls it: conv(x, (pos, pos[idx]), edge_index)."""
+    F_in, C1, C2 = 8, 16, 32
+    x, pos4, idx, ei = _sa_level_inputs(sizes, res, k, seed=11, surface=surface, F_in=F_in)
+    nn = _local_nn(F_in, C1, C2, seed=5)
+    ref = _message_reference(nn, x, pos4, pos4[idx], ei)
+    import copy
+    conv = H.PointNetConv(local_nn=copy.deepcopy(nn), global_nn=None, add_self_loops=False, radius=res).cuda().eval()
+    assert [n for n, _ in conv.state_dict().items()][:2] == ["local_nn.0.0.weight", "local_nn.0.0.bias"]   # the reference's key names
+    got = conv(x.cuda(), (pos4.cuda(), pos4[idx].cuda()), ei.cuda())
+    assert got.shape == ref.shape
+    assert (got.cpu() - ref).abs().max() <= 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+def test_message_passing_propagate_runs_the_reference_style_subclass(H):
+    """A PointNetConv written like the reference's (pointnet.py:19-132: subclass of MessagePassing with message(x_j, pos_i,
+    pos_j, edge_index_i), aggr = max) over ops.MessagePassing + ops.scatter_max: the unfused form of the same layer."""
+    F_in, C1, C2 = 8, 16, 32
+    x, pos4, idx, ei = _sa_level_inputs([1200, 200], 0.08, 32, seed=13, F_in=F_in)
+    nn = _local_nn(F_in, C1, C2, seed=6)
+
+    class RefStyleConv(H.MessagePassing):
+        def __init__(self, local_nn):
+            super().__init__(aggr="max")
+            self.local_nn = local_nn
+
+        def forward(self, x, pos, edge_index):
+            return self.propagate(edge_index, x=(x, None), pos=pos)
+
+        def message(self, x_j, pos_i, pos_j, edge_index_i):
+            msg = torch.zeros((pos_j.size(0), pos_j.size(1)), device=pos_j.device)
+            relative_pos = pos_j[:, :3] - pos_i[:, :3]
+            max_distances, _ = H.scatter_max(torch.norm(relative_pos, dim=1, keepdim=True), edge_index_i, dim=0)
+            msg[:, :3] = relative_pos / (max_distances[edge_index_i] + 1e-8)
+            msg[:, 3] = pos_j[:, 3]
+            return self.local_nn(torch.cat([x_j, msg], dim=1))
+
+    ref = _message_reference(nn, x, pos4, pos4[idx], ei)
+    import copy
+    conv = RefStyleConv(copy.deepcopy(nn)).cuda().eval()
+    with torch.no_grad():
+        got = conv(x.cuda(), (pos4.cuda(), pos4[idx].cuda()), ei.cuda())
+    assert (got.cpu() - ref).abs().max() <= 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("k,F", [(3, 24), (5, 10), (1, 7)])
+def test_knn_interpolate_general_k_and_width(H, k, F):
+    """PyG's default k = 3 (and other k, and widths that are not multiples of 4) against the oracle."""
+    b = _batch([2500, 60, 900], seed=21)
+    idx = O.consecutive_cluster(O.voxel_grid(b["pos"], 0.16, b["batch"]))[1]
+    feat = torch.randn(idx.numel(), F, generator=torch.Generator().manual_seed(4))
+    ref = O.knn_interpolate(feat, b["pos"][idx], b["pos"], b["batch"][idx], b["batch"], k=k)
+    got = H.knn_interpolate(feat.cuda(), b["pos"][idx].cuda(), b["pos"].cuda(), b["batch"][idx].cuda(), b["batch"].cuda(), k=k)
+    assert got.shape == ref.shape
+    assert (got.cpu() - ref).abs().max() <= 1e-5 * ref.abs().max()

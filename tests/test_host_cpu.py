@@ -300,6 +300,10 @@ def test_ply_round_trip_binary_ascii_and_big_endian(tmp_path):
     assert back["x"].dtype == np.float64 and back["red"].dtype == np.int32
     for k in cols:
         assert np.array_equal(back[k], np.asarray(cols[k]).astype(back[k].dtype))
+    # a column that does not convert to float64 is dropped silently, as the reference's writer does (io.py:72-78)
+    q = tmp_path / "text.ply"
+    pio.write_ply(str(q), {**cols, "species": np.array(["oak"] * n), "flag": np.ones(n, dtype=bool)})
+    assert list(pio.read_ply(str(q))) == ["x", "y", "z", "red", "green", "blue", "scalar_Reflectance", "flag"]
     # ascii and big-endian inputs
     header = "ply\nformat {} 1.0\nelement vertex 3\nproperty float x\nproperty float y\nproperty double z\nproperty uchar intensity\nend_header\n"
     a = tmp_path / "b.ply"
@@ -489,3 +493,96 @@ assert not B._stale() and os.path.getsize(B.LIB) == 100000
         assert p.returncode == 0, err[-2000:]
     assert len(open(tmp_path / "builds.log").read().split()) == 1       # one builder, three waiters
 
+
+
+# ---- multi-GPU readiness at world sizes 4 and 8 (gloo, CPU): partition + the plot pipeline's two exchanges -----------------
+class _FakeStreamModel:
+    """Net's streaming interface on the CPU: logits = a fixed function of positions and the voxel's own shift."""
+    def stream(self, batches):
+        for d in batches:
+            yield (d.pos.sum(dim=1) + 0.01 * d.local_shift.view(-1, 3)[d.batch].sum(dim=1)) * 0.7 - 0.2
+
+
+def _cpu_collect(cls_xyz, cls_pred, cls_prob, query_xyz, any_wood=1.0, k=1):
+    """Stand-in for backproject.collect_predictions (HIP) in the CPU tests: nearest classified point's prediction."""
+    if cls_xyz.shape[0] == 0 or query_xyz.shape[0] == 0:
+        z = torch.zeros(query_xyz.shape[0])
+        return z, z.clone()
+    j = torch.cat([torch.cdist(q, cls_xyz).argmin(dim=1) for q in query_xyz.split(4096)])
+    return cls_pred[j].clone(), cls_prob[j].clone()
+
+
+def _plot_worker(rank, world, port, max_points, q):
+    import torch.distributed as dist
+    from pointstowood_amd import pipeline
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    pipeline.collect_predictions = _cpu_collect
+    pc = _plot(n=12000, seed=3)
+    stats = {}
+    n_z, label, pwood = pipeline.segment_plot(pc, _FakeStreamModel(), (4.0,), min_pts=64, max_pts=100000, max_points=max_points,
+                                              generator=torch.Generator().manual_seed(0), stats=stats, dist=dist)
+    q.put((rank, float(label.sum()), float(pwood.double().sum()), float(n_z.double().sum()), stats.get("voxels")))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,max_points", [(4, 3000), (8, 100000)])
+def test_segment_plot_sharded_gloo_world4_and_8(world, max_points, monkeypatch):
+    """The sharded plot flow (pipeline.segment_plot: LPT-partitioned voxel batches -> all-gather of the classified points ->
+    plot slices -> all-gather of the per-point results) at world sizes 4 and 8, including ranks that get NO batch (world 8
+    with one large-budget batch: seven idle ranks) and ranks whose share is one small batch: every rank must end with the
+    single-process result."""
+    import torch.multiprocessing as mp
+    from pointstowood_amd import pipeline
+    from pointstowood_amd.dist import batch_cost, partition_batches
+    from pointstowood_amd.predicter import PointBudgetSampler
+    from pointstowood_amd.preprocessing import voxelise
+    monkeypatch.setattr(pipeline, "collect_predictions", _cpu_collect)
+    pc = _plot(n=12000, seed=3)
+    n_z, label, pwood = pipeline.segment_plot(pc, _FakeStreamModel(), (4.0,), min_pts=64, max_pts=100000, max_points=max_points,
+                                              generator=torch.Generator().manual_seed(0))
+    vox, _ = voxelise(pc, (4.0,), 64, 100000, generator=torch.Generator().manual_seed(0))
+    lengths = [int(v.shape[0]) for v in vox]
+    batches = list(PointBudgetSampler(lengths, max_points, 512))
+    plan = partition_batches([sum(batch_cost(lengths[i]) for i in b) for b in batches], world)
+    assert sorted(i for p in plan for i in p) == list(range(len(batches)))
+    if world == 8:
+        assert sum(1 for p in plan if not p) >= 1            # the case under test: idle ranks
+    else:
+        assert len(batches) >= world and all(plan)            # every rank busy, shares of one or two batches
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() + 13 * world) % 1000
+    ps = [ctx.Process(target=_plot_worker, args=(r, world, port, max_points, q)) for r in range(world)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    [p.join(60) for p in ps]
+    expect = (float(label.sum()), float(pwood.double().sum()), float(n_z.double().sum()))
+    for r in res:
+        assert r[1:4] == pytest.approx(expect, rel=1e-6, abs=1e-6), (r, expect)
+
+
+def _ragged_worker(rank, world, port, counts, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = torch.arange(counts[rank], dtype=torch.float32) + 1000 * rank
+    out = gather_logits(mine, dist, counts=counts)
+    q.put((rank, out.tolist()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("counts", [[5, 0, 9, 1], [3, 0, 0, 7, 1, 2, 0, 4]])
+def test_gather_logits_gloo_world4_and_8_with_empty_and_tiny_ranks(counts):
+    import torch.multiprocessing as mp
+    world = len(counts)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 32500 + (os.getpid() + 7 * world) % 1000
+    ps = [ctx.Process(target=_ragged_worker, args=(r, world, port, counts, q)) for r in range(world)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    [p.join(60) for p in ps]
+    expect = [float(i + 1000 * r) for r, c in enumerate(counts) for i in range(c)]
+    assert all(out == expect for _, out in res)

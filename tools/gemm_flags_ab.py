@@ -38,7 +38,7 @@ for M, K, N, kind in shapes:
     W[:N, : planes * K] = (torch.randn(N, planes * K, device=dev, generator=g) * 0.5).to(hdt)
     bias, sc, sh = (torch.randn(N, device=dev, generator=g) for _ in range(3))
     ldh_o = (N + ka - 1) // ka * ka
-    ep = Epilogue(ptr(bias), ptr(sc), ptr(sh), None, None, None, 0, 1, 1, 1, 0)    # relu0, sc0, relu1 (class 263 / 135)
+    ep = Epilogue(ptr(bias), ptr(sc), ptr(sh), None, None, None, 0, 1, 1, 0, 0)    # relu0, sc0, relu1 (class 263 / 135)
     if kind == "f":
         ep = Epilogue(ptr(bias), None, None, None, None, None, 0, 1, 0, 0, 0)      # bias + relu (class 129)
     outs = {}
@@ -66,5 +66,5 @@ for M, K, N, kind in shapes:
             t[fl].append(s.elapsed_time(e) / 4 * 1e3)
     gf = 2.0 * M * K * N / 1e9
     print(f"M={M:6d} K={K:4d} N={N:4d} out={kind} same={same}: " +
-          "  ".join(f"flags{fl}: {statistics.median(t[fl]):7.1f} us ({gf / statistics.median(t[fl]) * 1e3 / 1e3:5.0f} TF)" for fl in flagsets),
+          "  ".join(f"flags{fl}: {statistics.median(t[fl]):7.1f} us ({gf / statistics.median(t[fl]) * 1e3:5.0f} TF)" for fl in flagsets),
           flush=True)

@@ -6,7 +6,6 @@ import os
 import statistics
 import sys
 os.environ.setdefault("P2W_EXTRA_CFLAGS", "-DP2W_SA_STAMP")
-os.environ["P2W_SA_PACK"] = "0"   # one class of targets per level: the stamp buffer sits behind its descriptors
 
 import torch
 
@@ -16,7 +15,8 @@ from pointstowood_amd import synthetic_weights as weights  # noqa: E402
 from pointstowood_amd import Net  # noqa: E402
 
 dev = torch.device("cuda", 0)
-net = Net(1, C=bench.C, k=bench.K_NBR, precision=os.environ.get("P2W_PRECISION", "f16x3"))
+net = Net(1, C=bench.C, k=bench.K_NBR, precision=os.environ.get("P2W_PRECISION", "f16x3"),
+          sa_pack=False)   # one class of targets per level: the stamp buffer sits behind its descriptors
 net.load_state_dict(weights.synth_state_dict(1, bench.C, seed=0))
 net = net.to(dev).eval()
 d = bench.make_batch(0, dev)
