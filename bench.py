@@ -57,7 +57,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-full", action="store_true",
                     help="BASELINE.md section 4 in full: the whole batch 0 (8 voxels), 5 timed passes, thread counts {16, 64, all} swept "
-                         "(minutes of CPU time); default: a bounded sample (3 voxels, 3 timed passes, 16 threads)")
+                         "(minutes of CPU time); default: a bounded sample (voxel 0, median of 3 timed passes, 16 threads)")
     ap.add_argument("--no-workloads", action="store_true",
                     help="skip the extra `workloads` object (configs[2], configs[4] in f16x3 and fp16, a surface-like batch)")
     ap.add_argument("--workload", default="voxels", choices=["voxels", "plot"],
@@ -189,13 +189,14 @@ def cpu_model():
 def cpu_baseline(batch0, full=False):
     """CPU oracle (oracle/net.py, a port pinned to the reference's own outputs) on a bounded sample of batch 0 of this
     benchmark, as ONE batch like the GPU runs it (same batch definition, same k, C, weights): median of the timed passes.
-    default: the first 3 voxels, 1 warm-up + 3 timed passes, 16 torch threads (more only add contention on this path);
+    default: voxel 0, 1 warm-up + 3 timed passes, 16 torch threads (a few seconds; three voxels as one batch already take
+    10 s per pass on a 64-core EPYC - the oracle's [E, C] edge tensors fall out of cache);
     full: all 8 voxels, 5 timed passes, thread counts {16, 64, all} swept once, the best reported."""
     import torch
     from oracle import net as onet
     from pointstowood_amd import synthetic_weights as weights
     sd = weights.synth_state_dict(1, C, seed=0)
-    nvox = BATCH if full else 3
+    nvox = BATCH if full else 1
     n = int(batch0["ptr"][nvox])
     pos, refl = batch0["pos"][:n].clone(), batch0["reflectance"][:n].clone()
     bidx, sf = batch0["batch"][:n].clone(), batch0["sf"][:nvox].clone()

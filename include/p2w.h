@@ -267,6 +267,14 @@ int32_t p2w_packed_dims_h(int32_t prec, int32_t N, int32_t K, int32_t* N_pad, in
 int32_t p2w_gemm_h2(int32_t prec, const void* A_h, int32_t ldh_a, const void* Wh, float wscale, int32_t M, int32_t N,
                     int32_t K, const p2w_epilogue* epi, float* out_f32, int32_t ldo, void* out_h, int32_t ldh_o,
                     int32_t flags, p2w_stream_t stream);
+/* conv1 + BN + ReLU + conv2 for ONE output channel (model.py:241-243) as one operator: out[i] = dot(epilogue(A_h[i,:] * W^T), dot_w) +
+ * dot_b.  The [M, N] intermediate never reaches HBM: the GEMM's epilogue leaves one partial sum per row and 64-column slice in
+ * ws, a finishing pass adds the slices in a fixed order (deterministic).  epi->residual is not supported (P2W_EUNSUPPORTED).
+ * ws: 16-byte aligned, p2w_gemm_h2_rowdot_ws_bytes(M, N) bytes. */
+size_t p2w_gemm_h2_rowdot_ws_bytes(int32_t M, int32_t N);
+int32_t p2w_gemm_h2_rowdot(int32_t prec, const void* A_h, int32_t ldh_a, const void* Wh, float wscale, int32_t M, int32_t N,
+                           int32_t K, const p2w_epilogue* epi, const float* dot_w, float dot_b, float* out, void* ws,
+                           size_t ws_bytes, int32_t flags, p2w_stream_t stream);
 /* p2w_sa_conv with H weights W2h and fp32 and/or H outputs.  P (the hoisted layer-1 product, fp32) has n_src + 1 rows of
  * ldp >= round_up(C1, K granularity) floats: rows 0..n_src-1 = x_src * W1x^T + b1 with ZERO pad columns, row n_src all
  * zero (the row empty neighbour slots read; the kernel's loads are unconditional).

@@ -58,6 +58,8 @@ SIGNATURES = {
                            _vp, _i32, _vp]),
     "p2w_packed_dims_h": (_i32, [_i32, _i32, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
     "p2w_gemm_h2": (_i32, [_i32, _vp, _i32, _vp, _f32, _i32, _i32, _i32, C.POINTER(Epilogue), _vp, _i32, _vp, _i32, _i32, _vp]),
+    "p2w_gemm_h2_rowdot_ws_bytes": (_sz, [_i32, _i32]),
+    "p2w_gemm_h2_rowdot": (_i32, [_i32, _vp, _i32, _vp, _f32, _i32, _i32, _i32, C.POINTER(Epilogue), _vp, _f32, _vp, _vp, _sz, _i32, _vp]),
     "p2w_sa_conv_h_ws_bytes": (_sz, [_i32, _i32]),
     "p2w_sa_conv_h": (_i32, [_i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _f32, _i32, _i32, _vp, _vp,
                              _vp, _vp, _i32, _vp, _i32, _vp, _sz, _i32, _vp]),

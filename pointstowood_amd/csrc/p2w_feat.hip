@@ -362,6 +362,49 @@ extern "C" int32_t p2w_gemm_h2(int32_t prec, const void* A_h, int32_t ldh_a, con
                             p2w_s(stream));
 }
 
+// conv1 + BN + ReLU + conv2 with one output channel (model.py:241-243) without the [M, N] intermediate: the GEMM's epilogue
+// leaves, per row and 64-column slice, the slice's share of dot(row, dot_w) in ws; this pass adds the slices in fixed order.
+__global__ __launch_bounds__(256) void rowdot_finish_kernel(const float* __restrict__ part, int ldpart, int nslots, float b, int M,
+                                                            float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    float acc = 0.f;
+    for (int s = 0; s < nslots; ++s) acc = acc + part[(size_t)s * ldpart + i];
+    out[i] = acc + b;
+}
+static inline int rowdot_ldpart(int M) { return (M + 255) / 256 * 256; }
+extern "C" size_t p2w_gemm_h2_rowdot_ws_bytes(int32_t M, int32_t N) {
+    if (M < 0 || N <= 0) return 0;
+    return (size_t)((N + 63) / 64) * rowdot_ldpart(M) * sizeof(float);
+}
+extern "C" int32_t p2w_gemm_h2_rowdot(int32_t prec, const void* A_h, int32_t ldh_a, const void* Wh, float wscale, int32_t M, int32_t N,
+                                      int32_t K, const p2w_epilogue* epi, const float* dot_w, float dot_b, float* out, void* ws,
+                                      size_t ws_bytes, int32_t flags, p2w_stream_t stream) {
+    if (prec < P2W_PREC_F16X3 || prec > P2W_PREC_BF16) return P2W_EINVAL;
+    if (M == 0) return P2W_OK;
+    P2W_CHECK_PTR(A_h); P2W_CHECK_PTR(Wh); P2W_CHECK_PTR(dot_w); P2W_CHECK_PTR(out); P2W_CHECK_PTR(ws);
+    P2W_CHECK_ALIGN16(A_h); P2W_CHECK_ALIGN16(Wh); P2W_CHECK_ALIGN16(ws);
+    if (M < 0 || N <= 0 || K <= 0 || ldh_a < K || !(wscale > 0.f)) return P2W_EINVAL;
+    if ((flags & P2W_GEMM_TILE_128) && (flags & P2W_GEMM_TILE_256)) return P2W_EINVAL;
+    if (ws_bytes < p2w_gemm_h2_rowdot_ws_bytes(M, N)) return P2W_EWORKSPACE;
+    EpiArgs ep = {};
+    if (epi) {
+        if ((epi->sc0 && !epi->sh0) || (epi->sc1 && !epi->sh1)) return P2W_ENULL;
+        if (epi->residual) return P2W_EUNSUPPORTED;
+        ep = {epi->bias, epi->sc0, epi->sh0, epi->sc1, epi->sh1, nullptr, 0, epi->relu0, epi->relu1, epi->relu2, epi->relu_final};
+    }
+    const _Float16* Ah = static_cast<const _Float16*>(A_h);
+    const _Float16* Wp = static_cast<const _Float16*>(Wh);
+    float* part = static_cast<float*>(ws);
+    const int ldpart = rowdot_ldpart(M);
+    const int32_t rc = prec == P2W_PREC_F16X3
+        ? launch_gemm_h<0>(Ah, ldh_a, Wp, wscale, M, N, K, ep, nullptr, 0, nullptr, 0, flags, p2w_s(stream), dot_w, part, ldpart)
+        : p2w_gemm_h1_impl(prec, Ah, ldh_a, Wp, wscale, M, N, K, ep, nullptr, 0, nullptr, 0, flags, p2w_s(stream), dot_w, part, ldpart);
+    if (rc != P2W_OK) return rc;
+    rowdot_finish_kernel<<<p2w_cdiv(M, 256), 256, 0, p2w_s(stream)>>>(part, ldpart, (N + 63) / 64, dot_b, M, out);
+    return P2W_LAUNCH_STATUS();
+}
+
 // Rows of the fused PointNetConv's GEMM, 32 per MFMA tile, G per target (G = 32: a tile per target; G = 8: four targets per
 // tile).  Target of slot group gi: list[gi] (gi < *n_list_dev) or gi itself.  Writes per row the source's P row offset and
 // the normalised offset g = (rel / (dmax + 1e-8), refl_j) (pointnet.py:119-129), per group the descriptor

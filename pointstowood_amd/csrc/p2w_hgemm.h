@@ -169,8 +169,18 @@ struct EpiArgs {
     const float *bias, *sc0, *sh0, *sc1, *sh1, *residual;
     int ldr, relu0, relu1, relu2, relu_final;
 };
-// Outputs of a GEMM launch: optional fp32 [M, ldo] and / or optional H [M, ldh].
-struct OutArgs { float* f32; int ldo; _Float16* h2; int ldh; };
+// Outputs of a GEMM launch: optional fp32 [M, ldo] and / or optional H [M, ldh]; or (p2w_gemm_h2_rowdot) neither, but the dot
+// product of every output row with dotw[N], left as one partial sum per 64-column slice: part[(col0 / 64) * ldpart + row].
+struct OutArgs { float* f32; int ldo; _Float16* h2; int ldh; const float* dotw; float* part; int ldpart; };
+
+// sum over the 16 lanes of a DPP row (= the 16 column lanes of a 16 x 16 accumulator tile), the total in every lane: quad
+// swaps (1,0,3,2), (2,3,0,1), then the half-row and row mirrors; fp32 addition is commutative, so all lanes agree bit for bit
+__device__ __forceinline__ float row16_sum(float v) {
+#define P2W_DPP_ADD(ctrl) v = v + __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), ctrl, 0xf, 0xf, true))
+    P2W_DPP_ADD(0xB1); P2W_DPP_ADD(0x4E); P2W_DPP_ADD(0x141); P2W_DPP_ADD(0x140);
+#undef P2W_DPP_ADD
+    return v;
+}
 
 // Column ownership.  The W rows of a stage are staged PERMUTED (w_stage_row below): LDS row 32 t + r of a wave's column
 // range holds output channel 64 (t >> 1) + 2 r + (t & 1), so lane r of accumulator tiles 2 jp and 2 jp + 1 holds the two
@@ -331,7 +341,7 @@ __device__ __forceinline__ int w_stage_row16(int rho) {
     const int t = rho >> 4, c = rho & 15;
     return 32 * (t >> 1) + 2 * c + (t & 1);
 }
-template <int PREC, int RT16, int CT16, int EF>
+template <int PREC, int RT16, int CT16, int EF, bool DOTK = false>   // DOTK: the row-dot kernel (the plain kernel compiles none of it)
 __device__ __forceinline__ void gemm_epilogue_16(const f32x4 (&acc)[RT16][CT16], const EpiArgs& ep, float wscale, int row0, int col0,
                                                  int lane, int M, int N, const OutArgs& o) {
     static_assert(CT16 % 2 == 0, "column tiles come in interleaved pairs");
@@ -342,13 +352,15 @@ __device__ __forceinline__ void gemm_epilogue_16(const f32x4 (&acc)[RT16][CT16],
     const bool R2 = GEN ? ep.relu2 != 0 : (EF & 16) != 0, RES = GEN ? ep.residual != nullptr : (EF & 32) != 0;
     const bool RF = GEN ? ep.relu_final != 0 : (EF & 64) != 0, OF = GEN ? o.f32 != nullptr : (EF & 128) != 0;
     const bool OH = GEN ? o.h2 != nullptr : (EF & 256) != 0;
+    const bool DOT = DOTK && (GEN ? o.dotw != nullptr : (EF & 512) != 0);   // row . dotw partials instead of (or beside) the stores
     const int c16 = lane & 15, kg = lane >> 4;
     const int cb = col0 + 2 * c16;   // even column of pair 0; pair jq: + 32 jq
-    fpair bias[JQ], s0[JQ], t0[JQ], s1[JQ], t1[JQ];
+    fpair bias[JQ], s0[JQ], t0[JQ], s1[JQ], t1[JQ], dw[JQ];
 #pragma unroll
     for (int jq = 0; jq < JQ; ++jq) {
         const int c = cb + 32 * jq;
         bias[jq] = fpair{0.f, 0.f}; s0[jq] = fpair{1.f, 1.f}; t0[jq] = fpair{0.f, 0.f}; s1[jq] = fpair{1.f, 1.f}; t1[jq] = fpair{0.f, 0.f};
+        dw[jq] = fpair{0.f, 0.f};
         if constexpr (GEN) {
 #pragma unroll
             for (int e = 0; e < 2; ++e)
@@ -356,8 +368,10 @@ __device__ __forceinline__ void gemm_epilogue_16(const f32x4 (&acc)[RT16][CT16],
                     if (ep.bias) bias[jq][e] = ep.bias[c + e];
                     if (S0) { s0[jq][e] = ep.sc0[c + e]; t0[jq][e] = ep.sh0[c + e]; }
                     if (S1) { s1[jq][e] = ep.sc1[c + e]; t1[jq][e] = ep.sh1[c + e]; }
+                    if (DOT) dw[jq][e] = o.dotw[c + e];
                 }
         } else {
+            if (DOT) dw[jq] = *reinterpret_cast<const fpair*>(o.dotw + c);
             if (ep.bias) bias[jq] = *reinterpret_cast<const fpair*>(ep.bias + c);
             if (S0) { s0[jq] = *reinterpret_cast<const fpair*>(ep.sc0 + c); t0[jq] = *reinterpret_cast<const fpair*>(ep.sh0 + c); }
             if (S1) { s1[jq] = *reinterpret_cast<const fpair*>(ep.sc1 + c); t1[jq] = *reinterpret_cast<const fpair*>(ep.sh1 + c); }
@@ -386,6 +400,7 @@ __device__ __forceinline__ void gemm_epilogue_16(const f32x4 (&acc)[RT16][CT16],
     if constexpr (!GEN) {
         if (RES) load_res(rcur, 0);
     }
+    float dot4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int st = 0; st < NSTEP; ++st) {
         const int it = st >> 2, reg = st & 3;
@@ -399,10 +414,12 @@ __device__ __forceinline__ void gemm_epilogue_16(const f32x4 (&acc)[RT16][CT16],
                 if constexpr (PREC == 0) hp = o.h2 + ((unsigned)row * (unsigned)(2 * o.ldh) + (unsigned)(64 * (cb >> 5) + (cb & 31)));
                 else hp = o.h2 + ((unsigned)row * (unsigned)o.ldh + (unsigned)cb);
             }
+            float dsum = 0.f;
 #pragma unroll
             for (int jq = 0; jq < JQ; ++jq) {
                 const float va = value(acc[it][2 * jq][reg], bias[jq][0], s0[jq][0], t0[jq][0], s1[jq][0], t1[jq][0], rcur[jq][0]);
                 const float vb = value(acc[it][2 * jq + 1][reg], bias[jq][1], s0[jq][1], t0[jq][1], s1[jq][1], t1[jq][1], rcur[jq][1]);
+                if (DOT) dsum = fmaf(vb, dw[jq][1], fmaf(va, dw[jq][0], dsum));
                 if (OF) *reinterpret_cast<fpair*>(fp + 32 * jq) = fpair{va, vb};
                 if (OH) {
                     if constexpr (PREC == 0) {
@@ -415,11 +432,18 @@ __device__ __forceinline__ void gemm_epilogue_16(const f32x4 (&acc)[RT16][CT16],
                     }
                 }
             }
+            if (DOT) {   // the four rows of a lane (reg 0..3) are consecutive: one 16-byte store per row tile by the lanes of column 0
+                dot4[reg] = row16_sum(dsum);
+                if (reg == 3 && c16 == 0)
+                    *reinterpret_cast<float4*>(o.part + ((unsigned)(col0 >> 6) * (unsigned)o.ldpart + (unsigned)(row - 3))) =
+                        make_float4(dot4[0], dot4[1], dot4[2], dot4[3]);
+            }
             if (RES) {
 #pragma unroll
                 for (int jq = 0; jq < JQ; ++jq) rcur[jq] = rnxt[jq];
             }
         } else {
+            float dsum = 0.f;
             if (row < M) {
 #pragma unroll
                 for (int jq = 0; jq < JQ; ++jq) {
@@ -433,22 +457,34 @@ __device__ __forceinline__ void gemm_epilogue_16(const f32x4 (&acc)[RT16][CT16],
                         if (!cv) v[e] = 0.f;                       // pad columns of an H row must be zero
                         if (OF && cv) o.f32[(size_t)row * o.ldo + c + e] = v[e];
                     }
+                    if (DOT) dsum = fmaf(v[1], dw[jq][1], fmaf(v[0], dw[jq][0], dsum));
                     if (OH && c < o.ldh) h_store2<PREC>(o.h2, o.ldh, row, c, v[0], v[1]);
                 }
+            }
+            if (DOT) {   // (the 16 lanes of a DPP row share `row`, so they are in or out together)
+                dsum = row16_sum(dsum);
+                if (row < M && c16 == 0) o.part[(size_t)(col0 >> 6) * o.ldpart + row] = dsum;
             }
         }
     }
 }
 
-template <int PREC, int RT16, int CT16, bool WAIT_OLDER = false>
+template <int PREC, int RT16, int CT16, bool WAIT_OLDER = false, bool DOTK = false>
 __device__ __forceinline__ void gemm_epilogue_dispatch16(const f32x4 (&acc)[RT16][CT16], const EpiArgs& ep, float wscale, int row0,
                                                          int col0, int lane, int M, int N, const OutArgs& o, int ef) {
     const bool full = (row0 + 16 * RT16 <= M) && (col0 + 16 * CT16 <= N) && ef != 0;
     if (full) {
+        if constexpr (DOTK) {   // the row-dot kernel: one specialised class (bias + ReLU, the head: model.py:241-243), the rest generic
+            if (ef == 513) {
+                gemm_epilogue_16<PREC, RT16, CT16, 513, true>(acc, ep, wscale, row0, col0, lane, M, N, o);
+                if constexpr (WAIT_OLDER) __builtin_amdgcn_s_waitcnt(p2w_vmcnt_imm(RT16 < 63 ? RT16 : 63));
+                return;
+            }
+        } else
         switch (ef) {
 #define P2W_EPI_CASE(E) case E: { \
             gemm_epilogue_16<PREC, RT16, CT16, E>(acc, ep, wscale, row0, col0, lane, M, N, o); \
-            constexpr int n_st = RT16 * 4 * (CT16 / 2) * (((E) & 128 ? 1 : 0) + ((E) & 256 ? (PREC == 0 ? 2 : 1) : 0)); \
+            constexpr int n_st = RT16 * 4 * (CT16 / 2) * (((E) & 128 ? 1 : 0) + ((E) & 256 ? (PREC == 0 ? 2 : 1) : 0)) ; \
             if constexpr (WAIT_OLDER) __builtin_amdgcn_s_waitcnt(p2w_vmcnt_imm(n_st < 63 ? n_st : 63)); \
             return; }
             P2W_EPI_CASE(128) P2W_EPI_CASE(257) P2W_EPI_CASE(263) P2W_EPI_CASE(287) P2W_EPI_CASE(480) P2W_EPI_CASE(224)
@@ -457,7 +493,7 @@ __device__ __forceinline__ void gemm_epilogue_dispatch16(const f32x4 (&acc)[RT16
             default: break;
         }
     }
-    gemm_epilogue_16<PREC, RT16, CT16, -1>(acc, ep, wscale, row0, col0, lane, M, N, o);
+    gemm_epilogue_16<PREC, RT16, CT16, -1, DOTK>(acc, ep, wscale, row0, col0, lane, M, N, o);
     if constexpr (WAIT_OLDER) __builtin_amdgcn_s_waitcnt(p2w_vmcnt_imm(0));
 }
 
@@ -678,7 +714,7 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void gemm_h2g_kernel(const _Float1
 // ONE in-order counter on gfx950): that barrier waits with a COUNTED vmcnt - the DMA is older than every store of the
 // epilogue, so "at most n outstanding" with n <= the number of stores behind it means the DMA has landed.
 // ------------------------------------------------------------------------------------------------
-template <int PREC, int WR, int WC, int RT, int CT>
+template <int PREC, int WR, int WC, int RT, int CT, bool DOTK = false>
 __global__ __launch_bounds__(64 * WR * WC, 2) void gemm_hp_kernel(const _Float16* __restrict__ A, int ldh_a,
                                                                const _Float16* __restrict__ Wh, float wscale, int M, int N,
                                                                int Kpad, int nMt, int nNt, int nvb, EpiArgs ep, OutArgs o, int ef,
@@ -827,7 +863,7 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void gemm_hp_kernel(const _Float16
             for (int j = 0; j < CT16; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int s = 0; s + 1 < nslab; ++s) slab(s, std::false_type{}, 0, 0);
         slab(nslab - 1, std::true_type{}, mtn, ntn);
-        gemm_epilogue_dispatch16<PREC, RT16, CT16, true>(acc, ep, wscale, mt * BM + wr * 32 * RT, nt * BN + wc * 32 * CT, lane, M, N, o, ef);
+        gemm_epilogue_dispatch16<PREC, RT16, CT16, true, DOTK>(acc, ep, wscale, mt * BM + wr * 32 * RT, nt * BN + wc * 32 * CT, lane, M, N, o, ef);
         landed = true;
         if (!more) break;
         L = Ln; mt = mtn; nt = ntn;
@@ -839,12 +875,12 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void gemm_hp_kernel(const _Float16
 template <int PREC>
 static int32_t launch_gemm_h(const _Float16* Ah, int32_t ldh_a, const _Float16* Wp, float wscale, int32_t M, int32_t N, int32_t K,
                              const EpiArgs& ep, float* out_f32, int32_t ldo, _Float16* out_h2, int32_t ldh_o, int32_t flags,
-                             hipStream_t stream) {
+                             hipStream_t stream, const float* dotw = nullptr, float* part = nullptr, int32_t ldpart = 0) {
     constexpr int KA = HCfg<PREC>::kalign;
     const int Npad = (N + 255) / 256 * 256, Kpad = (K + KA - 1) / KA * KA;
     if ((ldh_a % KA) != 0 || ldh_a < Kpad) return P2W_EINVAL;     // K padding must exist (and be zero) in A as well
     if (out_h2 && (ldh_o > Npad || (ldh_o & 7))) return P2W_EINVAL;
-    OutArgs o = {out_f32, ldo, out_h2, ldh_o};
+    OutArgs o = {out_f32, ldo, out_h2, ldh_o, dotw, part, ldpart};
     const int dbg = (flags >> 16) & 0xff;
     // 256x256 tiles halve the L2->LDS bytes per MFMA; they need enough tiles to fill the CUs and a wide N:
     // one 256x256 workgroup per CU is worth it when N has no column padding at that width and the tiles fill >= 78 % of
@@ -867,7 +903,7 @@ static int32_t launch_gemm_h(const _Float16* Ah, int32_t ldh_a, const _Float16* 
     const bool use_s1 = ep.sc1 != nullptr;
 #endif
     int ef = (ep.relu0 ? 1 : 0) | (ep.sc0 ? 2 : 0) | (ep.relu1 ? 4 : 0) | (use_s1 ? 8 : 0) | (ep.relu2 ? 16 : 0) |
-             (ep.residual ? 32 : 0) | (ep.relu_final ? 64 : 0) | (out_f32 ? 128 : 0) | (out_h2 ? 256 : 0);
+             (ep.residual ? 32 : 0) | (ep.relu_final ? 64 : 0) | (out_f32 ? 128 : 0) | (out_h2 ? 256 : 0) | (dotw ? 512 : 0);
     const size_t lim = (size_t)1 << 31;
     if ((size_t)M * (size_t)(ldo > 2 * ldh_o ? ldo : 2 * ldh_o) >= lim || (ep.residual && (size_t)M * ep.ldr >= lim) ||
         (N & 1) || (flags & P2W_GEMM_GENERIC_EPI))
@@ -875,7 +911,7 @@ static int32_t launch_gemm_h(const _Float16* Ah, int32_t ldh_a, const _Float16* 
     // the specialised epilogue moves column PAIRS (float2 / one H word per lane): even pitches, 8-byte aligned vectors
     auto odd8 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 7) != 0; };
     if ((out_f32 && ((ldo & 1) || odd8(out_f32))) || (ep.residual && ((ep.ldr & 1) || odd8(ep.residual))) || odd8(ep.bias) ||
-        odd8(ep.sc0) || odd8(ep.sh0) || odd8(ep.sc1) || odd8(ep.sh1))
+        odd8(ep.sc0) || odd8(ep.sh0) || odd8(ep.sc1) || odd8(ep.sh1) || odd8(dotw) || (part && ((ldpart & 3) || (reinterpret_cast<uintptr_t>(part) & 15))))
         ef = 0;
     // tile order: keep W L2-resident per XCD when it does not fit an XCD's L2 (see tile_coords)
     const size_t w_bytes = (size_t)N * Kpad * 2 * HCfg<PREC>::planes;
@@ -913,11 +949,13 @@ static int32_t launch_gemm_h(const _Float16* Ah, int32_t ldh_a, const _Float16* 
     if (big) {
         const int nMt = p2w_cdiv(M, 256), nNt2 = Npad / 256;
         const int tm = pick_mode(nNt2), nvb = tile_grid(nMt, nNt2, tm);
-        gemm_hp_kernel<PREC, 2, 4, 4, 2><<<pgrid(nvb, 1), 512, 0, stream>>>(Ah, ldh_a, Wp, wscale, M, N, Kpad, nMt, nNt2, nvb, ep, o, ef, tm, stagger);
+        if (dotw) gemm_hp_kernel<PREC, 2, 4, 4, 2, true><<<pgrid(nvb, 1), 512, 0, stream>>>(Ah, ldh_a, Wp, wscale, M, N, Kpad, nMt, nNt2, nvb, ep, o, ef, tm, stagger);
+        else gemm_hp_kernel<PREC, 2, 4, 4, 2><<<pgrid(nvb, 1), 512, 0, stream>>>(Ah, ldh_a, Wp, wscale, M, N, Kpad, nMt, nNt2, nvb, ep, o, ef, tm, stagger);
     } else {
         const int nMt = p2w_cdiv(M, 128), nNt1 = p2w_cdiv(N, 128);
         const int tm = pick_mode(nNt1), nvb = tile_grid(nMt, nNt1, tm);
-        gemm_hp_kernel<PREC, 2, 2, 2, 2><<<pgrid(nvb, 2), 256, 0, stream>>>(Ah, ldh_a, Wp, wscale, M, N, Kpad, nMt, nNt1, nvb, ep, o, ef, tm, stagger);
+        if (dotw) gemm_hp_kernel<PREC, 2, 2, 2, 2, true><<<pgrid(nvb, 2), 256, 0, stream>>>(Ah, ldh_a, Wp, wscale, M, N, Kpad, nMt, nNt1, nvb, ep, o, ef, tm, stagger);
+        else gemm_hp_kernel<PREC, 2, 2, 2, 2><<<pgrid(nvb, 2), 256, 0, stream>>>(Ah, ldh_a, Wp, wscale, M, N, Kpad, nMt, nNt1, nvb, ep, o, ef, tm, stagger);
     }
 #endif
     return P2W_LAUNCH_STATUS();
@@ -1468,7 +1506,7 @@ static int32_t launch_sa_conv_h(const float* P, int32_t ldp, int32_t n_src, cons
 // entry points of the single-plane family (defined in p2w_feat_h1.hip, called by the extern "C" dispatchers)
 int32_t p2w_gemm_h1_impl(int32_t prec, const _Float16* Ah, int32_t ldh_a, const _Float16* Wp, float wscale, int32_t M, int32_t N,
                          int32_t K, const EpiArgs& ep, float* out_f32, int32_t ldo, _Float16* out_h2, int32_t ldh_o,
-                         int32_t flags, hipStream_t stream);
+                         int32_t flags, hipStream_t stream, const float* dotw = nullptr, float* part = nullptr, int32_t ldpart = 0);
 int32_t p2w_sa_conv_h1_impl(int32_t prec, const float* P, int32_t ldp, int32_t n_src, const float* xyzr_src, const int32_t* idx,
                             const int32_t* batch_dst, const float* sf, const int32_t* nbr, const int32_t* deg, int32_t kw,
                             int32_t M, const float* w1r4, const _Float16* W2h, float wscale, int32_t C1, int32_t C2,

@@ -600,7 +600,10 @@ class Engine:
             need_f32 = fl > 1 or keep is not None
             b = new(m, l1.N) if need_f32 else None
             yh = newh(mc, l1.N) if fl == 1 else None
-            hd = new(mc, F3) if (fl == 1 and w.num_classes == 1) else None
+            # head for one class (model.py:241-243): conv1 + BN + ReLU + conv2 as ONE operator, its [m, 512] intermediate never
+            # reaches HBM (p2w_gemm_h2_rowdot: per-slice partial dot products in the GEMM's epilogue + a finishing pass)
+            hws = (torch.empty(int(L.p2w_gemm_h2_rowdot_ws_bytes(mc, w.head1.N)), dtype=torch.uint8, device=dev)
+                   if (fl == 1 and w.num_classes == 1) else None)
             hdh = newh(mc, F3) if (fl == 1 and w.num_classes != 1) else None
             for r0 in range(0, m, chunk):
                 mm = min(chunk, m - r0)
@@ -611,9 +614,12 @@ class Engine:
                               out_h2=yh, ldh_o=pad8(l1.N))
                 if fl == 1:   # head (model.py:241-243) on the same chunk
                     if w.num_classes == 1:
-                        self._gemm_h2("gemm_mlp", yh, pad8(F3), mm, w.head1, out_f32=hd, ldo=F3)
-                        self._call("rowdot", L.p2w_rowdot, ptr(hd), F3, F3, ptr(w.head2_w), float(w.head2_b[0]), mm,
-                                   ptr(logits[r0:]))
+                        lin = w.head1
+                        ep = Epilogue(ptr(lin.bias), ptr(lin.sc0), ptr(lin.sh0), ptr(lin.sc1), ptr(lin.sh1), None, 0,
+                                      lin.relu0, lin.relu1, lin.relu2, lin.relu_final)
+                        self._call("gemm_mlp", L.p2w_gemm_h2_rowdot, prec, ptr(yh), pad8(F3), ptr(lin.w16), lin.wscale, mm, lin.N,
+                                   lin.K, C.byref(ep), ptr(w.head2_w), float(w.head2_b[0]), ptr(logits[r0:]), ptr(hws),
+                                   hws.numel(), self.gemm_flags)
                     else:   # multi-class head: conv2 is one more (narrow) GEMM over the H form of conv1's output
                         self._gemm_h2("gemm_mlp", yh, pad8(F3), mm, w.head1, out_h2=hdh, ldh_o=pad8(F3))
                         self._gemm_h2("gemm_mlp", hdh, pad8(F3), mm, w.head2, out_f32=o_multi[r0:], ldo=w.num_classes)

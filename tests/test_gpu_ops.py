@@ -209,6 +209,52 @@ def test_gemm_h_epilogue(prec, M, N, K, flags):
     assert float(out2[:, N:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("prec", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K,flags", [(1000, 512, 512, 0), (5, 512, 512, 0), (777, 100, 36, 0), (2049, 512, 64, 2), (2049, 512, 64, 1),
+                                         (300, 130, 200, 0), (4096, 256, 128, 2)])
+def test_gemm_h_rowdot_head(prec, M, N, K, flags):
+    """p2w_gemm_h2_rowdot (conv1 + BN + ReLU + conv2 for one class, model.py:241-243, without the [M, N] intermediate) against
+    fp64, and against p2w_gemm_h2 + p2w_rowdot on the same operands; interior tiles (specialised epilogue), edge tiles and odd
+    N (guarded epilogue), both tile sizes; deterministic."""
+    import ctypes as C
+    from pointstowood_amd._lib import Epilogue, check, lib, ptr, stream
+    g = torch.Generator().manual_seed(3 * M + N + K)
+    A = torch.randn(M, (K + 3) // 4 * 4, generator=g)
+    A[:, K:] = 0
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    bias, dotw = torch.randn(N, generator=g), torch.randn(N, generator=g)
+    dW, wscale, Kp = _pack_h(W, prec)
+    ka = 32 if prec == 0 else 64
+    ldh_a = (A.shape[1] + 4 + ka - 1) // ka * ka
+    Ah = _to_h(A, prec, ldh_a)
+    db, dw = bias.cuda(), dotw.cuda()
+    ep = Epilogue(ptr(db), None, None, None, None, None, 0, 1, 0, 0, 0)          # the head: bias (BN folded) + ReLU
+    need = int(lib().p2w_gemm_h2_rowdot_ws_bytes(M, N))
+    assert need >= ((N + 63) // 64) * M * 4
+    ws = torch.full((need,), 0xFF, dtype=torch.uint8, device="cuda")
+    out = torch.full((M,), float("nan"), device="cuda")
+    args = (prec, ptr(Ah), ldh_a, ptr(dW), wscale, M, N, K, C.byref(ep), ptr(dw), 0.25, ptr(out), ptr(ws), need, flags, stream())
+    check(lib().p2w_gemm_h2_rowdot(*args))
+    v = torch.relu(A[:, :K].double() @ W.double().t() + bias.double()) @ dotw.double() + 0.25
+    scale = max(1.0, float((torch.relu(A[:, :K].double() @ W.double().t() + bias.double()).abs() @ dotw.double().abs()).max()))
+    assert (out.cpu().double() - v).abs().max().item() <= H_TOL[prec] * scale
+    # the unfused pair on the same operands differs only by fp32 summation order
+    hd = torch.empty((M, N), device="cuda")
+    check(lib().p2w_gemm_h2(prec, ptr(Ah), ldh_a, ptr(dW), wscale, M, N, K, C.byref(ep), ptr(hd), N, None, 0, flags, stream()))
+    ref = (hd.double() @ dw.double() + 0.25).cpu()
+    assert (out.cpu().double() - ref).abs().max().item() <= 2e-6 * scale
+    out2 = torch.full((M,), float("nan"), device="cuda")
+    ws.fill_(0x7F)
+    check(lib().p2w_gemm_h2_rowdot(prec, ptr(Ah), ldh_a, ptr(dW), wscale, M, N, K, C.byref(ep), ptr(dw), 0.25, ptr(out2), ptr(ws),
+                                   need, flags, stream()))
+    assert torch.equal(out, out2)                                                  # fixed summation order
+    assert lib().p2w_gemm_h2_rowdot(prec, ptr(Ah), ldh_a, ptr(dW), wscale, M, N, K, C.byref(ep), ptr(dw), 0.25, ptr(out2), ptr(ws),
+                                    need - 1, flags, stream()) == -4            # P2W_EWORKSPACE
+    epr = Epilogue(ptr(db), None, None, None, None, ptr(hd), N, 1, 0, 0, 0)
+    assert lib().p2w_gemm_h2_rowdot(prec, ptr(Ah), ldh_a, ptr(dW), wscale, M, N, K, C.byref(epr), ptr(dw), 0.25, ptr(out2), ptr(ws),
+                                    need, flags, stream()) == -5               # residual: P2W_EUNSUPPORTED
+
+
 def test_gemm_h_random_shapes():
     """80 random (shape, precision, epilogue, tile flag) cases of p2w_gemm_h2 against fp64 (tools/stress_gemm.py: edge tiles of both
     tile sizes, single-slab K, one-row / one-column problems, odd N through the guarded epilogue, every output combination)."""

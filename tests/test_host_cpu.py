@@ -435,8 +435,9 @@ def test_hot_kernels_stay_off_the_register_cliff():
         return hits[0]
     for prec in (0, 1, 2):   # f16x3 (p2w_feat.hip), fp16 / bf16 (p2w_feat_h1.hip)
         for tile in ("Li2ELi4ELi4ELi2E", "Li2ELi2ELi2ELi2E"):   # the persistent GEMM, 256 x 256 and 128 x 128 tiles
-            g = one(f"gemm_hp_kernelILi{prec}E{tile}")
-            assert g["ScratchSize [bytes/lane]"] <= 16, g          # 8 today: one value parked across the tile loop, not in the slab loop
+            for dotk in ("Lb0E", "Lb1E"):                        # the plain kernel and its row-dot instantiation (the head)
+                g = one(f"gemm_hp_kernelILi{prec}E{tile}{dotk}")
+                assert g["ScratchSize [bytes/lane]"] <= 16, g      # 8 today: one value parked across the tile loop, not in the slab loop
         for k in (f"sa_conv16p_kernelILi{prec}ELi256ELi2ELi32E", f"sa_conv16p_kernelILi{prec}ELi128ELi2ELi32E",
                   f"sa_conv16p_kernelILi{prec}ELi256ELi2ELi8E", f"sa_conv16p_kernelILi{prec}ELi128ELi2ELi8E"):
             assert one(k)["VGPRs Spill"] == 0 and one(k)["LDS Size [bytes/block]"] <= 120 * 1024
