@@ -320,6 +320,28 @@ __device__ __forceinline__ TkGeom tk_geom(const VsHeader* h, const int* ptr, int
     return g;
 }
 
+// The table's cost follows the batch's ACTUAL grid, not the capacity the caller provisioned: only the cells the grid uses
+// (rounded up to whole scan tiles) are cleared, scanned and compacted; blocks beyond them leave at once.
+__device__ __forceinline__ long long tk_used(const TkGeom& g, long long T_cap) {
+    if (g.T > T_cap) return 0;                                  // does not fit: nothing is inserted (status), nothing to prepare
+    const long long up = (g.T + TK_TILE - 1) / TK_TILE * TK_TILE;
+    return up < T_cap ? up : T_cap;
+}
+__global__ __launch_bounds__(256) void tk_clear_kernel(const int* __restrict__ ptr, int B, float res, const VsHeader* __restrict__ h,
+                                                       long long T_cap, int* __restrict__ tab_max, int* __restrict__ cnt,
+                                                       int* __restrict__ fill) {
+    const long long t0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (ptr[B] == 0) return;
+    const long long lim = tk_used(tk_geom(h, ptr, B, res), T_cap);
+    if (t0 >= lim) return;
+    if (t0 + 4 <= lim) {   // T_cap is padded to 4 entries by the layout; lim is a multiple of TK_TILE or T_cap itself
+        *reinterpret_cast<int4*>(tab_max + t0) = make_int4(-1, -1, -1, -1);
+        if (cnt) { *reinterpret_cast<int4*>(cnt + t0) = make_int4(0, 0, 0, 0); *reinterpret_cast<int4*>(fill + t0) = make_int4(0, 0, 0, 0); }
+    } else {
+        for (long long t = t0; t < lim; ++t) { tab_max[t] = -1; if (cnt) { cnt[t] = 0; fill[t] = 0; } }
+    }
+}
+
 __global__ __launch_bounds__(256) void tk_insert_kernel(const float4* __restrict__ xyzr, const int* __restrict__ ptr, int B,
                                                         int n_bound, float res, const VsHeader* __restrict__ h, long long T_cap,
                                                         int* __restrict__ tab_max, int* __restrict__ cnt, int* __restrict__ key32,
@@ -357,9 +379,11 @@ __global__ __launch_bounds__(256) void tk_insert_kernel(const float4* __restrict
 // block-local exclusive scans of the occupancy flags (-> rank) and, optionally, of the counts (-> off); block totals
 __global__ __launch_bounds__(TK_BLOCK) void tk_scan1_kernel(const int* __restrict__ tab_max, const int* __restrict__ cnt, long long T_cap,
                                                            int* __restrict__ rank, int* __restrict__ off, int* __restrict__ bs_occ,
-                                                           int* __restrict__ bs_cnt, const int* __restrict__ status) {
+                                                           int* __restrict__ bs_cnt, const int* __restrict__ status,
+                                                           const int* __restrict__ ptr, int B, float res, const VsHeader* __restrict__ h) {
     __shared__ int wsum[2][TK_BLOCK / 64];
-    if (*status) return;
+    if (*status || ptr[B] == 0) return;
+    if ((long long)blockIdx.x * TK_TILE >= tk_used(tk_geom(h, ptr, B, res), T_cap)) return;   // tiles the grid does not reach
     const long long t0 = (long long)blockIdx.x * TK_TILE + (long long)threadIdx.x * TK_ITEMS;
     int f[TK_ITEMS], c[TK_ITEMS], sf = 0, sc = 0;
 #pragma unroll
@@ -395,10 +419,16 @@ __global__ __launch_bounds__(TK_BLOCK) void tk_scan1_kernel(const int* __restric
 
 // exclusive scan of the block totals, in place, by one workgroup
 __global__ __launch_bounds__(1024) void tk_scan2_kernel(int* __restrict__ bs_occ, int* __restrict__ bs_cnt, int nblk, int* __restrict__ total_out,
-                                                        const int* __restrict__ status) {
+                                                        const int* __restrict__ status, const int* __restrict__ ptr, int B, float res,
+                                                        const VsHeader* __restrict__ h, long long T_cap) {
     __shared__ int wsum[2][16];
     __shared__ int carry[2];
-    if (*status) return;
+    if (*status || ptr[B] == 0) return;
+    {   // only the tiles tk_scan1_kernel has written
+        const long long used = tk_used(tk_geom(h, ptr, B, res), T_cap);
+        const int nb = (int)((used + TK_TILE - 1) / TK_TILE);
+        nblk = nb < nblk ? nb : nblk;
+    }
     if (threadIdx.x == 0) { carry[0] = 0; carry[1] = 0; }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -547,17 +577,13 @@ extern "C" int32_t p2w_voxel_sample_table(const float* xyzr, const int32_t* ptr,
     int* total = reinterpret_cast<int*>(w + L.total);
     const auto* x4 = reinterpret_cast<const float4*>(xyzr);
     const int nblk_pts = p2w_cdiv(n_bound, 256);
-    e = hipMemsetAsync(tab_max, 0xff, sizeof(int) * (size_t)table_cells, s);   // -1 = empty cell
-    if (e != hipSuccess) return (int32_t)e;
-    if (order_out) {   // cnt and fill are adjacent
-        e = hipMemsetAsync(cnt, 0, (L.fill - L.cnt) + sizeof(int) * (size_t)table_cells, s);
-        if (e != hipSuccess) return (int32_t)e;
-    }
     vs_init_kernel<<<1, 64, 0, s>>>(hdr);
     vs_minmax_kernel<<<nblk_pts < 256 ? nblk_pts : 256, 256, 0, s>>>(x4, ptr, B, hdr);
+    // -1 = empty cell, zero counts: only over the part of the table this batch's grid uses (known on the device)
+    tk_clear_kernel<<<p2w_cdiv(table_cells, 1024), 256, 0, s>>>(ptr, B, res, hdr, (long long)table_cells, tab_max, cnt, fill);
     tk_insert_kernel<<<nblk_pts, 256, 0, s>>>(x4, ptr, B, n_bound, res, hdr, (long long)table_cells, tab_max, cnt, key32, status_out);
-    tk_scan1_kernel<<<L.nblk, TK_BLOCK, 0, s>>>(tab_max, cnt, (long long)table_cells, rank, off, bs_occ, bs_cnt, status_out);
-    tk_scan2_kernel<<<1, 1024, 0, s>>>(bs_occ, bs_cnt, L.nblk, total, status_out);
+    tk_scan1_kernel<<<L.nblk, TK_BLOCK, 0, s>>>(tab_max, cnt, (long long)table_cells, rank, off, bs_occ, bs_cnt, status_out, ptr, B, res, hdr);
+    tk_scan2_kernel<<<1, 1024, 0, s>>>(bs_occ, bs_cnt, L.nblk, total, status_out, ptr, B, res, hdr, (long long)table_cells);
     const long long cgrid = (table_cells > B + 1 ? table_cells : B + 1);
     tk_compact_kernel<<<p2w_cdiv(cgrid, 256), 256, 0, s>>>(tab_max, rank, bs_occ, total, (long long)table_cells, ptr, B, res, hdr, idx_out,
                                                             ptr_out, batch_out, reinterpret_cast<unsigned long long*>(cell_keys_out),

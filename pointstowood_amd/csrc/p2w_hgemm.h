@@ -463,7 +463,7 @@ __device__ __forceinline__ void gemm_epilogue_16(const f32x4 (&acc)[RT16][CT16],
             }
             if (DOT) {   // (the 16 lanes of a DPP row share `row`, so they are in or out together)
                 dsum = row16_sum(dsum);
-                if (row < M && c16 == 0) o.part[(size_t)(col0 >> 6) * o.ldpart + row] = dsum;
+                if (row < M && c16 == 0 && col0 < N) o.part[(size_t)(col0 >> 6) * o.ldpart + row] = dsum;   // (slices past N have no slot)
             }
         }
     }

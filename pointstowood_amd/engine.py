@@ -24,7 +24,7 @@ from dataclasses import dataclass, field, fields
 import torch
 
 from . import _lib
-from ._lib import PREC_F16X3, PREC_OF, SA_PACK8, SEARCH_Q_ROW_IN_W, SEARCH_X_INDEX_IN_W, Epilogue, check, lib, ptr
+from ._lib import PREC_F16X3, PREC_OF, SA_PACK8, SEARCH_BOX, SEARCH_Q_ROW_IN_W, SEARCH_X_INDEX_IN_W, Epilogue, check, lib, ptr
 
 BN_EPS = 1e-5
 SA_RES = (0.04, 0.08, 0.16)  # model.py:210-212
@@ -223,6 +223,8 @@ class EngineOptions:
     sampler: str = "table"        # grid sub-sampling: "table" = direct cell table (no sort; per-batch fallback to the sort), "sort"
     search: str = "grid"          # neighbour searches: "grid" = cell-indexed (p2w_*_grid), "brute" = whole-voxel streaming kernels
     table_cells_per_point: float = 32.0   # the table sampler is taken while its table has at most this many entries per point
+    search_box: int = 0           # bit mask: grid searches bounded in x too (P2W_SEARCH_BOX: one run per grid row): 1 ball query,
+                                  # 2 the k = 32 searches, 4 the interpolation searches (A/B: per-voxel rows are short)
     fp_hints: bool = True         # seed the k = 2 interpolation searches from the sampler's ranks (p2w_knn_hint2)
     sa_pack: bool = True          # P2W_SA_PACK8 on the ball-query level (targets with <= 8 neighbours share an MFMA tile)
     chunk_pick: bool = True       # fill-aware row-chunk sizes (pick_chunk); False: the plain budget
@@ -316,22 +318,23 @@ class Engine:
     TABLE_SCALE_MAX = 64               # growth factor cap of a level's table after overflows
 
     def _table_cells(self, level, B, N):
-        """Table entries for the sampler of `level`: B voxels x the cells of a 2.3 m cube at that resolution (+ margin), times
-        the level's growth factor.  0: use the sort.  The table's cost grows with its CELLS (12 B of memset per entry, two scan
-        passes, a compaction), the sort's with the POINTS: many small voxels (B in the hundreds, a few hundred points each) give
-        tens of millions of cells for half a million points, so the table is only taken while it has at most
-        ``table_cells_per_point`` entries per point (and fits TABLE_CELLS_MAX) - decided per batch, nothing is remembered."""
+        """Table capacity (entries) for the sampler of `level`, 0 = use the sort.  Provision: B voxels x the cells of a 2.3 m cube
+        at that resolution (+ margin), times the level's growth factor (x 8 after every overflow, i.e. twice the extent per
+        axis, while it fits TABLE_CELLS_MAX).  The kernels clear, scan and compact only the part of the table the batch's real
+        grid uses, so a generous capacity costs (almost) nothing - what costs is the GRID: it grows with the number of voxels,
+        the sort with the number of points.  Many small voxels (B in the hundreds, a few hundred points each) mean tens of
+        millions of cells for half a million points, so the table is only taken while the grid of B nominal voxels has at
+        most ``table_cells_per_point`` cells per point.  Decided per batch; only the growth factor is remembered."""
         if self.sampler != "table":
             return 0
         per_voxel = (int(2.3 / SA_RES[level]) + 3) ** 3
-        limit = min(self.TABLE_CELLS_MAX, self.table_cells_per_point * max(N, 1))
-        cells = B * per_voxel * self._table_scale[level]
-        if cells > limit and B * per_voxel <= limit:
-            # the room earlier (larger) voxels asked for no longer pays, the plain 2.3 m provision would: start over with it
-            # (a batch of large voxels then costs one repeated geometry pass, as the first one did)
-            self._table_scale[level] = 1
-            cells = B * per_voxel
-        return cells if cells <= limit else 0
+        if B * per_voxel > self.table_cells_per_point * max(N, 1):
+            return 0
+        scale = self._table_scale[level]
+        while scale > 1 and B * per_voxel * scale > self.TABLE_CELLS_MAX:
+            scale //= 8
+        cells = B * per_voxel * scale
+        return cells if cells <= self.TABLE_CELLS_MAX else 0
 
     def _table_workspace(self, n, cells, device):
         need = int(lib().p2w_voxel_sample_table_ws_bytes(n, cells))
@@ -411,7 +414,7 @@ class Engine:
                 if grid_search:
                     self._call("ball_query", L.p2w_ball_query_grid, ptr(sorted0), ptr(skeys0), ptr(src.ptr), ptr(grids[1]),
                                ptr(src.xyzr), ptr(lv.idx), ptr(lv.ptr), B, N, res * 2, k, ptr(lv.nbr), ptr(lv.deg),
-                               SEARCH_X_INDEX_IN_W)
+                               SEARCH_X_INDEX_IN_W | (SEARCH_BOX if self.search_box & 1 else 0))
                     aux0 = [order, sorted0, skeys0]
                 else:
                     box0 = torch.empty((nbox, 6), **f32)
@@ -421,7 +424,7 @@ class Engine:
                     aux0 = [order, box0, sorted0]
             elif grid_search:   # model.py:120
                 self._call("knn", L.p2w_knn_grid, ptr(src.xyzr), ptr(ckeys[l]), ptr(src.ptr), ptr(grids[l]), ptr(src.xyzr),
-                           ptr(lv.idx), ptr(lv.ptr), B, N, k, ptr(lv.nbr), ptr(lv.deg), None, 0)
+                           ptr(lv.idx), ptr(lv.ptr), B, N, k, ptr(lv.nbr), ptr(lv.deg), None, SEARCH_BOX if self.search_box & 2 else 0)
             else:
                 self._call("knn", L.p2w_knn, ptr(src.xyzr), ptr(src.ptr), ptr(src.xyzr), ptr(lv.idx), ptr(lv.ptr), B, N,
                            k, ptr(lv.nbr), ptr(lv.deg), ptr(boxes(l)), 0)
@@ -441,7 +444,8 @@ class Engine:
                                ptr(hint))
                     aux0.append(hint)
                 self._call("knn2", L.p2w_knn_grid, ptr(coarse.xyzr), ptr(ckeys[f + 1]), ptr(coarse.ptr), ptr(grids[f + 1]),
-                           ptr(q), None, ptr(fine.ptr), B, N, 2, ptr(nbr), ptr(deg), ptr(hint), fl)
+                           ptr(q), None, ptr(fine.ptr), B, N, 2, ptr(nbr), ptr(deg), ptr(hint),
+                           fl | (SEARCH_BOX if self.search_box & 4 else 0))
             else:
                 self._call("knn2", L.p2w_knn, ptr(coarse.xyzr), ptr(coarse.ptr), ptr(q), None, ptr(fine.ptr), B, N, 2,
                            ptr(nbr), ptr(deg), ptr(boxes(f + 1)), fl)
