@@ -162,7 +162,7 @@ def profile_step(net, data):
     import torch
     eng = net._engine
     eng.events, eng.events_grouped = [], True   # one HIP-event pair per run of consecutive launches of one kernel class
-    keep = {}
+    keep = {"geometry_only": True}   # the geometry (level sizes) without the fp32 copies a full `keep` asks the engine for
     streams, eng.res_streams = eng.res_streams, 1   # per-kernel durations: no two kernels in flight while they are timed
     net(data, keep=keep)
     eng.flush_events()

@@ -253,6 +253,7 @@ int32_t p2w_packed_dims_h(int32_t prec, int32_t N, int32_t K, int32_t* N_pad, in
 #define P2W_GEMM_GENERIC_EPI 4   /* run the runtime-flag epilogue instead of the specialised one */
 #define P2W_GEMM_ORDER_ROWS 8    /* tile order: an XCD owns whole row tiles (W re-read from its L2) */
 #define P2W_GEMM_ORDER_COLS 16   /* tile order: an XCD owns a slice of column tiles (A streamed per slice) */
+#define P2W_GEMM_RESIDUAL_H 32   /* epi->residual is an H tensor of the launch's precision (epi->ldr = its row pitch ldh), not fp32 */
 /* flags of p2w_sa_conv_h (0 = let the library choose the work-item shape by C2) */
 #define P2W_SA_ITEM_256 1        /* 4 targets x 256 output columns per work item */
 #define P2W_SA_ITEM_128 2        /* 8 targets x 128 output columns per work item */
@@ -263,7 +264,10 @@ int32_t p2w_packed_dims_h(int32_t prec, int32_t N, int32_t K, int32_t* N_pad, in
  * stagger of every other workgroup of an XCD in units of 2 us, bit 14 / 15 = persistent grid on 1/2 / 1/4 of the CUs. */
 
 /* p2w_gemm with an H A operand, H weights and fp32 and/or H outputs (either pointer may be NULL):
- * Linear / 1x1 Conv1d + folded BatchNorm / depthwise affines + ReLU + residual - model.py:75-85, :198-202, :241-242. */
+ * Linear / 1x1 Conv1d + folded BatchNorm / depthwise affines + ReLU + residual - model.py:75-85, :198-202, :241-242.
+ * ldh_a / ldh_o are row PITCHES: A_h / out_h may point into wider rows (e.g. the skip columns of a concatenated [interp | skip]
+ * row, model.py:151: the producer of the skip features writes them in place).  The launch writes its N output columns and the
+ * zero pad columns up to min(ldh_o, round_up(N, K granularity)); it never touches columns beyond that. */
 int32_t p2w_gemm_h2(int32_t prec, const void* A_h, int32_t ldh_a, const void* Wh, float wscale, int32_t M, int32_t N,
                     int32_t K, const p2w_epilogue* epi, float* out_f32, int32_t ldo, void* out_h, int32_t ldh_o,
                     int32_t flags, p2w_stream_t stream);
@@ -288,7 +292,9 @@ int32_t p2w_sa_conv_h(int32_t prec, const float* P, int32_t ldp, int32_t n_src, 
                       const float* b2, const float* bn_s, const float* bn_t, float* out, int32_t ldo, void* out_h,
                       int32_t ldh, void* ws, size_t ws_bytes, int32_t flags, p2w_stream_t stream);
 /* The small kernels writing H (and fp32 where given): stem (model.py:208,228), knn_interpolate + cat (:149-151),
- * cat(x, pos) (:135). */
+ * cat(x, pos) (:135).  For the stem and the interpolation `ldh` is the row pitch as in p2w_gemm_h2: they write their columns
+ * (C, resp. Fc + Fs) plus the zero pad to the next K-slab boundary and leave the rest of a wider row alone (p2w_interp_concat_h2
+ * with skip = NULL, Fs = 0 writes only the interpolated part of a row whose skip columns another producer has written). */
 int32_t p2w_stem_h2(int32_t prec, const float* xyzr, int32_t n, const float* w, const float* b, int32_t C, float* out,
                     void* out_h, int32_t ldh, p2w_stream_t stream);
 int32_t p2w_interp_concat_h2(int32_t prec, const float* xc, int32_t Fc, const float* xyzr_c, const float* xyzr_f,

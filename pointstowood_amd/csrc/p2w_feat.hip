@@ -154,7 +154,7 @@ extern "C" int32_t p2w_gemm(const float* A, int32_t lda, const float* Wp, int32_
         if ((epi->sc0 && !epi->sh0) || (epi->sc1 && !epi->sh1)) return P2W_ENULL;
         if (epi->residual && epi->ldr < N) return P2W_EINVAL;
         ep = {epi->bias, epi->sc0, epi->sh0, epi->sc1, epi->sh1, epi->residual,
-              epi->ldr, epi->relu0, epi->relu1, epi->relu2, epi->relu_final};
+              epi->ldr, epi->relu0, epi->relu1, epi->relu2, epi->relu_final, nullptr};
     }
     int Npad, Kpad;
     p2w_packed_dims(N, K, &Npad, &Kpad);
@@ -351,7 +351,12 @@ extern "C" int32_t p2w_gemm_h2(int32_t prec, const void* A_h, int32_t ldh_a, con
         if ((epi->sc0 && !epi->sh0) || (epi->sc1 && !epi->sh1)) return P2W_ENULL;
         if (epi->residual && epi->ldr < N) return P2W_EINVAL;
         ep = {epi->bias, epi->sc0, epi->sh0, epi->sc1, epi->sh1, epi->residual,
-              epi->ldr, epi->relu0, epi->relu1, epi->relu2, epi->relu_final};
+              epi->ldr, epi->relu0, epi->relu1, epi->relu2, epi->relu_final, nullptr};
+        if ((flags & P2W_GEMM_RESIDUAL_H) && epi->residual) {   // the residual is an H tensor of this precision, ldr its row pitch
+            if ((epi->ldr & 7) || (reinterpret_cast<uintptr_t>(epi->residual) & 15u)) return P2W_EALIGN;
+            ep.res_h = reinterpret_cast<const _Float16*>(epi->residual);
+            ep.residual = nullptr;
+        }
     }
     const _Float16* Ah = static_cast<const _Float16*>(A_h);
     const _Float16* Wp = static_cast<const _Float16*>(Wh);
@@ -391,7 +396,7 @@ extern "C" int32_t p2w_gemm_h2_rowdot(int32_t prec, const void* A_h, int32_t ldh
     if (epi) {
         if ((epi->sc0 && !epi->sh0) || (epi->sc1 && !epi->sh1)) return P2W_ENULL;
         if (epi->residual) return P2W_EUNSUPPORTED;
-        ep = {epi->bias, epi->sc0, epi->sh0, epi->sc1, epi->sh1, nullptr, 0, epi->relu0, epi->relu1, epi->relu2, epi->relu_final};
+        ep = {epi->bias, epi->sc0, epi->sh0, epi->sc1, epi->sh1, nullptr, 0, epi->relu0, epi->relu1, epi->relu2, epi->relu_final, nullptr};
     }
     const _Float16* Ah = static_cast<const _Float16*>(A_h);
     const _Float16* Wp = static_cast<const _Float16*>(Wh);
@@ -526,7 +531,7 @@ extern "C" int32_t p2w_sa_conv_h(int32_t prec, const float* P, int32_t ldp, int3
 template <int PREC>
 __device__ __forceinline__ void store4(const OutArgs& o, size_t row, int c, const float (&v)[4]) {
     if (o.f32 && c < o.ldo) *reinterpret_cast<float4*>(&o.f32[row * o.ldo + c]) = make_float4(v[0], v[1], v[2], v[3]);
-    if (o.h2 && c < o.ldh) h_store4<PREC>(o.h2, o.ldh, row, c, v);
+    if (o.h2 && c < o.hcols) h_store4<PREC>(o.h2, o.ldh, row, c, v);
 }
 // launch a kernel template instantiated for the three H precisions
 #define P2W_LAUNCH_PREC(prec, KERNEL, grid, block, stream, ...)                                          \
@@ -559,8 +564,10 @@ static int32_t stem_launch(int32_t prec, const float* xyzr, int32_t n, const flo
     P2W_CHECK_PTR(xyzr); P2W_CHECK_PTR(w); P2W_CHECK_PTR(b); P2W_CHECK_ALIGN16(xyzr);
     if (!out && !out_h2) return P2W_ENULL;
     if (n < 0 || C <= 0 || (C & 3) || (out_h2 && (ldh < C || (ldh & 7)))) return P2W_EINVAL;
-    OutArgs o = {out, C, static_cast<_Float16*>(out_h2), out_h2 ? ldh : 0};
-    const int q4 = (out_h2 ? ldh : C) >> 2;
+    const int ka = prec == P2W_PREC_F16X3 ? 32 : 64;
+    const int hcols = out_h2 ? (ldh < (C + ka - 1) / ka * ka ? ldh : (C + ka - 1) / ka * ka) : 0;   // C channels + zero pad to the K-slab boundary
+    OutArgs o = {out, C, static_cast<_Float16*>(out_h2), out_h2 ? ldh : 0, hcols, nullptr, nullptr, 0};
+    const int q4 = (out_h2 ? hcols : C) >> 2;
     P2W_LAUNCH_PREC(prec, stem_kernel, p2w_cdiv((long)n * q4, 256), 256, p2w_s(stream), reinterpret_cast<const float4*>(xyzr), n, w, b,
                     C, q4, o);
     return P2W_LAUNCH_STATUS();
@@ -649,8 +656,11 @@ static int32_t interp_launch(int32_t prec, const float* xc, int32_t Fc, const fl
     if (m < 0 || kw <= 0 || Fc <= 0 || Fs < 0 || (Fc & 3) || (Fs & 3)) return P2W_EINVAL;
     if (out && ((ldo & 3) || ldo < Fc + Fs)) return P2W_EINVAL;
     if (out_h2 && ((ldh & 7) || ldh < Fc + Fs)) return P2W_EINVAL;
-    const int width = (out ? ldo : 0) > (out_h2 ? ldh : 0) ? ldo : ldh;
-    OutArgs o = {out, out ? ldo : 0, static_cast<_Float16*>(out_h2), out_h2 ? ldh : 0};
+    const int ka = prec == P2W_PREC_F16X3 ? 32 : 64;
+    const int hfull = (Fc + Fs + ka - 1) / ka * ka;
+    const int hcols = out_h2 ? (ldh < hfull ? ldh : hfull) : 0;   // ldh is the pitch: the row may continue with columns another producer owns
+    const int width = (out ? ldo : 0) > hcols ? ldo : hcols;
+    OutArgs o = {out, out ? ldo : 0, static_cast<_Float16*>(out_h2), out_h2 ? ldh : 0, hcols, nullptr, nullptr, 0};
     P2W_LAUNCH_PREC(prec, interp_concat_kernel, p2w_cdiv(m, 4 * IC_ROWS), 256, p2w_s(stream),
         xc, Fc, reinterpret_cast<const float4*>(xyzr_c), reinterpret_cast<const float4*>(xyzr_f), nbr, deg, kw, skip, Fs, m,
         width >> 2, o);
@@ -697,7 +707,7 @@ static int32_t concat_launch(int32_t prec, const float* x, int32_t F, const floa
     if (out && ((ldo & 3) || ldo < F + 4)) return P2W_EINVAL;
     if (out_h2 && ((ldh & 7) || ldh < F + 4)) return P2W_EINVAL;
     const int width = (out ? ldo : 0) > (out_h2 ? ldh : 0) ? ldo : ldh;
-    OutArgs o = {out, out ? ldo : 0, static_cast<_Float16*>(out_h2), out_h2 ? ldh : 0};
+    OutArgs o = {out, out ? ldo : 0, static_cast<_Float16*>(out_h2), out_h2 ? ldh : 0, out_h2 ? ldh : 0, nullptr, nullptr, 0};
     P2W_LAUNCH_PREC(prec, concat_xyz_kernel, p2w_cdiv((long)m * (width >> 2), 256), 256, p2w_s(stream),
         x, F, reinterpret_cast<const float4*>(xyzr), m, width >> 2, o);
     return P2W_LAUNCH_STATUS();

@@ -168,10 +168,29 @@ static inline int p2w_cu_count() {
 struct EpiArgs {
     const float *bias, *sc0, *sh0, *sc1, *sh1, *residual;
     int ldr, relu0, relu1, relu2, relu_final;
+    const _Float16* res_h;   // P2W_GEMM_RESIDUAL_H: the residual as an H tensor of the launch's precision (row pitch ldr) instead of fp32
 };
+// value of two adjacent columns (col even) of H row `row`: the inverse of h_store2
+template <int PREC>
+__device__ __forceinline__ fpair h_load2(const _Float16* __restrict__ base, unsigned ldh, unsigned row, unsigned col) {
+    if constexpr (PREC == 0) {
+        const _Float16* p = base + (size_t)row * (2 * ldh) + 64 * (col >> 5) + (col & 31);
+        const hpairn hi = *reinterpret_cast<const hpairn*>(p), lo = *reinterpret_cast<const hpairn*>(p + 32);
+        return fpair{(float)hi[0] + (float)lo[0], (float)hi[1] + (float)lo[1]};
+    } else if constexpr (PREC == 1) {
+        const hpairn v = *reinterpret_cast<const hpairn*>(base + (size_t)row * ldh + col);
+        return fpair{(float)v[0], (float)v[1]};
+    } else {
+        const bpair v = *reinterpret_cast<const bpair*>(base + (size_t)row * ldh + col);
+        return fpair{(float)v[0], (float)v[1]};
+    }
+}
 // Outputs of a GEMM launch: optional fp32 [M, ldo] and / or optional H [M, ldh]; or (p2w_gemm_h2_rowdot) neither, but the dot
 // product of every output row with dotw[N], left as one partial sum per 64-column slice: part[(col0 / 64) * ldpart + row].
-struct OutArgs { float* f32; int ldo; _Float16* h2; int ldh; const float* dotw; float* part; int ldpart; };
+// ldh is the H rows' PITCH (a row may be wider than this launch's output: the producer of a skip connection writes its columns
+// straight into the concatenated rows the next layer reads, engine.py); hcols = the columns this launch covers, i.e. its N
+// outputs and the zero pad columns up to the next K-slab boundary (<= ldh).
+struct OutArgs { float* f32; int ldo; _Float16* h2; int ldh; int hcols; const float* dotw; float* part; int ldpart; };
 
 // sum over the 16 lanes of a DPP row (= the 16 column lanes of a 16 x 16 accumulator tile), the total in every lane: quad
 // swaps (1,0,3,2), (2,3,0,1), then the half-row and row mirrors; fp32 addition is commutative, so all lanes agree bit for bit
@@ -298,7 +317,7 @@ __device__ __forceinline__ void gemm_epilogue_il(const f32x16 (&acc)[RT][CT], co
                         if (!cv) v[e] = 0.f;                       // pad columns of an H row must be zero
                         if (OF && cv) o.f32[(size_t)row * o.ldo + c + e] = v[e];
                     }
-                    if (OH && c < o.ldh) h_store2<PREC>(o.h2, o.ldh, row, c, v[0], v[1]);
+                    if (OH && c < o.hcols) h_store2<PREC>(o.h2, o.ldh, row, c, v[0], v[1]);
                 }
             }
         }
@@ -349,9 +368,11 @@ __device__ __forceinline__ void gemm_epilogue_16(const f32x4 (&acc)[RT16][CT16],
     constexpr int JQ = CT16 / 2, NSTEP = RT16 * 4;
     const bool R0 = GEN ? ep.relu0 != 0 : (EF & 1) != 0, S0 = GEN ? ep.sc0 != nullptr : (EF & 2) != 0;
     const bool R1 = GEN ? ep.relu1 != 0 : (EF & 4) != 0, S1 = GEN ? ep.sc1 != nullptr : (EF & 8) != 0;
-    const bool R2 = GEN ? ep.relu2 != 0 : (EF & 16) != 0, RES = GEN ? ep.residual != nullptr : (EF & 32) != 0;
+    const bool R2 = GEN ? ep.relu2 != 0 : (EF & 16) != 0;
+    const bool RES = !DOTK && (GEN ? (ep.residual != nullptr || ep.res_h != nullptr) : (EF & 32) != 0);   // (the row-dot operator takes no residual)
     const bool RF = GEN ? ep.relu_final != 0 : (EF & 64) != 0, OF = GEN ? o.f32 != nullptr : (EF & 128) != 0;
     const bool OH = GEN ? o.h2 != nullptr : (EF & 256) != 0;
+    const bool RH = RES && (GEN ? ep.res_h != nullptr : (EF & 1024) != 0);   // the residual is an H tensor
     const bool DOT = DOTK && (GEN ? o.dotw != nullptr : (EF & 512) != 0);   // row . dotw partials instead of (or beside) the stores
     const int c16 = lane & 15, kg = lane >> 4;
     const int cb = col0 + 2 * c16;   // even column of pair 0; pair jq: + 32 jq
@@ -391,9 +412,14 @@ __device__ __forceinline__ void gemm_epilogue_16(const f32x4 (&acc)[RT16][CT16],
     };
     fpair rcur[JQ], rnxt[JQ];
     auto load_res = [&](fpair (&dst)[JQ], int st) {   // specialised path only
-        const float* rp = ep.residual + ((unsigned)row_of(st) * (unsigned)ep.ldr + (unsigned)cb);
+        if (RH) {
 #pragma unroll
-        for (int jq = 0; jq < JQ; ++jq) dst[jq] = *reinterpret_cast<const fpair*>(rp + 32 * jq);
+            for (int jq = 0; jq < JQ; ++jq) dst[jq] = h_load2<PREC>(ep.res_h, (unsigned)ep.ldr, (unsigned)row_of(st), (unsigned)(cb + 32 * jq));
+        } else {
+            const float* rp = ep.residual + ((unsigned)row_of(st) * (unsigned)ep.ldr + (unsigned)cb);
+#pragma unroll
+            for (int jq = 0; jq < JQ; ++jq) dst[jq] = *reinterpret_cast<const fpair*>(rp + 32 * jq);
+        }
     };
 #pragma unroll
     for (int jq = 0; jq < JQ; ++jq) { rcur[jq] = fpair{0.f, 0.f}; rnxt[jq] = fpair{0.f, 0.f}; }
@@ -452,13 +478,14 @@ __device__ __forceinline__ void gemm_epilogue_16(const f32x4 (&acc)[RT16][CT16],
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
                         const bool cv = c + e < N;
-                        const float res = (RES && cv) ? ep.residual[(size_t)row * ep.ldr + c + e] : 0.f;
+                        float res = 0.f;
+                        if (RES && cv) res = RH ? h_load2<PREC>(ep.res_h, (unsigned)ep.ldr, (unsigned)row, (unsigned)c)[e] : ep.residual[(size_t)row * ep.ldr + c + e];
                         v[e] = value(acc[it][2 * jq + e][reg], bias[jq][e], s0[jq][e], t0[jq][e], s1[jq][e], t1[jq][e], res);
                         if (!cv) v[e] = 0.f;                       // pad columns of an H row must be zero
                         if (OF && cv) o.f32[(size_t)row * o.ldo + c + e] = v[e];
                     }
                     if (DOT) dsum = fmaf(v[1], dw[jq][1], fmaf(v[0], dw[jq][0], dsum));
-                    if (OH && c < o.ldh) h_store2<PREC>(o.h2, o.ldh, row, c, v[0], v[1]);
+                    if (OH && c < o.hcols) h_store2<PREC>(o.h2, o.ldh, row, c, v[0], v[1]);
                 }
             }
             if (DOT) {   // (the 16 lanes of a DPP row share `row`, so they are in or out together)
@@ -487,8 +514,11 @@ __device__ __forceinline__ void gemm_epilogue_dispatch16(const f32x4 (&acc)[RT16
             constexpr int n_st = RT16 * 4 * (CT16 / 2) * (((E) & 128 ? 1 : 0) + ((E) & 256 ? (PREC == 0 ? 2 : 1) : 0)) ; \
             if constexpr (WAIT_OLDER) __builtin_amdgcn_s_waitcnt(p2w_vmcnt_imm(n_st < 63 ? n_st : 63)); \
             return; }
-            P2W_EPI_CASE(128) P2W_EPI_CASE(257) P2W_EPI_CASE(263) P2W_EPI_CASE(287) P2W_EPI_CASE(480) P2W_EPI_CASE(224)
+            P2W_EPI_CASE(128) P2W_EPI_CASE(257) P2W_EPI_CASE(263) P2W_EPI_CASE(287) P2W_EPI_CASE(224)
             P2W_EPI_CASE(131) P2W_EPI_CASE(259) P2W_EPI_CASE(387) P2W_EPI_CASE(129)
+            // the residual block's last layer: residual + ReLU with fp32 and H outputs (480, residual in fp32: the single-plane
+            // modes) / H output, residual read from the H tensor the block's first layer consumed (1376, + fp32 output 1504: f16x3)
+            P2W_EPI_CASE(480) P2W_EPI_CASE(1376) P2W_EPI_CASE(1504)
 #undef P2W_EPI_CASE
             default: break;
         }
@@ -879,8 +909,9 @@ static int32_t launch_gemm_h(const _Float16* Ah, int32_t ldh_a, const _Float16* 
     constexpr int KA = HCfg<PREC>::kalign;
     const int Npad = (N + 255) / 256 * 256, Kpad = (K + KA - 1) / KA * KA;
     if ((ldh_a % KA) != 0 || ldh_a < Kpad) return P2W_EINVAL;     // K padding must exist (and be zero) in A as well
-    if (out_h2 && (ldh_o > Npad || (ldh_o & 7))) return P2W_EINVAL;
-    OutArgs o = {out_f32, ldo, out_h2, ldh_o, dotw, part, ldpart};
+    if (out_h2 && (ldh_o & 7)) return P2W_EINVAL;
+    const int hcols = ldh_o < (N + KA - 1) / KA * KA ? ldh_o : (N + KA - 1) / KA * KA;   // outputs + zero pad to the K-slab boundary
+    OutArgs o = {out_f32, ldo, out_h2, ldh_o, hcols, dotw, part, ldpart};
     const int dbg = (flags >> 16) & 0xff;
     // 256x256 tiles halve the L2->LDS bytes per MFMA; they need enough tiles to fill the CUs and a wide N:
     // one 256x256 workgroup per CU is worth it when N has no column padding at that width and the tiles fill >= 78 % of
@@ -903,14 +934,16 @@ static int32_t launch_gemm_h(const _Float16* Ah, int32_t ldh_a, const _Float16* 
     const bool use_s1 = ep.sc1 != nullptr;
 #endif
     int ef = (ep.relu0 ? 1 : 0) | (ep.sc0 ? 2 : 0) | (ep.relu1 ? 4 : 0) | (use_s1 ? 8 : 0) | (ep.relu2 ? 16 : 0) |
-             (ep.residual ? 32 : 0) | (ep.relu_final ? 64 : 0) | (out_f32 ? 128 : 0) | (out_h2 ? 256 : 0) | (dotw ? 512 : 0);
+             ((ep.residual || ep.res_h) ? 32 : 0) | (ep.relu_final ? 64 : 0) | (out_f32 ? 128 : 0) | (out_h2 ? 256 : 0) | (dotw ? 512 : 0) |
+             (ep.res_h ? 1024 : 0);
     const size_t lim = (size_t)1 << 31;
-    if ((size_t)M * (size_t)(ldo > 2 * ldh_o ? ldo : 2 * ldh_o) >= lim || (ep.residual && (size_t)M * ep.ldr >= lim) ||
+    if ((size_t)M * (size_t)(ldo > 2 * ldh_o ? ldo : 2 * ldh_o) >= lim || ((ep.residual || ep.res_h) && (size_t)M * (size_t)ep.ldr * (ep.res_h ? 2 : 1) >= lim) ||
         (N & 1) || (flags & P2W_GEMM_GENERIC_EPI))
         ef = 0;
     // the specialised epilogue moves column PAIRS (float2 / one H word per lane): even pitches, 8-byte aligned vectors
     auto odd8 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 7) != 0; };
     if ((out_f32 && ((ldo & 1) || odd8(out_f32))) || (ep.residual && ((ep.ldr & 1) || odd8(ep.residual))) || odd8(ep.bias) ||
+        (ep.res_h && ((ep.ldr & 7) || (reinterpret_cast<uintptr_t>(ep.res_h) & 15))) ||
         odd8(ep.sc0) || odd8(ep.sh0) || odd8(ep.sc1) || odd8(ep.sh1) || odd8(dotw) || (part && ((ldpart & 3) || (reinterpret_cast<uintptr_t>(part) & 15))))
         ef = 0;
     // tile order: keep W L2-resident per XCD when it does not fit an XCD's L2 (see tile_coords)

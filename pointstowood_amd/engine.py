@@ -24,7 +24,7 @@ from dataclasses import dataclass, field, fields
 import torch
 
 from . import _lib
-from ._lib import PREC_F16X3, PREC_OF, SA_PACK8, SEARCH_BOX, SEARCH_Q_ROW_IN_W, SEARCH_X_INDEX_IN_W, Epilogue, check, lib, ptr
+from ._lib import GEMM_RESIDUAL_H, PREC_F16X3, PREC_OF, SA_PACK8, SEARCH_BOX, SEARCH_Q_ROW_IN_W, SEARCH_X_INDEX_IN_W, Epilogue, check, lib, ptr
 
 BN_EPS = 1e-5
 SA_RES = (0.04, 0.08, 0.16)  # model.py:210-212
@@ -486,15 +486,23 @@ class Engine:
             return self._features_h2(geo, keep)
         return self._features_fp32(geo, keep)
 
-    def _gemm_h2(self, name, A, ldh_a, M, lin: Linear, out_f32=None, ldo=0, out_h2=None, ldh_o=0, residual=None, ldr=0):
+    def _gemm_h2(self, name, A, ldh_a, M, lin: Linear, out_f32=None, ldo=0, out_h2=None, ldh_o=0, residual=None, ldr=0,
+                 residual_h=False):
         ep = Epilogue(ptr(lin.bias), ptr(lin.sc0), ptr(lin.sh0), ptr(lin.sc1), ptr(lin.sh1), ptr(residual), ldr,
                       lin.relu0, lin.relu1, lin.relu2, lin.relu_final)
         self._call(name, lib().p2w_gemm_h2, self.prec, ptr(A), ldh_a, ptr(lin.w16), lin.wscale, M, lin.N, lin.K, C.byref(ep),
-                   ptr(out_f32), ldo, ptr(out_h2), ldh_o, self.gemm_flags)
+                   ptr(out_f32), ldo, ptr(out_h2), ldh_o, self.gemm_flags | (GEMM_RESIDUAL_H if residual_h else 0))
 
     def _features_h2(self, geo: Geometry, keep: dict | None = None):
         """H pipeline (f16x3 / fp16 / bf16): every GEMM operand is an H tensor (16-bit planes: fp16 hi/lo for f16x3, one
-        fp16 / bf16 plane otherwise) written once by its producer."""
+        fp16 / bf16 plane otherwise) written once by its producer.
+
+        Skip connections are concatenated IN PLACE: the rows the first layer of FP module f reads are [interpolated coarse
+        features (Fc) | skip features (Fs)] (model.py:149-151); the buffer of every such level exists from the start and the
+        producer of the skip features (the stem, the residual blocks' last layer) writes its H output straight into the skip
+        columns, so nothing is copied later and no fp32 twin of those features is written.  In f16x3 the residual blocks also
+        read their residual from the H tensor their first layer consumes (hi + lo = the fp32 value to 2^-22) instead of an
+        fp32 copy.  ``keep`` (tests, profiling) additionally asks for the fp32 forms."""
         L, w = lib(), self.w
         dev = geo.sf.device
         Cw = w.C
@@ -504,13 +512,23 @@ class Engine:
         hdt = torch.bfloat16 if self.precision == "bf16" else torch.float16
         pad8 = lambda f: (f + ka - 1) // ka * ka   # H row pitch: zero-padded to the GEMM's K slab so it can be DMA-staged
         newh = lambda r, f: torch.empty((r, planes * pad8(f)), dtype=hdt, device=dev)
+        hcol = lambda t, c: t[:, planes * c:]      # view of an H tensor from column c on (c a multiple of the slab width)
         lv, N, B = geo.levels, geo.N, geo.B
-        x, xh = [new(N, Cw)], [newh(N, Cw)]
-        self._call("stem", L.p2w_stem_h2, prec, ptr(lv[0].xyzr), N, ptr(w.stem_w), ptr(w.stem_b), Cw, ptr(x[0]), ptr(xh[0]),
-                   pad8(Cw))
-        self.stem_out = x[0]
+        F3 = 16 * Cw
+        res_h = prec == PREC_F16X3                 # residual read from H (the single-plane modes keep their fp32 residual)
+        # concatenated rows of the four FP modules: fine level f = 0..3 gets [m_f, Fc + Fs_f], Fc = 16 C interpolated columns
+        Fs = [Cw, 4 * Cw, 8 * Cw, 16 * Cw]
+        rows = [N, lv[1].n, lv[2].n, lv[3].n]
+        cat = [newh(rows[f], F3 + Fs[f]) for f in range(4)]
+        pitch = [pad8(F3 + Fs[f]) for f in range(4)]
+        xh = [hcol(cat[f], F3) for f in range(4)]   # H features of level f = the skip columns of its FP module's rows
+        x0 = new(N, Cw)
+        self._call("stem", L.p2w_stem_h2, prec, ptr(lv[0].xyzr), N, ptr(w.stem_w), ptr(w.stem_b), Cw, ptr(x0), ptr(xh[0]),
+                   pitch[0])
+        self.stem_out = x0
         if keep is not None:
-            keep["stem"] = x[0]
+            keep["stem"] = x0
+        x3 = None
         for l in (1, 2, 3):
             p, src, dst = w.sa[l - 1], lv[l - 1], lv[l]
             M, C1, C2, E = dst.n, p["C1"], p["C2"], 4 * p["C2"]
@@ -521,8 +539,9 @@ class Engine:
             P[src.n].zero_()
             if C1p != C1:
                 P[:, C1:].zero_()
-            self._gemm_h2("gemm_hoist", xh[l - 1], pad8(p["F_in"]), src.n, p["hoist"], out_f32=P, ldo=C1p)
-            conv, convh = new(M, C2), newh(M, C2)
+            self._gemm_h2("gemm_hoist", xh[l - 1], pitch[l - 1], src.n, p["hoist"], out_f32=P, ldo=C1p)
+            conv = new(M, C2) if (keep is not None or not res_h) else None
+            convh = newh(M, C2)
             # level 1 is the ball query: on sparse input most targets have few neighbours, and those with <= 8 share an MFMA
             # tile four at a time (P2W_SA_PACK8); the kNN levels always fill their 32 slots
             sa_flags = self.sa_flags | (SA_PACK8 if (l == 1 and self.sa_pack) else 0)
@@ -533,8 +552,8 @@ class Engine:
                        ptr(geo.sf), ptr(dst.nbr), ptr(dst.deg), geo.k, M, ptr(p["w1r4"]), ptr(p["W2"].w16),
                        p["W2"].wscale, C1, C2, ptr(p["b2"]), ptr(p["bn_s"]), ptr(p["bn_t"]), ptr(conv), C2, ptr(convh),
                        pad8(C2), ptr(meta), meta.numel(), sa_flags)
-            out = new(M, C2)
-            outh = newh(M, C2) if l < 3 else None
+            # fp32 form of the level's output: level 3 feeds cat(x, pos) of the global module; otherwise only on request
+            out = new(M, C2) if (keep is not None or l == 3) else None
             # residual block in row chunks: the two 4F-wide intermediates of a chunk (2 x chunk x 4F x 4 B) are written
             # and re-read while they still sit in the 256 MiB Infinity Cache instead of round-tripping HBM
             chunk = self.res_chunk_rows if self.res_chunk_rows > 0 else M
@@ -560,22 +579,23 @@ class Engine:
                     self._gemm_h2("gemm_res", convh[r0:], pad8(C2), m, p["g1"], out_h2=e1, ldh_o=pad8(E))
                     self._gemm_h2("gemm_res", e1, pad8(E), m, p["g2"], out_h2=e2, ldh_o=pad8(E))
                     self._gemm_h2("gemm_res", e2, pad8(E), m, p["g3"], out_h2=e1, ldh_o=pad8(E))
-                    self._gemm_h2("gemm_res", e1, pad8(E), m, p["g4"], out_f32=out[r0:], ldo=C2,
-                                  out_h2=None if outh is None else outh[r0:], ldh_o=pad8(C2), residual=conv[r0:], ldr=C2)
+                    self._gemm_h2("gemm_res", e1, pad8(E), m, p["g4"], out_f32=None if out is None else out[r0:], ldo=C2,
+                                  out_h2=xh[l][r0:], ldh_o=pitch[l],
+                                  residual=convh[r0:] if res_h else conv[r0:], ldr=pad8(C2) if res_h else C2, residual_h=res_h)
             if nst > 1:   # join: everything after this level (and the buffers' reuse) is ordered behind both chains
                 done = torch.cuda.Event()
                 done.record(self._s_res)
                 cur.wait_event(done)
-            x.append(out)
-            xh.append(outh)
+            if l == 3:
+                x3 = out
             if keep is not None:
                 keep[f"sa{l}_module.conv"], keep[f"sa{l}_module.out"] = conv, out
         # GlobalSAModule (model.py:134-140)
-        F3, M3 = 16 * Cw, lv[3].n
-        cat = newh(M3, F3 + 4)
-        self._call("concat_xyz", L.p2w_concat_xyz_h2, prec, ptr(x[3]), F3, ptr(lv[3].xyzr), M3, ptr(cat), pad8(F3 + 4))
+        M3 = lv[3].n
+        cat_g = newh(M3, F3 + 4)
+        self._call("concat_xyz", L.p2w_concat_xyz_h2, prec, ptr(x3), F3, ptr(lv[3].xyzr), M3, ptr(cat_g), pad8(F3 + 4))
         h1, h2 = newh(M3, F3), new(M3, F3)
-        self._gemm_h2("gemm_mlp", cat, pad8(F3 + 4), M3, w.sa4[0], out_h2=h1, ldh_o=pad8(F3))
+        self._gemm_h2("gemm_mlp", cat_g, pad8(F3 + 4), M3, w.sa4[0], out_h2=h1, ldh_o=pad8(F3))
         self._gemm_h2("gemm_mlp", h1, pad8(F3), M3, w.sa4[1], out_f32=h2, ldo=F3)
         g = new(B, F3)
         self._call("segment_max", L.p2w_segment_max, ptr(h2), F3, F3, ptr(lv[3].ptr), B, ptr(g))
@@ -586,21 +606,21 @@ class Engine:
         deg4 = torch.empty(M3, dtype=torch.int32, device=dev)
         self._call("fill_batch_nbr", L.p2w_fill_batch_nbr, ptr(lv[3].batch), M3, ptr(nbr4), ptr(deg4))
         zeros_c = torch.zeros((B, 4), dtype=torch.float32, device=dev)
-        # Row-chunked chains: interp+concat -> MLP layer 0 -> MLP layer 1 (-> head for fp1) run chunk by chunk so the wide
+        # Row-chunked chains: interpolate -> MLP layer 0 -> MLP layer 1 (-> head for fp1) run chunk by chunk so the wide
         # intermediates of a chunk are consumed out of the Infinity Cache (same trick as the residual blocks).
         y, y_xyzr = g, zeros_c
         logits = torch.empty(N, dtype=torch.float32, device=dev) if w.num_classes == 1 else None
         o_multi = new(N, w.num_classes) if w.num_classes != 1 else None
         for fl in (4, 3, 2, 1):
             fine = lv[fl - 1]
-            m, Fc, Fs = fine.n, y.shape[1], x[fl - 1].shape[1]
+            m, Fc, cf, ld = fine.n, y.shape[1], cat[fl - 1], pitch[fl - 1]
             nbr, deg, kw = (nbr4, deg4, 1) if fl == 4 else (*geo.fp_nbr[fl - 1], 2)
             l0, l1 = w.fp[fl]
             chunk = self.res_chunk_rows if self.res_chunk_rows > 0 else m
-            chunk = max(256, min(m, pick_chunk(m, chunk * 512 // (Fc + Fs), max(1, l0.N // 256)) if self.chunk_pick
-                                 else (chunk * 512 // (Fc + Fs)) // 256 * 256))
+            chunk = max(256, min(m, pick_chunk(m, chunk * 512 // (Fc + Fs[fl - 1]), max(1, l0.N // 256)) if self.chunk_pick
+                                 else (chunk * 512 // (Fc + Fs[fl - 1])) // 256 * 256))
             mc = min(m, chunk)
-            cat, a = newh(mc, Fc + Fs), newh(mc, l0.N)
+            a = newh(mc, l0.N)
             need_f32 = fl > 1 or keep is not None
             b = new(m, l1.N) if need_f32 else None
             yh = newh(mc, l1.N) if fl == 1 else None
@@ -611,9 +631,10 @@ class Engine:
             hdh = newh(mc, F3) if (fl == 1 and w.num_classes != 1) else None
             for r0 in range(0, m, chunk):
                 mm = min(chunk, m - r0)
+                # the interpolated part only (skip = NULL): the skip columns of these rows were written by their producer
                 self._call("interp_concat", L.p2w_interp_concat_h2, prec, ptr(y), Fc, ptr(y_xyzr), ptr(fine.xyzr[r0:]),
-                           ptr(nbr[r0:]), ptr(deg[r0:]), kw, ptr(x[fl - 1][r0:]), Fs, mm, ptr(cat), pad8(Fc + Fs))
-                self._gemm_h2("gemm_mlp", cat, pad8(Fc + Fs), mm, l0, out_h2=a, ldh_o=pad8(l0.N))
+                           ptr(nbr[r0:]), ptr(deg[r0:]), kw, None, 0, mm, ptr(cf[r0:]), ld)
+                self._gemm_h2("gemm_mlp", cf[r0:], ld, mm, l0, out_h2=a, ldh_o=pad8(l0.N))
                 self._gemm_h2("gemm_mlp", a, pad8(l0.N), mm, l1, out_f32=None if b is None else b[r0:], ldo=l1.N,
                               out_h2=yh, ldh_o=pad8(l1.N))
                 if fl == 1:   # head (model.py:241-243) on the same chunk
@@ -711,6 +732,8 @@ class Engine:
         geo = self.geometry(pos, reflectance, ptr0, sf)
         if keep is not None:
             keep["geometry"] = geo
+            if keep.get("geometry_only"):   # profiling: the level sizes are wanted, the fp32 copies of the level features are not
+                keep = None
         return self.features(geo, keep)
 
     # -- two-stream software pipeline over a sequence of batches ---------------------------------------------

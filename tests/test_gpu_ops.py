@@ -211,7 +211,8 @@ def test_gemm_h_epilogue(prec, M, N, K, flags):
 
 @pytest.mark.parametrize("prec", [0, 1, 2])
 @pytest.mark.parametrize("M,N,K,flags", [(1000, 512, 512, 0), (5, 512, 512, 0), (777, 100, 36, 0), (2049, 512, 64, 2), (2049, 512, 64, 1),
-                                         (300, 130, 200, 0), (4096, 256, 128, 2)])
+                                         (300, 130, 200, 0), (4096, 256, 128, 2), (32768, 512, 512, 0), (70000, 512, 512, 0),
+                                         (70000, 512, 512, 1)])
 def test_gemm_h_rowdot_head(prec, M, N, K, flags):
     """p2w_gemm_h2_rowdot (conv1 + BN + ReLU + conv2 for one class, model.py:241-243, without the [M, N] intermediate) against
     fp64, and against p2w_gemm_h2 + p2w_rowdot on the same operands; interior tiles (specialised epilogue), edge tiles and odd
@@ -253,6 +254,87 @@ def test_gemm_h_rowdot_head(prec, M, N, K, flags):
     epr = Epilogue(ptr(db), None, None, None, None, ptr(hd), N, 1, 0, 0, 0)
     assert lib().p2w_gemm_h2_rowdot(prec, ptr(Ah), ldh_a, ptr(dW), wscale, M, N, K, C.byref(epr), ptr(dw), 0.25, ptr(out2), ptr(ws),
                                     need, flags, stream()) == -5               # residual: P2W_EUNSUPPORTED
+
+
+@pytest.mark.parametrize("prec", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K,flags", [(1000, 128, 512, 0), (515, 96, 100, 0), (2048, 256, 64, 2), (300, 32, 40, 0)])
+def test_gemm_h_writes_into_wider_rows_and_reads_an_h_residual(prec, M, N, K, flags):
+    """The two boundary features the in-place skip concatenation uses (engine.py): (1) ldh_o is a row PITCH - the launch writes
+    its N columns (+ zero pad to the K-slab boundary) at a column offset of wider rows and leaves every other column alone;
+    (2) P2W_GEMM_RESIDUAL_H - the residual is read from an H tensor.  Against fp64 and against the fp32-residual launch."""
+    import ctypes as C
+    from pointstowood_amd._lib import GEMM_RESIDUAL_H, Epilogue, check, lib, ptr, stream
+    g = torch.Generator().manual_seed(7 * M + N + K)
+    A = torch.randn(M, (K + 3) // 4 * 4, generator=g)
+    A[:, K:] = 0
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    bias = torch.randn(N, generator=g)
+    R = torch.randn(M, (N + 3) // 4 * 4, generator=g)
+    R[:, N:] = 0
+    dW, wscale, Kp = _pack_h(W, prec)
+    ka, planes = (32, 2) if prec == 0 else (64, 1)
+    ldh_a = (A.shape[1] + 4 + ka - 1) // ka * ka
+    ldr = (R.shape[1] + 4 + ka - 1) // ka * ka
+    Ah, Rh = _to_h(A, prec, ldh_a), _to_h(R, prec, ldr)
+    Rv = _from_h(Rh, prec, ldr)[:, :N]                       # the residual values the kernel sees (exactly, for every precision)
+    db = bias.cuda()
+    off, pitch = 2 * ka, 2 * ka + (N + ka - 1) // ka * ka + ka      # two slabs of foreign columns in front, one behind
+    wide = torch.full((M, planes * pitch), 7.0, dtype=Ah.dtype, device="cuda")
+    view = wide[:, planes * off:]
+    ep = Epilogue(ptr(db), None, None, None, None, ptr(Rh), ldr, 0, 0, 0, 1)
+    out = torch.full((M, N), float("nan"), device="cuda")
+    check(lib().p2w_gemm_h2(prec, ptr(Ah), ldh_a, ptr(dW), wscale, M, N, K, C.byref(ep), ptr(out), N, ptr(view), pitch,
+                            flags | GEMM_RESIDUAL_H, stream()))
+    v = torch.relu(A[:, :K].double() @ W.double().t() + bias.double() + Rv)
+    scale = max(1.0, v.abs().max().item())
+    assert (out.cpu().double() - v).abs().max().item() <= H_TOL[prec] * scale
+    got = _from_h(wide, prec, pitch)
+    npad = (N + ka - 1) // ka * ka
+    assert (got[:, off:off + N] - out.cpu().double()).abs().max().item() <= (2e-6 if prec == 0 else 1e-3 if prec == 1 else 8e-3) * scale
+    assert float(got[:, off + N:off + npad].abs().max() if npad > N else 0.0) == 0.0     # the launch's own zero pad
+    foreign = torch.cat([wide[:, : planes * off], wide[:, planes * (off + npad):]], 1)
+    assert bool((foreign == 7.0).all())                                                  # nobody else's columns were touched
+    # the same launch with the residual given in fp32 (the values the H tensor holds): identical outputs
+    dR = Rv.float().cuda().contiguous()
+    ep2 = Epilogue(ptr(db), None, None, None, None, ptr(dR), N, 0, 0, 0, 1)
+    out2 = torch.full((M, N), float("nan"), device="cuda")
+    check(lib().p2w_gemm_h2(prec, ptr(Ah), ldh_a, ptr(dW), wscale, M, N, K, C.byref(ep2), ptr(out2), N, None, 0, flags, stream()))
+    assert (out2 - out).abs().max().item() <= 2e-6 * scale
+
+
+def test_interp_and_stem_write_only_their_columns_of_wider_rows():
+    """p2w_interp_concat_h2 with skip = NULL and p2w_stem_h2 treat ldh as the row pitch: the interpolated part / the stem's
+    channels (+ zero pad to the slab boundary) are written, the other columns of the rows stay as they were."""
+    from pointstowood_amd._lib import check, lib, ptr, stream
+    b = _batch([1500, 300], seed=31)
+    idx = O.consecutive_cluster(O.voxel_grid(b["pos"], 0.16, b["batch"]))[1]
+    Fc, m = 64, b["pos"].shape[0]
+    feat = torch.randn(idx.numel(), Fc, generator=torch.Generator().manual_seed(5))
+    ref = O.knn_interpolate(feat, b["pos"][idx], b["pos"], b["batch"][idx], b["batch"], k=2)
+    from pointstowood_amd import ops as H
+    nbr, deg = H._search("knn", b["pos"][idx].cuda(), b["pos"].cuda(), None, b["batch"][idx].cuda(), b["batch"].cuda(), 2)
+    rc, rf = H._xyzr(b["pos"][idx].cuda()), H._xyzr(b["pos"].cuda())
+    for prec, (ka, planes, dt) in {0: (32, 2, torch.float16), 1: (64, 1, torch.float16), 2: (64, 1, torch.bfloat16)}.items():
+        pitch = Fc + 2 * ka
+        wide = torch.full((m, planes * pitch), 3.0, dtype=dt, device="cuda")
+        check(lib().p2w_interp_concat_h2(prec, ptr(feat.cuda()), Fc, ptr(rc), ptr(rf), ptr(nbr), ptr(deg), 2, None, 0, m,
+                                         ptr(wide), pitch, stream()))
+        got = _from_h(wide, prec, pitch)
+        tol = {0: 2e-6, 1: 1e-3, 2: 8e-3}[prec] * float(ref.abs().max())
+        assert (got[:, :Fc] - ref.double()).abs().max().item() <= tol + 1e-5 * float(ref.abs().max())
+        assert bool((wide[:, planes * Fc:] == 3.0).all())
+        # the stem into the last slab of the same rows
+        Cw = 8
+        w_, b_ = torch.randn(Cw, 3, generator=torch.Generator().manual_seed(6)), torch.randn(Cw, generator=torch.Generator().manual_seed(7))
+        x0 = torch.empty((m, Cw), device="cuda")
+        view = wide[:, planes * (Fc + ka):]
+        check(lib().p2w_stem_h2(prec, ptr(rf), m, ptr(w_.cuda()), ptr(b_.cuda()), Cw, ptr(x0), ptr(view), pitch, stream()))
+        sref = torch.relu(b["pos"].double() @ w_.double().t() + b_.double())
+        assert (x0.cpu().double() - sref).abs().max().item() <= 1e-5
+        got = _from_h(wide, prec, pitch)
+        assert (got[:, Fc + ka:Fc + ka + Cw] - sref).abs().max().item() <= {0: 2e-6, 1: 2e-3, 2: 2e-2}[prec] * max(1.0, float(sref.abs().max()))
+        assert float(got[:, Fc + ka + Cw:].abs().max()) == 0.0                         # zero pad up to the slab boundary = row end
+        assert bool((wide[:, planes * Fc: planes * (Fc + ka)] == 3.0).all())          # the slab between them: untouched
 
 
 def test_gemm_h_random_shapes():
