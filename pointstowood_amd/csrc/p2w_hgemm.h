@@ -193,11 +193,18 @@ __device__ __forceinline__ fpair h_load2(const _Float16* __restrict__ base, unsi
 struct OutArgs { float* f32; int ldo; _Float16* h2; int ldh; int hcols; const float* dotw; float* part; int ldpart; };
 
 // sum over the 16 lanes of a DPP row (= the 16 column lanes of a 16 x 16 accumulator tile), the total in every lane: quad
-// swaps (1,0,3,2), (2,3,0,1), then the half-row and row mirrors; fp32 addition is commutative, so all lanes agree bit for bit
+// swaps (1,0,3,2), (2,3,0,1), then the half-row and row mirrors; fp32 addition is commutative, so all lanes agree bit for bit.
+// Inline asm with its own wait states: hipcc SLP-packs the FMAs that produce `v` of two neighbouring rows into one
+// v_pk_fma_f32 and then allows the DPP read of the pair's FIRST register only the 2 wait states of a plain VALU producer -
+// measured on gfx950: that element is sporadically stale in lanes 48..63 (the second one, read a cycle later, never), and
+// only when the workgroups of a launch drift apart, i.e. when the SIMD partner does not happen to fill the gap.
 __device__ __forceinline__ float row16_sum(float v) {
-#define P2W_DPP_ADD(ctrl) v = v + __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), ctrl, 0xf, 0xf, true))
-    P2W_DPP_ADD(0xB1); P2W_DPP_ADD(0x4E); P2W_DPP_ADD(0x141); P2W_DPP_ADD(0x140);
-#undef P2W_DPP_ADD
+    asm volatile("s_nop 4\n\t"
+                 "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_nop 1"
+                 : "+v"(v));
     return v;
 }
 

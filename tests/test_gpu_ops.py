@@ -317,7 +317,8 @@ def test_interp_and_stem_write_only_their_columns_of_wider_rows():
     for prec, (ka, planes, dt) in {0: (32, 2, torch.float16), 1: (64, 1, torch.float16), 2: (64, 1, torch.bfloat16)}.items():
         pitch = Fc + 2 * ka
         wide = torch.full((m, planes * pitch), 3.0, dtype=dt, device="cuda")
-        check(lib().p2w_interp_concat_h2(prec, ptr(feat.cuda()), Fc, ptr(rc), ptr(rf), ptr(nbr), ptr(deg), 2, None, 0, m,
+        dfeat = feat.cuda()
+        check(lib().p2w_interp_concat_h2(prec, ptr(dfeat), Fc, ptr(rc), ptr(rf), ptr(nbr), ptr(deg), 2, None, 0, m,
                                          ptr(wide), pitch, stream()))
         got = _from_h(wide, prec, pitch)
         tol = {0: 2e-6, 1: 1e-3, 2: 8e-3}[prec] * float(ref.abs().max())
@@ -328,7 +329,8 @@ def test_interp_and_stem_write_only_their_columns_of_wider_rows():
         w_, b_ = torch.randn(Cw, 3, generator=torch.Generator().manual_seed(6)), torch.randn(Cw, generator=torch.Generator().manual_seed(7))
         x0 = torch.empty((m, Cw), device="cuda")
         view = wide[:, planes * (Fc + ka):]
-        check(lib().p2w_stem_h2(prec, ptr(rf), m, ptr(w_.cuda()), ptr(b_.cuda()), Cw, ptr(x0), ptr(view), pitch, stream()))
+        dw_, db_ = w_.cuda(), b_.cuda()          # (kept alive: a temporary's memory is recycled by the next allocation)
+        check(lib().p2w_stem_h2(prec, ptr(rf), m, ptr(dw_), ptr(db_), Cw, ptr(x0), ptr(view), pitch, stream()))
         sref = torch.relu(b["pos"].double() @ w_.double().t() + b_.double())
         assert (x0.cpu().double() - sref).abs().max().item() <= 1e-5
         got = _from_h(wide, prec, pitch)
