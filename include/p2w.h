@@ -90,11 +90,15 @@ int32_t p2w_voxel_sample(const float* xyzr, const int32_t* ptr, int32_t B, int32
  * (ptr_out = 0, so work already queued behind the call finds nothing to do) - the caller checks it (with the level sizes it reads back anyway) and repeats the level with p2w_voxel_sample.
  * ws: p2w_voxel_sample_table_ws_bytes(n_bound, table_cells) bytes (20 B per table entry). */
 size_t p2w_voxel_sample_table_ws_bytes(int32_t n_bound, int64_t table_cells);
+/* cell_start_out / cell_start_sorted_out (optional, table_cells + 1 int32 each; the second needs order_out): for every cell
+ * key t <= the grid's cell count the position of the first element with key >= t in the sampled level / in the cell-sorted
+ * order of the input points (the last used entry = the totals): p2w_knn_grid_indexed / p2w_ball_query_grid_indexed find
+ * their candidate runs with one load from such a table instead of bisecting the keys. */
 int32_t p2w_voxel_sample_table(const float* xyzr, const int32_t* ptr, int32_t B, int32_t n_bound, float res,
                                int32_t* idx_out, int32_t* ptr_out, int32_t* batch_out, int32_t* order_out,
                                uint64_t* sorted_keys_out, uint64_t* cell_keys_out, p2w_grid* grid_out, int32_t* inv_out,
-                               int32_t* rank_sorted_out, int32_t* status_out, int64_t table_cells, void* ws, size_t ws_bytes,
-                               p2w_stream_t stream);
+                               int32_t* rank_sorted_out, int32_t* cell_start_out, int32_t* cell_start_sorted_out,
+                               int32_t* status_out, int64_t table_cells, void* ws, size_t ws_bytes, p2w_stream_t stream);
 
 /* out[i] = (x, y, z, bit pattern of order[i]) of xyzr[order[i]] for i < ptr[B]: the records of a level in another
  * (e.g. cell-sorted) order, each carrying its own index - input for the P2W_SEARCH_*_IN_W modes below. */
@@ -159,6 +163,17 @@ int32_t p2w_knn_hint2(const float* xyzr_q, const int32_t* rank, const int32_t* p
 int32_t p2w_ball_query_grid(const float* xyzr_x, const uint64_t* keys_x, const int32_t* ptr_x, const p2w_grid* grid,
                             const float* xyzr_q, const int32_t* qidx, const int32_t* ptr_q, int32_t B, int32_t m_bound,
                             double r, int32_t cap, int32_t* nbr, int32_t* deg, int32_t flags, p2w_stream_t stream);
+/* The same two searches with the sampler's cell -> position table of the candidates (p2w_voxel_sample_table's
+ * cell_start_out when the candidates are the level it produced, cell_start_sorted_out when they are its input points in
+ * cell-sorted order; NULL = bisect keys_x as p2w_knn_grid does): identical results, the run tables cost one load per run end. */
+int32_t p2w_knn_grid_indexed(const float* xyzr_x, const uint64_t* keys_x, const int32_t* ptr_x, const p2w_grid* grid,
+                             const int32_t* cell_start, const float* xyzr_q, const int32_t* qidx, const int32_t* ptr_q, int32_t B,
+                             int32_t m_bound, int32_t k, int32_t* nbr, int32_t* deg, const float* hint, int32_t flags,
+                             p2w_stream_t stream);
+int32_t p2w_ball_query_grid_indexed(const float* xyzr_x, const uint64_t* keys_x, const int32_t* ptr_x, const p2w_grid* grid,
+                                    const int32_t* cell_start, const float* xyzr_q, const int32_t* qidx, const int32_t* ptr_q,
+                                    int32_t B, int32_t m_bound, double r, int32_t cap, int32_t* nbr, int32_t* deg, int32_t flags,
+                                    p2w_stream_t stream);
 
 /* ---- plot scale: back-projection of the classification onto the original points (predicter.py:107-142) ---- */
 

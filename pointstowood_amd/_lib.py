@@ -35,8 +35,10 @@ SIGNATURES = {
     "p2w_voxel_sample_ws_bytes": (_sz, [_i32]),
     "p2w_voxel_sample": (_i32, [_vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "p2w_voxel_sample_table_ws_bytes": (_sz, [_i32, C.c_int64]),
-    "p2w_voxel_sample_table": (_i32, [_vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _vp,
-                                      _sz, _vp]),
+    "p2w_voxel_sample_table": (_i32, [_vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64,
+                                      _vp, _sz, _vp]),
+    "p2w_knn_grid_indexed": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
+    "p2w_ball_query_grid_indexed": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, C.c_double, _i32, _vp, _vp, _i32, _vp]),
     "p2w_knn_hint2": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "p2w_knn_grid": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
     "p2w_ball_query_grid": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, C.c_double, _i32, _vp, _vp, _i32, _vp]),

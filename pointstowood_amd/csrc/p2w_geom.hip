@@ -461,7 +461,9 @@ __global__ __launch_bounds__(256) void tk_compact_kernel(const int* __restrict__
                                                          const int* __restrict__ ptr, int B, float res, const VsHeader* __restrict__ h,
                                                          int* __restrict__ idx_out, int* __restrict__ ptr_out, int* __restrict__ batch_out,
                                                          unsigned long long* __restrict__ cell_keys_out, p2w_grid* __restrict__ grid_out,
-                                                         const int* __restrict__ status) {
+                                                         const int* __restrict__ status, const int* __restrict__ off,
+                                                         const int* __restrict__ bs_cnt, int* __restrict__ cell_start_out,
+                                                         int* __restrict__ cell_start_sorted_out) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     const int n = ptr[B];
     if (*status || n == 0) {   // overflow: hand out an EMPTY level, so that whatever the caller has already queued behind this
@@ -487,10 +489,19 @@ __global__ __launch_bounds__(256) void tk_compact_kernel(const int* __restrict__
         const long long first = ((long long)t - g.b_lo) * g.cells;
         ptr_out[t] = (t <= g.b_lo) ? 0 : (first < g.T ? rank[first] + bs_occ[first / TK_TILE] : *total);
     }
+    // cell -> first element at or after it: in the sampled level (one point per occupied cell, ascending key) and in the
+    // cell-sorted order of the input points; entry g.T = the totals.  The grid searches look runs up here instead of
+    // bisecting the keys (p2w_knn_grid_indexed).
+    if (t == g.T && t <= T_cap) {
+        if (cell_start_out) cell_start_out[t] = *total;
+        if (cell_start_sorted_out) cell_start_sorted_out[t] = n;
+    }
     if (t >= g.T || t >= T_cap) return;
+    const int o = rank[t] + bs_occ[t / TK_TILE];
+    if (cell_start_out) cell_start_out[t] = o;
+    if (cell_start_sorted_out) cell_start_sorted_out[t] = off[t] + bs_cnt[t / TK_TILE];
     const int rep = tab_max[t];
     if (rep < 0) return;
-    const int o = rank[t] + bs_occ[t / TK_TILE];
     idx_out[o] = rep;
     if (batch_out) batch_out[o] = g.b_lo + (int)(t / g.cells);
     if (cell_keys_out) cell_keys_out[o] = (unsigned long long)t;
@@ -550,9 +561,11 @@ extern "C" size_t p2w_voxel_sample_table_ws_bytes(int32_t n_bound, int64_t table
 extern "C" int32_t p2w_voxel_sample_table(const float* xyzr, const int32_t* ptr, int32_t B, int32_t n_bound, float res,
                                           int32_t* idx_out, int32_t* ptr_out, int32_t* batch_out, int32_t* order_out,
                                           uint64_t* sorted_keys_out, uint64_t* cell_keys_out, p2w_grid* grid_out,
-                                          int32_t* inv_out, int32_t* rank_sorted_out, int32_t* status_out, int64_t table_cells,
+                                          int32_t* inv_out, int32_t* rank_sorted_out, int32_t* cell_start_out,
+                                          int32_t* cell_start_sorted_out, int32_t* status_out, int64_t table_cells,
                                           void* ws, size_t ws_bytes, p2w_stream_t stream) {
     P2W_CHECK_PTR(ptr); P2W_CHECK_PTR(ptr_out); P2W_CHECK_PTR(status_out);
+    if (cell_start_sorted_out && !order_out) return P2W_ENULL;   // the sorted order's counts are only kept when it is asked for
     if (B <= 0 || n_bound < 0 || !(res > 0.0f) || table_cells <= 0 || table_cells > ((int64_t)1 << 30)) return P2W_EINVAL;
     hipStream_t s = p2w_s(stream);
     hipError_t e = hipMemsetAsync(status_out, 0, sizeof(int), s);
@@ -584,10 +597,10 @@ extern "C" int32_t p2w_voxel_sample_table(const float* xyzr, const int32_t* ptr,
     tk_insert_kernel<<<nblk_pts, 256, 0, s>>>(x4, ptr, B, n_bound, res, hdr, (long long)table_cells, tab_max, cnt, key32, status_out);
     tk_scan1_kernel<<<L.nblk, TK_BLOCK, 0, s>>>(tab_max, cnt, (long long)table_cells, rank, off, bs_occ, bs_cnt, status_out, ptr, B, res, hdr);
     tk_scan2_kernel<<<1, 1024, 0, s>>>(bs_occ, bs_cnt, L.nblk, total, status_out, ptr, B, res, hdr, (long long)table_cells);
-    const long long cgrid = (table_cells > B + 1 ? table_cells : B + 1);
+    const long long cgrid = (table_cells + 1 > B + 1 ? table_cells + 1 : B + 1);
     tk_compact_kernel<<<p2w_cdiv(cgrid, 256), 256, 0, s>>>(tab_max, rank, bs_occ, total, (long long)table_cells, ptr, B, res, hdr, idx_out,
                                                             ptr_out, batch_out, reinterpret_cast<unsigned long long*>(cell_keys_out),
-                                                            grid_out, status_out);
+                                                            grid_out, status_out, off, bs_cnt, cell_start_out, cell_start_sorted_out);
     if (inv_out || order_out)
         tk_points_kernel<<<nblk_pts, 256, 0, s>>>(key32, rank, bs_occ, off, bs_cnt, fill, ptr, B, n_bound, inv_out, order_out,
                                                   reinterpret_cast<unsigned long long*>(sorted_keys_out), rank_sorted_out, status_out);
@@ -1087,7 +1100,7 @@ __global__ __launch_bounds__(256) void slab_search_kernel(const float4* __restri
                                                           const float4* __restrict__ xq, const int* __restrict__ qidx,
                                                           const int* __restrict__ ptr_q, int B, int k, float r, float r2,
                                                           int* __restrict__ nbr, int* __restrict__ deg, int flags,
-                                                          const float* __restrict__ hint) {
+                                                          const float* __restrict__ hint, const int* __restrict__ cell_start) {
     __shared__ float4 cand[TILE];
     __shared__ int run_start[G_MAXRUN];
     __shared__ int run_pre[G_MAXRUN + 1];
@@ -1208,8 +1221,11 @@ __global__ __launch_bounds__(256) void slab_search_kernel(const float4* __restri
                 const long long rowbase = (kb * g2 + z) * g1;
                 const unsigned long long ka = (unsigned long long)((rowbase + ya) * g0 + xa);
                 const unsigned long long kz = (unsigned long long)((rowbase + yb) * g0 + xb + 1);
-                const int s0 = lower_bound_key(keys, c0, c1, ka);   // (an 8-ary variant with independent probes measured slower)
-                const int s1 = lower_bound_key(keys, s0, c1, kz);
+                // first candidate at or after a key: one load from the sampler's cell -> position table when the caller has
+                // it (every key formed here is <= the grid's cell count, the table's last entry), else a bisection of the
+                // keys (14 dependent loads for a 16 k-point voxel: the run tables were most of a k = 2 search's time)
+                const int s0 = cell_start ? cell_start[ka] : lower_bound_key(keys, c0, c1, ka);
+                const int s1 = cell_start ? cell_start[kz] : lower_bound_key(keys, s0, c1, kz);
                 run_start[tid] = s0;
                 len = s1 - s0;
             }
@@ -1512,9 +1528,10 @@ static int32_t grid_args(const uint64_t* keys, const p2w_grid* grid, int32_t fla
     return P2W_OK;
 }
 
-extern "C" int32_t p2w_knn_grid(const float* xyzr_x, const uint64_t* keys_x, const int32_t* ptr_x, const p2w_grid* grid,
-                                const float* xyzr_q, const int32_t* qidx, const int32_t* ptr_q, int32_t B, int32_t m_bound,
-                                int32_t k, int32_t* nbr, int32_t* deg, const float* hint, int32_t flags, p2w_stream_t stream) {
+extern "C" int32_t p2w_knn_grid_indexed(const float* xyzr_x, const uint64_t* keys_x, const int32_t* ptr_x, const p2w_grid* grid,
+                                        const int32_t* cell_start, const float* xyzr_q, const int32_t* qidx, const int32_t* ptr_q,
+                                        int32_t B, int32_t m_bound, int32_t k, int32_t* nbr, int32_t* deg, const float* hint,
+                                        int32_t flags, p2w_stream_t stream) {
     if (m_bound == 0) return P2W_OK;
     int32_t st = search_args(xyzr_x, ptr_x, xyzr_q, ptr_q, B, m_bound, k, nbr, deg);
     if (st != P2W_OK) return st;
@@ -1524,14 +1541,19 @@ extern "C" int32_t p2w_knn_grid(const float* xyzr_x, const uint64_t* keys_x, con
                                           : ((k >= 8) ? slab_search_kernel<0, 2048, true, false> : slab_search_kernel<0, 1024, false, false>);
     kern<<<grid_dim, 256, 0, p2w_s(stream)>>>(
         reinterpret_cast<const float4*>(xyzr_x), reinterpret_cast<const unsigned long long*>(keys_x), ptr_x, grid,
-        reinterpret_cast<const float4*>(xyzr_q), qidx, ptr_q, B, k, 0.f, 0.f, nbr, deg, flags, hint);
+        reinterpret_cast<const float4*>(xyzr_q), qidx, ptr_q, B, k, 0.f, 0.f, nbr, deg, flags, hint, cell_start);
     return P2W_LAUNCH_STATUS();
 }
+extern "C" int32_t p2w_knn_grid(const float* xyzr_x, const uint64_t* keys_x, const int32_t* ptr_x, const p2w_grid* grid,
+                                const float* xyzr_q, const int32_t* qidx, const int32_t* ptr_q, int32_t B, int32_t m_bound,
+                                int32_t k, int32_t* nbr, int32_t* deg, const float* hint, int32_t flags, p2w_stream_t stream) {
+    return p2w_knn_grid_indexed(xyzr_x, keys_x, ptr_x, grid, nullptr, xyzr_q, qidx, ptr_q, B, m_bound, k, nbr, deg, hint, flags, stream);
+}
 
-extern "C" int32_t p2w_ball_query_grid(const float* xyzr_x, const uint64_t* keys_x, const int32_t* ptr_x, const p2w_grid* grid,
-                                       const float* xyzr_q, const int32_t* qidx, const int32_t* ptr_q, int32_t B,
-                                       int32_t m_bound, double r, int32_t cap, int32_t* nbr, int32_t* deg, int32_t flags,
-                                       p2w_stream_t stream) {
+extern "C" int32_t p2w_ball_query_grid_indexed(const float* xyzr_x, const uint64_t* keys_x, const int32_t* ptr_x, const p2w_grid* grid,
+                                               const int32_t* cell_start, const float* xyzr_q, const int32_t* qidx,
+                                               const int32_t* ptr_q, int32_t B, int32_t m_bound, double r, int32_t cap, int32_t* nbr,
+                                               int32_t* deg, int32_t flags, p2w_stream_t stream) {
     if (m_bound == 0) return P2W_OK;
     int32_t st = search_args(xyzr_x, ptr_x, xyzr_q, ptr_q, B, m_bound, cap, nbr, deg);
     if (st != P2W_OK) return st;
@@ -1541,8 +1563,14 @@ extern "C" int32_t p2w_ball_query_grid(const float* xyzr_x, const uint64_t* keys
     auto* kern = (flags & P2W_SEARCH_BOX) ? slab_search_kernel<1, 1024, false, true> : slab_search_kernel<1, 1024, false, false>;
     kern<<<grid_dim, 256, 0, p2w_s(stream)>>>(
         reinterpret_cast<const float4*>(xyzr_x), reinterpret_cast<const unsigned long long*>(keys_x), ptr_x, grid,
-        reinterpret_cast<const float4*>(xyzr_q), qidx, ptr_q, B, cap, (float)r, (float)(r * r), nbr, deg, flags, nullptr);
+        reinterpret_cast<const float4*>(xyzr_q), qidx, ptr_q, B, cap, (float)r, (float)(r * r), nbr, deg, flags, nullptr, cell_start);
     return P2W_LAUNCH_STATUS();
+}
+extern "C" int32_t p2w_ball_query_grid(const float* xyzr_x, const uint64_t* keys_x, const int32_t* ptr_x, const p2w_grid* grid,
+                                       const float* xyzr_q, const int32_t* qidx, const int32_t* ptr_q, int32_t B,
+                                       int32_t m_bound, double r, int32_t cap, int32_t* nbr, int32_t* deg, int32_t flags,
+                                       p2w_stream_t stream) {
+    return p2w_ball_query_grid_indexed(xyzr_x, keys_x, ptr_x, grid, nullptr, xyzr_q, qidx, ptr_q, B, m_bound, r, cap, nbr, deg, flags, stream);
 }
 
 

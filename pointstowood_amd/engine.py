@@ -223,6 +223,7 @@ class EngineOptions:
     sampler: str = "table"        # grid sub-sampling: "table" = direct cell table (no sort; per-batch fallback to the sort), "sort"
     search: str = "grid"          # neighbour searches: "grid" = cell-indexed (p2w_*_grid), "brute" = whole-voxel streaming kernels
     table_cells_per_point: float = 32.0   # the table sampler is taken while its table has at most this many entries per point
+    search_index: bool = True     # grid searches look candidate runs up in the table sampler's cell -> position tables (else bisect)
     search_box: int = 0           # bit mask: grid searches bounded in x too (P2W_SEARCH_BOX: one run per grid row): 1 ball query,
                                   # 2 the k = 32 searches, 4 the interpolation searches (A/B: per-voxel rows are short)
     fp_hints: bool = True         # seed the k = 2 interpolation searches from the sampler's ranks (p2w_knn_hint2)
@@ -383,6 +384,7 @@ class Engine:
         i64 = dict(dtype=torch.int64, device=dev)
         sorted0 = skeys0 = None   # level 0 in cell order (the level-1 sampler's sort), each record carrying its own index
         ckeys, grids, ranks = {}, {}, {}     # level -> cell key of every record (ascending) / p2w_grid of the sampling call
+        cstart, cstart0 = {}, None           # level -> cell -> position table of its records (table sampler only)
         for l, res in enumerate(SA_RES):
             src = geo.levels[l]
             lv = Level(xyzr=torch.empty((N, 4), **f32), ptr=torch.empty(B + 1, **i32), batch=torch.empty(N, **i32),
@@ -397,10 +399,14 @@ class Engine:
             if cells:
                 ws_t = self._table_workspace(N, cells, dev)
                 geo.table_levels.append(l)
+                # cell -> position tables of the level this call produces (and, for level 0, of its cell-sorted input): the grid
+                # searches INTO these candidates look their runs up instead of bisecting the keys
+                cstart[l + 1] = torch.empty(cells + 1, **i32) if self.search_index else None
+                cstart0 = torch.empty(cells + 1, **i32) if (self.search_index and l == 0) else None
                 self._call("voxel_sample", L.p2w_voxel_sample_table, ptr(src.xyzr), ptr(src.ptr), B, N, res, ptr(lv.idx),
                            ptr(lv.ptr), ptr(lv.batch), ptr(order), ptr(skeys), ptr(ckeys[l + 1]), ptr(grids[l + 1]),
-                           ptr(ranks[l]) if l > 0 else None, ptr(ranks[l]) if l == 0 else None, ptr(status[l:]), cells,
-                           ptr(ws_t), ws_t.numel())
+                           ptr(ranks[l]) if l > 0 else None, ptr(ranks[l]) if l == 0 else None, ptr(cstart[l + 1]),
+                           ptr(cstart0), ptr(status[l:]), cells, ptr(ws_t), ws_t.numel())
             else:
                 self._call("voxel_sample", L.p2w_voxel_sample, ptr(src.xyzr), ptr(src.ptr), B, N, res, ptr(lv.idx),
                            ptr(lv.ptr), ptr(lv.batch), ptr(order), ptr(skeys), ptr(ckeys[l + 1]), ptr(grids[l + 1]),
@@ -412,8 +418,8 @@ class Engine:
                 sorted0, skeys0 = torch.empty((N, 4), **f32), skeys
                 self._call("index_records", L.p2w_index_records, ptr(src.xyzr), ptr(order), ptr(src.ptr), B, N, ptr(sorted0))
                 if grid_search:
-                    self._call("ball_query", L.p2w_ball_query_grid, ptr(sorted0), ptr(skeys0), ptr(src.ptr), ptr(grids[1]),
-                               ptr(src.xyzr), ptr(lv.idx), ptr(lv.ptr), B, N, res * 2, k, ptr(lv.nbr), ptr(lv.deg),
+                    self._call("ball_query", L.p2w_ball_query_grid_indexed, ptr(sorted0), ptr(skeys0), ptr(src.ptr), ptr(grids[1]),
+                               ptr(cstart0), ptr(src.xyzr), ptr(lv.idx), ptr(lv.ptr), B, N, res * 2, k, ptr(lv.nbr), ptr(lv.deg),
                                SEARCH_X_INDEX_IN_W | (SEARCH_BOX if self.search_box & 1 else 0))
                     aux0 = [order, sorted0, skeys0]
                 else:
@@ -423,7 +429,8 @@ class Engine:
                                ptr(lv.ptr), B, N, res * 2, k, ptr(lv.nbr), ptr(lv.deg), ptr(box0), SEARCH_X_INDEX_IN_W)
                     aux0 = [order, box0, sorted0]
             elif grid_search:   # model.py:120
-                self._call("knn", L.p2w_knn_grid, ptr(src.xyzr), ptr(ckeys[l]), ptr(src.ptr), ptr(grids[l]), ptr(src.xyzr),
+                self._call("knn", L.p2w_knn_grid_indexed, ptr(src.xyzr), ptr(ckeys[l]), ptr(src.ptr), ptr(grids[l]), ptr(cstart.get(l)),
+                           ptr(src.xyzr),
                            ptr(lv.idx), ptr(lv.ptr), B, N, k, ptr(lv.nbr), ptr(lv.deg), None, SEARCH_BOX if self.search_box & 2 else 0)
             else:
                 self._call("knn", L.p2w_knn, ptr(src.xyzr), ptr(src.ptr), ptr(src.xyzr), ptr(lv.idx), ptr(lv.ptr), B, N,
@@ -443,14 +450,15 @@ class Engine:
                     self._call("knn_hint", L.p2w_knn_hint2, ptr(q), ptr(ranks[f]), ptr(fine.ptr), B, N, ptr(coarse.xyzr),
                                ptr(hint))
                     aux0.append(hint)
-                self._call("knn2", L.p2w_knn_grid, ptr(coarse.xyzr), ptr(ckeys[f + 1]), ptr(coarse.ptr), ptr(grids[f + 1]),
-                           ptr(q), None, ptr(fine.ptr), B, N, 2, ptr(nbr), ptr(deg), ptr(hint),
+                self._call("knn2", L.p2w_knn_grid_indexed, ptr(coarse.xyzr), ptr(ckeys[f + 1]), ptr(coarse.ptr), ptr(grids[f + 1]),
+                           ptr(cstart.get(f + 1)), ptr(q), None, ptr(fine.ptr), B, N, 2, ptr(nbr), ptr(deg), ptr(hint),
                            fl | (SEARCH_BOX if self.search_box & 4 else 0))
             else:
                 self._call("knn2", L.p2w_knn, ptr(coarse.xyzr), ptr(coarse.ptr), ptr(q), None, ptr(fine.ptr), B, N, 2,
                            ptr(nbr), ptr(deg), ptr(boxes(f + 1)), fl)
             geo.fp_nbr[f] = (nbr, deg)
         aux0 += list(ckeys.values()) + list(grids.values()) + [t for t in ranks.values() if t is not None]
+        aux0 += [t for t in list(cstart.values()) + [cstart0] if t is not None]
         geo.aux = list(bbox.values()) + aux0
         geo.counts_dev = torch.cat([torch.stack([geo.levels[l].ptr[B] for l in (1, 2, 3)]), status])
         geo.counts_host = torch.empty(6, dtype=torch.int32, pin_memory=True)

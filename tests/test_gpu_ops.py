@@ -498,12 +498,21 @@ def test_table_sampler_equals_sort_sampler(sizes, res, surface):
     cells = B * (int(2.3 / res) + 3) ** 3
     wt = torch.empty(int(L.p2w_voxel_sample_table_ws_bytes(n, cells)), dtype=torch.uint8, device="cuda")
     status = torch.full((1,), 9, **i32)
+    cs = torch.full((cells + 1,), -7, **i32)          # cell -> first representative at or after it
+    css = torch.full((cells + 1,), -7, **i32)         # cell -> first point at or after it in the cell-sorted order
     assert L.p2w_voxel_sample_table(ptr(xyzr), ptr(csr), B, n, res, ptr(t["idx"]), ptr(t["ptr"]), ptr(t["batch"]), ptr(t["order"]),
-                                    ptr(t["skeys"]), ptr(t["ckeys"]), ptr(t["grid"]), ptr(t["inv"]), ptr(t["rsort"]), ptr(status),
-                                    cells, ptr(wt), wt.numel(), stream()) == 0
+                                    ptr(t["skeys"]), ptr(t["ckeys"]), ptr(t["grid"]), ptr(t["inv"]), ptr(t["rsort"]), ptr(cs), ptr(css),
+                                    ptr(status), cells, ptr(wt), wt.numel(), stream()) == 0
     torch.cuda.synchronize()
     assert int(status) == 0
     m = int(a["ptr"][B])
+    # the cell -> position tables are lower bounds of the sorted keys, for every key up to the grid's cell count
+    dims = t["grid"].view(torch.int64)[4:7].tolist()
+    b_used = int((a["ptr"][1:] > a["ptr"][:-1]).nonzero().max()) - int((a["ptr"][1:] > a["ptr"][:-1]).nonzero().min()) + 1
+    T = dims[0] * dims[1] * dims[2] * b_used
+    probe = torch.cat([torch.arange(0, T + 1, max(1, T // 5000), device="cuda"), torch.tensor([T], device="cuda")])
+    assert torch.equal(cs[probe].long(), torch.searchsorted(a["ckeys"][:m].contiguous(), probe))
+    assert torch.equal(css[probe].long(), torch.searchsorted(a["skeys"].contiguous(), probe))
     assert torch.equal(t["ptr"], a["ptr"]) and m > 0
     for k in ("idx", "batch", "ckeys"):
         assert torch.equal(t[k][:m], a[k][:m]), k
@@ -515,15 +524,73 @@ def test_table_sampler_equals_sort_sampler(sizes, res, surface):
     # without the optional outputs
     t2 = outputs()
     assert L.p2w_voxel_sample_table(ptr(xyzr), ptr(csr), B, n, res, ptr(t2["idx"]), ptr(t2["ptr"]), ptr(t2["batch"]), None, None,
-                                    ptr(t2["ckeys"]), None, ptr(t2["inv"]), None, ptr(status), cells, ptr(wt), wt.numel(), stream()) == 0
+                                    ptr(t2["ckeys"]), None, ptr(t2["inv"]), None, None, None, ptr(status), cells, ptr(wt), wt.numel(), stream()) == 0
     assert torch.equal(t2["idx"][:m], a["idx"][:m]) and torch.equal(t2["inv"], a["inv"]) and int(status) == 0
     # a table that cannot hold the grid reports it instead of writing out of bounds
     small = 1000
     assert L.p2w_voxel_sample_table(ptr(xyzr), ptr(csr), B, n, res, ptr(t2["idx"]), ptr(t2["ptr"]), ptr(t2["batch"]), None, None,
-                                    None, None, None, None, ptr(status), small, ptr(wt), wt.numel(), stream()) == 0
+                                    None, None, None, None, None, None, ptr(status), small, ptr(wt), wt.numel(), stream()) == 0
     assert int(status) == 1 and int(t2["ptr"].abs().max()) == 0          # ... and hands out an empty level
     assert L.p2w_voxel_sample_table(ptr(xyzr), ptr(csr), B, n, res, ptr(t2["idx"]), ptr(t2["ptr"]), ptr(t2["batch"]), None, None,
-                                    None, None, None, None, ptr(status), cells, ptr(wt), 1024, stream()) == -4      # workspace
+                                    None, None, None, None, None, None, ptr(status), cells, ptr(wt), 1024, stream()) == -4      # workspace
+
+
+@pytest.mark.parametrize("box", [0, 4])
+@pytest.mark.parametrize("sizes,surface", [([5000], False), ([1500, 40, 2600], True), ([16384, 3000], False), ([300, 0, 9000], True)])
+def test_indexed_grid_searches_equal_the_bisecting_ones(sizes, surface, box):
+    """p2w_knn_grid_indexed / p2w_ball_query_grid_indexed with the table sampler's cell -> position tables (the engine's searches)
+    give the results of p2w_knn_grid / p2w_ball_query_grid bit for bit: interpolation search (level 0 -> level 1, k = 2), SA-style
+    search among the level itself (k = 32, queries = a coarser sample) and the ball query over the cell-sorted input points."""
+    from pointstowood_amd._lib import SEARCH_Q_ROW_IN_W, SEARCH_X_INDEX_IN_W, lib, ptr, stream
+    vox = [(synth.surface_voxel if surface else synth.uniform_voxel)(2.0, max(n, 1), 91 + i, True) for i, n in enumerate(sizes)]
+    b = synth.collate(vox)
+    keep = torch.cat([torch.ones(max(n, 1), dtype=torch.bool) if n > 0 else torch.zeros(1, dtype=torch.bool) for n in sizes])
+    pos = b["pos"][keep].cuda()
+    n, B, res = pos.shape[0], len(sizes), 0.04
+    L = lib()
+    xyzr = torch.zeros((n, 4), device="cuda")
+    xyzr[:, :3] = pos
+    csr = torch.tensor([0] + list(np.cumsum(sizes)), dtype=torch.int32, device="cuda")
+    i32, i64 = dict(dtype=torch.int32, device="cuda"), dict(dtype=torch.int64, device="cuda")
+    idx, ptr_out, batch_out, order = torch.empty(n, **i32), torch.empty(B + 1, **i32), torch.empty(n, **i32), torch.empty(n, **i32)
+    skeys, ckeys, grid = torch.empty(n, **i64), torch.empty(n, **i64), torch.zeros(8, **i64)
+    cells = B * (int(4.2 / res) + 3) ** 3      # surface voxels are centred on their mean: the batch box exceeds 2.3 m
+    wt = torch.empty(int(L.p2w_voxel_sample_table_ws_bytes(n, cells)), dtype=torch.uint8, device="cuda")
+    cs, css, status = torch.empty(cells + 1, **i32), torch.empty(cells + 1, **i32), torch.zeros(1, **i32)
+    assert L.p2w_voxel_sample_table(ptr(xyzr), ptr(csr), B, n, res, ptr(idx), ptr(ptr_out), ptr(batch_out), ptr(order), ptr(skeys),
+                                    ptr(ckeys), ptr(grid), None, None, ptr(cs), ptr(css), ptr(status), cells, ptr(wt), wt.numel(),
+                                    stream()) == 0
+    assert int(status) == 0
+    m = int(ptr_out[B])
+    rec = torch.empty((n, 4), device="cuda")
+    assert L.p2w_index_records(ptr(xyzr), ptr(order), ptr(csr), B, n, ptr(rec), stream()) == 0
+    coarse = xyzr[idx[:m].long()].contiguous()
+    new = lambda rows, k: (torch.full((rows, k), -7, **i32), torch.full((rows,), -7, **i32))
+    # k = 2, queries = all points in cell order, candidates = the sampled level
+    (a_n, a_d), (b_n, b_d) = new(n, 2), new(n, 2)
+    assert L.p2w_knn_grid(ptr(coarse), ptr(ckeys), ptr(ptr_out), ptr(grid), ptr(rec), None, ptr(csr), B, n, 2, ptr(a_n), ptr(a_d), None,
+                          SEARCH_Q_ROW_IN_W | box, stream()) == 0
+    assert L.p2w_knn_grid_indexed(ptr(coarse), ptr(ckeys), ptr(ptr_out), ptr(grid), ptr(cs), ptr(rec), None, ptr(csr), B, n, 2, ptr(b_n),
+                                  ptr(b_d), None, SEARCH_Q_ROW_IN_W | box, stream()) == 0
+    assert torch.equal(a_n, b_n) and torch.equal(a_d, b_d)
+    # k = 32 among the sampled level itself, queries = every third of them
+    q = torch.arange(0, m, 3, **i32)
+    pq = torch.searchsorted(batch_out[:m][q.long()].long().contiguous(), torch.arange(B + 1, device="cuda")).int()
+    (a_n, a_d), (b_n, b_d) = new(q.numel(), 32), new(q.numel(), 32)
+    assert L.p2w_knn_grid(ptr(coarse), ptr(ckeys), ptr(ptr_out), ptr(grid), ptr(coarse), ptr(q), ptr(pq), B, q.numel(), 32, ptr(a_n),
+                          ptr(a_d), None, box, stream()) == 0
+    assert L.p2w_knn_grid_indexed(ptr(coarse), ptr(ckeys), ptr(ptr_out), ptr(grid), ptr(cs), ptr(coarse), ptr(q), ptr(pq), B, q.numel(),
+                                  32, ptr(b_n), ptr(b_d), None, box, stream()) == 0
+    assert torch.equal(a_n, b_n) and torch.equal(a_d, b_d)
+    # ball query: candidates = the input points in cell-sorted order (carrying their own index), queries = the sampled level
+    (a_n, a_d), (b_n, b_d) = new(m, 32), new(m, 32)
+    assert L.p2w_ball_query_grid(ptr(rec), ptr(skeys), ptr(csr), ptr(grid), ptr(xyzr), ptr(idx), ptr(ptr_out), B, m, 0.08, 32, ptr(a_n),
+                                 ptr(a_d), SEARCH_X_INDEX_IN_W | box, stream()) == 0
+    assert L.p2w_ball_query_grid_indexed(ptr(rec), ptr(skeys), ptr(csr), ptr(grid), ptr(css), ptr(xyzr), ptr(idx), ptr(ptr_out), B, m, 0.08,
+                                         32, ptr(b_n), ptr(b_d), SEARCH_X_INDEX_IN_W | box, stream()) == 0
+    assert torch.equal(a_n, b_n) and torch.equal(a_d, b_d)
+    if surface:
+        assert int(a_d.max()) == 32
 
 
 @pytest.mark.parametrize("sizes,surface", [([5000], False), ([1500, 40, 2600], True), ([16384, 3000], False)])
