@@ -1224,8 +1224,10 @@ __global__ __launch_bounds__(256) void slab_search_kernel(const float4* __restri
                 // first candidate at or after a key: one load from the sampler's cell -> position table when the caller has
                 // it (every key formed here is <= the grid's cell count, the table's last entry), else a bisection of the
                 // keys (14 dependent loads for a 16 k-point voxel: the run tables were most of a k = 2 search's time)
-                const int s0 = cell_start ? cell_start[ka] : lower_bound_key(keys, c0, c1, ka);
-                const int s1 = cell_start ? cell_start[kz] : lower_bound_key(keys, s0, c1, kz);
+                // (clamped to the voxel's range: a sampler call whose grid did not fit its table leaves the table unwritten -
+                // the level is empty then, c0 == c1, and the caller repeats the geometry; nothing may be read through garbage)
+                const int s0 = cell_start ? min(max(cell_start[ka], c0), c1) : lower_bound_key(keys, c0, c1, ka);
+                const int s1 = cell_start ? min(max(cell_start[kz], s0), c1) : lower_bound_key(keys, s0, c1, kz);
                 run_start[tid] = s0;
                 len = s1 - s0;
             }
