@@ -184,6 +184,27 @@ size_t p2w_morton_order_ws_bytes(int32_t n);
 int32_t p2w_morton_order(const float* xyzr, int32_t n, const p2w_grid* grid, int32_t* order_out, void* ws, size_t ws_bytes,
                          p2w_stream_t stream);
 
+/* ---- plot -> voxels: the grid step of the reference's voxeliser (pointstowood/src/preprocessing.py:55-64, Voxelise.grid) -------
+ * cell_out[i] = PyG voxel_grid(P, size) with batch = None over ALL D <= 16 columns of the row-major table P[n, ld] (the
+ * reference hands the whole point table - x, y, z, reflectance, ..., n_z - to voxel_grid): sum_d trunc((P_id - lo_d) / size) *
+ * stride_d with the column minima lo_d and the running products of the per-column cell counts as strides (fp32 subtract /
+ * divide / truncate, int64 result).  ws: >= 256 bytes. */
+int32_t p2w_cells_nd(const float* P, int32_t n, int32_t D, int32_t ld, float size, int64_t* cell_out, void* ws, size_t ws_bytes,
+                     p2w_stream_t stream);
+/* STABLE ascending sort of n (64-bit key, int32 value) pairs - hand-written LSD radix sort, 8-bit digits, as many passes as the
+ * largest key has bytes (decided on the device).  vals_in NULL: values = 0..n-1, i.e. vals_out = the stable argsort the
+ * voxeliser needs (points of a voxel keep their order, as the reference's nonzero() scan gives them).  In and out buffers must
+ * differ.  ws: 16-byte aligned, p2w_sort_pairs_u64_ws_bytes(n) bytes. */
+size_t p2w_sort_pairs_u64_ws_bytes(int32_t n);
+int32_t p2w_sort_pairs_u64(const uint64_t* keys_in, uint64_t* keys_out, const int32_t* vals_in, int32_t* vals_out, int32_t n, void* ws,
+                           size_t ws_bytes, p2w_stream_t stream);
+/* Runs of equal keys in a SORTED key array that hold at least min_count elements (the voxeliser's min_pts filter,
+ * preprocessing.py:60-62): starts_out / counts_out[0 .. *n_out) in ascending order (buffers of n entries), *n_out on the device.
+ * ws: 16-byte aligned, p2w_key_runs_ws_bytes(n) bytes. */
+size_t p2w_key_runs_ws_bytes(int32_t n);
+int32_t p2w_key_runs(const uint64_t* keys_sorted, int32_t n, int32_t min_count, int32_t* starts_out, int32_t* counts_out, int32_t* n_out,
+                     void* ws, size_t ws_bytes, p2w_stream_t stream);
+
 /* PointCloudClassifier.compute_labels (predicter.py:112-127) over a neighbour table nbr[n,k] (indices into pred /
  * prob, deg[i] valid entries): pwood_out = median of the neighbours' probabilities (np.median: mean of the two middle
  * values for an even count); label_out: any_wood != 1 -> 1 if any neighbour's prediction > any_wood else 0;

@@ -50,6 +50,11 @@ SIGNATURES = {
     "p2w_knn": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
     "p2w_morton_order_ws_bytes": (_sz, [_i32]),
     "p2w_morton_order": (_i32, [_vp, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "p2w_cells_nd": (_i32, [_vp, _i32, _i32, _i32, _f32, _vp, _vp, _sz, _vp]),
+    "p2w_sort_pairs_u64_ws_bytes": (_sz, [_i32]),
+    "p2w_sort_pairs_u64": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _sz, _vp]),
+    "p2w_key_runs_ws_bytes": (_sz, [_i32]),
+    "p2w_key_runs": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "p2w_vote": (_i32, [_vp, _vp, _i32, _vp, _vp, _i32, _f32, _vp, _vp, _vp]),
     "p2w_tile_bbox": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp]),
     "p2w_tile_bbox_count": (_i32, [_i32, _i32]),

@@ -1,10 +1,9 @@
 // Geometry kernels: record packing, grid sub-sampling, level gather, ball query, exact kNN.
 // gfx950 only (wave64, LDS-staged candidate tiles, wave-level ballot/popcount selection).
 #include "p2w_common.h"
+#include "p2w_sort.h"
 #include <cstdlib>
 #include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
 
 // ------------------------------------------------------------------------------------------------
 // pack: xyzr + batch ids
@@ -173,13 +172,9 @@ struct VsLayout { size_t hdr, keys_in, keys_out, vals_in, vals_out, flags, scan,
 
 static hipError_t vs_layout(int n_bound, VsLayout* L) {
     auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
-    size_t sort_bytes = 0, scan_bytes = 0;
-    hipError_t e = rocprim::radix_sort_pairs(nullptr, sort_bytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr,
-                                             (int*)nullptr, (int*)nullptr, (size_t)n_bound, 0, 64, (hipStream_t)0);
-    if (e != hipSuccess) return e;
-    e = rocprim::exclusive_scan(nullptr, scan_bytes, (int*)nullptr, (int*)nullptr, 0, (size_t)n_bound, rocprim::plus<int>(),
-                                (hipStream_t)0);
-    if (e != hipSuccess) return e;
+    RsLayout R;
+    rs_layout(n_bound, &R);
+    const size_t sort_bytes = R.bytes, scan_bytes = xs_ws_bytes(n_bound);   // the hand-written sort / scan of p2w_sort.h
     size_t off = 0;
     L->hdr = off; off += up(sizeof(VsHeader));
     L->keys_in = off; off += up(sizeof(unsigned long long) * n_bound);
@@ -221,12 +216,12 @@ static int32_t vs_cluster(char* w, const VsLayout& L, const unsigned long long* 
     int* flags = reinterpret_cast<int*>(w + L.flags);
     int* scan = reinterpret_cast<int*>(w + L.scan);
     const int nblk = p2w_cdiv(n_bound, 256);
-    size_t tb = L.temp_bytes;
-    hipError_t e = rocprim::radix_sort_pairs(w + L.temp, tb, keys_in, keys_out, vals_in, vals_out, (size_t)n_bound, 0, 64, s);
+    // stable radix sort of the (key, point) pairs: only the valid ones (the padding keys beyond *n_dev stay where they are and
+    // would make every one of the eight digit passes run), then flags -> ranks
+    hipError_t e = rs_sort_pairs(w + L.temp, keys_in, keys_out, vals_in, vals_out, n_dev, n_bound, s);
     if (e != hipSuccess) return (int32_t)e;
     vs_flags_kernel<<<nblk, 256, 0, s>>>(keys_out, n_dev, n_bound, flags);
-    tb = L.temp_bytes;
-    e = rocprim::exclusive_scan(w + L.temp, tb, flags, scan, 0, (size_t)n_bound, rocprim::plus<int>(), s);
+    e = xs_exclusive_scan(w + L.temp, flags, scan, n_bound, s);
     if (e != hipSuccess) return (int32_t)e;
     const int nblk2 = p2w_cdiv((n_bound > B + 1 ? n_bound : B + 1), 256);
     vs_scatter_kernel<<<nblk2, 256, 0, s>>>(flags, scan, vals_out, ptr, B, n_dev, n_bound, idx_out, ptr_out, batch_out,
@@ -1642,21 +1637,18 @@ __global__ __launch_bounds__(256) void morton_keys_kernel(const float4* __restri
     const unsigned cy = (unsigned)grid_cell(p.y, grid->lo[1], res, 1ll << 21);
     const unsigned cz = (unsigned)grid_cell(p.z, grid->lo[2], res, 1ll << 21);
     keys[i] = spread3(cx) | (spread3(cy) << 1) | (spread3(cz) << 2);
-    vals[i] = i;
+    if (vals) vals[i] = i;
 }
 
-struct MoLayout { size_t keys_in, keys_out, vals_in, temp, temp_bytes, total; };
+struct MoLayout { size_t keys_in, keys_out, temp, temp_bytes, total; };
 static hipError_t mo_layout(int n, MoLayout* L) {
     auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
-    size_t sort_bytes = 0;
-    hipError_t e = rocprim::radix_sort_pairs(nullptr, sort_bytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr,
-                                             (int*)nullptr, (int*)nullptr, (size_t)n, 0, 63, (hipStream_t)0);
-    if (e != hipSuccess) return e;
+    RsLayout R;
+    rs_layout(n, &R);
     size_t off = 0;
     L->keys_in = off; off += up(sizeof(unsigned long long) * n);
     L->keys_out = off; off += up(sizeof(unsigned long long) * n);
-    L->vals_in = off; off += up(sizeof(int) * n);
-    L->temp = off; L->temp_bytes = up(sort_bytes); off += L->temp_bytes;
+    L->temp = off; L->temp_bytes = up(R.bytes); off += L->temp_bytes;
     L->total = off;
     return hipSuccess;
 }
@@ -1681,12 +1673,146 @@ extern "C" int32_t p2w_morton_order(const float* xyzr, int32_t n, const p2w_grid
     char* w = static_cast<char*>(ws);
     hipStream_t s = p2w_s(stream);
     auto* keys_in = reinterpret_cast<unsigned long long*>(w + L.keys_in);
-    morton_keys_kernel<<<p2w_cdiv(n, 256), 256, 0, s>>>(reinterpret_cast<const float4*>(xyzr), n, grid, keys_in,
-                                                       reinterpret_cast<int*>(w + L.vals_in));
-    size_t tb = L.temp_bytes;
-    e = rocprim::radix_sort_pairs(w + L.temp, tb, keys_in, reinterpret_cast<unsigned long long*>(w + L.keys_out),
-                                  reinterpret_cast<int*>(w + L.vals_in), order_out, (size_t)n, 0, 63, s);
+    morton_keys_kernel<<<p2w_cdiv(n, 256), 256, 0, s>>>(reinterpret_cast<const float4*>(xyzr), n, grid, keys_in, nullptr);
+    // argsort (values = 0..n-1) by the hand-written radix sort: as many digit passes as the largest key has bytes
+    e = rs_sort_pairs(w + L.temp, keys_in, reinterpret_cast<unsigned long long*>(w + L.keys_out), nullptr, order_out, nullptr, n, s);
     if (e != hipSuccess) return (int32_t)e;
+    return P2W_LAUNCH_STATUS();
+}
+
+// ------------------------------------------------------------------------------------------------
+// plot -> voxels (the reference's Voxelise.grid, pointstowood/src/preprocessing.py:55-64): cell ids over ALL columns of the
+// point table, a stable argsort of them, and the runs of equal cells that hold at least min_pts points
+// ------------------------------------------------------------------------------------------------
+constexpr int VC_MAXD = 16;
+struct VcHeader { unsigned lo[VC_MAXD], hi[VC_MAXD]; };
+__global__ void vc_init_kernel(VcHeader* h) {
+    if (threadIdx.x < VC_MAXD) { h->lo[threadIdx.x] = 0xffffffffu; h->hi[threadIdx.x] = 0u; }
+}
+__global__ __launch_bounds__(256) void vc_minmax_kernel(const float* __restrict__ P, int n, int D, int ld, VcHeader* h) {
+    __shared__ float red[4][2 * VC_MAXD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int d = 0; d < D; ++d) {
+        float lo = INFINITY, hi = -INFINITY;
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+            const float v = P[i * ld + d];
+            lo = fminf(lo, v); hi = fmaxf(hi, v);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { lo = fminf(lo, __shfl_xor(lo, off)); hi = fmaxf(hi, __shfl_xor(hi, off)); }
+        if (lane == 0) { red[wave][2 * d] = lo; red[wave][2 * d + 1] = hi; }
+    }
+    __syncthreads();
+    if (threadIdx.x < D) {
+        const int d = threadIdx.x;
+        float lo = red[0][2 * d], hi = red[0][2 * d + 1];
+        for (int w = 1; w < 4; ++w) { lo = fminf(lo, red[w][2 * d]); hi = fmaxf(hi, red[w][2 * d + 1]); }
+        atomicMin(&h->lo[d], f2ord(lo)); atomicMax(&h->hi[d], f2ord(hi));
+    }
+}
+// PyG voxel_grid(P, size) with batch = None: sum_d trunc((P_d - lo_d) / size) * stride_d, strides = running products of
+// the per-column cell counts trunc((hi_d - lo_d) / size) + 1 (fp32 subtract / divide / truncate as oracle/ops.py voxel_grid)
+__global__ __launch_bounds__(256) void vc_cells_kernel(const float* __restrict__ P, int n, int D, int ld, float size,
+                                                       const VcHeader* __restrict__ h, long long* __restrict__ cell) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    long long key = 0, stride = 1;
+    for (int d = 0; d < D; ++d) {
+        const float lo = ord2f(h->lo[d]), hi = ord2f(h->hi[d]);
+        const long long cnt = (long long)((hi - lo) / size) + 1;
+        key += (long long)((P[i * ld + d] - lo) / size) * stride;
+        stride *= cnt;
+    }
+    cell[i] = key;
+}
+extern "C" int32_t p2w_cells_nd(const float* P, int32_t n, int32_t D, int32_t ld, float size, int64_t* cell_out, void* ws,
+                                size_t ws_bytes, p2w_stream_t stream) {
+    if (n == 0) return P2W_OK;
+    P2W_CHECK_PTR(P); P2W_CHECK_PTR(cell_out); P2W_CHECK_PTR(ws);
+    if (n < 0 || D <= 0 || D > VC_MAXD || ld < D || !(size > 0.f)) return P2W_EINVAL;
+    if (ws_bytes < sizeof(VcHeader)) return P2W_EWORKSPACE;
+    hipStream_t s = p2w_s(stream);
+    auto* h = static_cast<VcHeader*>(ws);
+    const int nblk = p2w_cdiv(n, 256);
+    vc_init_kernel<<<1, 64, 0, s>>>(h);
+    vc_minmax_kernel<<<nblk < 512 ? nblk : 512, 256, 0, s>>>(P, n, D, ld, h);
+    vc_cells_kernel<<<nblk, 256, 0, s>>>(P, n, D, ld, size, h, reinterpret_cast<long long*>(cell_out));
+    return P2W_LAUNCH_STATUS();
+}
+
+extern "C" size_t p2w_sort_pairs_u64_ws_bytes(int32_t n) {
+    RsLayout R;
+    rs_layout(n > 0 ? n : 1, &R);
+    return R.bytes;
+}
+extern "C" int32_t p2w_sort_pairs_u64(const uint64_t* keys_in, uint64_t* keys_out, const int32_t* vals_in, int32_t* vals_out, int32_t n,
+                                      void* ws, size_t ws_bytes, p2w_stream_t stream) {
+    if (n == 0) return P2W_OK;
+    P2W_CHECK_PTR(keys_in); P2W_CHECK_PTR(keys_out); P2W_CHECK_PTR(vals_out); P2W_CHECK_PTR(ws); P2W_CHECK_ALIGN16(ws);
+    if (n < 0 || keys_in == keys_out || (vals_in && vals_in == vals_out)) return P2W_EINVAL;
+    if (ws_bytes < p2w_sort_pairs_u64_ws_bytes(n)) return P2W_EWORKSPACE;
+    return (int32_t)rs_sort_pairs(ws, reinterpret_cast<const unsigned long long*>(keys_in), reinterpret_cast<unsigned long long*>(keys_out),
+                                  vals_in, vals_out, nullptr, n, p2w_s(stream));
+}
+
+// runs of equal keys in a sorted array that hold at least min_count elements: (start, count) of each, in order, + how many
+__global__ __launch_bounds__(256) void vr_flag_kernel(const unsigned long long* __restrict__ keys, int n, int* __restrict__ flag) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) flag[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;      // first element of a run
+}
+__global__ __launch_bounds__(256) void vr_starts_kernel(const int* __restrict__ flag, const int* __restrict__ rank, int n,
+                                                        int* __restrict__ run_start, int* __restrict__ n_runs) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (flag[i]) run_start[rank[i]] = (int)i;
+    if (i == n - 1) { const int r = rank[i] + flag[i]; run_start[r] = n; *n_runs = r; }
+}
+__global__ __launch_bounds__(256) void vr_keep_kernel(const int* __restrict__ run_start, const int* __restrict__ n_runs, int min_count,
+                                                      int n, int* __restrict__ keep) {
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    keep[r] = (r < *n_runs && run_start[r + 1] - run_start[r] >= min_count) ? 1 : 0;
+}
+__global__ __launch_bounds__(256) void vr_compact_kernel(const int* __restrict__ run_start, const int* __restrict__ n_runs,
+                                                         const int* __restrict__ keep, const int* __restrict__ pos, int n,
+                                                         int* __restrict__ starts_out, int* __restrict__ counts_out,
+                                                         int* __restrict__ n_out) {
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int nr = *n_runs;
+    if (r == 0) *n_out = nr > 0 ? pos[nr - 1] + keep[nr - 1] : 0;
+    if (r >= nr || !keep[r]) return;
+    starts_out[pos[r]] = run_start[r];
+    counts_out[pos[r]] = run_start[r + 1] - run_start[r];
+}
+extern "C" size_t p2w_key_runs_ws_bytes(int32_t n) {
+    const size_t m = (size_t)(n > 0 ? n : 1) + 1;
+    return 4 * ((m * sizeof(int) + 255) & ~size_t(255)) + 256 + xs_ws_bytes(n);
+}
+extern "C" int32_t p2w_key_runs(const uint64_t* keys_sorted, int32_t n, int32_t min_count, int32_t* starts_out, int32_t* counts_out,
+                                int32_t* n_out, void* ws, size_t ws_bytes, p2w_stream_t stream) {
+    P2W_CHECK_PTR(n_out);
+    hipStream_t s = p2w_s(stream);
+    if (n == 0) return (int32_t)hipMemsetAsync(n_out, 0, sizeof(int), s);
+    P2W_CHECK_PTR(keys_sorted); P2W_CHECK_PTR(starts_out); P2W_CHECK_PTR(counts_out); P2W_CHECK_PTR(ws); P2W_CHECK_ALIGN16(ws);
+    if (n < 0) return P2W_EINVAL;
+    if (ws_bytes < p2w_key_runs_ws_bytes(n)) return P2W_EWORKSPACE;
+    const size_t seg = (((size_t)n + 1) * sizeof(int) + 255) & ~size_t(255);
+    char* w = static_cast<char*>(ws);
+    int* a = reinterpret_cast<int*>(w);             // run-start flags, then keep flags
+    int* b = reinterpret_cast<int*>(w + seg);       // their exclusive scans
+    int* run_start = reinterpret_cast<int*>(w + 2 * seg);
+    int* n_runs = reinterpret_cast<int*>(w + 3 * seg);
+    void* xs = w + 3 * seg + 256;
+    const int nblk = p2w_cdiv(n, 256);
+    const auto* k = reinterpret_cast<const unsigned long long*>(keys_sorted);
+    vr_flag_kernel<<<nblk, 256, 0, s>>>(k, n, a);
+    hipError_t e = xs_exclusive_scan(xs, a, b, n, s);
+    if (e != hipSuccess) return (int32_t)e;
+    vr_starts_kernel<<<nblk, 256, 0, s>>>(a, b, n, run_start, n_runs);
+    vr_keep_kernel<<<nblk, 256, 0, s>>>(run_start, n_runs, min_count, n, a);
+    e = xs_exclusive_scan(xs, a, b, n, s);
+    if (e != hipSuccess) return (int32_t)e;
+    vr_compact_kernel<<<nblk, 256, 0, s>>>(run_start, n_runs, a, b, n, starts_out, counts_out, n_out);
     return P2W_LAUNCH_STATUS();
 }
 

@@ -11,11 +11,17 @@ ids per grid size, voxels are contiguous segments of the sorted order.
   ``mode="compat"`` bins over every column like the reference (PyG ``voxel_grid`` is handed x, y, z, reflectance,
   ..., n_z - so voxels are also split by height above ground); ``mode="xyz"`` bins over x, y, z only.
 
-Pure tensor code (runs on whatever device the points are on); the accelerated hot path starts after this step.
+The grid step (cell ids over all columns, the stable argsort that groups the points of a voxel, the runs with at least
+``min_pts`` points) runs on hand-written HIP kernels behind the C ABI when the points are on the GPU: ``p2w_cells_nd``,
+``p2w_sort_pairs_u64`` (radix sort), ``p2w_key_runs``.  The same step in tensor operations (``_grid_segments_torch``) serves
+points that live on the host (the CPU tests of the host-side logic); both give identical voxels (tested on the GPU).  Ground
+normalisation and the reflectance quantile transform are cheap tensor code on whatever device the points are on.
 """
 from __future__ import annotations
 
 import torch
+
+from . import _lib
 
 
 def ground_normalise(pos, resolution: float = 5.0):
@@ -52,6 +58,38 @@ def _cells(P, size):
     return (((Pb - lo[None]) / S[None]).to(torch.long) * stride[None]).sum(dim=1)
 
 
+def _grid_segments_torch(P, size, min_pts):
+    """(order, starts, counts): stable argsort of the cell ids, start and length of every run with >= min_pts points."""
+    cell = _cells(P, size)
+    order = torch.argsort(cell, stable=True)          # points of a voxel keep their original relative order
+    _, counts = torch.unique_consecutive(cell[order], return_counts=True)
+    starts = torch.cumsum(counts, 0) - counts
+    keep = (counts >= min_pts).nonzero(as_tuple=True)[0]
+    return order, starts[keep], counts[keep]
+
+
+def _grid_segments_hip(P, size, min_pts):
+    """The same through libp2w_gfx950.so: p2w_cells_nd -> p2w_sort_pairs_u64 (stable radix argsort) -> p2w_key_runs."""
+    L, ptr, stream, check = _lib.lib(), _lib.ptr, _lib.stream, _lib.check
+    P = P.contiguous()
+    n, D = P.shape
+    dev = P.device
+    if D > 16:
+        raise ValueError("the voxeliser bins at most 16 columns")
+    u8 = lambda nbytes: torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
+    cell, cell_sorted = torch.empty(n, dtype=torch.int64, device=dev), torch.empty(n, dtype=torch.int64, device=dev)
+    order = torch.empty(n, dtype=torch.int32, device=dev)
+    ws = u8(max(L.p2w_sort_pairs_u64_ws_bytes(n), L.p2w_key_runs_ws_bytes(n)))
+    check(L.p2w_cells_nd(ptr(P), n, D, D, float(size), ptr(cell), ptr(ws), ws.numel(), stream()), "p2w_cells_nd")
+    check(L.p2w_sort_pairs_u64(ptr(cell), ptr(cell_sorted), None, ptr(order), n, ptr(ws), ws.numel(), stream()), "p2w_sort_pairs_u64")
+    starts, counts = torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.int32, device=dev)
+    n_out = torch.zeros(1, dtype=torch.int32, device=dev)
+    check(L.p2w_key_runs(ptr(cell_sorted), n, int(min_pts), ptr(starts), ptr(counts), ptr(n_out), ptr(ws), ws.numel(), stream()),
+          "p2w_key_runs")
+    k = int(n_out)                                     # the one host sync of a grid size
+    return order.long(), starts[:k].long(), counts[:k].long()
+
+
 def voxelise(pc, grid_sizes=(2.0, 4.0), min_pts: int = 128, max_pts: int = 16384, mode: str = "compat", generator=None,
              ground: bool = True):
     """pc: [N, >=4] (x, y, z, reflectance, ...).  Returns (voxels, n_z): ``voxels`` is a list of ``[n, cols+1]`` float32
@@ -67,21 +105,20 @@ def voxelise(pc, grid_sizes=(2.0, 4.0), min_pts: int = 128, max_pts: int = 16384
     if refl_on:
         pos[:, 3] = quantile_normalize_reflectance(pos[:, 3].reshape(-1))
     weight = (pos[:, 3] - pos[:, 3].min() + 1e-8) if refl_on else None
+    segments = _grid_segments_hip if pos.is_cuda else _grid_segments_torch
     voxels = []
     for size in grid_sizes:
-        cell = _cells(pos if mode == "compat" else pos[:, :3], size)
-        order = torch.argsort(cell, stable=True)          # points of a voxel keep their original relative order
-        uniq, counts = torch.unique_consecutive(cell[order], return_counts=True)
-        starts = torch.cumsum(counts, 0) - counts
-        keep = (counts >= min_pts).nonzero(as_tuple=True)[0]
+        order, starts, counts = segments(pos if mode == "compat" else pos[:, :3], size, min_pts)
         # One gather puts every voxel's rows next to each other; a voxel that needs neither the max_pts sampling nor
         # the NaN-row filter (almost all of them) is then just a VIEW of that tensor: no per-voxel kernels, one sync.
         gathered = pos[order]
         nan_row = torch.isnan(gathered).any(dim=1)
         nan_before = torch.cumsum(nan_row.to(torch.int64), 0) - nan_row.to(torch.int64)      # NaN rows before row i
-        ends = starts[keep] + counts[keep] - 1
-        nan_cnt = nan_before[ends] + nan_row[ends].to(torch.int64) - nan_before[starts[keep]]
-        for s, c, bad in zip(starts[keep].tolist(), counts[keep].tolist(), nan_cnt.tolist()):
+        if starts.numel() == 0:
+            continue
+        ends = starts + counts - 1
+        nan_cnt = nan_before[ends] + nan_row[ends].to(torch.int64) - nan_before[starts]
+        for s, c, bad in zip(starts.tolist(), counts.tolist(), nan_cnt.tolist()):
             if c <= max_pts and bad == 0:
                 voxels.append(gathered[s:s + c])
                 continue
