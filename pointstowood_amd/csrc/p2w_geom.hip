@@ -1302,20 +1302,34 @@ __global__ __launch_bounds__(256) void slab_search_kernel(const float4* __restri
             const bool pow2 = MODE != 0 || LADDER;
             const int tsz = pow2 ? ((TILE > 1024 && left > 1024) ? 2048 : (left > 512 ? 1024 : (left > 256 ? 512 : 256)))
                                  : min(TILE, (left + 255) & ~255);
+            // three sweeps over the thread's slots instead of one (the search kernels wait, they do not compute: VALU active
+            // 21-26 % of the wave cycles, profiles/r3_f16x3_valu.csv): all run lookups, then all record loads in flight
+            // together, then the LDS stores - not a bisection, a load and a store in a dependent chain per slot
+            int cidx[TILE / 256];
 #pragma unroll
             for (int rr = 0; rr < TILE / 256; ++rr) {
                 const int s = tid + 256 * rr;
-                if (s >= tsz) break;
                 const int g = tbase + (MODE != 0 ? s : (pow2 ? ((s * 389) & (tsz - 1)) : ((s * 389) % tsz)));
-                float4 v = make_float4(INFINITY, INFINITY, INFINITY, __int_as_float(0x7fffffff));
-                if (g < n_c) {
+                cidx[rr] = -1;
+                if (s < tsz && g < n_c) {
                     int lo = 0, hi = G_MAXRUN;   // largest run with run_pre[run] <= g
                     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (run_pre[mid] <= g) lo = mid; else hi = mid; }
-                    const int c = run_start[lo] + (g - run_pre[lo]);
-                    v = x[c];
-                    if (!index_in_w) v.w = __int_as_float(c);
+                    cidx[rr] = run_start[lo] + (g - run_pre[lo]);
                 }
-                cand[s] = v;
+            }
+            float4 cv[TILE / 256];
+#pragma unroll
+            for (int rr = 0; rr < TILE / 256; ++rr) {
+                cv[rr] = make_float4(INFINITY, INFINITY, INFINITY, __int_as_float(0x7fffffff));
+                if (cidx[rr] >= 0) {
+                    cv[rr] = x[cidx[rr]];
+                    if (!index_in_w) cv[rr].w = __int_as_float(cidx[rr]);
+                }
+            }
+#pragma unroll
+            for (int rr = 0; rr < TILE / 256; ++rr) {
+                const int s = tid + 256 * rr;
+                if (s < tsz) cand[s] = cv[rr];
             }
             __syncthreads();
             SLAB_STAMP(3);   // staging

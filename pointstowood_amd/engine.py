@@ -194,7 +194,7 @@ class Geometry:
         return [t for t in out if t is not None]
 
 
-def pick_chunk(m: int, budget: int, col_tiles: int, n_cu: int = 256) -> int:
+def pick_chunk(m: int, budget: int, col_tiles: int, n_cu: int = 256, full_rounds: bool = False) -> int:
     """Rows per chunk for a row-chunked GEMM chain over ``m`` rows: a multiple of 256 within [0.6, 1.25] x ``budget`` (the
     row count that keeps the chain's intermediates cache-resident) that minimises the number of chip rounds of 256 x 256
     tiles over all chunks (``col_tiles`` column tiles per row tile) - a 1122-row tail chunk or a chunk that fills 1.1
@@ -203,6 +203,15 @@ def pick_chunk(m: int, budget: int, col_tiles: int, n_cu: int = 256) -> int:
         return 256
     budget = max(256, budget // 256 * 256)
     if m <= budget * 5 // 4:
+        # one chunk - unless its 256 x 256 tiles would fill the last of several chip rounds so badly that the GEMM falls
+        # back to its small tile for ALL of them (the library takes the large tile from 78 % fill): then the whole rounds
+        # go first as a chunk of their own and the remainder follows as a small one (level 3 of the bench batch:
+        # 17506 rows x 8 column tiles = 2.16 rounds -> 16384 rows on the large tile + 1122 rows)
+        per_round = max(256, 256 * n_cu // max(1, col_tiles) // 256 * 256)
+        tiles = -(-m // 256) * col_tiles
+        rounds_ = -(-tiles // n_cu)
+        if full_rounds and m > per_round and tiles * 100 < rounds_ * n_cu * 78:
+            return m // per_round * per_round
         return -(-m // 256) * 256
     best, best_cost = budget, None
     lo, hi = max(256, budget * 3 // 5 // 256 * 256), budget * 5 // 4 // 256 * 256
@@ -229,6 +238,7 @@ class EngineOptions:
     fp_hints: bool = True         # seed the k = 2 interpolation searches from the sampler's ranks (p2w_knn_hint2)
     sa_pack: bool = True          # P2W_SA_PACK8 on the ball-query level (targets with <= 8 neighbours share an MFMA tile)
     chunk_pick: bool = True       # fill-aware row-chunk sizes (pick_chunk); False: the plain budget
+    chunk_full_rounds: bool = True   # a residual-block level whose tiles fill its last chip round badly: whole rounds first, rest after
     res_chunk_rows: int = 131072  # rows (at 4F = 512) per residual-block / FP chunk; 0 = whole level (swept: tools/chunk_sweep.sh)
     res_streams: int = 1          # residual-block chunk chains in flight (2: +0.6 %, measured)
     feature_streams: int = 1      # Net.stream(): feature phases in flight
@@ -565,7 +575,7 @@ class Engine:
             # residual block in row chunks: the two 4F-wide intermediates of a chunk (2 x chunk x 4F x 4 B) are written
             # and re-read while they still sit in the 256 MiB Infinity Cache instead of round-tripping HBM
             chunk = self.res_chunk_rows if self.res_chunk_rows > 0 else M
-            chunk = max(256, min(M, pick_chunk(M, chunk * 512 // E, E // 256) if self.chunk_pick
+            chunk = max(256, min(M, pick_chunk(M, chunk * 512 // E, E // 256, full_rounds=self.chunk_full_rounds) if self.chunk_pick
                                  else (chunk * 512 // E) // 256 * 256))   # ~same bytes per chunk at every level
             # Chunks are independent chains of four GEMMs; alternating them between two streams lets the tiles of one
             # chain fill the CUs the other leaves idle at its wave tails (a 1122-row tail chunk at level 3 otherwise
