@@ -240,10 +240,12 @@ class EngineOptions:
     chunk_pick: bool = True       # fill-aware row-chunk sizes (pick_chunk); False: the plain budget
     chunk_full_rounds: bool = True   # a residual-block level whose tiles fill its last chip round badly: whole rounds first, rest after
     res_chunk_rows: int = 131072  # rows (at 4F = 512) per residual-block / FP chunk; 0 = whole level (swept: tools/chunk_sweep.sh)
-    res_streams: int = 1          # residual-block chunk chains in flight (2: +0.6 %, measured)
+    res_streams: int = 2          # row-chunk chains (residual blocks, FP modules) in flight: the tiles of one chain fill the CUs the
+                                  # other leaves idle at its round tails (2 vs 1: -1 % of the bench step, same-box A/B)
     feature_streams: int = 1      # Net.stream(): feature phases in flight
     geo_priority: int = 0         # HIP stream priorities of the two-stream pipeline (features are the critical path)
     feat_priority: int = -1
+    res_priority: int = -1        # ... and of the second chunk-chain stream (part of the feature phase)
     gemm_flags: int = 0           # P2W_GEMM_* bits of include/p2w.h passed to every p2w_gemm_h2 call (A/B runs)
     sa_flags: int = 0             # P2W_SA_ITEM_* bits passed to p2w_sa_conv_h (A/B runs)
 
@@ -583,7 +585,7 @@ class Engine:
             nst = max(1, min(self.res_streams, -(-M // chunk)))
             cur = torch.cuda.current_stream()
             if nst > 1 and getattr(self, "_s_res", None) is None:
-                self._s_res = torch.cuda.Stream()
+                self._s_res = torch.cuda.Stream(priority=int(self.res_priority))
             lanes = [cur] + ([self._s_res] if nst > 1 else [])
             bufs = [(newh(min(M, chunk), E), newh(min(M, chunk), E)) for _ in lanes]
             if nst > 1:
@@ -638,34 +640,50 @@ class Engine:
             chunk = max(256, min(m, pick_chunk(m, chunk * 512 // (Fc + Fs[fl - 1]), max(1, l0.N // 256)) if self.chunk_pick
                                  else (chunk * 512 // (Fc + Fs[fl - 1])) // 256 * 256))
             mc = min(m, chunk)
-            a = newh(mc, l0.N)
             need_f32 = fl > 1 or keep is not None
             b = new(m, l1.N) if need_f32 else None
-            yh = newh(mc, l1.N) if fl == 1 else None
+            # chunk chains alternate between two streams like the residual blocks' (each lane has its own intermediates)
+            nst = max(1, min(self.res_streams, -(-m // chunk)))
+            cur = torch.cuda.current_stream()
+            if nst > 1 and getattr(self, "_s_res", None) is None:
+                self._s_res = torch.cuda.Stream(priority=int(self.res_priority))
+            lanes = [cur] + ([self._s_res] if nst > 1 else [])
             # head for one class (model.py:241-243): conv1 + BN + ReLU + conv2 as ONE operator, its [m, 512] intermediate never
             # reaches HBM (p2w_gemm_h2_rowdot: per-slice partial dot products in the GEMM's epilogue + a finishing pass)
-            hws = (torch.empty(int(L.p2w_gemm_h2_rowdot_ws_bytes(mc, w.head1.N)), dtype=torch.uint8, device=dev)
-                   if (fl == 1 and w.num_classes == 1) else None)
-            hdh = newh(mc, F3) if (fl == 1 and w.num_classes != 1) else None
-            for r0 in range(0, m, chunk):
+            one = fl == 1 and w.num_classes == 1
+            bufs = [dict(a=newh(mc, l0.N), yh=newh(mc, l1.N) if fl == 1 else None,
+                         hws=torch.empty(int(L.p2w_gemm_h2_rowdot_ws_bytes(mc, w.head1.N)), dtype=torch.uint8, device=dev) if one else None,
+                         hdh=newh(mc, F3) if (fl == 1 and not one) else None) for _ in lanes]
+            if nst > 1:
+                ready = torch.cuda.Event()
+                ready.record(cur)
+                self._s_res.wait_event(ready)
+            for ci, r0 in enumerate(range(0, m, chunk)):
                 mm = min(chunk, m - r0)
-                # the interpolated part only (skip = NULL): the skip columns of these rows were written by their producer
-                self._call("interp_concat", L.p2w_interp_concat_h2, prec, ptr(y), Fc, ptr(y_xyzr), ptr(fine.xyzr[r0:]),
-                           ptr(nbr[r0:]), ptr(deg[r0:]), kw, None, 0, mm, ptr(cf[r0:]), ld)
-                self._gemm_h2("gemm_mlp", cf[r0:], ld, mm, l0, out_h2=a, ldh_o=pad8(l0.N))
-                self._gemm_h2("gemm_mlp", a, pad8(l0.N), mm, l1, out_f32=None if b is None else b[r0:], ldo=l1.N,
-                              out_h2=yh, ldh_o=pad8(l1.N))
-                if fl == 1:   # head (model.py:241-243) on the same chunk
-                    if w.num_classes == 1:
-                        lin = w.head1
-                        ep = Epilogue(ptr(lin.bias), ptr(lin.sc0), ptr(lin.sh0), ptr(lin.sc1), ptr(lin.sh1), None, 0,
-                                      lin.relu0, lin.relu1, lin.relu2, lin.relu_final)
-                        self._call("gemm_mlp", L.p2w_gemm_h2_rowdot, prec, ptr(yh), pad8(F3), ptr(lin.w16), lin.wscale, mm, lin.N,
-                                   lin.K, C.byref(ep), ptr(w.head2_w), float(w.head2_b[0]), ptr(logits[r0:]), ptr(hws),
-                                   hws.numel(), self.gemm_flags)
-                    else:   # multi-class head: conv2 is one more (narrow) GEMM over the H form of conv1's output
-                        self._gemm_h2("gemm_mlp", yh, pad8(F3), mm, w.head1, out_h2=hdh, ldh_o=pad8(F3))
-                        self._gemm_h2("gemm_mlp", hdh, pad8(F3), mm, w.head2, out_f32=o_multi[r0:], ldo=w.num_classes)
+                bf, st = bufs[ci % len(lanes)], lanes[ci % len(lanes)]
+                a, yh, hws, hdh = bf["a"], bf["yh"], bf["hws"], bf["hdh"]
+                with torch.cuda.stream(st):
+                    # the interpolated part only (skip = NULL): the skip columns of these rows were written by their producer
+                    self._call("interp_concat", L.p2w_interp_concat_h2, prec, ptr(y), Fc, ptr(y_xyzr), ptr(fine.xyzr[r0:]),
+                               ptr(nbr[r0:]), ptr(deg[r0:]), kw, None, 0, mm, ptr(cf[r0:]), ld)
+                    self._gemm_h2("gemm_mlp", cf[r0:], ld, mm, l0, out_h2=a, ldh_o=pad8(l0.N))
+                    self._gemm_h2("gemm_mlp", a, pad8(l0.N), mm, l1, out_f32=None if b is None else b[r0:], ldo=l1.N,
+                                  out_h2=yh, ldh_o=pad8(l1.N))
+                    if fl == 1:   # head (model.py:241-243) on the same chunk
+                        if one:
+                            lin = w.head1
+                            ep = Epilogue(ptr(lin.bias), ptr(lin.sc0), ptr(lin.sh0), ptr(lin.sc1), ptr(lin.sh1), None, 0,
+                                          lin.relu0, lin.relu1, lin.relu2, lin.relu_final)
+                            self._call("gemm_mlp", L.p2w_gemm_h2_rowdot, prec, ptr(yh), pad8(F3), ptr(lin.w16), lin.wscale, mm, lin.N,
+                                       lin.K, C.byref(ep), ptr(w.head2_w), float(w.head2_b[0]), ptr(logits[r0:]), ptr(hws),
+                                       hws.numel(), self.gemm_flags)
+                        else:   # multi-class head: conv2 is one more (narrow) GEMM over the H form of conv1's output
+                            self._gemm_h2("gemm_mlp", yh, pad8(F3), mm, w.head1, out_h2=hdh, ldh_o=pad8(F3))
+                            self._gemm_h2("gemm_mlp", hdh, pad8(F3), mm, w.head2, out_f32=o_multi[r0:], ldo=w.num_classes)
+            if nst > 1:   # join
+                done = torch.cuda.Event()
+                done.record(self._s_res)
+                cur.wait_event(done)
             y, y_xyzr = b, fine.xyzr
             if keep is not None:
                 keep[f"fp{fl}_module.out"] = b

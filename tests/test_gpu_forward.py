@@ -310,7 +310,8 @@ def test_engine_switches_are_keyword_arguments_and_do_not_change_results():
     outs = []
     os.environ["P2W_SAMPLER"], os.environ["P2W_SEARCH"] = "nonsense", "nonsense"     # would have been read (and broken) before
     try:
-        for kw in ({}, dict(sampler="sort"), dict(search="brute"), dict(sa_pack=False, fp_hints=False), dict(table_cells_per_point=0.0)):
+        for kw in ({}, dict(sampler="sort"), dict(search="brute"), dict(sa_pack=False, fp_hints=False), dict(table_cells_per_point=0.0),
+                   dict(res_streams=1, chunk_full_rounds=False), dict(search_index=False, search_box=7), dict(res_chunk_rows=4096)):
             net = Net(num_classes=1, C=8, k=32, **kw)
             net.load_state_dict(sd, strict=True)
             outs.append(net.cuda().eval()(d).clone())
