@@ -24,10 +24,15 @@ hdt = torch.bfloat16 if PREC == 2 else torch.float16
 dev = torch.device("cuda")
 # (M, K, N, out): the bench forward's layers (level sizes of BASELINE configs[1]); out: h = H tensor, f = fp32
 shapes = [(131072, 32, 64, "f"), (123046, 128, 192, "f"), (81683, 256, 384, "f"),                  # hoists
-          (65536, 128, 512, "h"), (65536, 512, 512, "h"), (65536, 512, 128, "f"),                  # residual block, level 1
-          (32768, 256, 1024, "h"), (32768, 1024, 1024, "h"), (32768, 1024, 256, "f"),              # level 2
-          (17506, 512, 2048, "h"), (17506, 2048, 2048, "h"), (17506, 2048, 512, "f"),              # level 3
-          (61440, 544, 512, "h"), (61440, 512, 512, "h"), (61440, 512, 512, "f")]                  # fp1 / head
+          (123046, 128, 512, "h"), (123046, 512, 512, "h"), (123046, 512, 128, "f"),               # residual block, level 1
+          (81683, 256, 1024, "h"), (81683, 1024, 1024, "h"), (81683, 1024, 256, "f"),              # level 2
+          (17506, 512, 2048, "h"), (17506, 2048, 2048, "h"), (17506, 2048, 512, "f"),              # level 3 (whole)
+          (16384, 2048, 2048, "h"), (1122, 2048, 2048, "h"), (16384, 2048, 512, "f"),              # level 3 (whole rounds + rest)
+          (17506, 516, 512, "h"), (17506, 512, 512, "f"), (17506, 1024, 768, "h"), (17506, 768, 512, "f"),   # sa4, fp4
+          (81683, 768, 640, "h"), (81683, 640, 512, "f"), (123046, 640, 512, "h"),                 # fp3, fp2
+          (65536, 544, 512, "h"), (65536, 512, 512, "h")]                                          # fp1 / head
+if os.environ.get("SHAPES"):
+    shapes = [shapes[int(i)] for i in os.environ["SHAPES"].split(",")]
 g = torch.Generator(device="cuda").manual_seed(0)
 for M, K, N, kind in shapes:
     Np, Kp = _lib.packed_dims(N, K, PREC)
