@@ -289,7 +289,6 @@ int32_t p2w_packed_dims_h(int32_t prec, int32_t N, int32_t K, int32_t* N_pad, in
 #define P2W_GEMM_GENERIC_EPI 4   /* run the runtime-flag epilogue instead of the specialised one */
 #define P2W_GEMM_ORDER_ROWS 8    /* tile order: an XCD owns whole row tiles (W re-read from its L2) */
 #define P2W_GEMM_ORDER_COLS 16   /* tile order: an XCD owns a slice of column tiles (A streamed per slice) */
-#define P2W_GEMM_TILE_256x128 64 /* force the 256 x 128 workgroup tile */
 #define P2W_GEMM_RESIDUAL_H 32   /* epi->residual is an H tensor of the launch's precision (epi->ldr = its row pitch ldh), not fp32 */
 /* flags of p2w_sa_conv_h (0 = let the library choose the work-item shape by C2) */
 #define P2W_SA_ITEM_256 1        /* 4 targets x 256 output columns per work item */

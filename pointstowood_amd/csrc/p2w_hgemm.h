@@ -986,15 +986,7 @@ static int32_t launch_gemm_h(const _Float16* Ah, int32_t ldh_a, const _Float16* 
         if (g >= 8) g &= ~7;
         return g;
     };
-    // third shape: 256 rows x 128 columns (8 waves of 64 x 64, one workgroup per CU, 96 KB of stages): between the two in
-    // L2 -> LDS bytes per MFMA (0.75 x the small tile's), for layers the large tile does not fit - narrow N (N = 128 projects,
-    // hoists), N = 640, or too few 256 x 256 tiles to fill whole chip rounds
-    const bool mid = !dotw && (flags & P2W_GEMM_TILE_256x128) != 0;
-    if (mid) {
-        const int nMt = p2w_cdiv(M, 256), nNtm = p2w_cdiv(N, 128);
-        const int tm = pick_mode(nNtm), nvb = tile_grid(nMt, nNtm, tm);
-        gemm_hp_kernel<PREC, 4, 2, 2, 2><<<pgrid(nvb, 1), 512, 0, stream>>>(Ah, ldh_a, Wp, wscale, M, N, Kpad, nMt, nNtm, nvb, ep, o, ef, tm, stagger);
-    } else if (big) {
+    if (big) {
         const int nMt = p2w_cdiv(M, 256), nNt2 = Npad / 256;
         const int tm = pick_mode(nNt2), nvb = tile_grid(nMt, nNt2, tm);
         if (dotw) gemm_hp_kernel<PREC, 2, 4, 4, 2, true><<<pgrid(nvb, 1), 512, 0, stream>>>(Ah, ldh_a, Wp, wscale, M, N, Kpad, nMt, nNt2, nvb, ep, o, ef, tm, stagger);
