@@ -242,7 +242,8 @@ class EngineOptions:
     res_chunk_rows: int = 131072  # rows (at 4F = 512) per residual-block / FP chunk; 0 = whole level (swept: tools/chunk_sweep.sh)
     res_streams: int = 2          # row-chunk chains (residual blocks, FP modules) in flight: the tiles of one chain fill the CUs the
                                   # other leaves idle at its round tails (2 vs 1: -1 % of the bench step, same-box A/B)
-    feature_streams: int = 1      # Net.stream(): feature phases in flight
+    feature_streams: int = 2      # Net.stream(): feature phases in flight (2: the kernels of batch i + 1 fill the round tails of batch
+                                  # i's: -6 % of the bench step; 3: no further gain)
     geo_priority: int = 0         # HIP stream priorities of the two-stream pipeline (features are the critical path)
     feat_priority: int = -1
     res_priority: int = -1        # ... and of the second chunk-chain stream (part of the feature phase)
@@ -289,6 +290,15 @@ class Engine:
         self._ws = None
 
     # -- small helpers ------------------------------------------------------------------------
+    def _side_stream(self, cur):
+        """The second chunk-chain stream of the feature phase running on `cur` (one per feature stream: phases in flight on
+        different streams must not meet on a shared side stream)."""
+        pool = self.__dict__.setdefault("_side_streams", {})
+        key = cur.cuda_stream
+        if key not in pool:
+            pool[key] = torch.cuda.Stream(priority=int(self.res_priority))
+        return pool[key]
+
     def _call(self, name, fn, *args):
         ev = self.events
         if ev is None:
@@ -584,14 +594,13 @@ class Engine:
             # runs four GEMMs at 16 % chip fill).
             nst = max(1, min(self.res_streams, -(-M // chunk)))
             cur = torch.cuda.current_stream()
-            if nst > 1 and getattr(self, "_s_res", None) is None:
-                self._s_res = torch.cuda.Stream(priority=int(self.res_priority))
-            lanes = [cur] + ([self._s_res] if nst > 1 else [])
+            side = self._side_stream(cur) if nst > 1 else None
+            lanes = [cur] + ([side] if nst > 1 else [])
             bufs = [(newh(min(M, chunk), E), newh(min(M, chunk), E)) for _ in lanes]
             if nst > 1:
                 ready = torch.cuda.Event()
                 ready.record(cur)
-                self._s_res.wait_event(ready)
+                side.wait_event(ready)
             for ci, r0 in enumerate(range(0, M, chunk)):
                 m = min(chunk, M - r0)
                 (e1, e2), st = bufs[ci % len(lanes)], lanes[ci % len(lanes)]
@@ -604,7 +613,7 @@ class Engine:
                                   residual=convh[r0:] if res_h else conv[r0:], ldr=pad8(C2) if res_h else C2, residual_h=res_h)
             if nst > 1:   # join: everything after this level (and the buffers' reuse) is ordered behind both chains
                 done = torch.cuda.Event()
-                done.record(self._s_res)
+                done.record(side)
                 cur.wait_event(done)
             if l == 3:
                 x3 = out
@@ -645,9 +654,8 @@ class Engine:
             # chunk chains alternate between two streams like the residual blocks' (each lane has its own intermediates)
             nst = max(1, min(self.res_streams, -(-m // chunk)))
             cur = torch.cuda.current_stream()
-            if nst > 1 and getattr(self, "_s_res", None) is None:
-                self._s_res = torch.cuda.Stream(priority=int(self.res_priority))
-            lanes = [cur] + ([self._s_res] if nst > 1 else [])
+            side = self._side_stream(cur) if nst > 1 else None
+            lanes = [cur] + ([side] if nst > 1 else [])
             # head for one class (model.py:241-243): conv1 + BN + ReLU + conv2 as ONE operator, its [m, 512] intermediate never
             # reaches HBM (p2w_gemm_h2_rowdot: per-slice partial dot products in the GEMM's epilogue + a finishing pass)
             one = fl == 1 and w.num_classes == 1
@@ -657,7 +665,7 @@ class Engine:
             if nst > 1:
                 ready = torch.cuda.Event()
                 ready.record(cur)
-                self._s_res.wait_event(ready)
+                side.wait_event(ready)
             for ci, r0 in enumerate(range(0, m, chunk)):
                 mm = min(chunk, m - r0)
                 bf, st = bufs[ci % len(lanes)], lanes[ci % len(lanes)]
@@ -682,7 +690,7 @@ class Engine:
                             self._gemm_h2("gemm_mlp", hdh, pad8(F3), mm, w.head2, out_f32=o_multi[r0:], ldo=w.num_classes)
             if nst > 1:   # join
                 done = torch.cuda.Event()
-                done.record(self._s_res)
+                done.record(side)
                 cur.wait_event(done)
             y, y_xyzr = b, fine.xyzr
             if keep is not None:

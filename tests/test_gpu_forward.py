@@ -190,6 +190,17 @@ def test_stream_pipeline_equals_sequential_forward():
         got = [o.clone() for o in net.stream(mk(b) for b in batches)]
         torch.cuda.synchronize()
         assert len(got) == len(seq) and all(torch.equal(a, b) for a, b in zip(got, seq))
+    # feature phases of several batches in flight (the default is 2), with and without the second chunk-chain stream, over a
+    # longer sequence: same logits, same order
+    many = [batches[i % 4] for i in range(11)]
+    for kw in (dict(feature_streams=1, res_streams=1), dict(feature_streams=2, res_streams=2, res_chunk_rows=2048),
+               dict(feature_streams=3, res_streams=1)):
+        net2 = Net(num_classes=1, C=8, k=32, **kw)
+        net2.load_state_dict(weights.synth_state_dict(1, 8, seed=5), strict=True)
+        net2 = net2.cuda().eval()
+        got = [o.clone() for o in net2.stream(mk(b) for b in many)]
+        torch.cuda.synchronize()
+        assert len(got) == 11 and all(torch.equal(a, seq[i % 4]) for i, a in enumerate(got)), kw
 
 
 def test_predict_cli_on_a_voxel_directory(tmp_path):
