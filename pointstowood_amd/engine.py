@@ -240,8 +240,9 @@ class EngineOptions:
     chunk_pick: bool = True       # fill-aware row-chunk sizes (pick_chunk); False: the plain budget
     chunk_full_rounds: bool = True   # a residual-block level whose tiles fill its last chip round badly: whole rounds first, rest after
     res_chunk_rows: int = 131072  # rows (at 4F = 512) per residual-block / FP chunk; 0 = whole level (swept: tools/chunk_sweep.sh)
-    res_streams: int = 2          # row-chunk chains (residual blocks, FP modules) in flight: the tiles of one chain fill the CUs the
-                                  # other leaves idle at its round tails (2 vs 1: -1 % of the bench step, same-box A/B)
+    res_streams: int = 0          # row-chunk chains (residual blocks, FP modules) in flight: the tiles of one chain fill the CUs the
+                                  # other leaves idle at its round tails.  0 = automatic: 2 for a lone forward (-2 % of it), 1 when
+                                  # Net.stream() keeps two feature phases in flight (they fill each other's tails already)
     feature_streams: int = 2      # Net.stream(): feature phases in flight (2: the kernels of batch i + 1 fill the round tails of batch
                                   # i's: -6 % of the bench step; 3: no further gain)
     geo_priority: int = 0         # HIP stream priorities of the two-stream pipeline (features are the critical path)
@@ -290,6 +291,12 @@ class Engine:
         self._ws = None
 
     # -- small helpers ------------------------------------------------------------------------
+    def _chains(self):
+        """Chunk chains in flight inside one feature phase (EngineOptions.res_streams; 0 = automatic)."""
+        if self.res_streams > 0:
+            return self.res_streams
+        return 1 if getattr(self, "_phases_in_flight", 1) > 1 else 2
+
     def _side_stream(self, cur):
         """The second chunk-chain stream of the feature phase running on `cur` (one per feature stream: phases in flight on
         different streams must not meet on a shared side stream)."""
@@ -592,7 +599,7 @@ class Engine:
             # Chunks are independent chains of four GEMMs; alternating them between two streams lets the tiles of one
             # chain fill the CUs the other leaves idle at its wave tails (a 1122-row tail chunk at level 3 otherwise
             # runs four GEMMs at 16 % chip fill).
-            nst = max(1, min(self.res_streams, -(-M // chunk)))
+            nst = max(1, min(self._chains(), -(-M // chunk)))
             cur = torch.cuda.current_stream()
             side = self._side_stream(cur) if nst > 1 else None
             lanes = [cur] + ([side] if nst > 1 else [])
@@ -652,7 +659,7 @@ class Engine:
             need_f32 = fl > 1 or keep is not None
             b = new(m, l1.N) if need_f32 else None
             # chunk chains alternate between two streams like the residual blocks' (each lane has its own intermediates)
-            nst = max(1, min(self.res_streams, -(-m // chunk)))
+            nst = max(1, min(self._chains(), -(-m // chunk)))
             cur = torch.cuda.current_stream()
             side = self._side_stream(cur) if nst > 1 else None
             lanes = [cur] + ([side] if nst > 1 else [])
@@ -799,6 +806,13 @@ class Engine:
                             for _ in range(max(1, self.feature_streams))]
         s_geo = self._s_geo
         f_streams = self._s_feat[: max(1, self.feature_streams)]
+        self._phases_in_flight = len(f_streams)
+        try:
+            yield from self._forward_stream(inputs, cur_stream, s_geo, f_streams)
+        finally:
+            self._phases_in_flight = 1
+
+    def _forward_stream(self, inputs, cur_stream, s_geo, f_streams):
 
         def launch_geometry(args):
             s_geo.wait_stream(cur_stream)
