@@ -240,9 +240,10 @@ class EngineOptions:
     chunk_pick: bool = True       # fill-aware row-chunk sizes (pick_chunk); False: the plain budget
     chunk_full_rounds: bool = True   # a residual-block level whose tiles fill its last chip round badly: whole rounds first, rest after
     res_chunk_rows: int = 131072  # rows (at 4F = 512) per residual-block / FP chunk; 0 = whole level (swept: tools/chunk_sweep.sh)
-    res_streams: int = 0          # row-chunk chains (residual blocks, FP modules) in flight: the tiles of one chain fill the CUs the
-                                  # other leaves idle at its round tails.  0 = automatic: 2 for a lone forward (-2 % of it), 1 when
-                                  # Net.stream() keeps two feature phases in flight (they fill each other's tails already)
+    res_streams: int = 1          # row-chunk chains (residual blocks, FP modules) in flight inside ONE feature phase.  2 fills the
+                                  # round tails of a lone forward (-2 % of it) but adds nothing once Net.stream() keeps two feature
+                                  # phases in flight - and every extra high-priority stream competes for the few hardware queues
+                                  # (an idle third one cost the two-phase pipeline 5 %, measured): 1 by default
     feature_streams: int = 2      # Net.stream(): feature phases in flight (2: the kernels of batch i + 1 fill the round tails of batch
                                   # i's: -6 % of the bench step; 3: no further gain)
     geo_priority: int = 0         # HIP stream priorities of the two-stream pipeline (features are the critical path)
@@ -292,10 +293,8 @@ class Engine:
 
     # -- small helpers ------------------------------------------------------------------------
     def _chains(self):
-        """Chunk chains in flight inside one feature phase (EngineOptions.res_streams; 0 = automatic)."""
-        if self.res_streams > 0:
-            return self.res_streams
-        return 1 if getattr(self, "_phases_in_flight", 1) > 1 else 2
+        """Chunk chains in flight inside one feature phase (EngineOptions.res_streams)."""
+        return max(1, int(self.res_streams))
 
     def _side_stream(self, cur):
         """The second chunk-chain stream of the feature phase running on `cur` (one per feature stream: phases in flight on
@@ -806,11 +805,7 @@ class Engine:
                             for _ in range(max(1, self.feature_streams))]
         s_geo = self._s_geo
         f_streams = self._s_feat[: max(1, self.feature_streams)]
-        self._phases_in_flight = len(f_streams)
-        try:
-            yield from self._forward_stream(inputs, cur_stream, s_geo, f_streams)
-        finally:
-            self._phases_in_flight = 1
+        yield from self._forward_stream(inputs, cur_stream, s_geo, f_streams)
 
     def _forward_stream(self, inputs, cur_stream, s_geo, f_streams):
 
