@@ -236,7 +236,7 @@ def device_feed(vox, device):
     return Feed.to_device(synth.collate(vox), device)
 
 
-def measure_workload(net, data, reps=3):
+def measure_workload(net, data, reps=5):
     """One extra workload: setup forward (sizes the allocator), `reps` pipelined steps over the same batch, then one
     sequential profiled step for the per-kernel times and the algorithmic FLOPs of the level sizes actually produced."""
     import torch
