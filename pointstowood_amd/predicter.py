@@ -175,7 +175,31 @@ def classify_batch(model, data, is_wood: float, device):
     return out.cpu().numpy()
 
 
+def _consume(logits, data, is_wood: float):
+    """The post-processing of one batch (predicter.py:197-211) on the device: [n, 5] = un-shifted xyz, prediction, probability."""
+    probs = torch.sigmoid(torch.nan_to_num(logits)).reshape(-1)
+    preds = (probs >= is_wood).to(torch.int64)
+    shift = data.local_shift.reshape(-1, 3)[data.batch.long()]
+    xyz = data.pos[:, :3] + shift
+    return torch.cat([xyz, preds[:, None].to(xyz.dtype), probs[:, None].to(xyz.dtype)], dim=1)
+
+
 def classify(model, loader, is_wood: float = 0.5, device="cuda"):
+    """The reference's inference loop (predicter.py:193-213).  A model with a ``stream`` method (``pointstowood_amd.Net``) on a GPU
+    gets the batches through its software pipeline (geometry of the next batch beside the features of the current ones, no
+    device-to-host copy between batches); the rows and their order are those of one ``classify_batch`` per batch."""
+    if hasattr(model, "stream") and torch.device(device).type == "cuda":
+        held, outs = [], []
+
+        def feed():
+            for data in loader:
+                d = data.to(device)
+                held.append(d)
+                yield d
+        with torch.no_grad():
+            for logits in model.stream(feed()):
+                outs.append(_consume(logits, held.pop(0), is_wood))
+        return torch.cat(outs).cpu().numpy() if outs else np.zeros((0, 5), dtype=np.float32)
     outs = [classify_batch(model, data, is_wood, device) for data in loader]
     return np.vstack(outs) if outs else np.zeros((0, 5), dtype=np.float32)
 

@@ -29,7 +29,7 @@ for l in (1, 2, 3):
     M = geo.levels[l].n
     ws = keep[f"sa{l}_module.ws"]
     off = M * 32 * 20 + M * 4 + 64
-    st = ws[off: off + 256 * 2 * 8 * 8].view(torch.int64).view(256, 2, 8).cpu()
+    st = ws[off: off + 256 * 2 * 8 * 8].clone().view(torch.int64).view(256, 2, 8).cpu()   # (clone: the offset need not be 8-byte aligned)
     used = st[:, 0, 0] > 0
     med = lambda t: statistics.median(t.tolist())
     for w in (0, 1):
