@@ -30,6 +30,9 @@ typedef __attribute__((address_space(3))) void* lds_vp;
 typedef const __attribute__((address_space(1))) void* glb_vp;
 
 constexpr int H_BK = 32;   // k per plane of a PointNetConv slab
+#ifndef P2W_SA_PREFETCH_FRAGS
+#define P2W_SA_PREFETCH_FRAGS 1   // 0: the previous form (A/B: fused PointNetConv class -2.9 %)
+#endif
 constexpr int SA_EPI_COLS = 1024;   // capacity of the fused PointNetConv's LDS table of per-column epilogue parameters (C2 limit)
 
 
@@ -1363,8 +1366,27 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
         if (g + 1 < total && !(dbg & 2))
             issue((g + 1) & 1, W2h + (size_t)c1.nt * BN * NP * C1pad, c1.s * H_BK);
         const char* st = S + (size_t)(g & 1) * STAGE_CH * 16;
+#if P2W_SA_PREFETCH_FRAGS
+        // both k steps' fragments are requested up front (the kernel has the registers: 212 of 256): the second step's reads
+        // would otherwise sit behind the sched_barrier that closes the first step's producer interleave, i.e. be issued when
+        // their values are needed
+        h8 afq[2][NP][RT], bfq[2][NP][2];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+#pragma unroll
+                for (int t = 0; t < RT; ++t) afq[kk][p][t] = *reinterpret_cast<const h8*>(st + (offA[t] ^ (kk << 5) ^ (p << 6)));
+#pragma unroll
+                for (int t = 0; t < 2; ++t) bfq[kk][p][t] = *reinterpret_cast<const h8*>(st + (offB[t] ^ (kk << 5) ^ (p << 6)));
+            }
+#endif
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
+#if P2W_SA_PREFETCH_FRAGS
+            auto& af = afq[kk];
+            auto& bf = bfq[kk];
+#else
             h8 af[NP][RT], bf[NP][2];
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
@@ -1373,6 +1395,7 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
 #pragma unroll
                 for (int t = 0; t < 2; ++t) bf[p][t] = *reinterpret_cast<const h8*>(st + (offB[t] ^ (kk << 5) ^ (p << 6)));
             }
+#endif
             if (!(dbg & 4)) {
 #pragma unroll
             for (int i = 0; i < RT; ++i)
