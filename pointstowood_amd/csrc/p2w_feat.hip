@@ -590,6 +590,9 @@ extern "C" int32_t p2w_stem_h2(int32_t prec, const float* xyzr, int32_t n, const
 #define P2W_IC_ROWS 1   // swept 1..16 on the bench forward: 447 / 473 / 500 / 582 / 682 us for 1 / 2 / 4 / 8 / 16
 #endif
 constexpr int IC_ROWS = P2W_IC_ROWS;   // rows per wave (consecutive)
+#ifndef P2W_IC_PAIRS
+#define P2W_IC_PAIRS 1   // 0: one chunk per step (A/B: interpolation 0.355 -> 0.316 ms per bench step)
+#endif
 template <int PREC>
 __global__ __launch_bounds__(256) void interp_concat_kernel(const float* __restrict__ xc, int Fc, const float4* __restrict__ xyzr_c,
                                                             const float4* __restrict__ xyzr_f, const int* __restrict__ nbr,
@@ -616,7 +619,33 @@ __global__ __launch_bounds__(256) void interp_concat_kernel(const float* __restr
             if (s < 4) { js[s] = j; ws[s] = w; }
             den = den + w;
         }
+#if P2W_IC_PAIRS
+        // the common shape (k <= 2 neighbours, interpolated columns only): two 256-column chunks per step with all their loads
+        // issued before any arithmetic - the kernel waits for memory (VALU active 5 % of its wave cycles), so what counts is
+        // bytes in flight per lane
+        int c_first = 4 * lane;
+        if (d >= 1 && d <= 2 && Fs == 0) {
+            for (; c_first + 256 < Fc && c_first + 256 < 4 * q4; c_first += 512) {
+                float4 xa[2][2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    xa[u][0] = *reinterpret_cast<const float4*>(&xc[(size_t)js[0] * Fc + c_first + 256 * u]);
+                    xa[u][1] = d > 1 ? *reinterpret_cast<const float4*>(&xc[(size_t)js[1] * Fc + c_first + 256 * u]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    float4 num = make_float4(0.f, 0.f, 0.f, 0.f);
+                    num.x = num.x + xa[u][0].x * ws[0]; num.y = num.y + xa[u][0].y * ws[0]; num.z = num.z + xa[u][0].z * ws[0]; num.w = num.w + xa[u][0].w * ws[0];
+                    if (d > 1) { num.x = num.x + xa[u][1].x * ws[1]; num.y = num.y + xa[u][1].y * ws[1]; num.z = num.z + xa[u][1].z * ws[1]; num.w = num.w + xa[u][1].w * ws[1]; }
+                    const float v2[4] = {num.x / den, num.y / den, num.z / den, num.w / den};
+                    store4<PREC>(o, (size_t)q, c_first + 256 * u, v2);
+                }
+            }
+        }
+        for (int c = c_first; c < 4 * q4; c += 256) {
+#else
         for (int c = 4 * lane; c < 4 * q4; c += 256) {
+#endif
             float v[4] = {0.f, 0.f, 0.f, 0.f};
             if (c < Fc) {
                 float4 num = make_float4(0.f, 0.f, 0.f, 0.f);
