@@ -519,7 +519,8 @@ def main():
                        "setup": "one untimed pass over the distinct batches through the pipeline before the warmup steps (sizes the caching allocator's per-stream pools)",
                        "global_batch_voxels": world * BATCH, "points_per_step": world * BATCH * NPTS, "C": C,
                        "level_sizes_batch0": sizes, "parallelism": f"voxel-batch sharding x{world}, RCCL all-gather of logits",
-                       "pipeline": "2 HIP streams: geometry(i+1) || features(i) (features high priority)" if args.pipeline else "sequential"},
+                       "pipeline": ("HIP streams: geometry(i+1) || features(i), features alternating over "
+                                    f"{net.engine_options.feature_streams} high-priority streams") if args.pipeline else "sequential"},
             "end_to_end_tflops_algorithmic": 2.0 * total_macs * args.steps / dt / 1e12,
             "pcie_inclusive": pcie,
             "roofline": {"bound": "mfma", "kernel": kname.get(dom, dom), "achieved": achieved, "peak": peak,
