@@ -48,15 +48,17 @@ for mode in ("pipe", "seq"):
     if not files:
         continue
     rows = list(csv.DictReader(open(files[0])))
+    # the pipelined bench sizes the allocator pools with one forward more than the sequential one (bench.py, setup)
+    fwd_mode = forwards + (1 if (mode == "pipe" and "bench.py" in command) else 0)
     with open(os.path.join(root, f"{tag}_{prec}_{mode}_kernel_stats.csv"), "w", newline="") as f:
         w = csv.writer(f)
         cmd = re.sub(r"\S*/(bench\.py|tools/run_workload\.py)", r"\1", command).replace(" --pipeline 0", "") or "bench.py"
         w.writerow([f"# rocprofv3 --kernel-trace --stats of: python3 {cmd}" + (" --pipeline 0" if (mode == "seq" and "bench.py" in cmd) else "")
-                    + f" ({int(forwards)} forwards per process)"])
+                    + f" ({int(fwd_mode)} forwards per process)"])
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "per_forward_us"])
         for r in rows:
             w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"],
-                        f"{float(r['TotalDurationNs']) / forwards / 1e3:.1f}"])
+                        f"{float(r['TotalDurationNs']) / fwd_mode / 1e3:.1f}"])
 
 
 def counters(sub):
