@@ -956,26 +956,42 @@ static int32_t launch_gemm_h(const _Float16* Ah, int32_t ldh_a, const _Float16* 
         (ep.res_h && ((ep.ldr & 7) || (reinterpret_cast<uintptr_t>(ep.res_h) & 15))) ||
         odd8(ep.sc0) || odd8(ep.sh0) || odd8(ep.sc1) || odd8(ep.sh1) || odd8(dotw) || (part && ((ldpart & 3) || (reinterpret_cast<uintptr_t>(part) & 15))))
         ef = 0;
-    // tile order: keep W L2-resident per XCD when it does not fit an XCD's L2 (see tile_coords)
-    const size_t w_bytes = (size_t)N * Kpad * 2 * HCfg<PREC>::planes;
-    auto pick_mode = [&](int nNtx) {
+    // tile order (see tile_coords): the one that moves fewer bytes over the fabric.  Both orders were timed on every layer of
+    // the network: where they differ in time the one with less traffic is the faster one, and on the MFMA-bound layers the
+    // time is the same while the traffic differs up to 2.7 x (M = 16384, K = N = 2048: 408 MB against 1117 MB).
+    //  rows order:    the wpx workgroups of an XCD run R = wpx / nNt row tiles x all nNt column tiles side by side (they start
+    //                 together and their tiles are equally long, so a slab fetched by one is an L2 hit for the others):
+    //                 A once; W once per XCD when it stays in L2, else once per R row tiles of every XCD.
+    //  columns order: an XCD keeps its column slice of W and streams all of A (nNt >= 8), or 8 / nNt XCDs share a column tile.
+    const size_t w_bytes = (size_t)N * Kpad * 2 * HCfg<PREC>::planes, a_bytes = (size_t)M * Kpad * 2 * HCfg<PREC>::planes;
+    auto pick_mode = [&](int nNtx, int nMtx, int per_cu) {
         const bool ok = nNtx >= 8 || (nNtx > 0 && 8 % nNtx == 0);
         if (!ok) return 0;
         if (flags & P2W_GEMM_ORDER_ROWS) return 0;
         if (flags & P2W_GEMM_ORDER_COLS) return 1;
-        // column-slice order only pays when there are at least 8 column tiles (one or more per XCD); with fewer, several
-        // XCDs stream ALL of A for the same column tile (M = 17506, K = 2048, N = 512 at 128 x 128: 188 vs 134 us)
-        return (w_bytes > (size_t)3 * 1024 * 1024 && nNtx >= 8) ? 1 : 0;
+        const size_t l2_keep = (size_t)3 * 1024 * 1024;        // what an XCD's 4 MiB L2 keeps beside the streamed operand
+        const int wpx = n_cu / 8 * per_cu;                     // workgroups of an XCD in flight
+        const int R = wpx / nNtx > 0 ? wpx / nNtx : 1;
+        const int rows_px = p2w_cdiv(nMtx, 8), xcds = nMtx < 8 ? nMtx : 8;
+        const size_t t_rows = a_bytes * (size_t)p2w_cdiv(nNtx, wpx) + w_bytes * xcds * (w_bytes <= l2_keep ? 1 : p2w_cdiv(rows_px, R));
+        size_t t_cols;
+        if (nNtx >= 8) {
+            const int cpx = p2w_cdiv(nNtx, 8), Rc = wpx / cpx > 0 ? wpx / cpx : 1;
+            t_cols = a_bytes * 8 + w_bytes * (w_bytes / 8 <= l2_keep ? 1 : p2w_cdiv(nMtx, Rc));
+        } else {
+            t_cols = a_bytes * nNtx + w_bytes * 8 / nNtx;
+        }
+        return t_cols * 10 < t_rows * 9 ? 1 : 0;
     };
 #if defined(P2W_GEMM_STAMP) || defined(P2W_GEMM_ABLATE)   // diagnostic builds: one workgroup per tile, with the probes
     if (big) {
         const int nMt = p2w_cdiv(M, 256), nNt2 = Npad / 256;
-        const int tm = pick_mode(nNt2);
+        const int tm = pick_mode(nNt2, nMt, 1);
         gemm_h2g_kernel<PREC, 2, 4, 4, 2><<<tile_grid(nMt, nNt2, tm), 512, 0, stream>>>(
             Ah, ldh_a, Wp, (size_t)Npad * Kpad, wscale, M, N, Kpad, nMt, nNt2, ep, o, dbg, ef, tm);
     } else {
         const int nMt = p2w_cdiv(M, 128), nNt1 = p2w_cdiv(N, 128);
-        const int tm = pick_mode(nNt1);
+        const int tm = pick_mode(nNt1, nMt, 2);
         gemm_h2g_kernel<PREC, 2, 2, 2, 2><<<tile_grid(nMt, nNt1, tm), 256, 0, stream>>>(
             Ah, ldh_a, Wp, (size_t)Npad * Kpad, wscale, M, N, Kpad, nMt, nNt1, ep, o, dbg, ef, tm);
     }
@@ -991,12 +1007,12 @@ static int32_t launch_gemm_h(const _Float16* Ah, int32_t ldh_a, const _Float16* 
     };
     if (big) {
         const int nMt = p2w_cdiv(M, 256), nNt2 = Npad / 256;
-        const int tm = pick_mode(nNt2), nvb = tile_grid(nMt, nNt2, tm);
+        const int tm = pick_mode(nNt2, nMt, 1), nvb = tile_grid(nMt, nNt2, tm);
         if (dotw) gemm_hp_kernel<PREC, 2, 4, 4, 2, true><<<pgrid(nvb, 1), 512, 0, stream>>>(Ah, ldh_a, Wp, wscale, M, N, Kpad, nMt, nNt2, nvb, ep, o, ef, tm, stagger);
         else gemm_hp_kernel<PREC, 2, 4, 4, 2><<<pgrid(nvb, 1), 512, 0, stream>>>(Ah, ldh_a, Wp, wscale, M, N, Kpad, nMt, nNt2, nvb, ep, o, ef, tm, stagger);
     } else {
         const int nMt = p2w_cdiv(M, 128), nNt1 = p2w_cdiv(N, 128);
-        const int tm = pick_mode(nNt1), nvb = tile_grid(nMt, nNt1, tm);
+        const int tm = pick_mode(nNt1, nMt, 2), nvb = tile_grid(nMt, nNt1, tm);
         if (dotw) gemm_hp_kernel<PREC, 2, 2, 2, 2, true><<<pgrid(nvb, 2), 256, 0, stream>>>(Ah, ldh_a, Wp, wscale, M, N, Kpad, nMt, nNt1, nvb, ep, o, ef, tm, stagger);
         else gemm_hp_kernel<PREC, 2, 2, 2, 2><<<pgrid(nvb, 2), 256, 0, stream>>>(Ah, ldh_a, Wp, wscale, M, N, Kpad, nMt, nNt1, nvb, ep, o, ef, tm, stagger);
     }

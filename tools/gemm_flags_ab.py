@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Interleaved in-process A/B of p2w_gemm_h2 flag sets on the network's GEMM shapes (MI355X).
 
-    python tools/gemm_flags_ab.py 0 32            # LDS-staged vs direct epilogue
+    python tools/gemm_flags_ab.py 0 8 16          # library tile order vs row-tile / column-slice order per XCD
     PREC=1 python tools/gemm_flags_ab.py 0 1 2    # fp16: library choice vs forced 128 / 256 tiles
 
 Outputs of every flag set are compared with the first one's (the epilogue variants must agree bit for bit).
@@ -60,6 +60,12 @@ for M, K, N, kind in shapes:
     same = all(torch.equal(outs[fl].view(torch.int16 if kind == "h" else torch.int32),
                            outs[flagsets[0]].view(torch.int16 if kind == "h" else torch.int32)) for fl in flagsets[1:])
     t = {fl: [] for fl in flagsets}
+    if os.environ.get("ONCE"):       # counter passes: two launches per flag set and shape, no timing loop
+        for fl in flagsets:
+            run(fl)
+        torch.cuda.synchronize()
+        print(f"M={M:6d} K={K:4d} N={N:4d} out={kind} same={same}", flush=True)
+        continue
     for rnd in range(6):
         for fl in flagsets:
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
