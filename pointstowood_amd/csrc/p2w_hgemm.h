@@ -1120,6 +1120,7 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
                                                             float* __restrict__ out, int ldo, _Float16* __restrict__ out_h2,
                                                             int ldh, int dbg_) {
     // dbg (profiling ablations, -DP2W_SA_ABLATE builds only): 1 no epilogue, 2 no W2 DMA after the first, 4 no MFMA,
+    // 32 layer-1 weights of slab 0 in every slab, 64 fragments always from stage 0, 128 no barrier,
     // 8 no producer, 16 no P gather
 #ifdef P2W_SA_ABLATE
     const int dbg = dbg_;
@@ -1351,7 +1352,7 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
     Degs dg_;
     load_deg(c0.mt, dg_);   // item 0; later items' counts arrive one iteration ahead (dg_n)
 #ifdef P2W_SA_STAMP
-    unsigned long long t_wait = 0, t_epi = 0, t_mma = 0;
+    unsigned long long t_wait = 0, t_epi = 0, t_mma = 0, t_ld = 0;
     const unsigned long long t_start = p2w_stamp();
 #endif
     for (int g = 0; g < total; ++g) {
@@ -1362,7 +1363,7 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
         // No __syncthreads(): its fence would wait (vmcnt(0)) for the stores of an epilogue issued a moment ago.
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the producer's asm ds_writes of A(g) (see produce)
-        __builtin_amdgcn_s_barrier();
+        if (!(dbg & 128)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
 #ifdef P2W_SA_STAMP
         const unsigned long long t_b = p2w_stamp();
@@ -1377,11 +1378,11 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
         Degs dg_n;
         load_deg(c1.mt, dg_n);
         WRegs wk;
-        load_w(k_of(c1), wk);
+        if (!(dbg & 32)) load_w(k_of(c1), wk); else load_w(0, wk);   // (ablation 32: loop-invariant, hoisted by the compiler)
         __builtin_amdgcn_sched_barrier(0);
         if (g + 1 < total && !(dbg & 2))
             issue((g + 1) & 1, W2h + (size_t)c1.nt * BN * NP * C1pad, c1.s * H_BK);
-        const char* st = S + (size_t)(g & 1) * STAGE_CH * 16;
+        const char* st = S + (size_t)((dbg & 64) ? 0 : (g & 1)) * STAGE_CH * 16;   // (ablation 64: see the fragment reads)
 #if P2W_SA_PREFETCH_FRAGS
         // both k steps' fragments are requested up front (the kernel has the registers: 212 of 256): the second step's reads
         // would otherwise sit behind the sched_barrier that closes the first step's producer interleave, i.e. be issued when
@@ -1417,11 +1418,24 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
             for (int i = 0; i < RT; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
+#ifdef P2W_SA_MFMA16_TIMING   // timing only (wrong results): two 16x16x32 MFMAs on the same operand registers per 32x32x16
+                    auto t16 = [&](h8 a_, h8 b_) {
+                        f32x4 c0 = {acc[i][j][8 * kk], acc[i][j][8 * kk + 1], acc[i][j][8 * kk + 2], acc[i][j][8 * kk + 3]};
+                        f32x4 c1 = {acc[i][j][8 * kk + 4], acc[i][j][8 * kk + 5], acc[i][j][8 * kk + 6], acc[i][j][8 * kk + 7]};
+                        c0 = h_mfma16<PREC>(a_, b_, c0);
+                        c1 = h_mfma16<PREC>(a_, b_, c1);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { acc[i][j][8 * kk + e] = c0[e]; acc[i][j][8 * kk + 4 + e] = c1[e]; }
+                    };
+                    if constexpr (PREC == 0) { t16(af[1][i], bf[0][j]); t16(af[0][i], bf[1][j]); }
+                    t16(af[0][i], bf[0][j]);
+#else
                     if constexpr (PREC == 0) {
                         acc[i][j] = h_mfma<PREC>(af[1][i], bf[0][j], acc[i][j]);
                         acc[i][j] = h_mfma<PREC>(af[0][i], bf[1][j], acc[i][j]);
                     }
                     acc[i][j] = h_mfma<PREC>(af[0][i], bf[0][j], acc[i][j]);
+#endif
                 }
             }
             if (kk == 0) {
@@ -1456,6 +1470,9 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
 #pragma unroll
             for (int q = 0; q < GPT; ++q) asm volatile("" : "+v"(dg_n.d[i][q]));
         __builtin_amdgcn_s_waitcnt(p2w_vmcnt_imm(0));   // ... and the DMA (the compiler's own wait above normally is vmcnt(0) already)
+#ifdef P2W_SA_STAMP
+        t_ld += p2w_stamp() - t_c;     // the wait for the iteration's loads and the DMA alone
+#endif
         if (c0.s == nslab - 1) {  // item finished: reduce over neighbour slots and store, then start the next accumulation
             if (!(dbg & 1)) {
                 SaEpiRegs<RT, GPT> e;
@@ -1487,7 +1504,7 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
 #ifdef P2W_SA_STAMP
     if (lane == 0 && (wave == 0 || wave == 4) && blockIdx.x < 256) {   // stamp buffer: the 64 KiB behind the tile descriptors
         unsigned long long* sb = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(const_cast<int*>(desc) + (size_t)M * GPT) + 64) + (blockIdx.x * 2 + (wave ? 1 : 0)) * 8;
-        sb[0] = p2w_stamp() - t_start; sb[1] = t_wait; sb[2] = t_epi; sb[3] = t_mma; sb[4] = (unsigned long long)total; sb[5] = (unsigned long long)my_items;
+        sb[0] = p2w_stamp() - t_start; sb[1] = t_wait; sb[2] = t_epi; sb[3] = t_mma; sb[4] = (unsigned long long)total; sb[5] = (unsigned long long)my_items; sb[6] = t_ld;
     }
 #endif
 }

@@ -34,7 +34,7 @@ for l in (1, 2, 3):
     med = lambda t: statistics.median(t.tolist())
     for w in (0, 1):
         s_ = st[used, w]
-        tot, wait, epi, mma, slabs, items = (med(s_[:, i]) for i in range(6))
+        tot, wait, epi, mma, slabs, items, ld = (med(s_[:, i]) for i in range(7))
         print(f"level {l} (M={M}) wave{4*w}: {int(used.sum())} WGs, {items:.0f} items x {slabs/items:.0f} slabs: loop {tot:.0f} cyc "
               f"({tot/slabs:.0f}/slab), barrier wait {100*wait/tot:.0f} %, body {100*mma/tot:.0f} % ({mma/slabs:.0f}/slab), "
-              f"epilogue {100*epi/tot:.0f} % ({epi/items:.0f}/item)", flush=True)
+              f"end-of-slab load/DMA wait {100*ld/tot:.0f} % ({ld/slabs:.0f}/slab), epilogue {100*(epi-ld)/tot:.0f} % ({(epi-ld)/items:.0f}/item)", flush=True)
