@@ -1434,19 +1434,25 @@ __global__ __launch_bounds__(256) void slab_search_kernel(const float4* __restri
         if (MODE == 1) break;
         if (MODE == 0 && hint && pass == 0) {
             // a hint is only trusted after the fact: the ball it describes must have yielded k candidates (or all there
-            // are).  Otherwise that query forgets everything and the scanned region is declared empty, so the growth
-            // loop below rescans it without the bogus bound.
+            // are).  Otherwise the scanned region is declared empty, so that the growth loop below rescans it without the
+            // bogus bound - and EVERY query of the workgroup forgets what it holds: the rescan presents the region's
+            // candidates again, and a query that kept its list would keep each of them twice.
             bool bogus = false;
 #pragma unroll
             for (int j = 0; j < S_QPW; ++j) {
                 if (!((active >> j) & 1u)) continue;
                 const int found = __popcll(__ballot(best_i[j] != 0x7fffffff));
-                if (found < min(k, total)) { bogus = true; best_d[j] = INFINITY; best_i[j] = 0x7fffffff; thr[j] = INFINITY; }
+                if (found < min(k, total)) bogus = true;
             }
             __syncthreads();
             if (lane == 0) wred[wave][4] = bogus ? 1.f : 0.f;
             __syncthreads();
-            if (wred[0][4] + wred[1][4] + wred[2][4] + wred[3][4] > 0.f) { oXlo = 0; oXhi = -1; oYlo = 0; oYhi = -1; oZlo = 0; oZhi = -1; }
+            if (wred[0][4] + wred[1][4] + wred[2][4] + wred[3][4] > 0.f) {
+                oXlo = 0; oXhi = -1; oYlo = 0; oYhi = -1; oZlo = 0; oZhi = -1;
+#pragma unroll
+                for (int j = 0; j < S_QPW; ++j)
+                    if ((active >> j) & 1u) { best_d[j] = INFINITY; best_i[j] = 0x7fffffff; thr[j] = INFINITY; }
+            }
         }
         // which queries are final?  k-th distance <= distance to the nearest face of the scanned region
         float need = 0.f;

@@ -335,3 +335,72 @@ def test_engine_switches_are_keyword_arguments_and_do_not_change_results():
         Net(num_classes=1, C=8, no_such_option=1)
     with pytest.raises(ValueError):
         Net(num_classes=1, C=8, sampler="hash")
+
+
+def _fuzz_voxel(rng, seed):
+    """One random voxel: a generator, a size from a few points to a few thousand, and one of the shapes that stress the
+    geometry kernels' tie rules (exact duplicates, points in a plane, points on a lattice, a tiny extent)."""
+    n = int(rng.choice([12, 40, 130, 700, 1500, 3000]))
+    side = float(rng.choice([2.0, 4.0]))
+    refl = bool(rng.integers(0, 2))
+    v = synth.surface_voxel(side, max(n, 60), seed, refl) if rng.random() < 0.3 else synth.uniform_voxel(side, n, seed, refl)
+    p = v["pos"] + v["local_shift"]
+    kind = int(rng.integers(0, 5))
+    if kind == 1:                                   # a fifth of the points are exact copies of others
+        m = max(1, p.shape[0] // 5)
+        p[-m:] = p[:m]
+    elif kind == 2:                                 # all points in one horizontal plane
+        p[:, 2] = p[0, 2]
+    elif kind == 3:                                 # lattice: equal distances everywhere (ties decided by index)
+        p = torch.round(p / 0.125) * 0.125
+    elif kind == 4:                                 # 5 cm extent: every level's grid collapses to a few cells
+        p = p * 0.025
+    return synth._finish(p.contiguous(), v["reflectance"])
+
+
+def _fp_neighbours_expected(geo, f):
+    """knn_interpolate's k = 2 assignment of fine level f into level f + 1 by the CPU oracle, as [n, 2] (-1 = no neighbour)."""
+    from oracle import ops as oops
+    fine, coarse = geo.levels[f], geo.levels[f + 1]
+    nf, nc = fine.n, coarse.n
+    e = oops.knn(coarse.xyzr[:nc, :3].cpu(), fine.xyzr[:nf, :3].cpu(), 2, batch_x=coarse.batch[:nc].cpu().long(),
+                 batch_y=fine.batch[:nf].cpu().long())
+    first = torch.ones(e.shape[1], dtype=torch.bool)
+    first[1:] = e[0, 1:] != e[0, :-1]
+    exp = torch.full((nf, 2), -1, dtype=torch.long)
+    exp[e[0][first], 0] = e[1][first]
+    exp[e[0][~first], 1] = e[1][~first]
+    return exp
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("P2W_FUZZ_SEEDS", "24"))))
+def test_forward_fuzz_against_live_oracle(seed):
+    """Random small batches (ragged sizes down to fewer points than k, duplicates, planes, lattices, tiny extents, reflectance
+    on and off, C and k varied): neighbour structure bit-exact, wood probability within 1e-4 of the CPU oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    B = int(rng.integers(1, 6))
+    vox = [_fuzz_voxel(rng, 5000 + 17 * seed + b) for b in range(B)]
+    if not any(bool((v["reflectance"] != 0).any()) for v in vox) and seed % 2:
+        vox[0]["reflectance"] = torch.linspace(-1, 1, vox[0]["pos"].shape[0])
+    inp = synth.collate(vox)
+    C, k, wseed = int(rng.choice([4, 8])), int(rng.choice([8, 16, 32])), int(rng.integers(0, 100))
+    sd = weights.synth_state_dict(1, C, seed=wseed)
+    cap = {}
+    ref = onet.forward(sd, inp["pos"], inp["batch"], inp["reflectance"], inp["sf"], k=k, capture=cap)
+    keep = {}
+    got, _ = _run(inp, C, k, wseed, keep, "f16x3")
+    geo = keep["geometry"]
+    for l in (1, 2, 3):
+        lv = geo.levels[l]
+        assert torch.equal(lv.idx[: lv.n].long().cpu(), cap[f"sa{l}_module.idx"]), f"level {l} sample"
+        e = _edges(lv, k).cpu()
+        assert torch.equal(e[0], cap[f"sa{l}_module.edge_q"]) and torch.equal(e[1], cap[f"sa{l}_module.edge_c"]), f"level {l} edges"
+    for f in (0, 1, 2):   # the interpolation searches (a bogus-hint rescan once returned the nearest point twice)
+        nbr, deg = geo.fp_nbr[f]
+        n = geo.levels[f].n
+        ours = nbr[:n].cpu().long().clone()
+        ours[torch.arange(2)[None, :] >= deg[:n].cpu().long()[:, None]] = -1
+        assert torch.equal(ours, _fp_neighbours_expected(geo, f)), f"interpolation neighbours of level {f}"
+    assert torch.isfinite(got).all()
+    assert bool(((got.cpu() - ref).abs() <= 4e-4 + 2e-5 * ref.abs()).all())   # (logits of tiny voxels reach +-60)
+    assert (torch.sigmoid(got.cpu()) - torch.sigmoid(ref)).abs().max() <= 1e-4
