@@ -340,8 +340,8 @@ def test_engine_switches_are_keyword_arguments_and_do_not_change_results():
 def _fuzz_voxel(rng, seed):
     """One random voxel: a generator, a size from a few points to a few thousand, and one of the shapes that stress the
     geometry kernels' tie rules (exact duplicates, points in a plane, points on a lattice, a tiny extent)."""
-    n = int(rng.choice([12, 40, 130, 700, 1500, 3000]))
-    side = float(rng.choice([2.0, 4.0]))
+    n = int(rng.choice([12, 40, 130, 700, 1500, 3000, 6000]))
+    side = float(rng.choice([0.5, 2.0, 4.0, 9.0]))       # (the voxeliser makes 2 m and 4 m cells; the forward takes any extent)
     refl = bool(rng.integers(0, 2))
     v = synth.surface_voxel(side, max(n, 60), seed, refl) if rng.random() < 0.3 else synth.uniform_voxel(side, n, seed, refl)
     p = v["pos"] + v["local_shift"]
@@ -404,3 +404,36 @@ def test_forward_fuzz_against_live_oracle(seed):
     assert torch.isfinite(got).all()
     assert bool(((got.cpu() - ref).abs() <= 4e-4 + 2e-5 * ref.abs()).all())   # (logits of tiny voxels reach +-60)
     assert (torch.sigmoid(got.cpu()) - torch.sigmoid(ref)).abs().max() <= 1e-4
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("P2W_FUZZ_STREAMS", "3"))))
+def test_stream_pipeline_fuzz(seed):
+    """A random sequence of ragged batches through Net.stream (tables, workspaces and allocator pools are re-used across
+    batches of very different shapes): bit-identical to one forward per batch on a fresh model."""
+    from pointstowood_amd import Net
+    rng = np.random.default_rng(7000 + seed)
+    C, k = int(rng.choice([4, 8])), int(rng.choice([8, 32]))
+    batches = []
+    for i in range(9):
+        vox = [_fuzz_voxel(rng, 9000 + 100 * seed + 10 * i + b) for b in range(int(rng.integers(1, 5)))]
+        batches.append(synth.collate(vox))
+
+    def mk(b):
+        d = _D()
+        d.pos, d.batch, d.reflectance, d.sf = b["pos"].cuda(), b["batch"].cuda(), b["reflectance"].cuda(), b["sf"].cuda()
+        return d
+
+    def model():
+        net = Net(num_classes=1, C=C, k=k)
+        net.load_state_dict(weights.synth_state_dict(1, C, seed=seed), strict=True)
+        return net.cuda().eval()
+    seq = []
+    for b in batches:
+        seq.append(model()(mk(b)).clone())      # a fresh engine per batch: no state carried over
+    net = model()
+    for _ in range(2):
+        got = [o.clone() for o in net.stream(mk(b) for b in batches)]
+        torch.cuda.synchronize()
+        assert len(got) == len(seq)
+        for i, (a, b) in enumerate(zip(got, seq)):
+            assert torch.equal(a, b), f"batch {i}"
