@@ -158,21 +158,31 @@ def algorithmic_bytes(geo):
 KERNEL_OF = {"gemm_hoist": "gemm_kernel", "gemm_res": "gemm_kernel", "gemm_mlp": "gemm_kernel", "sa_conv": "sa_conv_kernel"}
 
 
-def profile_step(net, data):
+def profile_step(net, data, reps=3):
+    """Per-kernel-class GPU time of one sequential forward: HIP-event brackets around every run of consecutive launches of one
+    class, on the stream they are launched on.  One untimed pass (the pipelined region before it leaves the chip at another
+    clock), then `reps` bracketed forwards back to back; a class' time is the median over them."""
     import torch
     eng = net._engine
-    eng.events, eng.events_grouped = [], True   # one HIP-event pair per run of consecutive launches of one kernel class
-    keep = {"geometry_only": True}   # the geometry (level sizes) without the fp32 copies a full `keep` asks the engine for
+    keep = {}
     streams, eng.res_streams = eng.res_streams, 1   # per-kernel durations: no two kernels in flight while they are timed
-    net(data, keep=keep)
-    eng.flush_events()
-    torch.cuda.synchronize()
-    ev, eng.events, eng.events_grouped, eng.res_streams = eng.events, None, False, streams
-    per = {}
-    for name, s, e, launches in ev:
-        kname = KERNEL_OF.get(name, name)
-        t, n = per.get(kname, (0.0, 0))
-        per[kname] = (t + s.elapsed_time(e), n + launches)
+    net(data)
+    runs = []
+    for _ in range(reps):
+        eng.events, eng.events_grouped = [], True   # one HIP-event pair per run of consecutive launches of one kernel class
+        keep = {"geometry_only": True}   # the geometry (level sizes) without the fp32 copies a full `keep` asks the engine for
+        net(data, keep=keep)
+        eng.flush_events()
+        torch.cuda.synchronize()
+        ev, eng.events, eng.events_grouped = eng.events, None, False
+        per = {}
+        for name, s, e, launches in ev:
+            kname = KERNEL_OF.get(name, name)
+            t, n = per.get(kname, (0.0, 0))
+            per[kname] = (t + s.elapsed_time(e), n + launches)
+        runs.append(per)
+    eng.res_streams = streams
+    per = {kname: (statistics.median(r[kname][0] for r in runs), runs[0][kname][1]) for kname in runs[0]}
     return per, keep["geometry"]
 
 

@@ -10,7 +10,7 @@ PREC=${2:-f16x3}
 export TMPDIR=/tmp
 ROOT=$(pwd)
 if [ "$WHAT" = "bench" ]; then
-  NAME=$PREC; FWD=21   # forwards per sequential process: 8 allocator-sizing + 2 warmup + 10 steps + 1 profiled
+  NAME=$PREC; FWD=24   # forwards per sequential process: 8 allocator-sizing + 2 warmup + 10 steps + 4 of the profiled step (1 untimed + 3)
   CMD="$ROOT/bench.py --no-cpu-baseline --no-pcie --no-workloads --steps 10 --warmup 2 --precision $PREC"
   SEQ="--pipeline 0"
 else
