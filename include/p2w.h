@@ -205,6 +205,15 @@ size_t p2w_key_runs_ws_bytes(int32_t n);
 int32_t p2w_key_runs(const uint64_t* keys_sorted, int32_t n, int32_t min_count, int32_t* starts_out, int32_t* counts_out, int32_t* n_out,
                      void* ws, size_t ws_bytes, p2w_stream_t stream);
 
+/* Cell -> first-candidate table of a plot-level grid: table_out[c] = number of keys_sorted[0..n) below c, for c = 0 .. n_cells
+ * (n_cells + 1 entries; n_cells = dims[0] * dims[1] * dims[2] of the p2w_grid the keys were made on, times the voxel count).  It is
+ * the cell_start argument of p2w_knn_grid_indexed / p2w_ball_query_grid_indexed for levels that did not come from the table sampler -
+ * the back-projection's search over all classified points of a plot (predicter.py:129-142: the reference's KD-tree): one load per
+ * search run instead of a bisection of the keys.  n_cells < 2^31 - 1.  ws: 16-byte aligned, p2w_cell_starts_ws_bytes(n_cells) bytes. */
+size_t p2w_cell_starts_ws_bytes(int64_t n_cells);
+int32_t p2w_cell_starts(const uint64_t* keys_sorted, int32_t n, int64_t n_cells, int32_t* table_out, void* ws, size_t ws_bytes,
+                        p2w_stream_t stream);
+
 /* PointCloudClassifier.compute_labels (predicter.py:112-127) over a neighbour table nbr[n,k] (indices into pred /
  * prob, deg[i] valid entries): pwood_out = median of the neighbours' probabilities (np.median: mean of the two middle
  * values for an even count); label_out: any_wood != 1 -> 1 if any neighbour's prediction > any_wood else 0;

@@ -55,6 +55,8 @@ SIGNATURES = {
     "p2w_sort_pairs_u64": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _sz, _vp]),
     "p2w_key_runs_ws_bytes": (_sz, [_i32]),
     "p2w_key_runs": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "p2w_cell_starts_ws_bytes": (_sz, [C.c_int64]),
+    "p2w_cell_starts": (_i32, [_vp, _i32, C.c_int64, _vp, _vp, _sz, _vp]),
     "p2w_vote": (_i32, [_vp, _vp, _i32, _vp, _vp, _i32, _f32, _vp, _vp, _vp]),
     "p2w_tile_bbox": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp]),
     "p2w_tile_bbox_count": (_i32, [_i32, _i32]),

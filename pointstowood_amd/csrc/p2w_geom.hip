@@ -1836,6 +1836,39 @@ extern "C" int32_t p2w_key_runs(const uint64_t* keys_sorted, int32_t n, int32_t 
     return P2W_LAUNCH_STATUS();
 }
 
+// cell -> first-candidate table of a sorted key array (the plot-level grid of the back-projection): table[c] = number of
+// keys < c = the position a search run that starts at cell c begins at, for c = 0 .. n_cells (n_cells + 1 entries).  With it a
+// run lookup of the grid searches is one load; without it, a bisection of the key array (25 dependent loads at 19 M keys: two
+// thirds of the back-projection's search time).  One count per key (the keys are sorted: a wave's atomics fall on a few
+// neighbouring counters), then the exclusive scan in place.
+__global__ __launch_bounds__(256) void cs_count_kernel(const unsigned long long* __restrict__ keys, int n, long long n_cells, int* __restrict__ table) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long k = keys[i];
+    const bool first = i == 0 || keys[i - 1] != k;
+    if (!first || k >= (unsigned long long)n_cells) return;      // (keys beyond the table belong to no cell a search asks for)
+    int j = i + 1;                                               // run length: cells hold a few points, the walk is short
+    while (j < n && keys[j] == k) ++j;
+    table[k] = j - i;
+}
+extern "C" size_t p2w_cell_starts_ws_bytes(int64_t n_cells) { return xs_ws_bytes(n_cells + 1); }
+extern "C" int32_t p2w_cell_starts(const uint64_t* keys_sorted, int32_t n, int64_t n_cells, int32_t* table_out, void* ws, size_t ws_bytes,
+                                   p2w_stream_t stream) {
+    P2W_CHECK_PTR(table_out); P2W_CHECK_PTR(ws); P2W_CHECK_ALIGN16(ws);
+    if (n < 0 || n_cells < 0 || n_cells >= (int64_t)0x7fffffff) return P2W_EINVAL;     // the scan counts in int32
+    if (ws_bytes < p2w_cell_starts_ws_bytes(n_cells)) return P2W_EWORKSPACE;
+    hipStream_t s = p2w_s(stream);
+    hipError_t e = hipMemsetAsync(table_out, 0, sizeof(int) * (size_t)(n_cells + 1), s);
+    if (e != hipSuccess) return (int32_t)e;
+    if (n > 0) {
+        P2W_CHECK_PTR(keys_sorted);
+        cs_count_kernel<<<p2w_cdiv(n, 256), 256, 0, s>>>(reinterpret_cast<const unsigned long long*>(keys_sorted), n, (long long)n_cells, table_out);
+    }
+    e = xs_exclusive_scan(ws, table_out, table_out, (int)(n_cells + 1), s);
+    if (e != hipSuccess) return (int32_t)e;
+    return P2W_LAUNCH_STATUS();
+}
+
 // one wave per point: lane l holds neighbour l's (prediction, probability)
 __global__ __launch_bounds__(256) void vote_kernel(const int* __restrict__ nbr, const int* __restrict__ deg, int k,
                                                    const float* __restrict__ pred, const float* __restrict__ prob, int n,

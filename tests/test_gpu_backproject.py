@@ -137,3 +137,30 @@ def test_predict_cli_point_cloud_end_to_end(tmp_path):
     # statistic instead - rare, and bounded by the local spread of the probabilities
     err = np.abs(got["pwood"] - ref[:, 1])
     assert (err < 2e-4).mean() > 0.98 and np.median(err) < 2e-5 and np.quantile(err, 0.999) < 0.1   # ~1/64 steps
+
+
+def test_cell_start_table_and_search_through_it():
+    """p2w_cell_starts = searchsorted of every cell id in the sorted keys; the search through the table returns exactly the
+    neighbours the bisection path returns (table_cells = 0), for explicit and density-derived cell sizes."""
+    import ctypes as C
+    from pointstowood_amd import _lib
+    from pointstowood_amd.backproject import neighbours, auto_cell
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(3)
+    n_cells = 200_000
+    keys = torch.sort(torch.randint(0, n_cells + 50, (300_000,), generator=g)).values.cuda()   # (some keys beyond the table)
+    table = torch.empty(n_cells + 1, dtype=torch.int32, device="cuda")
+    ws = torch.empty(int(L.p2w_cell_starts_ws_bytes(n_cells)) + 256, dtype=torch.uint8, device="cuda")
+    _lib.check(L.p2w_cell_starts(_lib.ptr(keys), keys.numel(), n_cells, _lib.ptr(table), _lib.ptr(ws), ws.numel(), _lib.stream()), "cell_starts")
+    want = torch.searchsorted(keys, torch.arange(n_cells + 1, device="cuda"), right=False).to(torch.int32)
+    assert torch.equal(table, want)
+    _lib.check(L.p2w_cell_starts(None, 0, 10, _lib.ptr(table), _lib.ptr(ws), ws.numel(), _lib.stream()), "cell_starts")   # no keys
+    assert int(table[:11].abs().sum()) == 0
+
+    cls, pred, prob, q = _scene(60000, 20000, 9)
+    c, qq = torch.from_numpy(cls).cuda(), torch.from_numpy(q).cuda()
+    assert 0.02 <= auto_cell(c, 64) <= 2.0
+    for cell in (None, 0.07, 0.4):
+        a = [(r.clone(), n.clone(), d.clone()) for r, n, d in neighbours(c, qq, 64, cell)]
+        b = [(r.clone(), n.clone(), d.clone()) for r, n, d in neighbours(c, qq, 64, cell, table_cells=0)]
+        assert len(a) == len(b) and all(torch.equal(x, y) for ta, tb in zip(a, b) for x, y in zip(ta, tb))
