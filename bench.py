@@ -500,13 +500,14 @@ def main():
         kname = {"gemm_kernel": (f"gemm_hp_kernel<{args.precision}> (persistent; 256x256 and 128x128 tile instantiations, all launches)"
                                  if h else "gemm_kernel"),
                  "sa_conv_kernel": (f"sa_conv16p_kernel<{args.precision}> (+ sa_edge_meta_kernel)" if h else "sa_conv_kernel")}
-        traffic, traffic_src = None, None
+        traffic, traffic_src, traffic_step = None, None, None
         try:
             tfile = TRAFFIC_FILE.format(precision=args.precision)
             t = json.load(open(tfile))
             if t.get("precision") == args.precision and dom in t.get("kernels", {}):
                 k = t["kernels"][dom]
-                traffic = (k["fetch_bytes_per_step"] + k["write_bytes_per_step"]) / max(1, k["launches_per_step"])
+                traffic_step = k["fetch_bytes_per_step"] + k["write_bytes_per_step"]
+                traffic = traffic_step / max(1, dom_launches)    # per launch of THIS line's launch count: traffic x launches = the class' bytes per step
                 traffic_src = os.path.relpath(tfile, ROOT)
         except (OSError, ValueError, KeyError):
             pass
@@ -535,7 +536,7 @@ def main():
             "pcie_inclusive": pcie,
             "roofline": {"bound": "mfma", "kernel": kname.get(dom, dom), "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)",
-                         "traffic_source": traffic_src, "note": notes[args.precision],
+                         "traffic_bytes_per_step": traffic_step, "traffic_source": traffic_src, "note": notes[args.precision],
                          "launches_per_step": dom_launches, "kernel_ms_per_step": dom_ms,
                          "algorithmic_gflop_per_step": 2.0 * kmacs[dom] / 1e9},
             "hbm_kernels": hbm,
