@@ -348,7 +348,7 @@ def plot_main(args, world, rank, device, dist):
             "steps": steps, "warmup": warm, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"BASELINE configs[3]: {n}-point synthetic forest plot ({side:.0f} m square), grid_size 2.0/4.0, min_pts 128, "
-                                   "max_pts 16384, voxel batches of <= 524288 points / 512 voxels LPT-sharded over the ranks, one all-gather "
+                                   "max_pts 16384, voxel batches of a fifth of a rank's share (262144 .. 2097152 points, 1 voxel per 1024 points) LPT-sharded over the ranks, one all-gather "
                                    "of the classified points, back-projection (k=64 median vote) on contiguous plot slices, one all-gather",
                        "voxels": stats.get("voxels"), "classified_points": stats.get("classified_points"), "C": C,
                        "parallelism": f"voxel-batch sharding x{world} + plot-slice sharding x{world}, 2 RCCL all-gathers"},

@@ -23,13 +23,14 @@ def _sync(dev):
 
 
 def segment_plot(pc, model, grid_sizes=(2.0, 4.0), min_pts: int = 128, max_pts: int = 16384, is_wood: float = 0.5,
-                 any_wood: float = 1.0, max_points: int = 524288, mode: str = "compat", generator=None, stats=None,
-                 dist=None, max_voxels: int = 512, ground: bool = True):
+                 any_wood: float = 1.0, max_points: int | None = None, mode: str = "compat", generator=None, stats=None,
+                 dist=None, max_voxels: int | None = None, ground: bool = True):
     """pc: [N, >= 4] float tensor on the GPU (x, y, z, reflectance, ...), plot-local coordinates (fp32-safe).
     Returns (n_z [N], label [N], pwood [N]) float32 on the device: the three columns the reference appends
     (``predicter.py:233``).  ``stats`` (dict, optional) receives stage timings and counts.  ``max_points`` /
-    ``max_voxels``: budget of one forward (plots are mostly small voxels; 524288 points / 512 voxels classify 12 % faster
-    than 131072 / 128 and need ~12 GB).  ``ground=False``: ``pc`` already has an n_z column (its last one), see
+    ``max_voxels``: budget of one forward; default: a fifth of a rank's share of the classified points, between 262144 and
+    2097152 points (10 M-point plot on one GPU: 1.97 s of classification at 131072 points per forward, 1.84 at 524288, 1.78
+    at 2097152 / 47 GiB; a rank should still get several batches so that the LPT shares come out even), 1 voxel per 1024 points.  ``ground=False``: ``pc`` already has an n_z column (its last one), see
     ``preprocessing.voxelise``.
 
     ``dist`` (an initialised ``torch.distributed``, one process per GPU, every rank holding the same ``pc`` and the same
@@ -47,8 +48,12 @@ def segment_plot(pc, model, grid_sizes=(2.0, 4.0), min_pts: int = 128, max_pts: 
     if not vox:   # nothing dense enough to classify (predicter.py would fail on an empty loader)
         return n_z, torch.zeros(n, device=dev), torch.zeros(n, device=dev)
     lengths = [int(v.shape[0]) for v in vox]
-    batches = list(PointBudgetSampler(lengths, max_points, max_voxels))
     world, rank = (dist.get_world_size(), dist.get_rank()) if dist is not None else (1, 0)
+    if max_points is None:
+        max_points = min(max(sum(lengths) // (5 * world), 262144), 2097152)
+    if max_voxels is None:
+        max_voxels = max(1, max_points // 1024)
+    batches = list(PointBudgetSampler(lengths, max_points, max_voxels))
     if world > 1:
         mine = partition_batches([sum(batch_cost(lengths[i]) for i in b) for b in batches], world)[rank]   # LPT on est. FLOPs
         batches = [batches[i] for i in mine]
