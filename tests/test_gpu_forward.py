@@ -373,7 +373,10 @@ def _fp_neighbours_expected(geo, f):
     return exp
 
 
-@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("P2W_FUZZ_SEEDS", "24"))))
+_FUZZ0 = int(__import__("os").environ.get("P2W_FUZZ_SEED0", "0"))     # (longer hunts: P2W_FUZZ_SEED0=1000 P2W_FUZZ_SEEDS=1500)
+
+
+@pytest.mark.parametrize("seed", range(_FUZZ0, _FUZZ0 + int(__import__("os").environ.get("P2W_FUZZ_SEEDS", "24"))))
 def test_forward_fuzz_against_live_oracle(seed):
     """Random small batches (ragged sizes down to fewer points than k, duplicates, planes, lattices, tiny extents, reflectance
     on and off, C and k varied): neighbour structure bit-exact, wood probability within 1e-4 of the CPU oracle."""
