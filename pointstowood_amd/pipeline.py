@@ -51,6 +51,9 @@ def segment_plot(pc, model, grid_sizes=(2.0, 4.0), min_pts: int = 128, max_pts: 
     world, rank = (dist.get_world_size(), dist.get_rank()) if dist is not None else (1, 0)
     if max_points is None:
         max_points = min(max(sum(lengths) // (5 * world), 262144), 2097152)
+        if dev.type == "cuda":   # a forward's tensors take ~24 KiB per point (47 GiB at 2 M points): stay within 40 % of what is free
+            free = torch.cuda.mem_get_info(dev)[0]
+            max_points = max(65536, min(max_points, int(0.4 * free) // (24 * 1024)))
     if max_voxels is None:
         max_voxels = max(1, max_points // 1024)
     batches = list(PointBudgetSampler(lengths, max_points, max_voxels))
