@@ -1852,9 +1852,11 @@ __global__ __launch_bounds__(256) void cs_count_kernel(const unsigned long long*
     const unsigned long long k = keys[i];
     const bool first = i == 0 || keys[i - 1] != k;
     if (!first || k >= (unsigned long long)n_cells) return;      // (keys beyond the table belong to no cell a search asks for)
-    int j = i + 1;                                               // run length: cells hold a few points, the walk is short
-    while (j < n && keys[j] == k) ++j;
-    table[k] = j - i;
+    long long step = 1, lo = i, hi;                              // run end: gallop, then bisect (a cell may hold any number of points)
+    while ((hi = lo + step) < n && keys[hi] == k) { lo = hi; step <<= 1; }
+    hi = hi < n ? hi : n;                                        // keys[lo] == k, keys[hi] != k (or hi == n)
+    while (hi - lo > 1) { const long long mid = lo + ((hi - lo) >> 1); if (keys[mid] == k) lo = mid; else hi = mid; }
+    table[k] = (int)(hi - i);
 }
 extern "C" size_t p2w_cell_starts_ws_bytes(int64_t n_cells) { return xs_ws_bytes(n_cells + 1); }
 extern "C" int32_t p2w_cell_starts(const uint64_t* keys_sorted, int32_t n, int64_t n_cells, int32_t* table_out, void* ws, size_t ws_bytes,

@@ -148,7 +148,9 @@ def test_cell_start_table_and_search_through_it():
     L = _lib.lib()
     g = torch.Generator().manual_seed(3)
     n_cells = 200_000
-    keys = torch.sort(torch.randint(0, n_cells + 50, (300_000,), generator=g)).values.cuda()   # (some keys beyond the table)
+    keys = torch.randint(0, n_cells + 50, (300_000,), generator=g)   # (some keys beyond the table)
+    keys[1000:41000] = 777                                            # one cell with 40 000 points
+    keys = torch.sort(keys).values.cuda()
     table = torch.empty(n_cells + 1, dtype=torch.int32, device="cuda")
     ws = torch.empty(int(L.p2w_cell_starts_ws_bytes(n_cells)) + 256, dtype=torch.uint8, device="cuda")
     _lib.check(L.p2w_cell_starts(_lib.ptr(keys), keys.numel(), n_cells, _lib.ptr(table), _lib.ptr(ws), ws.numel(), _lib.stream()), "cell_starts")
