@@ -545,7 +545,7 @@ def test_segment_plot_sharded_gloo_world4_and_8(world, max_points, monkeypatch):
                                               generator=torch.Generator().manual_seed(0))
     vox, _ = voxelise(pc, (4.0,), 64, 100000, generator=torch.Generator().manual_seed(0))
     lengths = [int(v.shape[0]) for v in vox]
-    batches = list(PointBudgetSampler(lengths, max_points, 512))
+    batches = list(PointBudgetSampler(lengths, max_points, max(1, max_points // 1024)))   # segment_plot's default voxel cap
     plan = partition_batches([sum(batch_cost(lengths[i]) for i in b) for b in batches], world)
     assert sorted(i for p in plan for i in p) == list(range(len(batches)))
     if world == 8:
@@ -587,3 +587,27 @@ def test_gather_logits_gloo_world4_and_8_with_empty_and_tiny_ranks(counts):
     [p.join(60) for p in ps]
     expect = [float(i + 1000 * r) for r, c in enumerate(counts) for i in range(c)]
     assert all(out == expect for _, out in res)
+
+
+def test_auto_cell_and_default_forward_budget(monkeypatch):
+    """backproject.auto_cell follows the cloud's density (denser cloud -> smaller cells, clamped); segment_plot's default
+    budget is a fifth of the classified points, clamped to [262144, 2097152] (so a small plot goes through in one forward)."""
+    from pointstowood_amd import pipeline
+    from pointstowood_amd.backproject import auto_cell
+    g = torch.Generator().manual_seed(0)
+    sparse = torch.rand(20000, 3, generator=g) * 50.0
+    dense = torch.rand(20000, 3, generator=g) * 5.0
+    assert 0.02 <= auto_cell(dense, 64) < auto_cell(sparse, 64) <= 2.0
+    assert abs(auto_cell(sparse, 64) / auto_cell(dense, 64) - 10.0) < 0.5            # (k V / n)^(1/3): 10 x the extent
+    assert auto_cell(torch.zeros(5, 3), 64) == 0.02 and auto_cell(sparse * 1e4, 64) == 2.0
+    seen = {}
+
+    class _Sampler(list):
+        def __init__(self, lengths, max_points, max_voxels):
+            seen["budget"] = (max_points, max_voxels)
+            super().__init__([list(range(len(lengths)))])
+    monkeypatch.setattr(pipeline, "PointBudgetSampler", _Sampler)
+    monkeypatch.setattr(pipeline, "collect_predictions", _cpu_collect)
+    pipeline.segment_plot(_plot(n=12000, seed=3), _FakeStreamModel(), (4.0,), min_pts=64, max_pts=100000,
+                          generator=torch.Generator().manual_seed(0))
+    assert seen["budget"] == (262144, 256)
