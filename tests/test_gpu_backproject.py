@@ -125,7 +125,7 @@ def test_predict_cli_point_cloud_end_to_end(tmp_path):
     assert np.abs(got["n_z"] - n_z.numpy()).max() <= 1e-5
     lengths = [int(v.shape[0]) for v in vox]
     rows = []
-    for batch in PointBudgetSampler(lengths, 131072):
+    for batch in PointBudgetSampler(lengths, 262144, 256):   # segment_plot's default budget for a plot this small
         b = synth.collate([ohost.feed(vox[i]) for i in batch])
         logits = onet.forward(sd, b["pos"], b["batch"], b["reflectance"], b["sf"], k=32)
         rows.append(ohost.consume(logits, b["pos"], b["batch"], b["local_shift"], 0.5))
