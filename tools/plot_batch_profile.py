@@ -27,7 +27,10 @@ for mp in (131072, 524288, 2097152):
     per, geo = bench.profile_step(net, data)
     tot = sum(v[0] for v in per.values())
     top = sorted(per.items(), key=lambda kv: -kv[1][0])[:9]
-    print(f"budget {mp}: batch of {len(b)} voxels / {n} points, levels {[geo.levels[l].n for l in (1, 2, 3)]}: {tot:.2f} ms = {tot / n * 1e6:.2f} ns/point | "
+    total_macs, kmacs, _ = bench.algorithmic_macs(geo)
+    tf = {k: 2.0 * kmacs[k] / (per[k][0] * 1e-3) / 1e12 for k in ("gemm_kernel", "sa_conv_kernel")}
+    print(f"budget {mp}: batch of {len(b)} voxels / {n} points, levels {[geo.levels[l].n for l in (1, 2, 3)]}: {tot:.2f} ms = {tot / n * 1e6:.2f} ns/point "
+          f"(GEMM class {tf['gemm_kernel']:.0f} TF, PointNetConv {tf['sa_conv_kernel']:.0f} TF) | "
           + ", ".join(f"{k} {v[0] / n * 1e6:.2f}" for k, v in top), flush=True)
 
 if os.environ.get("SLAB"):      # in-kernel phase profile of the searches (build with P2W_EXTRA_CFLAGS=-DP2W_SLAB_PROFILE)
