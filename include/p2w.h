@@ -188,7 +188,10 @@ int32_t p2w_morton_order(const float* xyzr, int32_t n, const p2w_grid* grid, int
  * cell_out[i] = PyG voxel_grid(P, size) with batch = None over ALL D <= 16 columns of the row-major table P[n, ld] (the
  * reference hands the whole point table - x, y, z, reflectance, ..., n_z - to voxel_grid): sum_d trunc((P_id - lo_d) / size) *
  * stride_d with the column minima lo_d and the running products of the per-column cell counts as strides (fp32 subtract /
- * divide / truncate, int64 result).  ws: >= 256 bytes. */
+ * divide / truncate, int64 result).  A row with a non-finite value takes no part in the minima / maxima and gets the key
+ * P2W_CELL_NONFINITE (sorts last; the reference's own result on such input is the cast of a NaN, i.e. undefined).
+ * ws: >= 256 bytes. */
+#define P2W_CELL_NONFINITE INT64_MAX
 int32_t p2w_cells_nd(const float* P, int32_t n, int32_t D, int32_t ld, float size, int64_t* cell_out, void* ws, size_t ws_bytes,
                      p2w_stream_t stream);
 /* STABLE ascending sort of n (64-bit key, int32 value) pairs - hand-written LSD radix sort, 8-bit digits, as many passes as the

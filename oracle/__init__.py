@@ -16,8 +16,6 @@ What it restates (reference = harryjfowen/PointsToWood @ 2025-09-12):
 * ``oracle.host``  - the feed/consume pieces of ``pointstowood/src/predicter.py:78-105,193-215``.
 * ``oracle.preprocess`` / ``oracle.backproject`` - the voxeliser (``preprocessing.py:18-127``) and the
                      back-projection vote (``predicter.py:107-142``) for the "next" rows.
-* ``oracle.synth`` / ``oracle.weights`` are re-exports of the package's synthetic input / checkpoint generators
-                     (``pointstowood_amd/synthetic_*.py``: data generators, no reference arithmetic).
 
 Parity pinning: the reference has no tests/golden vectors of its own and the
 third-party wheels are absent and un-pinned (only the wheel index

@@ -1721,7 +1721,7 @@ __global__ __launch_bounds__(256) void vc_minmax_kernel(const float* __restrict_
         float lo = INFINITY, hi = -INFINITY;
         for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
             const float v = P[i * ld + d];
-            lo = fminf(lo, v); hi = fmaxf(hi, v);
+            if (isfinite(v)) { lo = fminf(lo, v); hi = fmaxf(hi, v); }   // non-finite values take no part in the grid (see vc_cells_kernel)
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) { lo = fminf(lo, __shfl_xor(lo, off)); hi = fmaxf(hi, __shfl_xor(hi, off)); }
@@ -1736,19 +1736,26 @@ __global__ __launch_bounds__(256) void vc_minmax_kernel(const float* __restrict_
     }
 }
 // PyG voxel_grid(P, size) with batch = None: sum_d trunc((P_d - lo_d) / size) * stride_d, strides = running products of
-// the per-column cell counts trunc((hi_d - lo_d) / size) + 1 (fp32 subtract / divide / truncate as oracle/ops.py voxel_grid)
+// the per-column cell counts trunc((hi_d - lo_d) / size) + 1 (fp32 subtract / divide / truncate as oracle/ops.py voxel_grid).
+// Rows with a non-finite value: the reference's min / max propagate a NaN into the grid origin and every cell id of the plot
+// becomes the cast of a NaN (undefined); here such rows stay out of the minima / maxima and get the dedicated key
+// P2W_CELL_NONFINITE (INT64_MAX: they sort last as a run of their own, which the voxeliser drops) - defined behaviour on both
+// the HIP and the tensor path (preprocessing._cells), identical to the reference on finite input.
 __global__ __launch_bounds__(256) void vc_cells_kernel(const float* __restrict__ P, int n, int D, int ld, float size,
                                                        const VcHeader* __restrict__ h, long long* __restrict__ cell) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     long long key = 0, stride = 1;
+    bool finite = true;
     for (int d = 0; d < D; ++d) {
         const float lo = ord2f(h->lo[d]), hi = ord2f(h->hi[d]);
+        const float v = P[i * ld + d];
+        finite = finite && isfinite(v);
         const long long cnt = (long long)((hi - lo) / size) + 1;
-        key += (long long)((P[i * ld + d] - lo) / size) * stride;
+        key += (long long)(((finite ? v : lo) - lo) / size) * stride;
         stride *= cnt;
     }
-    cell[i] = key;
+    cell[i] = finite ? key : 0x7fffffffffffffffll;
 }
 extern "C" int32_t p2w_cells_nd(const float* P, int32_t n, int32_t D, int32_t ld, float size, int64_t* cell_out, void* ws,
                                 size_t ws_bytes, p2w_stream_t stream) {

@@ -16,6 +16,7 @@
 #include "p2w_common.h"
 
 constexpr int RS_BLOCK = 256, RS_TILE = 4096, RS_RADIX = 256;
+constexpr int RS_SCAN_ONE = 65536;   // histogram tables up to this many entries are scanned by one workgroup (8 rounds)
 
 struct RsCtl { unsigned long long orv; int pad[2]; };   // OR of all keys (-> number of passes), zeroed by the host call
 
@@ -100,6 +101,41 @@ __global__ __launch_bounds__(1024) void rs_scan_kernel(int* __restrict__ hist, i
     if (pass >= rs_passes(ctl)) return;
     rs_block_scan_inplace(hist, (long long)RS_RADIX * nblk, nullptr);
 }
+// Above RS_SCAN_ONE entries the [digit][tile] table is scanned on two levels like xs_exclusive_scan (4096-entry tiles by as many workgroups, one
+// workgroup over the tile sums, add): at plot scale (19 M keys: 1.19 M table entries) a single workgroup would walk 145
+// rounds of 8192 entries per digit pass on one CU while the chip idles.  In place: a thread loads its 4 entries before it
+// stores them (no __restrict__ on the table).
+__global__ __launch_bounds__(1024) void rs_scan_tile_kernel(int* hist, int len, int pass, const RsCtl* __restrict__ ctl,
+                                                            int* __restrict__ tsum) {
+    __shared__ int wsum[16];
+    if (pass >= rs_passes(ctl)) return;
+    const long long i0 = (long long)blockIdx.x * 4096 + (long long)threadIdx.x * 4;
+    int v[4], s = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = (i0 + e < len) ? hist[i0 + e] : 0; s += v[e]; }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int before = 0, tot = 0;
+    for (int w = 0; w < 16; ++w) { if (w < wave) before += wsum[w]; tot += wsum[w]; }
+    int run = before + inc - s;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { if (i0 + e < len) hist[i0 + e] = run; run += v[e]; }
+    if (threadIdx.x == 0) tsum[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(1024) void rs_scan_sums_kernel(int* __restrict__ tsum, int nt, int pass, const RsCtl* __restrict__ ctl) {
+    if (pass >= rs_passes(ctl)) return;
+    rs_block_scan_inplace(tsum, nt, nullptr);
+}
+__global__ __launch_bounds__(256) void rs_scan_add_kernel(int* __restrict__ hist, int len, int pass, const RsCtl* __restrict__ ctl,
+                                                          const int* __restrict__ tsum) {
+    if (pass >= rs_passes(ctl)) return;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < len) hist[i] += tsum[i >> 12];
+}
 
 __global__ __launch_bounds__(RS_BLOCK) void rs_scatter_kernel(const unsigned long long* __restrict__ kin, const unsigned long long* __restrict__ kout,
                                                               const unsigned long long* __restrict__ ktmp, unsigned long long* __restrict__ kout_w,
@@ -171,7 +207,7 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_finish_kernel(const unsigned long
     }
 }
 
-struct RsLayout { size_t ctl, hist, ktmp, vtmp, bytes; int nblk; };
+struct RsLayout { size_t ctl, hist, tsum, ktmp, vtmp, bytes; int nblk; };
 static inline void rs_layout(long long n_bound, RsLayout* L) {
     auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
     const long long n = n_bound > 0 ? n_bound : 1;
@@ -179,6 +215,7 @@ static inline void rs_layout(long long n_bound, RsLayout* L) {
     size_t o = 0;
     L->ctl = o; o += 256;
     L->hist = o; o += up(sizeof(int) * (size_t)RS_RADIX * L->nblk);
+    L->tsum = o; o += up(sizeof(int) * (((size_t)RS_RADIX * L->nblk + 4095) / 4096));
     L->ktmp = o; o += up(sizeof(unsigned long long) * (size_t)n);
     L->vtmp = o; o += up(sizeof(int) * (size_t)n);
     L->bytes = o;
@@ -194,6 +231,8 @@ static inline hipError_t rs_sort_pairs(void* ws, const unsigned long long* keys_
     char* w = static_cast<char*>(ws);
     auto* ctl = reinterpret_cast<RsCtl*>(w + L.ctl);
     int* hist = reinterpret_cast<int*>(w + L.hist);
+    int* tsum = reinterpret_cast<int*>(w + L.tsum);
+    const int hlen = RS_RADIX * L.nblk, ht = (hlen + 4095) / 4096;
     auto* ktmp = reinterpret_cast<unsigned long long*>(w + L.ktmp);
     int* vtmp = reinterpret_cast<int*>(w + L.vtmp);
     hipError_t e = hipMemsetAsync(ctl, 0, sizeof(RsCtl), s);
@@ -202,7 +241,13 @@ static inline hipError_t rs_sort_pairs(void* ws, const unsigned long long* keys_
     rs_or_kernel<<<g1, RS_BLOCK, 0, s>>>(keys_in, n_dev, n_bound, ctl);
     for (int p = 0; p < 8; ++p) {
         rs_hist_kernel<<<L.nblk, RS_BLOCK, 0, s>>>(keys_in, keys_out, ktmp, n_dev, n_bound, p, ctl, L.nblk, hist);
-        rs_scan_kernel<<<1, 1024, 0, s>>>(hist, L.nblk, p, ctl);
+        if (hlen <= RS_SCAN_ONE) {
+            rs_scan_kernel<<<1, 1024, 0, s>>>(hist, L.nblk, p, ctl);
+        } else {
+            rs_scan_tile_kernel<<<ht, 1024, 0, s>>>(hist, hlen, p, ctl, tsum);
+            rs_scan_sums_kernel<<<1, 1024, 0, s>>>(tsum, ht, p, ctl);
+            rs_scan_add_kernel<<<(hlen + 255) / 256, 256, 0, s>>>(hist, hlen, p, ctl, tsum);
+        }
         rs_scatter_kernel<<<L.nblk, RS_BLOCK, 0, s>>>(keys_in, keys_out, ktmp, keys_out, ktmp, vals_in, vals_out, vtmp, vals_out, vtmp,
                                                        n_dev, n_bound, p, ctl, L.nblk, hist);
     }
@@ -211,7 +256,8 @@ static inline hipError_t rs_sort_pairs(void* ws, const unsigned long long* keys_
 }
 
 // ---- exclusive scan of int32 (two levels: 4096-element tiles, one workgroup over the tile sums, add) ----------------------
-__global__ __launch_bounds__(1024) void xs_tile_kernel(const int* __restrict__ in, int* __restrict__ out, int n, int* __restrict__ tsum) {
+// (`in` may be `out`: a thread loads its 4 values before it stores them, hence no __restrict__ on the two)
+__global__ __launch_bounds__(1024) void xs_tile_kernel(const int* in, int* out, int n, int* __restrict__ tsum) {
     __shared__ int wsum[16];
     const long long i0 = (long long)blockIdx.x * 4096 + (long long)threadIdx.x * 4;
     int v[4], s = 0;
@@ -236,7 +282,7 @@ __global__ __launch_bounds__(256) void xs_add_kernel(int* __restrict__ out, int 
     if (i < n) out[i] += tsum[i >> 12];
 }
 static inline size_t xs_ws_bytes(long long n) { return (size_t)(((n > 0 ? n : 1) + 4095) / 4096) * sizeof(int) + 256; }
-// out[i] = sum of in[0..i-1] for i < n; `ws`: xs_ws_bytes(n)
+// out[i] = sum of in[0..i-1] for i < n (in place allowed: in == out); `ws`: xs_ws_bytes(n)
 static inline hipError_t xs_exclusive_scan(void* ws, const int* in, int* out, int n, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     int* tsum = static_cast<int*>(ws);

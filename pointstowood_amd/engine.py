@@ -284,6 +284,7 @@ class Engine:
         for name in EngineOptions.names():      # the switches live on the engine (tools flip them between runs)
             setattr(self, name, getattr(self.options, name))
         self._table_scale = [1, 1, 1]   # per level: grows by 8 (up to TABLE_SCALE_MAX) after an overflow
+        self._table_rest = [0, 0, 0]    # per level: batches the table sits out after overflowing at its largest scale
         self._ws_t = None
         self.events = None  # set to a list to record (name, start, end) events per launch
         self.events_grouped = False   # True: (name, start, end, launches) per run of consecutive same-name launches
@@ -345,6 +346,9 @@ class Engine:
 
     TABLE_CELLS_MAX = 1 << 26          # 64 M entries x 20 B = 1.3 GB of workspace at most
     TABLE_SCALE_MAX = 64               # growth factor cap of a level's table after overflows
+    TABLE_REST = 64                    # a level that overflows even at that scale (voxels > 9 m, non-finite coordinates) takes the
+                                       # sort for this many batches before the table is tried again: a workload of such batches
+                                       # pays the discarded geometry pass once per 64 batches instead of on every one
 
     def _table_cells(self, level, B, N):
         """Table capacity (entries) for the sampler of `level`, 0 = use the sort.  Provision: B voxels x the cells of a 2.3 m cube
@@ -355,6 +359,9 @@ class Engine:
         millions of cells for half a million points, so the table is only taken while the grid of B nominal voxels has at
         most ``table_cells_per_point`` cells per point.  Decided per batch; only the growth factor is remembered."""
         if self.sampler != "table":
+            return 0
+        if self._table_rest[level] > 0:
+            self._table_rest[level] -= 1
             return 0
         per_voxel = (int(2.3 / SA_RES[level]) + 3) ** 3
         if B * per_voxel > self.table_cells_per_point * max(N, 1):
@@ -504,6 +511,8 @@ class Engine:
             # downstream of the first of them is undefined.  Repeat the geometry with the sort (rare: voxels much larger than
             # 2 m), and give the table 8 x the room next time.
             for l in overflow:   # more room next time (capped); whether a batch's table is worth taking is _table_cells' decision
+                if self._table_scale[l] >= self.TABLE_SCALE_MAX:
+                    self._table_rest[l] = self.TABLE_REST     # no more room to give: the sort serves the next batches
                 self._table_scale[l] = min(self._table_scale[l] * 8, self.TABLE_SCALE_MAX)
             with torch.cuda.stream(geo.stream):
                 redo = self._geometry_async(*geo.args, force_sort=True)

@@ -22,6 +22,30 @@ def _sync(dev):
         torch.cuda.synchronize(dev)
 
 
+BYTES_PER_POINT = 24 * 1024   # a forward's tensors (47 GiB at 2 M points)
+
+
+def _free_bytes(dev):
+    """Free device memory (None on the CPU: the sharding logic is exercised there with stand-in stages)."""
+    return torch.cuda.mem_get_info(dev)[0] if dev.type == "cuda" else None
+
+
+def default_budget(total_points: int, world: int, free, dist=None) -> int:
+    """Points per forward when the caller names no budget: a fifth of a rank's share of the classified points, between 262144
+    and 2097152, within 40 % of the free device memory.  The batch list must be IDENTICAL on every rank (each rank takes its
+    LPT share of it BY INDEX), so the memory cap comes from the rank with the least free memory (one all-reduce(MIN) of a
+    scalar), never from a rank's own reading."""
+    budget = min(max(total_points // (5 * world), 262144), 2097152)
+    if free is not None:
+        if world > 1:
+            backend = dist.get_backend() if hasattr(dist, "get_backend") else "gloo"
+            t = torch.tensor([int(free)], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            free = int(t)
+        budget = max(65536, min(budget, int(0.4 * free) // BYTES_PER_POINT))
+    return budget
+
+
 def segment_plot(pc, model, grid_sizes=(2.0, 4.0), min_pts: int = 128, max_pts: int = 16384, is_wood: float = 0.5,
                  any_wood: float = 1.0, max_points: int | None = None, mode: str = "compat", generator=None, stats=None,
                  dist=None, max_voxels: int | None = None, ground: bool = True):
@@ -50,16 +74,16 @@ def segment_plot(pc, model, grid_sizes=(2.0, 4.0), min_pts: int = 128, max_pts: 
     lengths = [int(v.shape[0]) for v in vox]
     world, rank = (dist.get_world_size(), dist.get_rank()) if dist is not None else (1, 0)
     if max_points is None:
-        max_points = min(max(sum(lengths) // (5 * world), 262144), 2097152)
-        if dev.type == "cuda":   # a forward's tensors take ~24 KiB per point (47 GiB at 2 M points): stay within 40 % of what is free
-            free = torch.cuda.mem_get_info(dev)[0]
-            max_points = max(65536, min(max_points, int(0.4 * free) // (24 * 1024)))
+        max_points = default_budget(sum(lengths), world, _free_bytes(dev), dist)
     if max_voxels is None:
         max_voxels = max(1, max_points // 1024)
     batches = list(PointBudgetSampler(lengths, max_points, max_voxels))
     if world > 1:
         mine = partition_batches([sum(batch_cost(lengths[i]) for i in b) for b in batches], world)[rank]   # LPT on est. FLOPs
         batches = [batches[i] for i in mine]
+    if stats is not None:
+        stats["max_points"], stats["max_voxels"] = int(max_points), int(max_voxels)
+        stats["batch_points"] = [sum(lengths[i] for i in b) for b in batches]     # this rank's forwards
     pending = collections.deque()
 
     def feed():

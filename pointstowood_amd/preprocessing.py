@@ -14,7 +14,8 @@ ids per grid size, voxels are contiguous segments of the sorted order.
 The grid step (cell ids over all columns, the stable argsort that groups the points of a voxel, the runs with at least
 ``min_pts`` points) runs on hand-written HIP kernels behind the C ABI when the points are on the GPU: ``p2w_cells_nd``,
 ``p2w_sort_pairs_u64`` (radix sort), ``p2w_key_runs``.  The same step in tensor operations (``_grid_segments_torch``) serves
-points that live on the host (the CPU tests of the host-side logic); both give identical voxels (tested on the GPU).  Ground
+points that live on the host (the CPU tests of the host-side logic); both give identical voxels, rows with non-finite values
+included (they belong to no voxel; tested on the GPU).  Ground
 normalisation and the reflectance quantile transform are cheap tensor code on whatever device the points are on.
 """
 from __future__ import annotations
@@ -45,27 +46,45 @@ def quantile_normalize_reflectance(refl):
     return 2 * (n - n.min()) / (n.max() - n.min()) - 1
 
 
+CELL_NONFINITE = (1 << 63) - 1   # P2W_CELL_NONFINITE of include/p2w.h
+
+
 def _cells(P, size):
-    """PyG voxel_grid(P, size) with batch=None: every column of P is binned with the same cell size."""
+    """PyG voxel_grid(P, size) with batch=None: every column of P is binned with the same cell size.  Rows with a non-finite
+    value stay out of the column minima / maxima and get the key CELL_NONFINITE (like p2w_cells_nd: the reference's own
+    grid on such input is the integer cast of a NaN, i.e. undefined); on finite input this is the reference's arithmetic."""
     n = P.shape[0]
     Pb = torch.cat([P, torch.zeros((n, 1), dtype=P.dtype, device=P.device)], dim=1)
     S = torch.cat([torch.full((P.shape[1],), float(size), dtype=P.dtype, device=P.device),
                    torch.ones(1, dtype=P.dtype, device=P.device)])
-    lo, hi = Pb.min(dim=0).values, Pb.max(dim=0).values
+    fin = torch.isfinite(Pb)
+    row_ok = fin.all(dim=1)
+    inf = torch.full_like(Pb, float("inf"))
+    lo, hi = torch.where(fin, Pb, inf).min(dim=0).values, torch.where(fin, Pb, -inf).max(dim=0).values
     cnt = ((hi - lo) / S).to(torch.long) + 1
     stride = torch.ones_like(cnt)
     stride[1:] = torch.cumprod(cnt, 0)[:-1]
-    return (((Pb - lo[None]) / S[None]).to(torch.long) * stride[None]).sum(dim=1)
+    Pb = torch.where(row_ok[:, None], Pb, lo[None].expand_as(Pb))
+    cell = (((Pb - lo[None]) / S[None]).to(torch.long) * stride[None]).sum(dim=1)
+    return torch.where(row_ok, cell, torch.full_like(cell, CELL_NONFINITE))
+
+
+def _drop_nonfinite_run(cell_sorted, starts, counts):
+    """The run of CELL_NONFINITE keys (rows with a non-finite value; it sorts last) is not a voxel."""
+    if starts.numel() and int(cell_sorted[starts[-1]]) == CELL_NONFINITE:
+        return starts[:-1], counts[:-1]
+    return starts, counts
 
 
 def _grid_segments_torch(P, size, min_pts):
     """(order, starts, counts): stable argsort of the cell ids, start and length of every run with >= min_pts points."""
     cell = _cells(P, size)
     order = torch.argsort(cell, stable=True)          # points of a voxel keep their original relative order
-    _, counts = torch.unique_consecutive(cell[order], return_counts=True)
+    cell_sorted = cell[order]
+    _, counts = torch.unique_consecutive(cell_sorted, return_counts=True)
     starts = torch.cumsum(counts, 0) - counts
     keep = (counts >= min_pts).nonzero(as_tuple=True)[0]
-    return order, starts[keep], counts[keep]
+    return (order, *_drop_nonfinite_run(cell_sorted, starts[keep], counts[keep]))
 
 
 def _grid_segments_hip(P, size, min_pts):
@@ -87,7 +106,7 @@ def _grid_segments_hip(P, size, min_pts):
     check(L.p2w_key_runs(ptr(cell_sorted), n, int(min_pts), ptr(starts), ptr(counts), ptr(n_out), ptr(ws), ws.numel(), stream()),
           "p2w_key_runs")
     k = int(n_out)                                     # the one host sync of a grid size
-    return order.long(), starts[:k].long(), counts[:k].long()
+    return (order.long(), *_drop_nonfinite_run(cell_sorted, starts[:k].long(), counts[:k].long()))
 
 
 def voxelise(pc, grid_sizes=(2.0, 4.0), min_pts: int = 128, max_pts: int = 16384, mode: str = "compat", generator=None,

@@ -1,5 +1,5 @@
 """Synthetic voxel generators: inputs for bench.py, the profiling tools and the tests.
-No reference arithmetic lives here (the CPU oracle is ``oracle/``; ``oracle.synth`` re-exports this module).
+No reference arithmetic lives here (the CPU oracle is ``oracle/``).
 
 ``forest_plot`` generates a whole plot for the voxeliser; ``mixed_sizes`` the voxel sizes of BASELINE configs[4].
 ``uniform_voxel`` is the canonical ``U(side, N, seed)``: N points uniform in a cube,

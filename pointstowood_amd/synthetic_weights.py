@@ -1,6 +1,6 @@
 """Checkpoint layout of the reference ``Net`` and a recipe for synthetic checkpoints.
 
-Data generator for bench.py, the profiling tools and the tests (``oracle.weights`` re-exports this module); no
+Data generator for bench.py, the profiling tools and the tests; no
 reference arithmetic lives here.
 
 ``key_table`` lists the state-dict keys/shapes that ``Net(num_classes, C)``

@@ -5,7 +5,7 @@ Runs only in the authoring container: it puts ``oracle/stubs`` (our own re-expor
 ``oracle/ops.py`` under the torch_geometric / torch_scatter module paths, which are
 not installed here) and ``/root/reference/pointstowood`` on ``sys.path``, imports the
 reference's unmodified ``src.model.Net`` (which pulls in ``src.pointnet``), loads a
-recipe-generated checkpoint (``oracle/weights.py``; the trained ``global.pth`` is
+recipe-generated checkpoint (``pointstowood_amd/synthetic_weights.py``; the trained ``global.pth`` is
 absent from the mount) and records inputs, per-level sample indices, neighbour
 lists, level outputs and logits.  The reference's source never enters this repo;
 only these data vectors do.
@@ -29,7 +29,7 @@ sys.path.insert(0, os.path.join(ROOT, "oracle", "stubs"))
 sys.path.insert(0, "/root/reference/pointstowood")
 
 import src.model as ref_model  # noqa: E402  (the reference, over the stubs)
-from oracle import synth, weights  # noqa: E402
+from pointstowood_amd import synthetic_voxels as synth, synthetic_weights as weights  # noqa: E402
 
 FULL_LIMIT = 50_000  # tensors with more elements are stored as checksum + sampled rows
 SAMPLE_ROWS = 16

@@ -43,7 +43,7 @@ sys.path.insert(0, "/root/reference/pointstowood")
 
 import src.io as ref_io  # noqa: E402
 import src.predicter as ref  # noqa: E402
-from oracle import weights  # noqa: E402
+from pointstowood_amd import synthetic_weights as weights  # noqa: E402
 
 
 def raw_voxels(seed=9):

@@ -96,7 +96,8 @@ def test_predict_cli_point_cloud_end_to_end(tmp_path):
     restatements composed the same way (oracle preprocess / host / net / backproject)."""
     import importlib.util
     import os
-    from oracle import host as ohost, net as onet, preprocess as OP, synth, weights
+    from oracle import host as ohost, net as onet, preprocess as OP
+    from pointstowood_amd import synthetic_voxels as synth, synthetic_weights as weights
     from pointstowood_amd import io as pio
     from pointstowood_amd.predicter import PointBudgetSampler
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

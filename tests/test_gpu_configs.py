@@ -16,7 +16,7 @@ import pytest
 import torch
 
 from oracle import net as onet
-from oracle import synth, weights
+from pointstowood_amd import synthetic_voxels as synth, synthetic_weights as weights
 
 pytestmark = pytest.mark.gpu
 
@@ -229,3 +229,73 @@ def test_config3_downscaled_plot():
     got = logits.cpu()
     assert (got - ref).abs().max() <= 4e-4
     assert (torch.sigmoid(got) - torch.sigmoid(ref)).abs().max() <= 1e-4
+
+
+def test_config3_full_size_10m_point_plot():
+    """BASELINE configs[3] AT ITS STATED SIZE on one GPU: the 10 M-point synthetic forest plot (bench.py --workload plot's
+    generator and defaults) through ``segment_plot`` with its default forward budget - voxelise (2 m + 4 m grids, min 128 /
+    max 16384 points) -> classify every voxel -> back-project (k = 64 median vote).  The reference's counterpart is
+    ``predict.py:116-156`` + ``src/predicter.py:193-234`` + ``src/preprocessing.py:79-127``; at this size the CPU oracle
+    cannot run the plot, so the checks are the size-independent ones: every voxel classified exactly once, ``min_pts`` /
+    ``max_pts`` respected, structure of the largest and the smallest forward, labels in {0, 1}, finite ``pwood`` in [0, 1],
+    idempotence (a second run gives the same bits), and oracle parity of ``Net.forward`` on one <= 40 k-point batch of the
+    plot's own voxels."""
+    from pointstowood_amd.pipeline import segment_plot
+    from pointstowood_amd.predicter import PointBudgetSampler, collate_device
+    from pointstowood_amd.preprocessing import voxelise
+    n = 10_000_000
+    pc = synth.forest_plot(n, side=100.0).cuda()
+    net = _net()
+    gen = lambda: torch.Generator(device="cuda").manual_seed(0)
+    stats = {}
+    n_z, label, pwood = segment_plot(pc, net, (2.0, 4.0), min_pts=128, max_pts=16384, stats=stats, generator=gen())
+    torch.cuda.synchronize()
+    assert n_z.shape == label.shape == pwood.shape == (n,)
+    assert set(label.unique().tolist()) <= {0.0, 1.0}
+    assert bool(torch.isfinite(pwood).all()) and float(pwood.min()) >= 0.0 and float(pwood.max()) <= 1.0
+    assert bool(torch.isfinite(n_z).all())
+    assert 0.02 < float(label.mean()) < 0.98                     # synthetic weights: both classes occur
+    # the voxel list the run classified, re-derived: sizes within [min_pts, max_pts], every voxel in exactly one forward
+    vox, n_z2 = voxelise(pc, (2.0, 4.0), 128, 16384, generator=gen())
+    assert torch.equal(n_z, n_z2)
+    lengths = [int(v.shape[0]) for v in vox]
+    assert len(vox) == stats["voxels"] > 5000 and min(lengths) >= 128 and max(lengths) <= 16384
+    assert sum(lengths) == stats["classified_points"] > n        # the 2 m and the 4 m grid both cover the plot
+    batches = list(PointBudgetSampler(lengths, stats["max_points"], stats["max_voxels"]))
+    assert sorted(i for b in batches for i in b) == list(range(len(vox)))
+    assert [sum(lengths[i] for i in b) for b in batches] == stats["batch_points"]
+    assert max(stats["batch_points"]) <= max(stats["max_points"], max(lengths))
+    big = max(batches, key=lambda b: sum(lengths[i] for i in b))
+    small = min(batches, key=lambda b: sum(lengths[i] for i in b))
+    for b in (big, small):
+        d = collate_device([vox[i] for i in b])
+        keep = {"geometry_only": True}      # the geometry without fp32 copies of the level features (2 M-point forward)
+        logits = net(d, keep=keep)
+        torch.cuda.synchronize()
+        assert logits.shape == (int(d.pos.shape[0]),) and bool(torch.isfinite(logits).all())
+        check_structure(keep["geometry"], int(d.pos.shape[0]))
+        del keep, logits, d
+    torch.cuda.empty_cache()
+    # oracle parity on a batch of the plot's own voxels (<= 40 k points: the smallest voxels of each grid size)
+    order = sorted(range(len(vox)), key=lambda i: lengths[i])
+    pick, tot = [], 0
+    for i in order[:: max(1, len(order) // 400)]:
+        if tot + lengths[i] > 40000 or len(pick) >= 24:
+            break
+        pick.append(i)
+        tot += lengths[i]
+    d = collate_device([vox[i] for i in sorted(pick)])
+    got = net(d).cpu()
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    ref = onet.forward(_sd(0), d.pos.cpu(), d.batch.cpu(), d.reflectance.cpu(), d.sf.cpu(), k=K)
+    assert (got - ref).abs().max() <= 4e-4
+    assert (torch.sigmoid(got) - torch.sigmoid(ref)).abs().max() <= 1e-4
+    # idempotence: the same plot, generator state and budget give the same bits (no atomics-order dependence anywhere)
+    stats2 = {}
+    n_z3, label2, pwood2 = segment_plot(pc, net, (2.0, 4.0), min_pts=128, max_pts=16384, stats=stats2, generator=gen(),
+                                        max_points=stats["max_points"], max_voxels=stats["max_voxels"])
+    assert torch.equal(label, label2) and torch.equal(pwood, pwood2) and stats2["batch_points"] == stats["batch_points"]
+    os.makedirs("gpurun_out", exist_ok=True)
+    import json
+    json.dump({k: v for k, v in stats.items() if k != "batch_points"} | {"forwards": len(stats["batch_points"])},
+              open(os.path.join("gpurun_out", "config3_full_plot_stats.json"), "w"), indent=1)

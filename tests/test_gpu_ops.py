@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import ops as O
-from oracle import synth
+from pointstowood_amd import synthetic_voxels as synth
 
 pytestmark = pytest.mark.gpu
 

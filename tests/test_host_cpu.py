@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from oracle import host as ohost
-from oracle import synth, weights
+from pointstowood_amd import synthetic_voxels as synth, synthetic_weights as weights
 from pointstowood_amd import Batch, Data, DataLoader, Net, checkpoint_layout
 from pointstowood_amd import _lib
 from pointstowood_amd.dist import gather_logits, partition_batches
@@ -562,6 +562,51 @@ def test_segment_plot_sharded_gloo_world4_and_8(world, max_points, monkeypatch):
     expect = (float(label.sum()), float(pwood.double().sum()), float(n_z.double().sum()))
     for r in res:
         assert r[1:4] == pytest.approx(expect, rel=1e-6, abs=1e-6), (r, expect)
+
+
+def _budget_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from pointstowood_amd import pipeline
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    pipeline.collect_predictions = _cpu_collect
+    # every rank reads a DIFFERENT amount of free memory; rank 1's is the smallest and must set everybody's budget
+    free = [40, 6, 17, 29][rank] * 1024 ** 3
+    pipeline._free_bytes = lambda dev: free
+    budget = pipeline.default_budget(10_000_000, world, free, dist)
+    seen = []
+
+    class _Sampler(list):
+        def __init__(self, lengths, max_points, max_voxels):
+            seen.append((max_points, max_voxels))
+            super().__init__([[i] for i in range(len(lengths))])
+    pipeline.PointBudgetSampler = _Sampler
+    pc = _plot(n=12000, seed=3)
+    n_z, label, pwood = pipeline.segment_plot(pc, _FakeStreamModel(), (4.0,), min_pts=64, max_pts=100000,
+                                              generator=torch.Generator().manual_seed(0), dist=dist)
+    q.put((rank, budget, seen[0], float(label.sum()), float(pwood.double().sum())))
+    dist.destroy_process_group()
+
+
+def test_default_budget_is_rank_invariant_gloo():
+    """ADVICE r3: with different free memory per GPU every rank must still build the SAME batch list (ranks index into it);
+    the cap is the all-reduced minimum."""
+    import torch.multiprocessing as mp
+    from pointstowood_amd import pipeline
+    world = 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 1000
+    ps = [ctx.Process(target=_budget_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    [p.join(60) for p in ps]
+    expect = int(0.4 * 6 * 1024 ** 3) // pipeline.BYTES_PER_POINT
+    assert [r[1] for r in res] == [expect] * world                     # 10 M points / 20 = 500 k, capped by rank 1's 6 GiB
+    assert len({r[2] for r in res}) == 1 and res[0][2][0] == min(262144, expect) > 65536
+    assert len({r[3:] for r in res}) == 1                              # and the same plot result everywhere
+    assert pipeline.default_budget(10_000_000, 1, None) == 2_000_000 and pipeline.default_budget(100, 1, None) == 262144
 
 
 def _ragged_worker(rank, world, port, counts, q):

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import net as onet
-from oracle import synth, weights
+from pointstowood_amd import synthetic_voxels as synth, synthetic_weights as weights
 from tests import golden_util as G
 
 
