@@ -16,8 +16,10 @@ region): reported as ``pcie_inclusive`` (SURVEY.md 8d's wording of the metric), 
 ``--gpus N`` (N > 1) from a plain shell spawns ``python -m torch.distributed.run`` with N ranks
 as a CHILD process (the parent never touches the GPU) and exits with its code; when the driver
 has already launched the ranks (WORLD_SIZE == N) it just runs.  Every rank runs its own batches
-(weak scaling, voxel batches are independent) and each step ends with the path's only
-collective: an RCCL all-gather of the per-point logits.  Rank 0 prints ONE JSON line.
+(weak scaling, voxel batches are independent); the path's only collective, an RCCL all-gather of the
+per-point logits, runs once behind the last step over all steps' logits (``--gather final``, the
+default: north_star's "RCCL only for the final gather") or after every step (``--gather per-step``),
+inside the timed region either way.  Rank 0 prints ONE JSON line.
 
 ``roofline`` is measured live: after the timed regions one extra, sequential step is run with HIP
 events around every run of consecutive launches of one kernel class (on the launch stream) and the
@@ -56,10 +58,16 @@ def parse_args(argv=None):
     ap.add_argument("--batches", type=int, default=8, help="distinct seeded voxel batches the steps rotate over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-full", action="store_true",
-                    help="BASELINE.md section 4 in full: the whole batch 0 (8 voxels), 5 timed passes, thread counts {16, 64, all} swept "
-                         "(minutes of CPU time); default: a bounded sample (voxel 0, median of 3 timed passes, 16 threads)")
+                    help="BASELINE.md section 4 in full: the whole batch 0 (8 voxels) as one batch instead of voxel 0 (minutes of CPU "
+                         "time); either way thread counts {16, 64, all} are each timed once and the best re-timed (median of 3)")
+    ap.add_argument("--cpu-baseline-child", default=None, metavar="THREADS:VOXELS:PASSES", help=argparse.SUPPRESS)
+    ap.add_argument("--gather", default="final", choices=["final", "per-step"],
+                    help="--gpus N: 'final' (default) = the path's only collective, the RCCL all-gather of the per-point logits, runs ONCE "
+                         "after the last step over all steps' logits (north_star: 'RCCL only for the final gather'; still inside the "
+                         "timed region); 'per-step' = one all-gather per step on the launch stream")
     ap.add_argument("--no-workloads", action="store_true",
                     help="skip the extra `workloads` object (configs[2], configs[4] in f16x3 and fp16, a surface-like batch)")
+    ap.add_argument("--no-plot-workload", action="store_true", help="skip the configs[3] 10 M-point plot entry of `workloads` (~10 s)")
     ap.add_argument("--workload", default="voxels", choices=["voxels", "plot"],
                     help="voxels (default): BASELINE configs[1], one voxel batch per GPU per step (weak scaling); plot: BASELINE "
                          "configs[3], ONE synthetic plot voxelised, classified and back-projected by all ranks together (strong scaling)")
@@ -155,6 +163,21 @@ def algorithmic_bytes(geo):
     return out
 
 
+def search_pairs(geo):
+    """the neighbour searches' ALGORITHMIC work = candidate-distance evaluations of the reference's brute-force
+    definition, sum over voxels of queries x candidates (model.py:118 radius: M1 x N; :120 knn: M2 x M1, M3 x M2; :149
+    knn_interpolate: M2 x M3, M1 x M2, N x M1).  The grid-indexed kernels evaluate far fewer (only candidates within reach of
+    a query block); like the FLOP formula, the figure is the reference algorithm's, not this implementation's."""
+    import torch
+    cnt = [torch.diff(geo.levels[l].ptr.long()).cpu() for l in range(4)]
+    dot = lambda a, b: int((cnt[a] * cnt[b]).sum())
+    return {"ball_query": dot(1, 0), "knn": dot(2, 1) + dot(3, 2), "knn2": dot(2, 3) + dot(1, 2) + dot(0, 1)}
+
+
+# fp32 VALU peak (MI355X_MICROARCH.md: 157.3 TFLOP/s vector fp32) in candidate-distance evaluations: 3 subtracts, 3 multiplies,
+# 2 adds per pair (oracle/ops.py's ((dx*dx)+(dy*dy))+(dz*dz), no FMA) = 8 FLOP; the compare / insertion is not counted
+PEAK_PAIRS_PER_S = 157.3e12 / 8.0
+
 KERNEL_OF = {"gemm_hoist": "gemm_kernel", "gemm_res": "gemm_kernel", "gemm_mlp": "gemm_kernel", "sa_conv": "sa_conv_kernel"}
 
 
@@ -196,49 +219,66 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(batch0, full=False):
-    """CPU oracle (oracle/net.py, a port pinned to the reference's own outputs) on a bounded sample of batch 0 of this
-    benchmark, as ONE batch like the GPU runs it (same batch definition, same k, C, weights): median of the timed passes.
-    default: voxel 0, 1 warm-up + 3 timed passes, 16 torch threads (a few seconds; three voxels as one batch already take
-    10 s per pass on a 64-core EPYC - the oracle's [E, C] edge tensors fall out of cache);
-    full: all 8 voxels, 5 timed passes, thread counts {16, 64, all} swept once, the best reported."""
+def cpu_baseline_child(spec):
+    """One timing leg of the CPU baseline in a FRESH process (bench.py --cpu-baseline-child THREADS:VOXELS:PASSES): the
+    thread pools are sized before the first torch call of the process (OMP / MKL environment set by the parent, then
+    torch.set_num_threads), nothing of the GPU run's host state (pinned buffers, HIP runtime threads, the allocator) is
+    around.  Prints {"times": [...], "points": n}: 1 untimed warm-up pass, then PASSES timed ones."""
+    threads, nvox, passes = (int(v) for v in spec.split(":"))
     import torch
+    torch.set_num_threads(threads)
     from oracle import net as onet
     from pointstowood_amd import synthetic_weights as weights
+    batch0 = host_batch(0, 0)
     sd = weights.synth_state_dict(1, C, seed=0)
-    nvox = BATCH if full else 1
     n = int(batch0["ptr"][nvox])
     pos, refl = batch0["pos"][:n].clone(), batch0["reflectance"][:n].clone()
     bidx, sf = batch0["batch"][:n].clone(), batch0["sf"][:nvox].clone()
     run = lambda: onet.forward(sd, pos, bidx, refl, sf, k=K_NBR)
+    run()
+    ts = []
+    for _ in range(passes):
+        t0 = time.perf_counter()
+        run()
+        ts.append(time.perf_counter() - t0)
+    print(json.dumps({"times": ts, "points": n, "threads": torch.get_num_threads()}), flush=True)
+
+
+def cpu_baseline(full=False):
+    """CPU oracle (oracle/net.py, a port pinned to the reference's own outputs) on a bounded sample of batch 0 of this
+    benchmark, as ONE batch like the GPU runs it (same batch definition, same k, C, weights) - BASELINE.md section 4.
+    Sample: voxel 0 of batch 0 (default; the whole 8-voxel batch takes ~30 s per pass on a 64-core EPYC - the oracle's [E, C]
+    edge tensors fall out of cache - and is what --cpu-baseline-full times).  Thread counts {16, 64, all host cores} are each
+    timed once (after a warm-up pass), the best is re-timed and its median of 3 reported.  Every leg is a fresh child
+    process with its thread pools pinned before the first torch call, so the number does not depend on what the GPU part
+    of this run left behind on the host (round 3: 3.9 k vs 13.6 k points/s for the same code)."""
+    nvox = BATCH if full else 1
     cores = os.cpu_count() or 1
-    sweep = sorted({min(cores, t) for t in ((16, 64, cores) if full else (16,))})
-    reps, best, tried = (5 if full else 3), None, {}
+    sweep = sorted({min(cores, t) for t in (16, 64, cores)})
+
+    def leg(threads, passes):
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), OMP_PROC_BIND="false",
+                   OMP_WAIT_POLICY="PASSIVE", HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", f"{threads}:{nvox}:{passes}"],
+                           env=env, capture_output=True, text=True, timeout=1800)
+        if r.returncode != 0:
+            raise RuntimeError("cpu baseline child failed: " + r.stderr[-2000:])
+        return json.loads(r.stdout.strip().splitlines()[-1])
+
+    tried = {}
     for threads in sweep:
-        torch.set_num_threads(threads)
-        run()  # warm-up
-        ts = []
-        for _ in range(reps if threads == sweep[0] or not full else 2):   # the sweep's other settings: 2 passes each
-            t0 = time.perf_counter()
-            run()
-            ts.append(time.perf_counter() - t0)
-        tried[threads] = statistics.median(ts)
-        if best is None or tried[threads] < tried[best]:
-            best = threads
-    if full and best != sweep[0]:   # the winner gets its full number of passes
-        torch.set_num_threads(best)
-        ts = []
-        for _ in range(reps):
-            t0 = time.perf_counter()
-            run()
-            ts.append(time.perf_counter() - t0)
-        tried[best] = statistics.median(ts)
-    dt = tried[best]
+        out = leg(threads, 1)
+        tried[threads], n = out["times"][0], out["points"]
+    best = min(tried, key=lambda t: (tried[t], t))
+    final = leg(best, 3)
+    dt = statistics.median(final["times"])
     return {"value": n / dt, "unit": "points/s", "cores": best, "kind": "port", "cpu_model": cpu_model(), "host_cores": cores,
-            "ms_per_batch": dt * 1e3, "voxels": nvox,
+            "cores_used_of_present": f"{best}/{cores}", "ms_per_batch": dt * 1e3, "voxels": nvox,
             "threads_tried": {str(t): round(v, 3) for t, v in tried.items()},
-            "sample": f"voxels 0..{nvox - 1} of batch 0 as one batch ({n} pts, U2-16k seeds 123..{122 + nvox}), k={K_NBR}, C={C}, fp32, "
-                      f"median of {reps} timed passes after 1 warm-up, {dt:.2f} s per pass, {best} torch threads"}
+            "passes_s": [round(t, 3) for t in final["times"]],
+            "sample": f"voxels 0..{nvox - 1} of batch 0 as one batch ({n} pts, U2-16k seeds 123..{122 + nvox}), k={K_NBR}, C={C}, fp32; "
+                      f"thread counts {sweep} timed once each in fresh processes, best ({best}) re-timed: median of 3 passes after 1 "
+                      f"warm-up, {dt:.2f} s per pass"}
 
 
 def device_feed(vox, device):
@@ -272,6 +312,39 @@ def measure_workload(net, data, reps=5):
     return out
 
 
+def plot_workload(net, args, device, n=10_000_000, reps=2):
+    """BASELINE configs[3] at its stated size on this GPU: the 10 M-point synthetic forest plot through
+    pipeline.segment_plot (voxelise 2 m + 4 m -> classify every voxel -> back-project with the k = 64 median vote;
+    reference predict.py:116-156, src/predicter.py:193-234, src/preprocessing.py:79-127).  One untimed run (allocator), then
+    `reps` timed ones; the stage times are those of the last run."""
+    import torch
+    from pointstowood_amd.pipeline import segment_plot
+    from pointstowood_amd.synthetic_voxels import forest_plot
+    pc = forest_plot(n, side=100.0).to(device)
+    gen = lambda: torch.Generator(device=device).manual_seed(0)
+    segment_plot(pc, net, generator=gen())
+    times, stats = [], {}
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        stats = {}
+        t0 = time.perf_counter()
+        n_z, label, pwood = segment_plot(pc, net, generator=gen(), stats=stats)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    ok = bool(torch.isfinite(pwood).all()) and set(label.unique().tolist()) <= {0.0, 1.0}
+    dt = min(times)
+    out = {"points": n, "voxels": stats.get("voxels"), "classified_points": stats.get("classified_points"), "runs": reps,
+           "ms_per_plot": round(dt * 1e3, 1), "ms_per_plot_all": [round(t * 1e3, 1) for t in times],
+           "plot_points_per_s": round(n / dt, 1),
+           "classified_points_per_s": round(stats.get("classified_points", 0) / max(stats.get("classify_s", 1e-9), 1e-9), 1),
+           "stages_s_last_run": {k: round(v, 4) for k, v in stats.items() if k.endswith("_s")},
+           "forwards": len(stats.get("batch_points", [])), "max_points_per_forward": stats.get("max_points"),
+           "outputs_ok": ok, "dtype": args.precision}
+    del pc, n_z, label, pwood
+    torch.cuda.empty_cache()
+    return out
+
+
 def extra_workloads(net, args, device):
     """The other BASELINE.json workloads and a surface-like batch, measured in the same run as the bench line (a few steps
     each): driver-observable numbers for configs[2], configs[4] (f16x3 and, as the config says fp16, fp16) and for input
@@ -287,6 +360,8 @@ def extra_workloads(net, args, device):
         ("surface B=8 x 16384 xyz-only (cylinders + blobs: ball-query cap saturated)",
          lambda: [synth.surface_voxel(2.0, NPTS, 300 + i, False) for i in range(BATCH)]),
     ]
+    if not args.no_plot_workload:
+        out["configs[3] 10 M-point plot (voxelise + classify + back-project, 1 GPU)"] = plot_workload(net, args, device)
     for name, make in cases:
         d = device_feed(make(), device)
         out[name] = dict(measure_workload(net, d), dtype=args.precision)
@@ -362,6 +437,8 @@ def plot_main(args, world, rank, device, dist):
 
 def main():
     args = parse_args()
+    if args.cpu_baseline_child:
+        return cpu_baseline_child(args.cpu_baseline_child)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         if "RANK" in os.environ:
@@ -406,20 +483,28 @@ def main():
         With --pipeline the engine's two-stream software pipeline overlaps the geometry phase of step i+1 with the
         feature phase of step i.  pcie: inputs come from pinned host memory, logits go back to it, inside the region."""
         out = None
+        held = []   # --gather final: every step's logits, gathered once behind the last step
 
         def feed():
             for i in range(n):
                 yield Feed.to_device(pinned[i % nb], device, non_blocking=True) if pcie else resident[i % nb]
 
+        def gather(t):
+            # the path's only collective, bracketed by events on the launch stream (its own time)
+            g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            g0.record()
+            o = gather_logits(t, dist)
+            g1.record()
+            gather_marks.append((g0, g1))
+            return o
+
         def finish(i, logits):
-            if world > 1:   # the path's only collective, bracketed by events on the launch stream (its own time per step)
-                g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                g0.record()
-                o = gather_logits(logits, dist)
-                g1.record()
-                gather_marks.append((g0, g1))
-            else:
-                o = logits
+            o = logits
+            if world > 1:
+                if args.gather == "per-step":
+                    o = gather(logits)
+                else:
+                    held.append(logits)
             if pcie:
                 out_host[i % nb].copy_(logits, non_blocking=True)
             if stamps is not None:
@@ -433,6 +518,8 @@ def main():
         else:
             for i, d in enumerate(feed()):
                 out = finish(i, net(d))
+        if held:   # ONE all-gather of all n steps' logits (n x 0.5 MB per rank), still inside the timed region
+            out = gather(torch.cat(held))
         return out
 
     def timed(n, pcie):
@@ -454,7 +541,8 @@ def main():
         if world > 1:
             # every rank's own wall time and the time its gathers took (diagnosis of a scaling curve: a slow rank, or the
             # collective, shows up here); `dt` = the maximum over ranks, as the contract says
-            gather_ms = sum(a.elapsed_time(b) for a, b in gather_marks[-n:]) / n
+            marks_ = gather_marks[-n:] if args.gather == "per-step" else gather_marks[-1:]
+            gather_ms = sum(a.elapsed_time(b) for a, b in marks_) / n
             mine = torch.tensor([dt, gather_ms], device=device, dtype=torch.float64)
             allr = [torch.zeros_like(mine) for _ in range(world)]
             dist.all_gather(allr, mine)
@@ -518,6 +606,20 @@ def main():
                 gbps = nbytes / (per[name][0] * 1e-3) / 1e9
                 hbm[name] = {"algorithmic_bytes_per_step": nbytes, "ms_per_step": round(per[name][0], 4), "launches": per[name][1],
                              "achieved_GBps": round(gbps, 1), "frac_of_8TBps": round(gbps / PEAK_HBM_GBPS, 4)}
+        pairs = search_pairs(geo)
+        search = {"unit": "candidate-distance evaluations/s (reference brute-force definition: queries x candidates per voxel)",
+                  "peak": PEAK_PAIRS_PER_S, "peak_note": "fp32 VALU peak 157.3 TFLOP/s / 8 FLOP per evaluation",
+                  "kernels": {}}
+        for name, npairs in pairs.items():
+            if name in per and per[name][0] > 0:
+                rate = npairs / (per[name][0] * 1e-3)
+                search["kernels"][name] = {"pairs_per_step": npairs, "ms_per_step": round(per[name][0], 4), "launches": per[name][1],
+                                           "achieved": rate, "frac_of_valu_peak": round(rate / PEAK_PAIRS_PER_S, 4)}
+        tot_ms = sum(v["ms_per_step"] for v in search["kernels"].values())
+        if tot_ms > 0:
+            search["ms_per_step"] = round(tot_ms, 4)
+            search["achieved"] = sum(pairs[k] for k in search["kernels"]) / (tot_ms * 1e-3)
+            search["frac_of_valu_peak"] = round(search["achieved"] / PEAK_PAIRS_PER_S, 4)
         notes = {"f16x3": "f16x3 issues 3 fp16 MFMAs per algorithmic product: ceiling for algorithmic FLOPs is peak/3",
                  "fp16": "one fp16 MFMA per product", "bf16": "one bf16 MFMA per product", "fp32": "exact fp32 MFMA"}
         line = {
@@ -529,7 +631,10 @@ def main():
                                    f"{nb} distinct seeded batches in rotation, inputs resident in HBM",
                        "setup": "one untimed pass over the distinct batches through the pipeline before the warmup steps (sizes the caching allocator's per-stream pools)",
                        "global_batch_voxels": world * BATCH, "points_per_step": world * BATCH * NPTS, "C": C,
-                       "level_sizes_batch0": sizes, "parallelism": f"voxel-batch sharding x{world}, RCCL all-gather of logits",
+                       "level_sizes_batch0": sizes, "parallelism": f"voxel-batch sharding x{world}, RCCL all-gather of logits "
+                                                                    + ("once after the last step (all steps' logits in one collective, inside the timed region)"
+                                                                       if args.gather == "final" else "after every step"),
+                       "gather": args.gather,
                        "pipeline": ("HIP streams: geometry(i+1) || features(i), features alternating over "
                                     f"{net.engine_options.feature_streams} high-priority streams") if args.pipeline else "sequential"},
             "end_to_end_tflops_algorithmic": 2.0 * total_macs * args.steps / dt / 1e12,
@@ -540,6 +645,7 @@ def main():
                          "launches_per_step": dom_launches, "kernel_ms_per_step": dom_ms,
                          "algorithmic_gflop_per_step": 2.0 * kmacs[dom] / 1e9},
             "hbm_kernels": hbm,
+            "search": search,
             "kernel_ms_per_step": {kname: round(v[0], 4) for kname, v in sorted(per.items(), key=lambda kv: -kv[1][0])},
         }
         if rank_stats is not None:
@@ -547,7 +653,7 @@ def main():
         if world == 1 and not args.no_workloads:
             line["workloads"] = extra_workloads(net, args, device)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(host[0], full=args.cpu_baseline_full)
+            line["cpu_baseline"] = cpu_baseline(full=args.cpu_baseline_full)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

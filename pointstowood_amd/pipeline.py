@@ -78,9 +78,10 @@ def segment_plot(pc, model, grid_sizes=(2.0, 4.0), min_pts: int = 128, max_pts: 
     if max_voxels is None:
         max_voxels = max(1, max_points // 1024)
     batches = list(PointBudgetSampler(lengths, max_points, max_voxels))
+    plan, batch_rows = None, [sum(lengths[i] for i in b) for b in batches]
     if world > 1:
-        mine = partition_batches([sum(batch_cost(lengths[i]) for i in b) for b in batches], world)[rank]   # LPT on est. FLOPs
-        batches = [batches[i] for i in mine]
+        plan = partition_batches([sum(batch_cost(lengths[i]) for i in b) for b in batches], world)   # LPT on est. FLOPs
+        batches = [batches[i] for i in plan[rank]]
     if stats is not None:
         stats["max_points"], stats["max_voxels"] = int(max_points), int(max_voxels)
         stats["batch_points"] = [sum(lengths[i] for i in b) for b in batches]     # this rank's forwards
@@ -103,6 +104,15 @@ def segment_plot(pc, model, grid_sizes=(2.0, 4.0), min_pts: int = 128, max_pts: 
         cls = torch.zeros((0, 4), dtype=torch.float32, device=dev)
     if world > 1:
         cls = gather_rows(cls, dist)
+        # the gather returns rank-major rows; put them back into batch order, the order a single process classifies in: the
+        # vote's k nearest classified points break distance ties by index, so only then is the sharded result bit-identical
+        start, off = {}, 0
+        for r in range(world):
+            for b in plan[r]:
+                start[b], off = off, off + batch_rows[b]
+        if off != cls.shape[0]:
+            raise RuntimeError(f"gathered {cls.shape[0]} classified points, the batch plan holds {off}")
+        cls = torch.cat([cls[start[b]: start[b] + batch_rows[b]] for b in range(len(batch_rows))]) if batch_rows else cls
     cls_xyz, cls_prob = cls[:, :3].contiguous(), cls[:, 3].contiguous()
     cls_pred = (cls_prob >= is_wood).to(torch.float32)                                       # predicter.py:200
     if stats is not None:
