@@ -59,7 +59,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-full", action="store_true",
                     help="BASELINE.md section 4 in full: the whole batch 0 (8 voxels) as one batch instead of voxel 0 (minutes of CPU "
-                         "time); either way thread counts {16, 64, all} are each timed once and the best re-timed (median of 3)")
+                         "time); either way thread counts {16, 64, all} are each timed once and the best re-timed (median of 5)")
     ap.add_argument("--cpu-baseline-child", default=None, metavar="THREADS:VOXELS:PASSES", help=argparse.SUPPRESS)
     ap.add_argument("--gather", default="final", choices=["final", "per-step"],
                     help="--gpus N: 'final' (default) = the path's only collective, the RCCL all-gather of the per-point logits, runs ONCE "
@@ -249,7 +249,8 @@ def cpu_baseline(full=False):
     benchmark, as ONE batch like the GPU runs it (same batch definition, same k, C, weights) - BASELINE.md section 4.
     Sample: voxel 0 of batch 0 (default; the whole 8-voxel batch takes ~30 s per pass on a 64-core EPYC - the oracle's [E, C]
     edge tensors fall out of cache - and is what --cpu-baseline-full times).  Thread counts {16, 64, all host cores} are each
-    timed once (after a warm-up pass), the best is re-timed and its median of 3 reported.  Every leg is a fresh child
+    timed once (after a warm-up pass), the best is re-timed and its median of 5 reported (the pool's 256-core hosts are shared:
+    single passes of the same process were seen 2 x apart; `passes_s` lists them, `best_pass_points_per_s` is the fastest).  Every leg is a fresh child
     process with its thread pools pinned before the first torch call, so the number does not depend on what the GPU part
     of this run left behind on the host (round 3: 3.9 k vs 13.6 k points/s for the same code)."""
     nvox = BATCH if full else 1
@@ -270,14 +271,14 @@ def cpu_baseline(full=False):
         out = leg(threads, 1)
         tried[threads], n = out["times"][0], out["points"]
     best = min(tried, key=lambda t: (tried[t], t))
-    final = leg(best, 3)
+    final = leg(best, 5)
     dt = statistics.median(final["times"])
     return {"value": n / dt, "unit": "points/s", "cores": best, "kind": "port", "cpu_model": cpu_model(), "host_cores": cores,
             "cores_used_of_present": f"{best}/{cores}", "ms_per_batch": dt * 1e3, "voxels": nvox,
             "threads_tried": {str(t): round(v, 3) for t, v in tried.items()},
-            "passes_s": [round(t, 3) for t in final["times"]],
+            "passes_s": [round(t, 3) for t in final["times"]], "best_pass_points_per_s": round(n / min(final["times"]), 1),
             "sample": f"voxels 0..{nvox - 1} of batch 0 as one batch ({n} pts, U2-16k seeds 123..{122 + nvox}), k={K_NBR}, C={C}, fp32; "
-                      f"thread counts {sweep} timed once each in fresh processes, best ({best}) re-timed: median of 3 passes after 1 "
+                      f"thread counts {sweep} timed once each in fresh processes, best ({best}) re-timed: median of 5 passes after 1 "
                       f"warm-up, {dt:.2f} s per pass"}
 
 

@@ -1043,6 +1043,54 @@ __global__ __launch_bounds__(256) void ball_kernel(const float4* __restrict__ x,
 }
 
 
+
+// ---- wave-wide sorting network on packed (d2, index) keys -------------------------------------------------------
+// One 64-bit key per lane.  xl<M>(v): the value lane ^ M holds - DPP inside a row of 16 (quad_perm for 1 and 2, the two
+// bank-masked row shifts for 4, row_ror:8 for 8), v_permlane16_swap / v_permlane32_swap (gfx950) across rows.  The keys
+// come out of integer selects (never out of packed fp32 arithmetic: DESIGN "packed-FMA -> DPP hazard").
+template <int M>
+__device__ __forceinline__ unsigned xl(unsigned v, int lane) {
+    if constexpr (M == 1) return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xf, 0xf, false);        // quad_perm [1,0,3,2]
+    else if constexpr (M == 2) return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+    else if constexpr (M == 4) {
+        const int t = __builtin_amdgcn_update_dpp((int)v, (int)v, 0x104, 0xf, 0x5, false);    // banks 0, 2: row_shl:4 (lane + 4)
+        return (unsigned)__builtin_amdgcn_update_dpp(t, (int)v, 0x114, 0xf, 0xA, false);      // banks 1, 3: row_shr:4 (lane - 4)
+    } else if constexpr (M == 8) return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xf, 0xf, false);   // row_ror:8
+    else if constexpr (M == 16) {
+        const auto sw = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+        return (lane & 16) ? sw[0] : sw[1];
+    } else {
+        static_assert(M == 32, "xor masks 1 .. 32");
+        const auto sw = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+        return (lane & 32) ? sw[0] : sw[1];
+    }
+}
+// compare-exchange with lane ^ M: the lane keeps the smaller key when `take_min`
+template <int M>
+__device__ __forceinline__ unsigned long long cx64(unsigned long long v, int lane, bool take_min) {
+    const unsigned long long o = ((unsigned long long)xl<M>((unsigned)(v >> 32), lane) << 32) | xl<M>((unsigned)v, lane);
+    return ((o < v) == take_min) ? o : v;
+}
+// bitonic merge of a bitonic 64-sequence (ascending result)
+__device__ __forceinline__ unsigned long long merge64_asc(unsigned long long v, int lane) {
+    v = cx64<32>(v, lane, (lane & 32) == 0); v = cx64<16>(v, lane, (lane & 16) == 0); v = cx64<8>(v, lane, (lane & 8) == 0);
+    v = cx64<4>(v, lane, (lane & 4) == 0);   v = cx64<2>(v, lane, (lane & 2) == 0);   v = cx64<1>(v, lane, (lane & 1) == 0);
+    return v;
+}
+// bitonic sort of 64 keys, DESCENDING (lane 0 ends with the largest): 21 compare-exchange stages
+__device__ __forceinline__ unsigned long long sort64_desc(unsigned long long v, int lane) {
+#define P2W_CX(SIZE, M) v = cx64<M>(v, lane, (((lane & (M)) == 0) == ((SIZE) == 64 ? false : ((lane & (SIZE)) != 0))))
+    P2W_CX(2, 1);
+    P2W_CX(4, 2); P2W_CX(4, 1);
+    P2W_CX(8, 4); P2W_CX(8, 2); P2W_CX(8, 1);
+    P2W_CX(16, 8); P2W_CX(16, 4); P2W_CX(16, 2); P2W_CX(16, 1);
+    P2W_CX(32, 16); P2W_CX(32, 8); P2W_CX(32, 4); P2W_CX(32, 2); P2W_CX(32, 1);
+    P2W_CX(64, 32); P2W_CX(64, 16); P2W_CX(64, 8); P2W_CX(64, 4); P2W_CX(64, 2); P2W_CX(64, 1);
+#undef P2W_CX
+    return v;
+}
+constexpr unsigned long long TOPK_EMPTY = 0x7f8000007fffffffull;   // (d2 = +inf, index = 0x7fffffff): an unused slot of a top-k list
+
 // ------------------------------------------------------------------------------------------------
 // grid-indexed neighbour search
 //
@@ -1095,7 +1143,7 @@ extern "C" int32_t p2w_debug_slab_prof(unsigned long long* out, int reset) {
 // BOX: the gathered region is also bounded in x (one run per grid row instead of one per z layer) - for grids whose
 // rows are much longer than a workgroup's reach (plot-scale searches); per-voxel searches gather whole rows.
 template <int MODE, int TILE, bool LADDER, bool BOX>
-__global__ __launch_bounds__(256) void slab_search_kernel(const float4* __restrict__ x, const unsigned long long* __restrict__ keys,
+__global__ __launch_bounds__(256, (MODE == 0 && LADDER) ? 3 : 1) void slab_search_kernel(const float4* __restrict__ x, const unsigned long long* __restrict__ keys,
                                                           const int* __restrict__ ptr_x, const p2w_grid* __restrict__ grid,
                                                           const float4* __restrict__ xq, const int* __restrict__ qidx,
                                                           const int* __restrict__ ptr_q, int B, int k, float r, float r2,
@@ -1106,6 +1154,11 @@ __global__ __launch_bounds__(256) void slab_search_kernel(const float4* __restri
     __shared__ int run_pre[G_MAXRUN + 1];
     __shared__ int wsum[4];
     __shared__ float wred[4][8];
+    // k >= 8 (LADDER): candidates under a query's threshold are COLLECTED (ballot-compacted into the query's pending list, up
+    // to 64 packed (d2, index) keys) and merged into its sorted top-k list by ONE sorting network per 64 of them, instead of one
+    // sorted insertion (~15 dependent cross-lane instructions) per candidate: see collect / flush below
+    constexpr bool COLLECT = MODE == 0 && LADDER;
+    __shared__ unsigned long long pend[COLLECT ? 4 : 1][COLLECT ? S_QPW : 1][COLLECT ? 64 : 1];
     int b, q0, q1;
     if (!search_tile(ptr_q, B, blockIdx.x, &b, &q0, &q1)) return;
     const int c0 = ptr_x[b], c1 = ptr_x[b + 1];
@@ -1128,13 +1181,14 @@ __global__ __launch_bounds__(256) void slab_search_kernel(const float4* __restri
     UQuery uq[S_QPW];
     float best_d[S_QPW], thr[S_QPW];
     int best_i[S_QPW], cnt[S_QPW];
+    int pc[S_QPW];          // COLLECT: keys in the query's pending list (wave-uniform)
     unsigned active = 0u;   // queries of this wave whose result is not final yet
     float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY, zmin = INFINITY, zmax = -INFINITY;
     float hmax = 0.f, hinted = (MODE == 0 && hint) ? 1.f : 0.f;   // largest hint / every query of the workgroup has one
 #pragma unroll
     for (int j = 0; j < S_QPW; ++j) {
         uq[j] = load_query(xq, qidx, qw + j, q1);
-        best_d[j] = INFINITY; best_i[j] = 0x7fffffff; cnt[j] = 0;
+        best_d[j] = INFINITY; best_i[j] = 0x7fffffff; cnt[j] = 0; pc[j] = 0;
         thr[j] = MODE == 0 ? INFINITY : __int_as_float(0x7fffffff);   // ball: thr holds the index threshold's bits
         if (uq[j].valid) {
             active |= 1u << j;
@@ -1164,6 +1218,21 @@ __global__ __launch_bounds__(256) void slab_search_kernel(const float4* __restri
     const bool in_k = lane < k;
     const int total = c1 - c0;
     SLAB_STAMP(0);   // setup
+    // COLLECT: merge query j's pending keys into its top-k list (ascending across lanes 0 .. k-1, TOPK_EMPTY beyond): sort the
+    // pending keys descending (21 stages), the lane-wise minimum with the ascending list is a bitonic sequence of the 64
+    // smallest keys of both, 6 merge stages sort it; lanes >= k are cut off and the threshold drops to the k-th distance.
+    // Exactly the list the insertions built: the k smallest (d2, index) keys seen so far, ties by index.
+    auto flush = [&](int j) {
+        unsigned long long pk = lane < pc[j] ? pend[COLLECT ? wave : 0][COLLECT ? j : 0][COLLECT ? lane : 0] : TOPK_EMPTY;
+        pk = sort64_desc(pk, lane);
+        const unsigned long long bk = ((unsigned long long)__float_as_uint(best_d[j]) << 32) | (unsigned)best_i[j];
+        unsigned long long v = merge64_asc(pk < bk ? pk : bk, lane);
+        if (!in_k) v = TOPK_EMPTY;
+        best_d[j] = __uint_as_float((unsigned)(v >> 32));
+        best_i[j] = (int)(unsigned)v;
+        thr[j] = fminf(thr[j], rdlane(best_d[j], k - 1));   // slot k-1 is +inf until k keys are kept
+        pc[j] = 0;
+    };
 
     // The region is the cell box "bounding box of the queries grown by rho" (all of x unless BOX).  region() moves the
     // target box n* (never shrinking below the scanned box o*) and returns the number of runs that are NEW relative to
@@ -1286,7 +1355,7 @@ __global__ __launch_bounds__(256) void slab_search_kernel(const float4* __restri
 #pragma unroll
             for (int j = 0; j < S_QPW; ++j) {
                 if ((active >> j) & 1u) {
-                    best_d[j] = INFINITY; best_i[j] = 0x7fffffff; cnt[j] = 0;
+                    best_d[j] = INFINITY; best_i[j] = 0x7fffffff; cnt[j] = 0; pc[j] = 0;
                     thr[j] = MODE == 0 ? INFINITY : __int_as_float(0x7fffffff);
                 }
             }
@@ -1366,7 +1435,54 @@ __global__ __launch_bounds__(256) void slab_search_kernel(const float4* __restri
                     thr[j] = t;
                 }
             }
-            if (MODE == 0) {
+            if (MODE == 0 && COLLECT) {
+                // One flush site for the whole kernel (a flush is ~250 instructions and is inlined per query): a virtual
+                // group behind the tile's last one merges every query's pending keys - eight independent sorting networks in
+                // straight-line code for the scheduler to interleave - and so does any group boundary at which a list is
+                // nearly full.  A chunk whose admissions do not fit its query's list is left for the next round of the same
+                // group, which starts with a forced flush (an empty list takes any chunk: 64 lanes), so nothing is ever dropped.
+                const int ngr = tsz >> 8;
+                bool force = false;
+                for (int gr = 0; gr <= ngr; ++gr) {
+                    const bool last = gr == ngr;
+                    unsigned done = last ? 0xffffffffu : 0u;   // bit 4 j + u: chunk u of this group was presented to query j
+                    float4 c[4];
+                    if (!last) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) c[u] = cand[gr * 256 + u * 64 + lane];
+                    }
+                    for (;;) {
+                        int fullest = 0;
+#pragma unroll
+                        for (int j = 0; j < S_QPW; ++j) fullest = max(fullest, pc[j]);
+                        if (force || last || fullest > 48) {
+#pragma unroll
+                            for (int j = 0; j < S_QPW; ++j) flush(j);
+                        }
+                        if (last) break;
+                        force = false;
+#pragma unroll
+                        for (int j = 0; j < S_QPW; ++j) {
+                            if (!((active >> j) & 1u)) continue;   // wave-uniform
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                if ((done >> (4 * j + u)) & 1u) continue;
+                                const float d = p2w_d2(uq[j].x, uq[j].y, uq[j].z, c[u].x, c[u].y, c[u].z);
+                                const unsigned long long m = __ballot(d <= thr[j]);
+                                const int n = __popcll(m);
+                                if (pc[j] + n > 64) { force = true; continue; }
+                                done |= 1u << (4 * j + u);
+                                if (n == 0) continue;
+                                const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(c[u].w);
+                                const int slot = pc[j] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                                if ((m >> lane) & 1ull) pend[COLLECT ? wave : 0][COLLECT ? j : 0][COLLECT ? slot : 0] = key;
+                                pc[j] += n;
+                            }
+                        }
+                        if (!force) break;
+                    }
+                }
+            } else if (MODE == 0) {
                 for (int gr = 0; gr < (tsz >> 8); ++gr) {
                     float4 c[4];
 #pragma unroll
@@ -1456,7 +1572,7 @@ __global__ __launch_bounds__(256) void slab_search_kernel(const float4* __restri
                 oXlo = 0; oXhi = -1; oYlo = 0; oYhi = -1; oZlo = 0; oZhi = -1;
 #pragma unroll
                 for (int j = 0; j < S_QPW; ++j)
-                    if ((active >> j) & 1u) { best_d[j] = INFINITY; best_i[j] = 0x7fffffff; thr[j] = INFINITY; }
+                    if ((active >> j) & 1u) { best_d[j] = INFINITY; best_i[j] = 0x7fffffff; thr[j] = INFINITY; pc[j] = 0; }
             }
         }
         // which queries are final?  k-th distance <= distance to the nearest face of the scanned region
