@@ -1065,21 +1065,32 @@ __device__ __forceinline__ unsigned xl(unsigned v, int lane) {
         return (lane & 32) ? sw[0] : sw[1];
     }
 }
-// compare-exchange with lane ^ M: the lane keeps the smaller key when `take_min`
-template <int M>
-__device__ __forceinline__ unsigned long long cx64(unsigned long long v, int lane, bool take_min) {
-    const unsigned long long o = ((unsigned long long)xl<M>((unsigned)(v >> 32), lane) << 32) | xl<M>((unsigned)v, lane);
-    return ((o < v) == take_min) ? o : v;
+// The networks below run on NQ independent keys per lane (one per query of the wave) STAGE by stage: the exchange of query
+// j + 1 fills the wait states behind query j's DPP / permlane instructions (a single network is a chain of dependent
+// cross-lane operations, and hipcc pads every one of them with s_nop when nothing independent stands next to it).
+template <int M, int NQ>
+__device__ __forceinline__ void cx64n(unsigned long long (&v)[NQ], int lane, bool take_min) {
+    unsigned hi[NQ], lo[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) hi[j] = xl<M>((unsigned)(v[j] >> 32), lane);
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) lo[j] = xl<M>((unsigned)v[j], lane);
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        const unsigned long long o = ((unsigned long long)hi[j] << 32) | lo[j];
+        v[j] = ((o < v[j]) == take_min) ? o : v[j];
+    }
 }
-// bitonic merge of a bitonic 64-sequence (ascending result)
-__device__ __forceinline__ unsigned long long merge64_asc(unsigned long long v, int lane) {
-    v = cx64<32>(v, lane, (lane & 32) == 0); v = cx64<16>(v, lane, (lane & 16) == 0); v = cx64<8>(v, lane, (lane & 8) == 0);
-    v = cx64<4>(v, lane, (lane & 4) == 0);   v = cx64<2>(v, lane, (lane & 2) == 0);   v = cx64<1>(v, lane, (lane & 1) == 0);
-    return v;
+// bitonic merge of bitonic 64-sequences (ascending result)
+template <int NQ>
+__device__ __forceinline__ void merge64_asc(unsigned long long (&v)[NQ], int lane) {
+    cx64n<32>(v, lane, (lane & 32) == 0); cx64n<16>(v, lane, (lane & 16) == 0); cx64n<8>(v, lane, (lane & 8) == 0);
+    cx64n<4>(v, lane, (lane & 4) == 0);   cx64n<2>(v, lane, (lane & 2) == 0);   cx64n<1>(v, lane, (lane & 1) == 0);
 }
 // bitonic sort of 64 keys, DESCENDING (lane 0 ends with the largest): 21 compare-exchange stages
-__device__ __forceinline__ unsigned long long sort64_desc(unsigned long long v, int lane) {
-#define P2W_CX(SIZE, M) v = cx64<M>(v, lane, (((lane & (M)) == 0) == ((SIZE) == 64 ? false : ((lane & (SIZE)) != 0))))
+template <int NQ>
+__device__ __forceinline__ void sort64_desc(unsigned long long (&v)[NQ], int lane) {
+#define P2W_CX(SIZE, M) cx64n<M>(v, lane, (((lane & (M)) == 0) == ((SIZE) == 64 ? false : ((lane & (SIZE)) != 0))))
     P2W_CX(2, 1);
     P2W_CX(4, 2); P2W_CX(4, 1);
     P2W_CX(8, 4); P2W_CX(8, 2); P2W_CX(8, 1);
@@ -1087,7 +1098,6 @@ __device__ __forceinline__ unsigned long long sort64_desc(unsigned long long v, 
     P2W_CX(32, 16); P2W_CX(32, 8); P2W_CX(32, 4); P2W_CX(32, 2); P2W_CX(32, 1);
     P2W_CX(64, 32); P2W_CX(64, 16); P2W_CX(64, 8); P2W_CX(64, 4); P2W_CX(64, 2); P2W_CX(64, 1);
 #undef P2W_CX
-    return v;
 }
 constexpr unsigned long long TOPK_EMPTY = 0x7f8000007fffffffull;   // (d2 = +inf, index = 0x7fffffff): an unused slot of a top-k list
 
@@ -1139,11 +1149,22 @@ extern "C" int32_t p2w_debug_slab_prof(unsigned long long* out, int reset) {
 #define SLAB_COUNT(i, v) do {} while (0)
 #endif
 
-// MODE: 0 = kNN, 1 = ball query; TILE: candidates per LDS stage; LADDER: kNN starts from a counted threshold (k >= 8);
+// MODE: 0 = kNN, 1 = ball query; TILE: candidates per LDS stage; SEL (kNN): 0 = sorted insertion from a cold start (small k),
+// 1 = counted threshold ladder + sorted insertion (k >= 8, the default), 2 = ladder + collected candidates merged by sorting
+// networks (k >= 8 with P2W_SEARCH_COLLECT; measured SLOWER than 1 on MI355X - DESIGN.md "Searches" - and kept for A/B runs);
 // BOX: the gathered region is also bounded in x (one run per grid row instead of one per z layer) - for grids whose
 // rows are much longer than a workgroup's reach (plot-scale searches); per-voxel searches gather whole rows.
-template <int MODE, int TILE, bool LADDER, bool BOX>
-__global__ __launch_bounds__(256, (MODE == 0 && LADDER) ? 3 : 1) void slab_search_kernel(const float4* __restrict__ x, const unsigned long long* __restrict__ keys,
+#ifndef P2W_COLLECT_WAVES
+#define P2W_COLLECT_WAVES 3   // waves per SIMD the collecting kernel is compiled for (its LDS allows three workgroups per CU)
+#endif
+#ifndef P2W_FLUSH_NQ
+#define P2W_FLUSH_NQ 4        // sorting networks in flight in a flush
+#endif
+#ifndef P2W_COLLECT_TILE
+#define P2W_COLLECT_TILE 2048   // candidates per LDS stage of the collecting kernel
+#endif
+template <int MODE, int TILE, int SEL, bool BOX>
+__global__ __launch_bounds__(256, (MODE == 0 && SEL == 2) ? P2W_COLLECT_WAVES : 1) void slab_search_kernel(const float4* __restrict__ x, const unsigned long long* __restrict__ keys,
                                                           const int* __restrict__ ptr_x, const p2w_grid* __restrict__ grid,
                                                           const float4* __restrict__ xq, const int* __restrict__ qidx,
                                                           const int* __restrict__ ptr_q, int B, int k, float r, float r2,
@@ -1154,10 +1175,10 @@ __global__ __launch_bounds__(256, (MODE == 0 && LADDER) ? 3 : 1) void slab_searc
     __shared__ int run_pre[G_MAXRUN + 1];
     __shared__ int wsum[4];
     __shared__ float wred[4][8];
-    // k >= 8 (LADDER): candidates under a query's threshold are COLLECTED (ballot-compacted into the query's pending list, up
-    // to 64 packed (d2, index) keys) and merged into its sorted top-k list by ONE sorting network per 64 of them, instead of one
-    // sorted insertion (~15 dependent cross-lane instructions) per candidate: see collect / flush below
-    constexpr bool COLLECT = MODE == 0 && LADDER;
+    // SEL == 2: candidates under a query's threshold are COLLECTED (ballot-compacted into the query's pending list, up to 64
+    // packed (d2, index) keys) and merged into its sorted top-k list by ONE sorting network per 64 of them, instead of one
+    // sorted insertion (~15 dependent cross-lane instructions) per candidate: see the scan and flush_all below
+    constexpr bool LADDER = SEL >= 1, COLLECT = MODE == 0 && SEL == 2;
     __shared__ unsigned long long pend[COLLECT ? 4 : 1][COLLECT ? S_QPW : 1][COLLECT ? 64 : 1];
     int b, q0, q1;
     if (!search_tile(ptr_q, B, blockIdx.x, &b, &q0, &q1)) return;
@@ -1218,22 +1239,36 @@ __global__ __launch_bounds__(256, (MODE == 0 && LADDER) ? 3 : 1) void slab_searc
     const bool in_k = lane < k;
     const int total = c1 - c0;
     SLAB_STAMP(0);   // setup
-    // COLLECT: merge query j's pending keys into its top-k list (ascending across lanes 0 .. k-1, TOPK_EMPTY beyond): sort the
-    // pending keys descending (21 stages), the lane-wise minimum with the ascending list is a bitonic sequence of the 64
+    // COLLECT: merge every query's pending keys into its top-k list (ascending across lanes 0 .. k-1, TOPK_EMPTY beyond): sort
+    // the pending keys descending (21 stages), the lane-wise minimum with the ascending list is a bitonic sequence of the 64
     // smallest keys of both, 6 merge stages sort it; lanes >= k are cut off and the threshold drops to the k-th distance.
     // Exactly the list the insertions built: the k smallest (d2, index) keys seen so far, ties by index.
-    auto flush = [&](int j) {
-        unsigned long long pk = lane < pc[j] ? pend[COLLECT ? wave : 0][COLLECT ? j : 0][COLLECT ? lane : 0] : TOPK_EMPTY;
-        pk = sort64_desc(pk, lane);
-        const unsigned long long bk = ((unsigned long long)__float_as_uint(best_d[j]) << 32) | (unsigned)best_i[j];
-        unsigned long long v = merge64_asc(pk < bk ? pk : bk, lane);
-        if (!in_k) v = TOPK_EMPTY;
-        best_d[j] = __uint_as_float((unsigned)(v >> 32));
-        best_i[j] = (int)(unsigned)v;
-        thr[j] = fminf(thr[j], rdlane(best_d[j], k - 1));   // slot k-1 is +inf until k keys are kept
-        pc[j] = 0;
+    auto flush_all = [&]() {
+        constexpr int NQ = P2W_FLUSH_NQ;   // networks in flight (all eight at once spill: 16 key registers + 16 in exchange per network set)
+#pragma unroll
+        for (int h = 0; h < S_QPW / NQ; ++h) {
+            unsigned long long pk[NQ];
+#pragma unroll
+            for (int j = 0; j < NQ; ++j)
+                pk[j] = lane < pc[NQ * h + j] ? pend[COLLECT ? wave : 0][COLLECT ? NQ * h + j : 0][COLLECT ? lane : 0] : TOPK_EMPTY;
+            sort64_desc(pk, lane);
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                const unsigned long long bk = ((unsigned long long)__float_as_uint(best_d[NQ * h + j]) << 32) | (unsigned)best_i[NQ * h + j];
+                pk[j] = pk[j] < bk ? pk[j] : bk;
+            }
+            merge64_asc(pk, lane);
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                const int q = NQ * h + j;
+                const unsigned long long v = in_k ? pk[j] : TOPK_EMPTY;
+                best_d[q] = __uint_as_float((unsigned)(v >> 32));
+                best_i[q] = (int)(unsigned)v;
+                thr[q] = fminf(thr[q], rdlane(best_d[q], k - 1));   // slot k-1 is +inf until k keys are kept
+                pc[q] = 0;
+            }
+        }
     };
-
     // The region is the cell box "bounding box of the queries grown by rho" (all of x unless BOX).  region() moves the
     // target box n* (never shrinking below the scanned box o*) and returns the number of runs that are NEW relative to
     // the scanned box; build(rb) fills the LDS run table with runs rb .. rb+G_MAXRUN-1 of them and returns how many
@@ -1371,11 +1406,14 @@ __global__ __launch_bounds__(256, (MODE == 0 && LADDER) ? 3 : 1) void slab_searc
             const int left = n_c - tbase;
             // kNN tiles are staged shuffled (storage order approaches a query monotonically: every candidate would be a new
             // admission - even k = 2 runs 40 % slower unshuffled).  slot -> (slot * 389) mod tsz is a permutation for
-            // every tsz that is not a multiple of the prime 389; k >= 8 rounds tsz up to a power of two (cheap mask,
-            // whole 256-candidate groups), small k to the next multiple of 256 so that short gathers scan less
-            const bool pow2 = MODE != 0 || LADDER;
-            const int tsz = pow2 ? ((TILE > 1024 && left > 1024) ? 2048 : (left > 512 ? 1024 : (left > 256 ? 512 : 256)))
-                                 : min(TILE, (left + 255) & ~255);
+            // every tsz that is not a multiple of the prime 389; tsz = the candidates left rounded up to whole 256-candidate
+            // groups (round 4: the k >= 8 kernels used to round up to a power of two for a cheap mask - a 1190-candidate
+            // gather, the typical k = 32 region, then ran its threshold ladder and its scan over 2048 slots, 42 % of them
+            // padding; the modulo is now one division per tile and thread, the slots of a thread follow by addition)
+            const bool pow2 = MODE != 0;
+            const int tsz = pow2 ? (left > 512 ? 1024 : (left > 256 ? 512 : 256)) : min(TILE, (left + 255) & ~255);
+            const int g_step = pow2 ? 0 : (256 * 389) % tsz;
+            int g_run = pow2 ? 0 : (tid * 389) % tsz;
             // three sweeps over the thread's slots instead of one (the search kernels wait, they do not compute: VALU active
             // 21-26 % of the wave cycles, profiles/r3_f16x3_valu.csv): all run lookups, then all record loads in flight
             // together, then the LDS stores - not a bisection, a load and a store in a dependent chain per slot
@@ -1383,7 +1421,9 @@ __global__ __launch_bounds__(256, (MODE == 0 && LADDER) ? 3 : 1) void slab_searc
 #pragma unroll
             for (int rr = 0; rr < TILE / 256; ++rr) {
                 const int s = tid + 256 * rr;
-                const int g = tbase + (MODE != 0 ? s : (pow2 ? ((s * 389) & (tsz - 1)) : ((s * 389) % tsz)));
+                const int g = tbase + (MODE != 0 ? s : g_run);      // (s * 389) mod tsz
+                g_run += g_step;
+                g_run -= g_run >= tsz ? tsz : 0;
                 cidx[rr] = -1;
                 if (s < tsz && g < n_c) {
                     int lo = 0, hi = G_MAXRUN;   // largest run with run_pre[run] <= g
@@ -1435,49 +1475,37 @@ __global__ __launch_bounds__(256, (MODE == 0 && LADDER) ? 3 : 1) void slab_searc
                     thr[j] = t;
                 }
             }
+            SLAB_STAMP(6);   // (ladder, when taken; else ~0)
             if (MODE == 0 && COLLECT) {
-                // One flush site for the whole kernel (a flush is ~250 instructions and is inlined per query): a virtual
-                // group behind the tile's last one merges every query's pending keys - eight independent sorting networks in
-                // straight-line code for the scheduler to interleave - and so does any group boundary at which a list is
-                // nearly full.  A chunk whose admissions do not fit its query's list is left for the next round of the same
-                // group, which starts with a forced flush (an empty list takes any chunk: 64 lanes), so nothing is ever dropped.
-                const int ngr = tsz >> 8;
+                // One flush site for the whole kernel (interleaved sorting networks: ~2000 instructions): a virtual chunk behind
+                // the tile's last one merges every query's pending keys.  A chunk whose admissions do not fit its query's list
+                // is presented again after a forced flush - an empty list takes any chunk (64 lanes), so nothing is ever
+                // dropped and no input (all points equal) can stall it.
+                const int nch = tsz >> 6;
                 bool force = false;
-                for (int gr = 0; gr <= ngr; ++gr) {
-                    const bool last = gr == ngr;
-                    unsigned done = last ? 0xffffffffu : 0u;   // bit 4 j + u: chunk u of this group was presented to query j
-                    float4 c[4];
-                    if (!last) {
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) c[u] = cand[gr * 256 + u * 64 + lane];
-                    }
+#pragma unroll 1
+                for (int ch = 0; ch <= nch; ++ch) {   // (a rolled loop: unrolled over several chunks the compiler computes all their
+                    const bool last = ch == nch;      //  distances up front and the kernel needs 190 registers)
+                    unsigned done = last ? 0xffu : 0u;   // bit j: this chunk was presented to query j
+                    float4 c = make_float4(INFINITY, INFINITY, INFINITY, __int_as_float(0x7fffffff));
+                    if (!last) c = cand[ch * 64 + lane];
                     for (;;) {
-                        int fullest = 0;
-#pragma unroll
-                        for (int j = 0; j < S_QPW; ++j) fullest = max(fullest, pc[j]);
-                        if (force || last || fullest > 48) {
-#pragma unroll
-                            for (int j = 0; j < S_QPW; ++j) flush(j);
-                        }
+                        if (force || last) { SLAB_STAMP(4); flush_all(); SLAB_STAMP(7); SLAB_COUNT(12, 1); }
                         if (last) break;
                         force = false;
 #pragma unroll
                         for (int j = 0; j < S_QPW; ++j) {
-                            if (!((active >> j) & 1u)) continue;   // wave-uniform
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                if ((done >> (4 * j + u)) & 1u) continue;
-                                const float d = p2w_d2(uq[j].x, uq[j].y, uq[j].z, c[u].x, c[u].y, c[u].z);
-                                const unsigned long long m = __ballot(d <= thr[j]);
-                                const int n = __popcll(m);
-                                if (pc[j] + n > 64) { force = true; continue; }
-                                done |= 1u << (4 * j + u);
-                                if (n == 0) continue;
-                                const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(c[u].w);
-                                const int slot = pc[j] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                                if ((m >> lane) & 1ull) pend[COLLECT ? wave : 0][COLLECT ? j : 0][COLLECT ? slot : 0] = key;
-                                pc[j] += n;
-                            }
+                            if (!((active >> j) & 1u) || ((done >> j) & 1u)) continue;   // wave-uniform
+                            const float d = p2w_d2(uq[j].x, uq[j].y, uq[j].z, c.x, c.y, c.z);
+                            const unsigned long long m = __ballot(d <= thr[j]);
+                            const int n = __popcll(m);
+                            if (pc[j] + n > 64) { force = true; continue; }
+                            done |= 1u << j;
+                            if (n == 0) continue;
+                            const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(c.w);
+                            const int slot = pc[j] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                            if ((m >> lane) & 1ull) pend[COLLECT ? wave : 0][COLLECT ? j : 0][COLLECT ? slot : 0] = key;
+                            pc[j] += n;
                         }
                         if (!force) break;
                     }
@@ -1605,6 +1633,7 @@ __global__ __launch_bounds__(256, (MODE == 0 && LADDER) ? 3 : 1) void slab_searc
         if (!(need > 0.f)) break;          // every query of the workgroup is final
         rho = fmaxf(need, rho);
     }
+    SLAB_COUNT(11, 1);
     const int kept_max = min(k, total);
 #pragma unroll
     for (int j = 0; j < S_QPW; ++j) {
@@ -1662,7 +1691,7 @@ extern "C" int32_t p2w_ball_query(const float* xyzr_x, const int32_t* ptr_x, con
 static int32_t grid_args(const uint64_t* keys, const p2w_grid* grid, int32_t flags) {
     P2W_CHECK_PTR(keys); P2W_CHECK_PTR(grid);
     if ((reinterpret_cast<uintptr_t>(keys) & 7u) || (reinterpret_cast<uintptr_t>(grid) & 7u)) return P2W_EALIGN;
-    if (flags & ~(P2W_SEARCH_X_INDEX_IN_W | P2W_SEARCH_Q_ROW_IN_W | P2W_SEARCH_BOX)) return P2W_EINVAL;
+    if (flags & ~(P2W_SEARCH_X_INDEX_IN_W | P2W_SEARCH_Q_ROW_IN_W | P2W_SEARCH_BOX | P2W_SEARCH_COLLECT)) return P2W_EINVAL;
     return P2W_OK;
 }
 
@@ -1675,8 +1704,11 @@ extern "C" int32_t p2w_knn_grid_indexed(const float* xyzr_x, const uint64_t* key
     if (st != P2W_OK) return st;
     if ((st = grid_args(keys_x, grid, flags)) != P2W_OK) return st;
     const int grid_dim = p2w_cdiv(m_bound, S_QT) + B;
-    auto* kern = (flags & P2W_SEARCH_BOX) ? ((k >= 8) ? slab_search_kernel<0, 2048, true, true> : slab_search_kernel<0, 1024, false, true>)
-                                          : ((k >= 8) ? slab_search_kernel<0, 2048, true, false> : slab_search_kernel<0, 1024, false, false>);
+    const bool col = (flags & P2W_SEARCH_COLLECT) != 0;
+    auto* kern = (flags & P2W_SEARCH_BOX) ? ((k >= 8) ? (col ? slab_search_kernel<0, P2W_COLLECT_TILE, 2, true> : slab_search_kernel<0, 2048, 1, true>)
+                                                      : slab_search_kernel<0, 1024, 0, true>)
+                                          : ((k >= 8) ? (col ? slab_search_kernel<0, P2W_COLLECT_TILE, 2, false> : slab_search_kernel<0, 2048, 1, false>)
+                                                      : slab_search_kernel<0, 1024, 0, false>);
     kern<<<grid_dim, 256, 0, p2w_s(stream)>>>(
         reinterpret_cast<const float4*>(xyzr_x), reinterpret_cast<const unsigned long long*>(keys_x), ptr_x, grid,
         reinterpret_cast<const float4*>(xyzr_q), qidx, ptr_q, B, k, 0.f, 0.f, nbr, deg, flags, hint, cell_start);
@@ -1698,7 +1730,7 @@ extern "C" int32_t p2w_ball_query_grid_indexed(const float* xyzr_x, const uint64
     if ((st = grid_args(keys_x, grid, flags)) != P2W_OK) return st;
     if (!(r > 0.0)) return P2W_EINVAL;
     const int grid_dim = p2w_cdiv(m_bound, S_QT) + B;
-    auto* kern = (flags & P2W_SEARCH_BOX) ? slab_search_kernel<1, 1024, false, true> : slab_search_kernel<1, 1024, false, false>;
+    auto* kern = (flags & P2W_SEARCH_BOX) ? slab_search_kernel<1, 1024, 0, true> : slab_search_kernel<1, 1024, 0, false>;
     kern<<<grid_dim, 256, 0, p2w_s(stream)>>>(
         reinterpret_cast<const float4*>(xyzr_x), reinterpret_cast<const unsigned long long*>(keys_x), ptr_x, grid,
         reinterpret_cast<const float4*>(xyzr_q), qidx, ptr_q, B, cap, (float)r, (float)(r * r), nbr, deg, flags, nullptr, cell_start);

@@ -24,7 +24,7 @@ from dataclasses import dataclass, field, fields
 import torch
 
 from . import _lib
-from ._lib import GEMM_RESIDUAL_H, PREC_F16X3, PREC_OF, SA_PACK8, SEARCH_BOX, SEARCH_Q_ROW_IN_W, SEARCH_X_INDEX_IN_W, Epilogue, check, lib, ptr
+from ._lib import GEMM_RESIDUAL_H, PREC_F16X3, PREC_OF, SA_PACK8, SEARCH_BOX, SEARCH_COLLECT, SEARCH_Q_ROW_IN_W, SEARCH_X_INDEX_IN_W, Epilogue, check, lib, ptr
 
 BN_EPS = 1e-5
 SA_RES = (0.04, 0.08, 0.16)  # model.py:210-212
@@ -235,6 +235,7 @@ class EngineOptions:
     search_index: bool = True     # grid searches look candidate runs up in the table sampler's cell -> position tables (else bisect)
     search_box: int = 0           # bit mask: grid searches bounded in x too (P2W_SEARCH_BOX: one run per grid row): 1 ball query,
                                   # 2 the k = 32 searches, 4 the interpolation searches (A/B: per-voxel rows are short)
+    search_insert: bool = False   # k = 32 searches by per-candidate sorted insertion (P2W_SEARCH_COLLECT) instead of collect + sorting network
     fp_hints: bool = True         # seed the k = 2 interpolation searches from the sampler's ranks (p2w_knn_hint2)
     sa_pack: bool = True          # P2W_SA_PACK8 on the ball-query level (targets with <= 8 neighbours share an MFMA tile)
     chunk_pick: bool = True       # fill-aware row-chunk sizes (pick_chunk); False: the plain budget
@@ -466,7 +467,8 @@ class Engine:
             elif grid_search:   # model.py:120
                 self._call("knn", L.p2w_knn_grid_indexed, ptr(src.xyzr), ptr(ckeys[l]), ptr(src.ptr), ptr(grids[l]), ptr(cstart.get(l)),
                            ptr(src.xyzr),
-                           ptr(lv.idx), ptr(lv.ptr), B, N, k, ptr(lv.nbr), ptr(lv.deg), None, SEARCH_BOX if self.search_box & 2 else 0)
+                           ptr(lv.idx), ptr(lv.ptr), B, N, k, ptr(lv.nbr), ptr(lv.deg), None,
+                           (SEARCH_BOX if self.search_box & 2 else 0) | (SEARCH_COLLECT if self.search_collect else 0))
             else:
                 self._call("knn", L.p2w_knn, ptr(src.xyzr), ptr(src.ptr), ptr(src.xyzr), ptr(lv.idx), ptr(lv.ptr), B, N,
                            k, ptr(lv.nbr), ptr(lv.deg), ptr(boxes(l)), 0)

@@ -753,6 +753,38 @@ def test_knn_grid_matches_brute_force_subset_queries(sizes, k, res2, surface, bo
     assert torch.equal(out[0][0], out[1][0])
 
 
+@pytest.mark.parametrize("sizes,k,surface,dup", [([5000], 32, False, False), ([3000, 33, 9000], 32, True, False), ([16384], 8, False, False),
+                                                 ([2000, 16384], 64, True, False), ([4000], 32, False, True), ([70], 64, False, True)])
+@pytest.mark.parametrize("box", [0, 4])
+def test_knn_grid_collect_selection_equals_insertion(sizes, k, surface, dup, box):
+    """P2W_SEARCH_COLLECT (candidates under the threshold collected in LDS and merged 64 at a time by a wave-wide sorting
+    network) gives the neighbour tables of the default per-candidate sorted insertion, bit for bit - k = 8 .. 64, voxels with
+    fewer points than k, and clouds of exact duplicates (more admissions than a pending list holds: the forced-flush path)."""
+    from pointstowood_amd._lib import SEARCH_COLLECT, ptr, stream
+    b = _batch(sizes, seed=43, surface=surface)
+    if dup:   # a quarter of the points, each four times: massive (d2, index) ties, lists overflow inside one chunk
+        pos = b["pos"].clone()
+        o = 0
+        for n in sizes:
+            q = max(1, n // 4)
+            pos[o:o + n] = pos[o:o + q].repeat(4, 1)[:n] if n >= 4 else pos[o:o + n]
+            o += n
+        b = dict(b, pos=pos)
+    s = _sorted_level(b, 0.04)
+    L, B = s["L"], s["B"]
+    coarse, _ = _level1(s)
+    m1 = s["m"]
+    out = []
+    for fl in (0, SEARCH_COLLECT):
+        nbr = torch.full((m1, k), -7, dtype=torch.int32, device="cuda")
+        deg = torch.full((m1,), -7, dtype=torch.int32, device="cuda")
+        assert L.p2w_knn_grid(ptr(coarse), ptr(s["ckeys"]), ptr(s["ptr_out"]), ptr(s["grid"]), ptr(coarse), None, ptr(s["ptr_out"]),
+                              B, m1, k, ptr(nbr), ptr(deg), None, box | fl, stream()) == 0
+        out.append((nbr.cpu(), deg.cpu()))
+    assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][0], out[1][0])
+    assert int(out[0][1].min()) >= 1 and bool((out[0][0][:, 0] == torch.arange(m1)).all() or dup)   # self first (unique points)
+
+
 @pytest.mark.parametrize("sizes,cap,surface", [([4000], 32, False), ([3000], 8, True), ([1500, 40, 2600], 16, True),
                                                ([16384, 3000], 32, False)])
 @pytest.mark.parametrize("box", [0, 4])

@@ -97,3 +97,40 @@ def test_voxelise_on_the_gpu_equals_the_tensor_path(refl, mode):
         assert torch.equal(a[:, :3].cpu(), b[:, :3])                          # membership and order: exact
         d = (a.cpu() - b).abs()
         assert d[:, 4:].max() <= 2e-5 and d[:, 3].max() <= 5e-4              # erfinv on GPU vs CPU: last bits of the quantiles
+
+
+def test_voxeliser_keeps_non_finite_rows_out_of_every_voxel():
+    """rows with a NaN / inf value take no part in the grid (minima, maxima, cell counts) and belong to no voxel, on the
+    HIP path and on the tensor path alike (P2W_CELL_NONFINITE: they sort last as a run of their own, which is dropped); the
+    voxels of the finite rows are those of the same cloud without the bad rows."""
+    from pointstowood_amd import preprocessing as PP
+    from pointstowood_amd._lib import ptr, stream
+    from pointstowood_amd import synthetic_voxels as synth
+    L = _L()
+    pc = synth.forest_plot(60000, seed=4, side=12.0)
+    n = pc.shape[0]
+    g = torch.Generator().manual_seed(9)
+    bad = torch.randperm(n, generator=g)[:300]
+    dirty = pc.clone()
+    dirty[bad[:100], 0] = float("nan")
+    dirty[bad[100:200], 2] = float("inf")
+    dirty[bad[200:], 3] = float("-inf")
+    # cell ids: the finite rows get the ids of the clean cloud restricted to them (same minima / maxima: the extremes are finite rows)
+    keep = torch.ones(n, dtype=torch.bool)
+    keep[bad] = False
+    P = dirty[:, :4].contiguous()
+    cell = torch.empty(n, dtype=torch.int64, device="cuda")
+    ws = torch.empty(256, dtype=torch.uint8, device="cuda")
+    assert L.p2w_cells_nd(ptr(P.cuda()), n, 4, 4, 2.0, ptr(cell), ptr(ws), ws.numel(), stream()) == 0
+    ref = PP._cells(P, 2.0)
+    assert torch.equal(cell.cpu(), ref)
+    assert bool((cell.cpu()[bad] == PP.CELL_NONFINITE).all()) and bool((cell.cpu()[keep] != PP.CELL_NONFINITE).all())
+    assert torch.equal(ref[keep], PP._cells(P[keep], 2.0))
+    # whole voxeliser, ground normalisation off (its bucketize would see the NaN): GPU == host, no voxel holds a bad row
+    dirty5 = torch.cat([dirty, torch.zeros(n, 1)], 1)
+    vg, _ = PP.voxelise(dirty5.cuda(), (2.0, 4.0), 64, 16384, ground=False)
+    vh, _ = PP.voxelise(dirty5, (2.0, 4.0), 64, 16384, ground=False)
+    assert len(vg) == len(vh) > 10
+    for a, b in zip(vg, vh):
+        assert torch.equal(a.cpu(), b) and bool(torch.isfinite(b).all())
+    assert sum(v.shape[0] for v in vh) <= 2 * int(keep.sum())          # (two grid sizes; no bad row anywhere)

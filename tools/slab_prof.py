@@ -2,17 +2,20 @@
 """In-kernel phase profile of the grid searches (diagnostic build: P2W_EXTRA_CFLAGS=-DP2W_SLAB_PROFILE).
 Prints, per search launch of one forward, the mean cycles a workgroup spent in each phase."""
 import ctypes as C, os, sys
-os.environ.setdefault("P2W_EXTRA_CFLAGS", "-DP2W_SLAB_PROFILE")
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from pointstowood_amd import synthetic_weights as weights
 from pointstowood_amd import Net
 from pointstowood_amd import engine as E
+from pointstowood_amd import _lib as _libmod
 from pointstowood_amd._lib import lib
+if len(sys.argv) > 1:      # a library built with -DP2W_SLAB_PROFILE (tools/build_variant.sh prof "-DP2W_SLAB_PROFILE")
+    _libmod.LIB_PATH = os.path.abspath(sys.argv[1])
+COLLECT = len(sys.argv) > 2 and sys.argv[2] == "collect"
 
 dev = torch.device("cuda", 0)
-net = Net(num_classes=1, C=bench.C, k=bench.K_NBR).to(dev).eval()
+net = Net(num_classes=1, C=bench.C, k=bench.K_NBR, search_collect=COLLECT).to(dev).eval()
 net.load_state_dict(weights.synth_state_dict(1, bench.C, seed=0), strict=True)
 net = net.to(dev)
 data = bench.make_batch(0, dev)
@@ -24,7 +27,7 @@ L.p2w_debug_slab_prof.argtypes = [C.c_void_p, C.c_int]
 buf = (C.c_ulonglong * 16)()
 L.p2w_debug_slab_prof(buf, 1)
 orig = E.Engine._call
-names = ["setup", "probe", "plan", "stage", "scan", "check", "output"]
+names = ["setup", "probe", "plan", "stage", "scan", "check", "ladder", "flush"]
 
 def call(self, name, fn, *args):
     r = orig(self, name, fn, *args)
@@ -33,7 +36,7 @@ def call(self, name, fn, *args):
         L.p2w_debug_slab_prof(buf, 1)
         blocks = max(buf[11], 1)
         print(f"{name:10s} blocks={buf[11]:5d} passes/blk={buf[8]/blocks:.2f} cand/pass={buf[9]/max(buf[8],1):7.1f} "
-              f"active/pass={buf[10]/max(buf[8],1):5.1f} | " + " ".join(f"{n}={buf[i]/blocks:7.0f}" for i, n in enumerate(names)))
+              f"active/pass={buf[10]/max(buf[8],1):5.1f} flushes/blk={buf[12]/blocks:.2f} | " + " ".join(f"{n}={buf[i]/blocks:7.0f}" for i, n in enumerate(names)))
     return r
 
 E.Engine._call = call
