@@ -311,6 +311,8 @@ int32_t p2w_packed_dims_h(int32_t prec, int32_t N, int32_t K, int32_t* N_pad, in
 #define P2W_SA_ITEM_256 1        /* 4 targets x 256 output columns per work item */
 #define P2W_SA_ITEM_128 2        /* 8 targets x 128 output columns per work item */
 #define P2W_SA_PACK8 4           /* targets with <= 8 neighbours share a 32-row MFMA tile four at a time (sparse ball-query levels) */
+#define P2W_SA_SPECIALIZED 8     /* 256-column items by the wave-specialised kernel: 4 producer waves (gather, layer-1 correction, A rows,
+                                    W2 DMA) + 4 consumer waves (MFMAs on 128 x 64 wave tiles, epilogue); same results */
 /* bits 16..23 of `flags` of p2w_gemm_h2 / p2w_sa_conv_h: profiling ablations, honoured only by diagnostic builds
  * (-DP2W_GEMM_ABLATE / -DP2W_SA_ABLATE); production builds ignore them.
  * bits 8..15 of `flags` of p2w_gemm_h2: scheduling experiments (tools/gemm_desync.py; results unchanged): bits 8..13 = start

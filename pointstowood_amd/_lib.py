@@ -26,7 +26,7 @@ SEARCH_X_INDEX_IN_W, SEARCH_Q_ROW_IN_W, SEARCH_BOX, SEARCH_COLLECT = 1, 2, 4, 8 
 PREC_F16X3, PREC_F16, PREC_BF16 = 0, 1, 2                      # include/p2w.h P2W_PREC_*
 PREC_OF = {"f16x3": PREC_F16X3, "fp16": PREC_F16, "bf16": PREC_BF16}
 GEMM_TILE_128, GEMM_TILE_256, GEMM_GENERIC_EPI, GEMM_ORDER_ROWS, GEMM_ORDER_COLS, GEMM_RESIDUAL_H = 1, 2, 4, 8, 16, 32   # P2W_GEMM_*
-SA_ITEM_256, SA_ITEM_128, SA_PACK8 = 1, 2, 4                                                       # P2W_SA_*
+SA_ITEM_256, SA_ITEM_128, SA_PACK8, SA_SPECIALIZED = 1, 2, 4, 8                                                       # P2W_SA_*
 
 SIGNATURES = {
     "p2w_version": (_i32, []),

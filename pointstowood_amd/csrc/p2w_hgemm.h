@@ -1509,6 +1509,346 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------
+// Wave-specialised form of the kernel above (round 4; P2W_SA_SPECIALIZED): same items (4 tiles x 256 columns), same LDS image
+// of a slab, same metadata, same epilogue - but the 8 waves no longer all do everything:
+//   waves 0..3 = PRODUCERS: metadata + P-row gather (global loads, three slabs ahead, in registers), the layer-1 correction +
+//                ReLU + hi/lo split on the VALU, A rows -> LDS (2 rows x 8 k per thread and slab), and the whole W2 DMA;
+//   waves 4..7 = CONSUMERS: fragment reads + MFMAs on a 128-row x 64-column wave tile (all four row tiles of the item against
+//                the wave's quarter of the columns: 128 accumulator registers, which no wave could spare beside the producer's
+//                state) and the item's epilogue.
+// One producer and one consumer share a SIMD.  A consumer never executes a vector memory load, so no `vmcnt` wait and no
+// producer VALU instruction stands in the MFMA stream, and a B fragment read serves four MFMA row tiles instead of two.
+// The producers' memory operations are ALL inline asm with hand-counted `s_waitcnt vmcnt(n)` (hipcc drains to vmcnt(0) around
+// LDS-DMA and at every register rotation of a software pipeline; a producer's iteration is 560 cycles of VALU work, so any
+// such drain would make the memory latency - 1.1 us from issue to landing for the DMA under load - the length of a slab):
+// per slab a producer thread issues, in this order, 2 metadata index loads (slab g+4), 8 DMA pieces (slab g+2 of W2, into a
+// ring of THREE B stages), 4 P-row loads (slab g+3) and 2 metadata vector loads (slab g+3) = 16 operations, and the three waits
+// of an iteration are "all but the newest 24 / 32 / 22" (derivation at the waits).  Register sets rotate by the slab number
+// modulo 3 (gathered values, metadata vectors) and 2 (metadata indices), the stages by modulo 2 (A) and 3 (B): the loop body is
+// instantiated for the 6 phases, no register is ever copied.  LDS: 2 x 16 KiB (A) + 3 x 32 KiB (B) + 20 KiB of tables.
+// One s_barrier per slab: at barrier g the consumers have finished slab g-1 and slab g is complete in A stage g & 1 / B stage g % 3.
+// ------------------------------------------------------------------------------------------------
+typedef float v4f __attribute__((ext_vector_type(4)));
+template <int PREC, int G>
+__global__ __launch_bounds__(512, 2) void sa_conv16s_kernel(const float* __restrict__ P, int ldp, const int* __restrict__ meta_j,
+                                                            const float4* __restrict__ meta_g, const int* __restrict__ desc,
+                                                            const int* __restrict__ tiles_dev, int M, const float* __restrict__ w1r4, int C1, int C1pad,
+                                                            const _Float16* __restrict__ W2h, float wscale, int C2,
+                                                            int nMt_, int nNt, const float* __restrict__ b2,
+                                                            const float* __restrict__ bn_s, const float* __restrict__ bn_t,
+                                                            float* __restrict__ out, int ldo, _Float16* __restrict__ out_h2, int ldh, int dbg_) {
+    // dbg (profiling ablations, -DP2W_SA_ABLATE builds only; wrong results): 2 no W2 DMA, 4 no MFMA, 16 no P gather, 8 no producer VALU
+#ifdef P2W_SA_ABLATE
+    const int dbg = dbg_;
+#else
+    constexpr int dbg = 0;
+    (void)dbg_;
+#endif
+    constexpr int NP = HCfg<PREC>::planes;
+    constexpr int BN = 256, BM = 128, RT = 4, NR = 2;      // consumer: RT row tiles x 2 column tiles; producer: NR rows per thread
+    constexpr int GPT = 32 / G;
+    if (tiles_dev) M = *tiles_dev;
+    const int nMt = tiles_dev ? (M + BM / 32 - 1) / (BM / 32) : nMt_;
+    if (M <= 0) return;
+    constexpr int A_CH = 4 * NP * BM, B_CH = 4 * NP * BN;   // 16-byte chunks of an A / a B stage
+    constexpr int NI = B_CH / 64 / 4;                        // W2 DMA pieces (1 KiB) per producer wave and slab
+    __shared__ __attribute__((aligned(16))) char S[(2 * A_CH + 3 * B_CH) * 16 + 4 * 512 * 4 + 3 * SA_EPI_COLS * 4];   // ONE object (see above)
+    float* const Wr = reinterpret_cast<float*>(S + (2 * A_CH + 3 * B_CH) * 16);
+    float* const Ep = Wr + 4 * 512;
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < 4 * C1pad; i += 512) Wr[i] = w1r4[i];
+    for (int i = tid; i < C2; i += 512) { Ep[i] = b2[i]; Ep[SA_EPI_COLS + i] = bn_s[i]; Ep[2 * SA_EPI_COLS + i] = bn_t[i]; }
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nitems = nMt * nNt, nslab = C1pad / H_BK;
+    int first, stride, limit;   // XCD-aware work assignment, as above
+    if ((gridDim.x & 7) == 0) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per = gridDim.x >> 3;
+        const int chunk = (nitems + 7) >> 3;
+        first = xcd * chunk + slot; stride = per; limit = min((xcd + 1) * chunk, nitems);
+    } else {
+        first = blockIdx.x; stride = gridDim.x; limit = nitems;
+    }
+    if (first >= limit) return;
+    const int my_items = (limit - first + stride - 1) / stride;
+    const int total = my_items * nslab;
+    auto item_mt = [&](int it) { return (first + it * stride) / nNt; };
+    auto item_nt = [&](int it) { return (first + it * stride) % nNt; };
+    constexpr int RCH = 4 * NP;
+    auto img = [](int row, int chunk) { return (row * RCH + (NP == 2 ? (chunk ^ ((row >> 1) & 7)) : (chunk ^ ((row >> 2) & 3)))) * 16; };
+    struct Cur { int it, s, mt, nt; };   // a slab: its item, its number within the item, the item's row / column tile (past the end: the last one)
+    auto nxt = [&](Cur c) {
+        if (++c.s == nslab) {
+            c.s = 0; ++c.it;
+            const int itc = min(c.it, my_items - 1);
+            c.mt = item_mt(itc); c.nt = item_nt(itc);
+        }
+        return c;
+    };
+    auto k_of = [&](Cur c) { return (c.it < my_items ? c.s : nslab - 1) * H_BK; };
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_vp)S;
+    __syncthreads();   // Wr / Ep staged
+
+    if (wave < 4) {
+        // ------------------------------------------------ producers ------------------------------------------------
+        const int prow = tid >> 2, pq = tid & 3;   // rows prow, prow + 64 of the item; 8 k values (one 16-byte chunk per plane)
+        const unsigned a_dst = lds_base + (unsigned)img(prow, pq);
+        const _Float16* bsrc[NI];                  // per-lane source of the wave's DMA pieces (item and slab offsets are added at issue)
+        unsigned bdst[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int g2 = wave + 4 * i;
+            const int row = (NP == 2 ? 8 : 16) * g2 + (lane >> (NP == 2 ? 3 : 2));
+            const int c = NP == 2 ? ((lane & 7) ^ ((row >> 1) & 7)) : ((lane & 3) ^ ((row >> 2) & 3));
+            bsrc[i] = W2h + (size_t)row * (NP * C1pad) + 8 * c;
+            bdst[i] = lds_base + (unsigned)(2 * A_CH + g2 * 64) * 16u;
+        }
+        constexpr int KADV = NP == 2 ? 2 : 1;
+        auto dma = [&](int bstage, Cur c) {        // W2 slab of `c` -> B stage `bstage` (8 x 1 KiB per wave)
+            const size_t off = (size_t)c.nt * BN * NP * C1pad + (size_t)(KADV * k_of(c));
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                             :: "v"(bsrc[i] + off), "s"(bdst[i] + (unsigned)bstage * (B_CH * 16u)) : "m0", "memory");
+        };
+        const int last_row = M * 32 - 1;
+        auto rows_of = [&](Cur c, int u) { return min(c.mt * BM + prow + 64 * u, last_row); };
+        int js[2][NR];        // metadata index (P row offset in float4 units) of the thread's rows, slab s -> js[s & 1]
+        v4f gs[3][NR];        // metadata vector (normalised offset, reflectance), slab s -> gs[s % 3]
+        v4f vs[3][NR][2];     // gathered P values, slab s -> vs[s % 3]
+        auto load_j = [&](int set, Cur c) {
+#pragma unroll
+            for (int u = 0; u < NR; ++u) asm volatile("global_load_dword %0, %1, off" : "=&v"(js[set][u]) : "v"(meta_j + rows_of(c, u)) : "memory");
+        };
+        auto load_g = [&](int set, Cur c) {
+#pragma unroll
+            for (int u = 0; u < NR; ++u) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(gs[set][u]) : "v"(meta_g + rows_of(c, u)) : "memory");
+        };
+        auto gather = [&](int set, int jset, Cur c) {   // unconditional (empty slots point at P's zero row)
+            const unsigned k4 = (unsigned)(k_of(c) >> 2) + 2u * pq;
+#pragma unroll
+            for (int u = 0; u < NR; ++u) {
+                const float4* p = reinterpret_cast<const float4*>(P) + ((unsigned)js[jset][u] + k4);
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(vs[set][u][0]) : "v"(p) : "memory");
+                asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=&v"(vs[set][u][1]) : "v"(p) : "memory");
+            }
+        };
+        auto produce = [&](int astage, int set, Cur c) {   // A rows of slab `c` from vs[set], gs[set] -> A stage `astage`
+            const int k = k_of(c) + 8 * pq;
+            float4 w[2][4];
+#pragma unroll
+            for (int half = 0; half < 2; ++half)
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) w[half][cc] = *reinterpret_cast<const float4*>(&Wr[cc * C1pad + k + 4 * half]);
+#pragma unroll
+            for (int u = 0; u < NR; ++u) {
+                const v4f rg = gs[set][u];
+                unsigned hiw[4], low[4];
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const float4 wx = w[half][0], wy = w[half][1], wz = w[half][2], wf = w[half][3];
+                    const v4f p = vs[set][u][half];
+                    // two k values per instruction (v_pk_fma_f32): the producers' VALU work stands in the consumers' MFMA issue slots
+                    const fpair g0 = {rg[0], rg[0]}, g1 = {rg[1], rg[1]}, g2 = {rg[2], rg[2]}, g3 = {rg[3], rg[3]};
+                    fpair a = {p[0], p[1]}, b = {p[2], p[3]};
+                    a = __builtin_elementwise_fma(g0, fpair{wx.x, wx.y}, a); b = __builtin_elementwise_fma(g0, fpair{wx.z, wx.w}, b);
+                    a = __builtin_elementwise_fma(g1, fpair{wy.x, wy.y}, a); b = __builtin_elementwise_fma(g1, fpair{wy.z, wy.w}, b);
+                    a = __builtin_elementwise_fma(g2, fpair{wz.x, wz.y}, a); b = __builtin_elementwise_fma(g2, fpair{wz.z, wz.w}, b);
+                    a = __builtin_elementwise_fma(g3, fpair{wf.x, wf.y}, a); b = __builtin_elementwise_fma(g3, fpair{wf.z, wf.w}, b);
+                    float v[4] = {fmaxf(a[0], 0.f), fmaxf(a[1], 0.f), fmaxf(b[0], 0.f), fmaxf(b[1], 0.f)};
+                    if constexpr (PREC == 0) {
+                        unsigned h01, l01, h23, l23;
+                        split_pair(v[0], v[1], h01, l01);
+                        split_pair(v[2], v[3], h23, l23);
+                        hiw[2 * half] = h01; hiw[2 * half + 1] = h23;
+                        low[2 * half] = l01; low[2 * half + 1] = l23;
+                    } else {
+                        hiw[2 * half] = pack_pair<PREC>(v[0], v[1]); hiw[2 * half + 1] = pack_pair<PREC>(v[2], v[3]);
+                    }
+                }
+                const unsigned sa = a_dst + (unsigned)astage * (A_CH * 16u) + (unsigned)(u * 64 * RCH * 16);
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 hv = {hiw[0], hiw[1], hiw[2], hiw[3]};
+                asm volatile("ds_write_b128 %0, %1" :: "v"(sa), "v"(hv) : "memory");
+                if constexpr (PREC == 0) {
+                    const u32x4 lv = {low[0], low[1], low[2], low[3]};
+                    asm volatile("ds_write_b128 %0, %1" :: "v"(sa ^ 64u), "v"(lv) : "memory");
+                }
+            }
+        };
+        // `s_waitcnt vmcnt(n)` that the compiler must keep in front of every use of the named register set (one lambda per count:
+        // the count is an assembler immediate, and asm operands cannot name captured variables inside a generic lambda)
+#define P2W_WAIT_J(NAME, N) auto NAME = [&](int set) { asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(js[set][0]), "+v"(js[set][1]) :: "memory"); }
+#define P2W_WAIT_V(NAME, N) auto NAME = [&](int set) { \
+            asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(vs[set][0][0]), "+v"(vs[set][0][1]), "+v"(vs[set][1][0]), "+v"(vs[set][1][1]), \
+                                                    "+v"(gs[set][0]), "+v"(gs[set][1]) :: "memory"); }
+        P2W_WAIT_J(wait_j0, 0);
+        P2W_WAIT_J(wait_j24, 24);
+        P2W_WAIT_V(wait_v0, 0);
+        P2W_WAIT_V(wait_v32, 32);
+#undef P2W_WAIT_J
+#undef P2W_WAIT_V
+        auto wait_dma22 = [&]() { asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); };
+        auto wait_lds = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+        auto dummy_loads = [&](int n) {   // ablation builds: n loads of one hot line, so that the operation count of an iteration stays 16
+            int sink;
+            for (int i = 0; i < n; ++i) asm volatile("global_load_dword %0, %1, off" : "=&v"(sink) : "v"(meta_j) : "memory");
+        };
+        // cursors of slabs g+1 .. g+4 (c[0] = slab g+1)
+        Cur c[4];
+        c[0] = nxt(Cur{0, 0, item_mt(0), item_nt(0)});
+        c[1] = nxt(c[0]); c[2] = nxt(c[1]); c[3] = nxt(c[2]);
+        {   // prologue (synchronous): slab 0 complete in A stage 0 / B stage 0, B(1) landed, slabs 1 and 2 gathered, indices of slab 3
+            const Cur s0 = {0, 0, item_mt(0), item_nt(0)};
+            load_j(0, s0); load_j(1, c[0]);
+            wait_j0(0); wait_j0(1);
+            gather(0, 0, s0); load_g(0, s0);
+            gather(1, 1, c[0]); load_g(1, c[0]);
+            load_j(0, c[1]);
+            wait_j0(0);
+            gather(2, 0, c[1]); load_g(2, c[1]);
+            load_j(1, c[2]);                      // slab 3 -> js[1]
+            dma(0, s0); dma(1, c[0]);
+            wait_v0(0); wait_v0(1); wait_v0(2); wait_j0(1);
+            produce(0, 0, s0);
+        }
+        // iteration g, phase ph = g % 6: slab numbers modulo 2 / 3 are compile-time functions of ph
+        auto step = [&](auto ph_, int g) -> bool {
+            constexpr int ph = decltype(ph_)::value;
+            if (g >= total) return false;
+            wait_lds();                                            // this wave's ds_writes of A(g)
+            __builtin_amdgcn_s_barrier();                          // slab g complete for the consumers; stages of slab g-1 free
+            load_j((ph + 4) & 1, c[3]);                            // 2: indices of slab g+4
+            if (!(dbg & 2)) dma((ph + 2) % 3, c[1]);               // 8: W2 of slab g+2
+            else dummy_loads(NI);                                  // (ablation: the hand-counted waits need the operations' number)
+            // indices of slab g+3: issued first in iteration g-1; newer: 14 of that iteration + the 10 above
+            wait_j24((ph + 3) & 1);
+            if (!(dbg & 16)) gather(ph % 3, (ph + 3) & 1, c[2]);   // 4: P rows of slab g+3 (set (g+3) % 3 = g % 3)
+            else dummy_loads(2 * NR);
+            load_g(ph % 3, c[2]);                                  // 2: metadata vectors of slab g+3
+            // values + vectors of slab g+1: the last 6 operations of iteration g-2; newer: 16 + 16
+            wait_v32((ph + 1) % 3);
+            if (!(dbg & 8)) produce((ph + 1) & 1, (ph + 1) % 3, c[0]);   // A rows of slab g+1
+            // W2 of slab g+1: operations 3..10 of iteration g-1; newer: 6 of that iteration + 16
+            wait_dma22();
+            c[0] = c[1]; c[1] = c[2]; c[2] = c[3]; c[3] = nxt(c[3]);
+            return true;
+        };
+        for (int g = 0;; g += 6) {
+            if (!step(std::integral_constant<int, 0>{}, g)) break;
+            if (!step(std::integral_constant<int, 1>{}, g + 1)) break;
+            if (!step(std::integral_constant<int, 2>{}, g + 2)) break;
+            if (!step(std::integral_constant<int, 3>{}, g + 3)) break;
+            if (!step(std::integral_constant<int, 4>{}, g + 4)) break;
+            if (!step(std::integral_constant<int, 5>{}, g + 5)) break;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing of this wave may still be landing in LDS when the workgroup retires
+        return;
+    }
+
+    // ---------------------------------------------------- consumers ----------------------------------------------------
+    const int cw = wave - 4;                       // the wave's quarter of the item's 256 columns
+    const int r = lane & 31, h = lane >> 5;
+    int offA[RT], offB[2];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) offA[t] = img(32 * t + r, h);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) offB[t] = 2 * A_CH * 16 + img(cw * 64 + 32 * t + r, h);
+    f32x16 acc[RT][2];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    struct Degs { int d[RT][GPT]; };
+    auto load_deg = [&](int mt_, Degs& e) {
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int q = 0; q < GPT; ++q) e.d[i][q] = desc[min(mt_ * (BM / 32) + i, M - 1) * GPT + q];
+    };
+    Cur c0 = {0, 0, item_mt(0), item_nt(0)}, c1 = nxt(c0);
+    Degs dg_;
+    load_deg(c0.mt, dg_);
+    int b3 = 0;                                    // g % 3
+    for (int g = 0; g < total; ++g) {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();             // slab g is complete in A stage g & 1 / B stage g % 3
+        asm volatile("" ::: "memory");
+        Degs dg_n;
+        load_deg(c1.mt, dg_n);                    // descriptors of slab g+1's item (wave-uniform: scalar loads)
+        const char* sa_ = S + (size_t)(g & 1) * (A_CH * 16);
+        const char* sb_ = S + (size_t)b3 * (B_CH * 16);
+        b3 = b3 == 2 ? 0 : b3 + 1;
+        h8 af[2][NP][RT], bf[2][NP][2];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+#pragma unroll
+                for (int t = 0; t < RT; ++t) af[kk][p][t] = *reinterpret_cast<const h8*>(sa_ + (offA[t] ^ (kk << 5) ^ (p << 6)));
+#pragma unroll
+                for (int t = 0; t < 2; ++t) bf[kk][p][t] = *reinterpret_cast<const h8*>(sb_ + (offB[t] ^ (kk << 5) ^ (p << 6)));
+            }
+        __builtin_amdgcn_sched_barrier(0);        // all 24 fragment reads are requested before the first MFMA (the compiler would sink them)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            if (dbg & 4) {   // (ablation: the fragments are still read)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+#pragma unroll
+                    for (int t = 0; t < RT; ++t) asm volatile("" :: "v"(af[kk][p][t]));
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) asm volatile("" :: "v"(bf[kk][p][t]));
+                }
+                continue;
+            }
+            // product-major order: the three MFMAs into one accumulator tile are eight instructions apart
+            if constexpr (PREC == 0) {
+#pragma unroll
+                for (int i = 0; i < RT; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = h_mfma<PREC>(af[kk][1][i], bf[kk][0][j], acc[i][j]);
+#pragma unroll
+                for (int i = 0; i < RT; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = h_mfma<PREC>(af[kk][0][i], bf[kk][1][j], acc[i][j]);
+            }
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = h_mfma<PREC>(af[kk][0][i], bf[kk][0][j], acc[i][j]);
+        }
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int q = 0; q < GPT; ++q) asm volatile("" : "+v"(dg_n.d[i][q]));
+        if (c0.s == nslab - 1) {   // item finished: reduce over the neighbour slots, store, start the next accumulation
+            SaEpiRegs<RT, GPT> e;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = min(c0.nt * BN + cw * 64 + j * 32 + (lane & 31), C2 - 1);
+                e.bias[j] = Ep[col]; e.s[j] = Ep[SA_EPI_COLS + col]; e.t[j] = Ep[2 * SA_EPI_COLS + col];
+            }
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int q = 0; q < GPT; ++q) e.dsc[i][q] = (c0.mt * (BM / 32) + i >= M) ? -1 : dg_.d[i][q];
+            sa_epilogue_regs<PREC, RT, G>(acc, wscale, c0.nt * BN, cw, lane, e, C2, out, ldo, out_h2, ldh);
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e2 = 0; e2 < 16; ++e2) acc[i][j][e2] = 0.f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        dg_ = dg_n;
+        c0 = c1; c1 = nxt(c1);
+    }
+}
+
 // pre-pass kernels (p2w_feat.hip)
 __global__ __launch_bounds__(256) void sa_edge_meta_kernel(const float4* __restrict__ xyzr, const int* __restrict__ idx, const int* __restrict__ batch_dst,
                                     const float* __restrict__ sf, const int* __restrict__ nbr, const int* __restrict__ deg, int kw,
@@ -1560,7 +1900,11 @@ static int32_t launch_sa_conv_h(const float* P, int32_t ldp, int32_t n_src, cons
         int grid = (int)(items < n_cu ? items : n_cu);
         if (grid >= 8) grid &= ~7;   // whole XCD rounds (see the kernel's work assignment)
         const int nMt3 = (int)p2w_cdiv(tiles_max, tpi);
-        if (wide)
+        if (wide && (flags & P2W_SA_SPECIALIZED))
+            sa_conv16s_kernel<PREC, G><<<grid, 512, 0, stream>>>(
+                P, ldp, meta_j, meta_g, desc, tiles_dev, (int)tiles_max, w1r4, C1, C1pad, W2h, wscale, C2, nMt3, nNt3, b2, bn_s, bn_t,
+                out, ldo, out_h2, ldh, sadbg);
+        else if (wide)
             sa_conv16p_kernel<PREC, 256, 2, G><<<grid, 512, 0, stream>>>(
                 P, ldp, meta_j, meta_g, desc, tiles_dev, (int)tiles_max, w1r4, C1, C1pad, W2h, (size_t)C2pad * C1pad, wscale, C2, nMt3,
                 nNt3, b2, bn_s, bn_t, out, ldo, out_h2, ldh, sadbg);

@@ -24,7 +24,7 @@ from dataclasses import dataclass, field, fields
 import torch
 
 from . import _lib
-from ._lib import GEMM_RESIDUAL_H, PREC_F16X3, PREC_OF, SA_PACK8, SEARCH_BOX, SEARCH_COLLECT, SEARCH_Q_ROW_IN_W, SEARCH_X_INDEX_IN_W, Epilogue, check, lib, ptr
+from ._lib import GEMM_RESIDUAL_H, PREC_F16X3, PREC_OF, SA_PACK8, SA_SPECIALIZED, SEARCH_BOX, SEARCH_COLLECT, SEARCH_Q_ROW_IN_W, SEARCH_X_INDEX_IN_W, Epilogue, check, lib, ptr
 
 BN_EPS = 1e-5
 SA_RES = (0.04, 0.08, 0.16)  # model.py:210-212
@@ -235,8 +235,10 @@ class EngineOptions:
     search_index: bool = True     # grid searches look candidate runs up in the table sampler's cell -> position tables (else bisect)
     search_box: int = 0           # bit mask: grid searches bounded in x too (P2W_SEARCH_BOX: one run per grid row): 1 ball query,
                                   # 2 the k = 32 searches, 4 the interpolation searches (A/B: per-voxel rows are short)
-    search_insert: bool = False   # k = 32 searches by per-candidate sorted insertion (P2W_SEARCH_COLLECT) instead of collect + sorting network
+    search_collect: bool = False  # k = 32 searches select by collected candidates + sorting networks (P2W_SEARCH_COLLECT) instead of sorted
+                                  # insertions (A/B: 0.645 vs 0.562 ms per bench step, tools/search_ab.py)
     fp_hints: bool = True         # seed the k = 2 interpolation searches from the sampler's ranks (p2w_knn_hint2)
+    sa_specialized: bool = False  # 256-column PointNetConv items by the wave-specialised kernel (P2W_SA_SPECIALIZED: 4 producer + 4 consumer waves)
     sa_pack: bool = True          # P2W_SA_PACK8 on the ball-query level (targets with <= 8 neighbours share an MFMA tile)
     chunk_pick: bool = True       # fill-aware row-chunk sizes (pick_chunk); False: the plain budget
     chunk_full_rounds: bool = True   # a residual-block level whose tiles fill its last chip round badly: whole rounds first, rest after
@@ -591,7 +593,7 @@ class Engine:
             convh = newh(M, C2)
             # level 1 is the ball query: on sparse input most targets have few neighbours, and those with <= 8 share an MFMA
             # tile four at a time (P2W_SA_PACK8); the kNN levels always fill their 32 slots
-            sa_flags = self.sa_flags | (SA_PACK8 if (l == 1 and self.sa_pack) else 0)
+            sa_flags = self.sa_flags | (SA_PACK8 if (l == 1 and self.sa_pack) else 0) | (SA_SPECIALIZED if self.sa_specialized else 0)
             meta = torch.empty(int(L.p2w_sa_conv_h_ws_bytes(M, sa_flags)) + 65536, dtype=torch.uint8, device=dev)   # per-edge (j, normalised offset) scratch (+ room for diagnostics)
             if keep is not None:
                 keep[f"sa{l}_module.ws"] = meta
