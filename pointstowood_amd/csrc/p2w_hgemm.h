@@ -1682,13 +1682,20 @@ __global__ __launch_bounds__(512, 2) void sa_conv16s_kernel(const float* __restr
 #define P2W_WAIT_V(NAME, N) auto NAME = [&](int set) { \
             asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(vs[set][0][0]), "+v"(vs[set][0][1]), "+v"(vs[set][1][0]), "+v"(vs[set][1][1]), \
                                                     "+v"(gs[set][0]), "+v"(gs[set][1]) :: "memory"); }
+        // operations per iteration: 2 + NI + 4 + 2 = 16 (f16x3: NI = 8 DMA pieces) or 12 (single plane: NI = 4)
+        static_assert(NI == 8 || NI == 4, "the hand-counted waits below are written for 8 or 4 DMA pieces per wave and slab");
         P2W_WAIT_J(wait_j0, 0);
-        P2W_WAIT_J(wait_j24, 24);
+        P2W_WAIT_J(wait_j24, 24);   // NI = 8: (8 + 4 + 2) of the previous iteration + (2 + 8) of this one
+        P2W_WAIT_J(wait_j16, 16);   // NI = 4: (4 + 4 + 2) + (2 + 4)
         P2W_WAIT_V(wait_v0, 0);
-        P2W_WAIT_V(wait_v32, 32);
+        P2W_WAIT_V(wait_v32, 32);   // NI = 8: 16 + 16
+        P2W_WAIT_V(wait_v24, 24);   // NI = 4: 12 + 12
 #undef P2W_WAIT_J
 #undef P2W_WAIT_V
-        auto wait_dma22 = [&]() { asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); };
+        auto wait_dma = [&]() {     // NI = 8: (4 + 2) + 16 = 22; NI = 4: (4 + 2) + 12 = 18
+            if constexpr (NI == 8) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+        };
         auto wait_lds = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
         auto dummy_loads = [&](int n) {   // ablation builds: n loads of one hot line, so that the operation count of an iteration stays 16
             int sink;
@@ -1722,15 +1729,15 @@ __global__ __launch_bounds__(512, 2) void sa_conv16s_kernel(const float* __restr
             if (!(dbg & 2)) dma((ph + 2) % 3, c[1]);               // 8: W2 of slab g+2
             else dummy_loads(NI);                                  // (ablation: the hand-counted waits need the operations' number)
             // indices of slab g+3: issued first in iteration g-1; newer: 14 of that iteration + the 10 above
-            wait_j24((ph + 3) & 1);
+            if constexpr (NI == 8) wait_j24((ph + 3) & 1); else wait_j16((ph + 3) & 1);
             if (!(dbg & 16)) gather(ph % 3, (ph + 3) & 1, c[2]);   // 4: P rows of slab g+3 (set (g+3) % 3 = g % 3)
             else dummy_loads(2 * NR);
             load_g(ph % 3, c[2]);                                  // 2: metadata vectors of slab g+3
             // values + vectors of slab g+1: the last 6 operations of iteration g-2; newer: 16 + 16
-            wait_v32((ph + 1) % 3);
+            if constexpr (NI == 8) wait_v32((ph + 1) % 3); else wait_v24((ph + 1) % 3);
             if (!(dbg & 8)) produce((ph + 1) & 1, (ph + 1) % 3, c[0]);   // A rows of slab g+1
             // W2 of slab g+1: operations 3..10 of iteration g-1; newer: 6 of that iteration + 16
-            wait_dma22();
+            wait_dma();
             c[0] = c[1]; c[1] = c[2]; c[2] = c[3]; c[3] = nxt(c[3]);
             return true;
         };
@@ -1747,20 +1754,24 @@ __global__ __launch_bounds__(512, 2) void sa_conv16s_kernel(const float* __restr
     }
 
     // ---------------------------------------------------- consumers ----------------------------------------------------
+    // MFMA shape v_mfma_f32_16x16x32: one instruction contracts the slab's whole 32 k of a 16 x 16 tile (lane = row l & 15, k octet
+    // l >> 4: a 16-byte chunk of the row's plane, the GEMM kernel's fragment).  Same MACs per cycle as 32x32x16; a timing-only
+    // substitution promised -11 % on this kernel (the shorter instruction leaves the producer's VALU work more issue slots), the
+    // real re-tiling with its epilogue gave -3 %: 1.83 ms against 1.88 ms with 32x32x16 tiles and 1.72 - 1.80 ms for the 8-wave
+    // kernel above, which therefore stays the default (DESIGN.md "PointNetConv: what the wave-specialised kernel showed").
     const int cw = wave - 4;                       // the wave's quarter of the item's 256 columns
-    const int r = lane & 31, h = lane >> 5;
-    int offA[RT], offB[2];
+    const int r16 = lane & 15, kg = lane >> 4;
+    constexpr int RT16 = 8, CT16 = 4;              // 16-row tiles of the item's 128 rows, 16-column tiles of the wave's 64 columns
+    int offA[RT16], offB[CT16];                    // plane 0; the lo plane (f16x3) is ^ 64
 #pragma unroll
-    for (int t = 0; t < RT; ++t) offA[t] = img(32 * t + r, h);
+    for (int t = 0; t < RT16; ++t) offA[t] = img(16 * t + r16, kg);
 #pragma unroll
-    for (int t = 0; t < 2; ++t) offB[t] = 2 * A_CH * 16 + img(cw * 64 + 32 * t + r, h);
-    f32x16 acc[RT][2];
+    for (int t = 0; t < CT16; ++t) offB[t] = 2 * A_CH * 16 + img(cw * 64 + 16 * t + r16, kg);
+    f32x4 acc[RT16][CT16];
 #pragma unroll
-    for (int i = 0; i < RT; ++i)
+    for (int i = 0; i < RT16; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        for (int j = 0; j < CT16; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     struct Degs { int d[RT][GPT]; };
     auto load_deg = [&](int mt_, Degs& e) {
 #pragma unroll
@@ -1781,67 +1792,99 @@ __global__ __launch_bounds__(512, 2) void sa_conv16s_kernel(const float* __restr
         const char* sa_ = S + (size_t)(g & 1) * (A_CH * 16);
         const char* sb_ = S + (size_t)b3 * (B_CH * 16);
         b3 = b3 == 2 ? 0 : b3 + 1;
-        h8 af[2][NP][RT], bf[2][NP][2];
+        h8 af[NP][RT16], bf[NP][CT16];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
+        for (int p = 0; p < NP; ++p) {
+#pragma unroll
+            for (int t = 0; t < CT16; ++t) bf[p][t] = *reinterpret_cast<const h8*>(sb_ + (offB[t] ^ (p << 6)));
+#pragma unroll
+            for (int t = 0; t < RT16; ++t) af[p][t] = *reinterpret_cast<const h8*>(sa_ + (offA[t] ^ (p << 6)));
+        }
+        if (!(dbg & 4)) {
+            // product-major order: the three MFMAs into one accumulator tile are 32 instructions apart
+            if constexpr (PREC == 0) {
+#pragma unroll
+                for (int i = 0; i < RT16; ++i)
+#pragma unroll
+                    for (int j = 0; j < CT16; ++j) acc[i][j] = h_mfma16<PREC>(af[1][i], bf[0][j], acc[i][j]);
+#pragma unroll
+                for (int i = 0; i < RT16; ++i)
+#pragma unroll
+                    for (int j = 0; j < CT16; ++j) acc[i][j] = h_mfma16<PREC>(af[0][i], bf[1][j], acc[i][j]);
+            }
+#pragma unroll
+            for (int i = 0; i < RT16; ++i)
+#pragma unroll
+                for (int j = 0; j < CT16; ++j) acc[i][j] = h_mfma16<PREC>(af[0][i], bf[0][j], acc[i][j]);
+        } else {
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
 #pragma unroll
-                for (int t = 0; t < RT; ++t) af[kk][p][t] = *reinterpret_cast<const h8*>(sa_ + (offA[t] ^ (kk << 5) ^ (p << 6)));
+                for (int t = 0; t < RT16; ++t) asm volatile("" :: "v"(af[p][t]));
 #pragma unroll
-                for (int t = 0; t < 2; ++t) bf[kk][p][t] = *reinterpret_cast<const h8*>(sb_ + (offB[t] ^ (kk << 5) ^ (p << 6)));
+                for (int t = 0; t < CT16; ++t) asm volatile("" :: "v"(bf[p][t]));
             }
-        __builtin_amdgcn_sched_barrier(0);        // all 24 fragment reads are requested before the first MFMA (the compiler would sink them)
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            if (dbg & 4) {   // (ablation: the fragments are still read)
-#pragma unroll
-                for (int p = 0; p < NP; ++p) {
-#pragma unroll
-                    for (int t = 0; t < RT; ++t) asm volatile("" :: "v"(af[kk][p][t]));
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) asm volatile("" :: "v"(bf[kk][p][t]));
-                }
-                continue;
-            }
-            // product-major order: the three MFMAs into one accumulator tile are eight instructions apart
-            if constexpr (PREC == 0) {
-#pragma unroll
-                for (int i = 0; i < RT; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = h_mfma<PREC>(af[kk][1][i], bf[kk][0][j], acc[i][j]);
-#pragma unroll
-                for (int i = 0; i < RT; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = h_mfma<PREC>(af[kk][0][i], bf[kk][1][j], acc[i][j]);
-            }
-#pragma unroll
-            for (int i = 0; i < RT; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = h_mfma<PREC>(af[kk][0][i], bf[kk][0][j], acc[i][j]);
         }
 #pragma unroll
         for (int i = 0; i < RT; ++i)
 #pragma unroll
             for (int q = 0; q < GPT; ++q) asm volatile("" : "+v"(dg_n.d[i][q]));
         if (c0.s == nslab - 1) {   // item finished: reduce over the neighbour slots, store, start the next accumulation
-            SaEpiRegs<RT, GPT> e;
+            // layer-2 bias + ReLU + BN affine and the max over a target's valid neighbour slots, as sa_epilogue_regs (monotone
+            // transform: the extremum of the raw accumulators is transformed once per column), for 16 x 16 accumulator tiles:
+            // lane l holds column l & 15 and rows 4 (l >> 4) + 0..3 of a tile; a 32-row tile (one target, or four targets of
+            // 8 slots with P2W_SA_PACK8) is two of them.
+            const int n0 = c0.nt * BN + cw * 64;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = min(c0.nt * BN + cw * 64 + j * 32 + (lane & 31), C2 - 1);
-                e.bias[j] = Ep[col]; e.s[j] = Ep[SA_EPI_COLS + col]; e.t[j] = Ep[2 * SA_EPI_COLS + col];
+            for (int j = 0; j < CT16; ++j) {
+                const int col = n0 + 16 * j + r16;
+                const int colc = min(col, C2 - 1);
+                const float bias = Ep[colc], bs = Ep[SA_EPI_COLS + colc], bt = Ep[2 * SA_EPI_COLS + colc];
+                const bool cv = col < C2;
+                const float sgn = bs < 0.f ? -1.f : 1.f;
+#pragma unroll
+                for (int t = 0; t < RT; ++t) {
+#pragma unroll
+                    for (int q = 0; q < GPT; ++q) {
+                        const int dsc = (c0.mt * (BM / 32) + t >= M) ? -1 : __builtin_amdgcn_readfirstlane(dg_.d[t][q]);
+                        if (dsc < 0) continue;   // wave-uniform
+                        const int tgt = dsc >> 6, d = dsc & 63;
+                        float ext = -INFINITY;
+                        bool store_lane;
+                        if constexpr (G == 32) {
+#pragma unroll
+                            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                                for (int rr = 0; rr < 4; ++rr)
+                                    if (16 * hh + 4 * kg + rr < d) ext = fmaxf(ext, sgn * acc[2 * t + hh][j][rr]);
+                            const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(ext), __float_as_uint(ext), false, false);
+                            ext = fmaxf(__uint_as_float(s16[0]), __uint_as_float(s16[1]));
+                            const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(ext), __float_as_uint(ext), false, false);
+                            ext = fmaxf(__uint_as_float(s32[0]), __uint_as_float(s32[1]));
+                            store_lane = kg == 0;
+                        } else {   // rows 8 q .. 8 q + 7 of the 32-row tile: 16-row tile q >> 1, lane groups 2 (q & 1) and 2 (q & 1) + 1
+                            const bool mine = (kg >> 1) == (q & 1);
+#pragma unroll
+                            for (int rr = 0; rr < 4; ++rr)
+                                if (mine && 4 * (kg & 1) + rr < d) ext = fmaxf(ext, sgn * acc[2 * t + (q >> 1)][j][rr]);
+                            const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(ext), __float_as_uint(ext), false, false);
+                            ext = fmaxf(__uint_as_float(s16[0]), __uint_as_float(s16[1]));
+                            store_lane = kg == 2 * (q & 1);
+                        }
+                        float vmax = fmaf(fmaxf(fmaf(sgn * ext, wscale, bias), 0.f), bs, bt);
+                        if (d == 0 || !cv) vmax = 0.f;   // rows without neighbours; pad columns of an H row stay zero
+                        if (cv && store_lane && out) out[(size_t)tgt * ldo + col] = vmax;
+                        if (out_h2) {   // lanes (2p, 2p+1) hold adjacent columns: the even lane stores both as one word per plane
+                            const float nb = __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(vmax), 0xB1, 0xf, 0xf, false));
+                            if (store_lane && (lane & 1) == 0 && col < ldh) h_store2<PREC>(out_h2, ldh, tgt, col, vmax, nb);
+                        }
+                    }
+                }
             }
 #pragma unroll
-            for (int i = 0; i < RT; ++i)
+            for (int i = 0; i < RT16; ++i)
 #pragma unroll
-                for (int q = 0; q < GPT; ++q) e.dsc[i][q] = (c0.mt * (BM / 32) + i >= M) ? -1 : dg_.d[i][q];
-            sa_epilogue_regs<PREC, RT, G>(acc, wscale, c0.nt * BN, cw, lane, e, C2, out, ldo, out_h2, ldh);
-#pragma unroll
-            for (int i = 0; i < RT; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int e2 = 0; e2 < 16; ++e2) acc[i][j][e2] = 0.f;
+                for (int j = 0; j < CT16; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         __builtin_amdgcn_sched_barrier(0);
         dg_ = dg_n;

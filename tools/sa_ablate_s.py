@@ -15,8 +15,11 @@ dev = torch.device("cuda")
 data = bench.make_batch(0, dev, 0)
 names = {0: "all on", 2: "no W2 DMA", 16: "no P gather", 8: "no producer VALU", 4: "no MFMA", 2 | 16: "no DMA, no gather", 2 | 16 | 8: "consumers only",
          4 | 8: "memory streams only (no MFMA, no VALU)", 4 | 8 | 16: "W2 DMA only", 4 | 8 | 2: "P gather only"}
+only = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else None   # optional: ablation masks to run
 for spec in (True, False):
     for mask, what in names.items():
+        if only is not None and mask not in only:
+            continue
         net = Net(num_classes=1, C=32, k=32, sa_specialized=spec, sa_flags=mask << 16)
         net.load_state_dict(weights.synth_state_dict(1, 32, seed=0), strict=True)
         net = net.to(dev).eval()
