@@ -24,7 +24,7 @@ inside the timed region either way.  Rank 0 prints ONE JSON line.
 ``roofline`` is measured live: after the timed regions one extra, sequential step is run with HIP
 events around every run of consecutive launches of one kernel class (on the launch stream) and the
 dominant kernel's algorithmic FLOPs are divided by its measured time; ``traffic`` comes from the
-committed rocprofv3 PMC summary of the same command (``profiles/r3_<precision>_hbm_traffic.json``).
+committed rocprofv3 PMC summary of the same command (``profiles/r4_<precision>_hbm_traffic.json``).
 ``hbm_kernels`` gives the memory-bound kernels' algorithmic bytes / measured time
 against the 8 TB/s HBM peak.  ``cpu_baseline`` times the CPU oracle (``oracle/net.py``, a port of
 the reference forward pinned to the reference's own outputs) on a bounded sample of batch 0.
@@ -47,7 +47,7 @@ sys.path.insert(0, ROOT)
 PEAK_TFLOPS = {"fp32": 157.3, "f16x3": 2500.0, "fp16": 2500.0, "bf16": 2500.0}
 PEAK_HBM_GBPS = 8000.0
 C, K_NBR, BATCH, NPTS = 32, 32, 8, 16384
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r3_{precision}_hbm_traffic.json")   # written by tools/profile_r3.sh
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r4_{precision}_hbm_traffic.json")   # written by tools/profile_round.sh
 
 
 def parse_args(argv=None):

@@ -4,7 +4,7 @@
     python tools/gemm_traffic.py gpurun_out/prof_r3_f16x3 [gpurun_out/gemm_list.json]
 
 Takes the LAST forward of the profiled sequential bench (the profiled step: batch 0, the batch tools/gemm_list.py logs) from the
-FETCH_SIZE and WRITE_SIZE passes of tools/profile_r3.sh and prints, launch by launch, counter bytes (FETCH x 2 + WRITE, KiB -> B)
+FETCH_SIZE and WRITE_SIZE passes of tools/profile_round.sh and prints, launch by launch, counter bytes (FETCH x 2 + WRITE, KiB -> B)
 beside read + write bytes of one pass over A, W, residual and outputs."""
 import csv
 import glob

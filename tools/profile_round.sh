@@ -1,10 +1,11 @@
 #!/bin/bash
-# Round-3 profiles on the GPU box (run through gpurun).  Every pass is its own rocprofv3 run (PMC passes never share a run with
-# each other's counter groups or with --stats, as the MI355X guide prescribes); summaries -> gpurun_out/prof_r3_<name>/r3_*.
-#   tools/profile_r3.sh bench [precision]     the bench command (BASELINE configs[1]): kernel stats (pipelined + sequential),
+# Round profiles (TAG, default r4) on the GPU box (run through gpurun).  Every pass is its own rocprofv3 run (PMC passes never share a run with
+# each other's counter groups or with --stats, as the MI355X guide prescribes); summaries -> gpurun_out/prof_${TAG}_<name>/${TAG}_*.
+#   tools/profile_round.sh bench [precision]     the bench command (BASELINE configs[1]): kernel stats (pipelined + sequential),
 #                                             FETCH_SIZE / WRITE_SIZE, MFMA busy, VALU issue counters
-#   tools/profile_r3.sh config2|config4|surface   the named workload, 3 sequential forwards: kernel stats, FETCH / WRITE, MFMA busy
+#   tools/profile_round.sh config2|config4|surface   the named workload, 3 sequential forwards: kernel stats, FETCH / WRITE, MFMA busy
 set -u
+TAG=${TAG:-r4}
 WHAT=${1:-bench}
 PREC=${2:-f16x3}
 export TMPDIR=/tmp
@@ -18,7 +19,7 @@ else
   CMD="$ROOT/tools/run_workload.py $WHAT 3 $PREC"
   SEQ=""
 fi
-OUT=$ROOT/gpurun_out/prof_r3_$NAME
+OUT=$ROOT/gpurun_out/prof_${TAG}_$NAME
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp
 if [ "$WHAT" = "bench" ]; then
@@ -32,5 +33,5 @@ if [ "$WHAT" = "bench" ]; then
   rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/valu -- python3 $CMD $SEQ > $OUT/valu.json 2> $OUT/valu.err
 fi
 cd $ROOT
-python3 tools/profile_summary.py $OUT $NAME $FWD r3 "$CMD $SEQ"
+python3 tools/profile_summary.py $OUT $NAME $FWD $TAG "$CMD $SEQ"
 ls $OUT | head -30

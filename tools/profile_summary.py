@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summaries of tools/profile_r3.sh's rocprofv3 runs -> small files for profiles/:
+"""Summaries of tools/profile_round.sh's rocprofv3 runs -> small files for profiles/:
   <tag>_<name>_{pipe,seq}_kernel_stats.csv   rocprofv3 --stats per-kernel table (names shortened)
   <tag>_<name>_hbm_traffic.json              FETCH_SIZE (x2: gfx950 counts wide reads at half their bytes) and WRITE_SIZE per kernel
                                              class and step, launches per step -> what bench.py reads for roofline.traffic
@@ -33,7 +33,7 @@ def short(name):
 def klass(name):
     if "gemm_h2g_kernel" in name or "gemm_hp_kernel" in name or name.startswith("gemm_kernel") or "rowdot_finish" in name:
         return "gemm_kernel"
-    if "sa_conv16p_kernel" in name or "sa_edge_meta" in name or "sa_part_" in name or name.startswith("sa_conv_kernel"):
+    if "sa_conv16p_kernel" in name or "sa_conv16s_kernel" in name or "sa_edge_meta" in name or "sa_part_" in name or name.startswith("sa_conv_kernel"):
         return "sa_conv_kernel"
     for k in ("interp_concat", "segment_max", "level_gather", "rowdot", "stem_kernel", "concat_xyz", "slab_search", "knn_hint"):
         if k in name:
