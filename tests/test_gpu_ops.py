@@ -767,7 +767,7 @@ def test_knn_grid_collect_selection_equals_insertion(sizes, k, surface, dup, box
         o = 0
         for n in sizes:
             q = max(1, n // 4)
-            pos[o:o + n] = pos[o:o + q].repeat(4, 1)[:n] if n >= 4 else pos[o:o + n]
+            pos[o:o + n] = pos[o:o + q].clone().repeat(-(-n // q), 1)[:n]
             o += n
         b = dict(b, pos=pos)
     s = _sorted_level(b, 0.04)

@@ -131,6 +131,7 @@ def test_voxeliser_keeps_non_finite_rows_out_of_every_voxel():
     vg, _ = PP.voxelise(dirty5.cuda(), (2.0, 4.0), 64, 16384, ground=False)
     vh, _ = PP.voxelise(dirty5, (2.0, 4.0), 64, 16384, ground=False)
     assert len(vg) == len(vh) > 10
-    for a, b in zip(vg, vh):
-        assert torch.equal(a.cpu(), b) and bool(torch.isfinite(b).all())
+    for a, b in zip(vg, vh):   # same rows in the same order (the normalised reflectance differs in erfinv's last bits between devices)
+        assert a.shape == b.shape and torch.equal(a.cpu()[:, :3], b[:, :3]) and torch.allclose(a.cpu(), b, rtol=0, atol=5e-4)
+        assert bool(torch.isfinite(b).all()) and bool(torch.isfinite(a).all())
     assert sum(v.shape[0] for v in vh) <= 2 * int(keep.sum())          # (two grid sizes; no bad row anywhere)
