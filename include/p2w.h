@@ -40,7 +40,8 @@ typedef void* p2w_stream_t; /* hipStream_t */
 #define P2W_EWORKSPACE (-4)/* workspace too small                             */
 #define P2W_EUNSUPPORTED (-5)
 
-#define P2W_MAX_K 64       /* neighbours per query of the searches (wave64: one lane per slot) */
+#define P2W_MAX_K 64       /* neighbours per query of the wave-wide searches (wave64: one lane per slot): the grid searches' limit */
+#define P2W_MAX_K_WIDE 100 /* p2w_knn / p2w_ball_query also take 65 .. 100 (torch-cluster's limit) on a one-thread-per-query path */
 #define P2W_MAX_K_CONV 32  /* neighbour slots per target of p2w_sa_conv*: one 32-row MFMA tile (Net(k=...) <= 32) */
 
 int32_t p2w_version(void);

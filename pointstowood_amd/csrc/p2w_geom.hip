@@ -1650,20 +1650,69 @@ __global__ __launch_bounds__(256, (MODE == 0 && SEL == 2) ? P2W_COLLECT_WAVES : 
 }
 
 static int32_t search_args(const float* xyzr_x, const int32_t* ptr_x, const float* xyzr_q, const int32_t* ptr_q, int32_t B,
-                           int32_t m_bound, int32_t k, const int32_t* nbr, const int32_t* deg) {
+                           int32_t m_bound, int32_t k, const int32_t* nbr, const int32_t* deg, int32_t k_max = P2W_MAX_K) {
     P2W_CHECK_PTR(xyzr_x); P2W_CHECK_PTR(ptr_x); P2W_CHECK_PTR(xyzr_q); P2W_CHECK_PTR(ptr_q); P2W_CHECK_PTR(nbr);
     P2W_CHECK_PTR(deg); P2W_CHECK_ALIGN16(xyzr_x); P2W_CHECK_ALIGN16(xyzr_q);
-    if (B <= 0 || m_bound < 0 || k <= 0 || k > P2W_MAX_K) return P2W_EINVAL;
+    if (B <= 0 || m_bound < 0 || k <= 0 || k > k_max) return P2W_EINVAL;
     return P2W_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k in 65 .. 100 (torch-cluster's limit is 100; the wave-wide kernels keep one list slot per lane, i.e. 64): ONE THREAD per
+// query, upstream's CUDA algorithm itself - the candidates of the query's voxel in storage order, a list of the k smallest
+// (d2, index) keys per thread (in scratch: nothing on the inference path uses k > 64 - model.py:210-212: 32, predicter.py:137: 64 -
+// so this path is for the operators' completeness, not for speed).  Same arithmetic, tie rule and flags as knn_kernel / ball_kernel.
+// ------------------------------------------------------------------------------------------------
+template <int MODE>   // 0 = kNN (k smallest (d2, index) keys, ascending), 1 = ball query (the `cap` lowest indices with d2 < r2, ascending)
+__global__ __launch_bounds__(64) void search_wide_kernel(const float4* __restrict__ x, const int* __restrict__ ptr_x,
+                                                         const float4* __restrict__ xq, const int* __restrict__ qidx,
+                                                         const int* __restrict__ ptr_q, int B, int k, float r2, int* __restrict__ nbr,
+                                                         int* __restrict__ deg, int flags) {
+    const int q = blockIdx.x * 64 + threadIdx.x;
+    if (q >= ptr_q[B]) return;
+    const int b = p2w_find_segment(ptr_q, B, q);
+    const int c0 = ptr_x[b], c1 = ptr_x[b + 1];
+    const float4 pq = xq[qidx ? qidx[q] : q];
+    const bool index_in_w = (flags & P2W_SEARCH_X_INDEX_IN_W) != 0;
+    unsigned long long key[P2W_MAX_K_WIDE];   // sorted ascending; kNN: (d2 bits << 32) | index, ball: index
+    int kept = 0, hits = 0;
+    for (int c = c0; c < c1; ++c) {
+        const float4 pc = x[c];
+        const float d = p2w_d2(pq.x, pq.y, pq.z, pc.x, pc.y, pc.z);
+        const unsigned idx = (unsigned)(index_in_w ? __float_as_int(pc.w) : c);
+        unsigned long long kn;
+        if (MODE == 0) {
+            if (!(d <= INFINITY)) continue;   // a NaN distance admits nothing
+            kn = ((unsigned long long)__float_as_uint(d) << 32) | idx;
+        } else {
+            if (!(d < r2)) continue;
+            ++hits;
+            kn = idx;
+        }
+        if (kept == k && kn >= key[k - 1]) continue;
+        int pos = kept < k ? kept : k - 1;     // the slot that falls off (or the free one) ...
+        while (pos > 0 && key[pos - 1] > kn) { key[pos] = key[pos - 1]; --pos; }   // ... moves down to the insertion point
+        key[pos] = kn;
+        if (kept < k) ++kept;
+    }
+    const int row = (flags & P2W_SEARCH_Q_ROW_IN_W) ? __float_as_int(pq.w) : q;
+    const int n_out = MODE == 0 ? kept : min(hits, k);
+    for (int s = 0; s < k; ++s) nbr[(size_t)row * k + s] = s < n_out ? (int)(unsigned)key[s] : -1;
+    deg[row] = n_out;
 }
 
 extern "C" int32_t p2w_knn(const float* xyzr_x, const int32_t* ptr_x, const float* xyzr_q, const int32_t* qidx,
                            const int32_t* ptr_q, int32_t B, int32_t m_bound, int32_t k, int32_t* nbr, int32_t* deg,
                            const float* tile_bbox, int32_t flags, p2w_stream_t stream) {
     if (m_bound == 0) return P2W_OK;
-    const int32_t st = search_args(xyzr_x, ptr_x, xyzr_q, ptr_q, B, m_bound, k, nbr, deg);
+    const int32_t st = search_args(xyzr_x, ptr_x, xyzr_q, ptr_q, B, m_bound, k, nbr, deg, P2W_MAX_K_WIDE);
     if (st != P2W_OK) return st;
     if (flags & ~(P2W_SEARCH_X_INDEX_IN_W | P2W_SEARCH_Q_ROW_IN_W)) return P2W_EINVAL;
+    if (k > P2W_MAX_K) {   // 65 .. 100: one thread per query (see search_wide_kernel)
+        search_wide_kernel<0><<<p2w_cdiv(m_bound, 64), 64, 0, p2w_s(stream)>>>(reinterpret_cast<const float4*>(xyzr_x), ptr_x,
+                                                                               reinterpret_cast<const float4*>(xyzr_q), qidx, ptr_q, B, k, 0.f, nbr, deg, flags);
+        return P2W_LAUNCH_STATUS();
+    }
     const int grid = p2w_cdiv(m_bound, S_QT) + B;  // upper bound on sum_b ceil(m_b / QT)
     knn_kernel<<<grid, 256, 0, p2w_s(stream)>>>(reinterpret_cast<const float4*>(xyzr_x), ptr_x,
                                                 reinterpret_cast<const float4*>(xyzr_q), qidx, ptr_q, B, k, nbr, deg,
@@ -1675,11 +1724,16 @@ extern "C" int32_t p2w_ball_query(const float* xyzr_x, const int32_t* ptr_x, con
                                   const int32_t* ptr_q, int32_t B, int32_t m_bound, double r, int32_t cap, int32_t* nbr,
                                   int32_t* deg, const float* tile_bbox, int32_t flags, p2w_stream_t stream) {
     if (m_bound == 0) return P2W_OK;
-    const int32_t st = search_args(xyzr_x, ptr_x, xyzr_q, ptr_q, B, m_bound, cap, nbr, deg);
+    const int32_t st = search_args(xyzr_x, ptr_x, xyzr_q, ptr_q, B, m_bound, cap, nbr, deg, P2W_MAX_K_WIDE);
     if (st != P2W_OK) return st;
     const float r2 = (float)(r * r);
     if (!(r > 0.0)) return P2W_EINVAL;
     if (flags & ~(P2W_SEARCH_X_INDEX_IN_W | P2W_SEARCH_Q_ROW_IN_W)) return P2W_EINVAL;
+    if (cap > P2W_MAX_K) {
+        search_wide_kernel<1><<<p2w_cdiv(m_bound, 64), 64, 0, p2w_s(stream)>>>(reinterpret_cast<const float4*>(xyzr_x), ptr_x,
+                                                                               reinterpret_cast<const float4*>(xyzr_q), qidx, ptr_q, B, cap, r2, nbr, deg, flags);
+        return P2W_LAUNCH_STATUS();
+    }
     const int grid = p2w_cdiv(m_bound, S_QT) + B;
     ball_kernel<<<grid, 256, 0, p2w_s(stream)>>>(reinterpret_cast<const float4*>(xyzr_x), ptr_x,
                                                  reinterpret_cast<const float4*>(xyzr_q), qidx, ptr_q, B, r2, cap, nbr, deg,

@@ -113,16 +113,16 @@ def _edges(nbr, deg):
 
 
 def radius(x, y, r, batch_x=None, batch_y=None, max_num_neighbors=32, num_workers=1):
-    if not 1 <= max_num_neighbors <= 64:
-        raise RuntimeError("max_num_neighbors must be in 1..64")
+    if not 1 <= max_num_neighbors <= 100:   # torch-cluster's limit (65 .. 100 run on the one-thread-per-query path)
+        raise RuntimeError("max_num_neighbors must be in 1..100")
     return _edges(*_search("radius", x, y, r, batch_x, batch_y, int(max_num_neighbors)))
 
 
 def knn(x, y, k, batch_x=None, batch_y=None, cosine=False, num_workers=1):
     if cosine:
         raise RuntimeError("cosine distance is not supported")
-    if not 1 <= k <= 64:
-        raise RuntimeError("k must be in 1..64")   # torch-cluster's CUDA limit is 100
+    if not 1 <= k <= 100:
+        raise RuntimeError("`k` needs to smaller than or equal to 100")   # torch-cluster's TORCH_CHECK (65 .. 100: one thread per query)
     return _edges(*_search("knn", x, y, None, batch_x, batch_y, int(k)))
 
 
@@ -144,11 +144,11 @@ def scatter_max(src, index, dim=0, out=None, dim_size=None):
 
 
 def knn_interpolate(x, pos_x, pos_y, batch_x=None, batch_y=None, k=3, num_workers=1):
-    """PyG's signature and default (k = 3); any 1 <= k <= 64 and any feature width (rows are padded to a multiple of 4
+    """PyG's signature and default (k = 3); any 1 <= k <= 100 and any feature width (rows are padded to a multiple of 4
     floats for the kernel's 16-byte accesses)."""
     _lib.require_cuda(x, pos_x, pos_y)
-    if not 1 <= k <= 64:
-        raise RuntimeError("knn_interpolate: k must be in 1..64")
+    if not 1 <= k <= 100:
+        raise RuntimeError("knn_interpolate: k must be in 1..100")
     nbr, deg = _search("knn", pos_x, pos_y, None, batch_x, batch_y, int(k))
     m, F0 = pos_y.shape[0], x.shape[1]
     F = (F0 + 3) // 4 * 4

@@ -35,7 +35,8 @@ def test_voxel_grid_and_cluster_exact(H, sizes, res):
     assert torch.equal(inv.cpu(), inv_ref)
 
 
-@pytest.mark.parametrize("sizes,cap,surface", [([2048], 32, False), ([3000], 32, True), ([1500, 40, 700], 16, True)])
+@pytest.mark.parametrize("sizes,cap,surface", [([2048], 32, False), ([3000], 32, True), ([1500, 40, 700], 16, True),
+                                               ([3000, 70], 100, True), ([2500], 65, True)])   # 65 .. 100: torch-cluster's upper range
 def test_radius_exact(H, sizes, cap, surface):
     b = _batch(sizes, seed=5, surface=surface)
     idx = O.consecutive_cluster(O.voxel_grid(b["pos"], 0.04, b["batch"]))[1]
@@ -45,7 +46,8 @@ def test_radius_exact(H, sizes, cap, surface):
     assert torch.equal(got.cpu(), ref)
 
 
-@pytest.mark.parametrize("sizes,k", [([2048], 32), ([2048], 16), ([700, 20, 3000], 32), ([5000], 2), ([9], 32), ([300], 64)])
+@pytest.mark.parametrize("sizes,k", [([2048], 32), ([2048], 16), ([700, 20, 3000], 32), ([5000], 2), ([9], 32), ([300], 64),
+                                     ([1500, 80, 400], 100), ([90], 65)])   # 65 .. 100: torch-cluster's upper range (k <= 100)
 def test_knn_exact(H, sizes, k):
     b = _batch(sizes, seed=7)
     idx = O.consecutive_cluster(O.voxel_grid(b["pos"], 0.08, b["batch"]))[1]
@@ -67,6 +69,9 @@ def test_knn_ties_prefer_lower_index(H):
     lat = torch.stack(torch.meshgrid(*[torch.arange(9.0)] * 3, indexing="ij"), -1).reshape(-1, 3) * 0.125
     lat = lat[torch.randperm(lat.shape[0], generator=g)]
     assert torch.equal(H.knn(lat.cuda(), lat[:200].cuda(), 32).cpu(), O.knn(lat, lat[:200], 32))
+    assert torch.equal(H.knn(lat.cuda(), lat[:200].cuda(), 100).cpu(), O.knn(lat, lat[:200], 100))   # the one-thread-per-query path
+    with pytest.raises(RuntimeError):
+        H.knn(lat.cuda(), lat[:200].cuda(), 101)
     assert torch.equal(H.radius(lat.cuda(), lat[:200].cuda(), 0.25, max_num_neighbors=32).cpu(),
                        O.radius(lat, lat[:200], 0.25, max_num_neighbors=32))
 
