@@ -347,12 +347,25 @@ int32_t p2w_sa_conv_h(int32_t prec, const float* P, int32_t ldp, int32_t n_src, 
                       int32_t M, const float* w1r4, const void* W2h, float wscale, int32_t C1, int32_t C2,
                       const float* b2, const float* bn_s, const float* bn_t, float* out, int32_t ldo, void* out_h,
                       int32_t ldh, void* ws, size_t ws_bytes, int32_t flags, p2w_stream_t stream);
+/* p2w_sa_conv_h for a P whose rows are NOT in the source points' own order: src_row[j] = the P row of source point j (NULL =
+ * identity = p2w_sa_conv_h).  The engine keeps the level-0 features in the sampler's cell order (p2w_stem_h2_indexed): neighbours
+ * in space are neighbours in memory for the P gather and for the last interpolation. */
+int32_t p2w_sa_conv_h_rows(int32_t prec, const float* P, int32_t ldp, int32_t n_src, const float* xyzr_src, const int32_t* idx,
+                           const int32_t* batch_dst, const float* sf, const int32_t* nbr, const int32_t* deg, int32_t kw,
+                           int32_t M, const float* w1r4, const void* W2h, float wscale, int32_t C1, int32_t C2,
+                           const float* b2, const float* bn_s, const float* bn_t, float* out, int32_t ldo, void* out_h,
+                           int32_t ldh, void* ws, size_t ws_bytes, int32_t flags, const int32_t* src_row, p2w_stream_t stream);
 /* The small kernels writing H (and fp32 where given): stem (model.py:208,228), knn_interpolate + cat (:149-151),
  * cat(x, pos) (:135).  For the stem and the interpolation `ldh` is the row pitch as in p2w_gemm_h2: they write their columns
  * (C, resp. Fc + Fs) plus the zero pad to the next K-slab boundary and leave the rest of a wider row alone (p2w_interp_concat_h2
  * with skip = NULL, Fs = 0 writes only the interpolated part of a row whose skip columns another producer has written). */
 int32_t p2w_stem_h2(int32_t prec, const float* xyzr, int32_t n, const float* w, const float* b, int32_t C, float* out,
                     void* out_h, int32_t ldh, p2w_stream_t stream);
+/* ... for records that come in another order (p2w_index_records: e.g. the sampler's cell order) and carry their own row as the
+ * int32 in .w: the fp32 row of record i is out[.w], its H row is out_h[i] (model.py:228 stores the stem features on the batch in
+ * input order; the H copy feeds the GEMMs in the records' order). */
+int32_t p2w_stem_h2_indexed(int32_t prec, const float* xyzr, int32_t n, const float* w, const float* b, int32_t C, float* out,
+                            void* out_h, int32_t ldh, p2w_stream_t stream);
 int32_t p2w_interp_concat_h2(int32_t prec, const float* xc, int32_t Fc, const float* xyzr_c, const float* xyzr_f,
                              const int32_t* nbr, const int32_t* deg, int32_t kw, const float* skip, int32_t Fs, int32_t m,
                              void* out_h, int32_t ldh, p2w_stream_t stream);

@@ -73,6 +73,9 @@ SIGNATURES = {
     "p2w_sa_conv_h": (_i32, [_i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _f32, _i32, _i32, _vp, _vp,
                              _vp, _vp, _i32, _vp, _i32, _vp, _sz, _i32, _vp]),
     "p2w_stem_h2": (_i32, [_i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp]),
+    "p2w_stem_h2_indexed": (_i32, [_i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp]),
+    "p2w_sa_conv_h_rows": (_i32, [_i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _f32, _i32, _i32, _vp, _vp,
+                                  _vp, _vp, _i32, _vp, _i32, _vp, _sz, _i32, _vp, _vp]),
     "p2w_interp_concat_h2": (_i32, [_i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _i32, _vp]),
     "p2w_concat_xyz_h2": (_i32, [_i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp]),
     "p2w_interp_concat": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _i32, _vp]),

@@ -418,8 +418,8 @@ __global__ __launch_bounds__(256) void sa_edge_meta_kernel(const float4* __restr
                                                            const int* __restrict__ batch_dst, const float* __restrict__ sf,
                                                            const int* __restrict__ nbr, const int* __restrict__ deg, int kw,
                                                            int M, int n_src, int ldp4, int G, const int* __restrict__ list,
-                                                           const int* __restrict__ n_list_dev, int* __restrict__ meta_j,
-                                                           float4* __restrict__ meta_g, int* __restrict__ desc) {
+                                                           const int* __restrict__ n_list_dev, const int* __restrict__ src_row,
+                                                           int* __restrict__ meta_j, float4* __restrict__ meta_g, int* __restrict__ desc) {
     const long g = (long)blockIdx.x * 256 + threadIdx.x;
     const int n_groups = list ? *n_list_dev : M;                 // slot groups that have a target
     const int gpt = 32 / G;
@@ -449,7 +449,8 @@ __global__ __launch_bounds__(256) void sa_edge_meta_kernel(const float4* __restr
     for (int off = G >> 1; off >= 1; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off));  // G lanes = one target
     const float den = dmax + 1e-8f;
     // offset of the source's P row in float4 units; empty slot: P's all-zero row + a zero offset give a zero A row (the epilogue masks it)
-    meta_j[g] = (valid ? j : n_src) * ldp4;
+    // (src_row: the P row of source point j when P's rows are not in the points' own order - p2w_sa_conv_h_rows)
+    meta_j[g] = (valid ? (src_row ? src_row[j] : j) : n_src) * ldp4;
     meta_g[g] = make_float4(rx / den, ry / den, rz / den, rf);
     if (slot == 0) desc[gi] = tgt >= 0 ? ((tgt << 6) | d) : -1;
 }
@@ -500,12 +501,12 @@ __global__ __launch_bounds__(SA_PART_BLOCK) void sa_part_scatter_kernel(const in
 
 extern "C" size_t p2w_sa_conv_h_ws_bytes(int32_t M, int32_t flags) { return sa_conv_ws_bytes(M < 0 ? 0 : M, flags); }
 
-extern "C" int32_t p2w_sa_conv_h(int32_t prec, const float* P, int32_t ldp, int32_t n_src, const float* xyzr_src, const int32_t* idx,
+extern "C" int32_t p2w_sa_conv_h_rows(int32_t prec, const float* P, int32_t ldp, int32_t n_src, const float* xyzr_src, const int32_t* idx,
                                  const int32_t* batch_dst, const float* sf, const int32_t* nbr, const int32_t* deg,
                                  int32_t kw, int32_t M, const float* w1r4, const void* W2h, float wscale, int32_t C1,
                                  int32_t C2, const float* b2, const float* bn_s, const float* bn_t, float* out,
                                  int32_t ldo, void* out_h, int32_t ldh, void* ws, size_t ws_bytes, int32_t flags,
-                                 p2w_stream_t stream) {
+                                 const int32_t* src_row, p2w_stream_t stream) {
     if (prec < P2W_PREC_F16X3 || prec > P2W_PREC_BF16) return P2W_EINVAL;
     if (M == 0) return P2W_OK;
     P2W_CHECK_PTR(P); P2W_CHECK_PTR(xyzr_src); P2W_CHECK_PTR(idx); P2W_CHECK_PTR(batch_dst); P2W_CHECK_PTR(sf);
@@ -519,9 +520,19 @@ extern "C" int32_t p2w_sa_conv_h(int32_t prec, const float* P, int32_t ldp, int3
     const _Float16* W2 = static_cast<const _Float16*>(W2h);
     if (prec == P2W_PREC_F16X3)
         return launch_sa_conv_h<0>(P, ldp, n_src, xyzr_src, idx, batch_dst, sf, nbr, deg, kw, M, w1r4, W2, wscale, C1, C2, b2, bn_s, bn_t,
-                                   out, ldo, static_cast<_Float16*>(out_h), ldh, ws, ws_bytes, flags, p2w_s(stream));
+                                   out, ldo, static_cast<_Float16*>(out_h), ldh, ws, ws_bytes, flags, p2w_s(stream), src_row);
     return p2w_sa_conv_h1_impl(prec, P, ldp, n_src, xyzr_src, idx, batch_dst, sf, nbr, deg, kw, M, w1r4, W2, wscale, C1, C2, b2, bn_s,
-                               bn_t, out, ldo, static_cast<_Float16*>(out_h), ldh, ws, ws_bytes, flags, p2w_s(stream));
+                               bn_t, out, ldo, static_cast<_Float16*>(out_h), ldh, ws, ws_bytes, flags, p2w_s(stream), src_row);
+}
+
+extern "C" int32_t p2w_sa_conv_h(int32_t prec, const float* P, int32_t ldp, int32_t n_src, const float* xyzr_src, const int32_t* idx,
+                                 const int32_t* batch_dst, const float* sf, const int32_t* nbr, const int32_t* deg,
+                                 int32_t kw, int32_t M, const float* w1r4, const void* W2h, float wscale, int32_t C1,
+                                 int32_t C2, const float* b2, const float* bn_s, const float* bn_t, float* out,
+                                 int32_t ldo, void* out_h, int32_t ldh, void* ws, size_t ws_bytes, int32_t flags,
+                                 p2w_stream_t stream) {
+    return p2w_sa_conv_h_rows(prec, P, ldp, n_src, xyzr_src, idx, batch_dst, sf, nbr, deg, kw, M, w1r4, W2h, wscale, C1, C2, b2, bn_s, bn_t,
+                              out, ldo, out_h, ldh, ws, ws_bytes, flags, nullptr, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -541,7 +552,9 @@ __device__ __forceinline__ void store4(const OutArgs& o, size_t row, int c, cons
         else KERNEL<0><<<grid, block, 0, stream>>>(__VA_ARGS__);                                         \
     } while (0)
 
-template <int PREC>
+// INDEXED: the records come in another (e.g. cell-sorted) order and carry their own row in .w: the fp32 output goes to that row,
+// the H output to the record's position (p2w_stem_h2_indexed)
+template <int PREC, bool INDEXED = false>
 __global__ __launch_bounds__(256) void stem_kernel(const float4* __restrict__ xyzr, int n, const float* __restrict__ w,
                                                    const float* __restrict__ b, int C, int q4, OutArgs o) {
     const long g = (long)blockIdx.x * 256 + threadIdx.x;  // one thread per (row, 4 channels incl. zero padding)
@@ -554,11 +567,17 @@ __global__ __launch_bounds__(256) void stem_kernel(const float4* __restrict__ xy
         const int c = c0 + e;
         v[e] = (c < C) ? fmaxf(fmaf(p.z, w[c * 3 + 2], fmaf(p.y, w[c * 3 + 1], fmaf(p.x, w[c * 3 + 0], b[c]))), 0.f) : 0.f;
     }
-    store4<PREC>(o, (size_t)row, c0, v);
+    if constexpr (INDEXED) {
+        if (o.f32 && c0 < o.ldo) *reinterpret_cast<float4*>(&o.f32[(size_t)__float_as_int(p.w) * o.ldo + c0]) = make_float4(v[0], v[1], v[2], v[3]);
+        if (o.h2 && c0 < o.hcols) h_store4<PREC>(o.h2, o.ldh, (size_t)row, c0, v);
+    } else {
+        store4<PREC>(o, (size_t)row, c0, v);
+    }
 }
 
+
 static int32_t stem_launch(int32_t prec, const float* xyzr, int32_t n, const float* w, const float* b, int32_t C, float* out,
-                           void* out_h2, int32_t ldh, p2w_stream_t stream) {
+                           void* out_h2, int32_t ldh, p2w_stream_t stream, bool indexed = false) {
     if (prec < P2W_PREC_F16X3 || prec > P2W_PREC_BF16) return P2W_EINVAL;
     if (n == 0) return P2W_OK;
     P2W_CHECK_PTR(xyzr); P2W_CHECK_PTR(w); P2W_CHECK_PTR(b); P2W_CHECK_ALIGN16(xyzr);
@@ -568,6 +587,14 @@ static int32_t stem_launch(int32_t prec, const float* xyzr, int32_t n, const flo
     const int hcols = out_h2 ? (ldh < (C + ka - 1) / ka * ka ? ldh : (C + ka - 1) / ka * ka) : 0;   // C channels + zero pad to the K-slab boundary
     OutArgs o = {out, C, static_cast<_Float16*>(out_h2), out_h2 ? ldh : 0, hcols, nullptr, nullptr, 0};
     const int q4 = (out_h2 ? hcols : C) >> 2;
+    if (indexed) {
+        const int grid = p2w_cdiv((long)n * q4, 256);
+        const float4* x4 = reinterpret_cast<const float4*>(xyzr);
+        if (prec == P2W_PREC_F16) stem_kernel<1, true><<<grid, 256, 0, p2w_s(stream)>>>(x4, n, w, b, C, q4, o);
+        else if (prec == P2W_PREC_BF16) stem_kernel<2, true><<<grid, 256, 0, p2w_s(stream)>>>(x4, n, w, b, C, q4, o);
+        else stem_kernel<0, true><<<grid, 256, 0, p2w_s(stream)>>>(x4, n, w, b, C, q4, o);
+        return P2W_LAUNCH_STATUS();
+    }
     P2W_LAUNCH_PREC(prec, stem_kernel, p2w_cdiv((long)n * q4, 256), 256, p2w_s(stream), reinterpret_cast<const float4*>(xyzr), n, w, b,
                     C, q4, o);
     return P2W_LAUNCH_STATUS();
@@ -580,6 +607,10 @@ extern "C" int32_t p2w_stem(const float* xyzr, int32_t n, const float* w, const 
 extern "C" int32_t p2w_stem_h2(int32_t prec, const float* xyzr, int32_t n, const float* w, const float* b, int32_t C, float* out,
                                void* out_h2, int32_t ldh, p2w_stream_t stream) {
     return stem_launch(prec, xyzr, n, w, b, C, out, out_h2, ldh, stream);
+}
+extern "C" int32_t p2w_stem_h2_indexed(int32_t prec, const float* xyzr, int32_t n, const float* w, const float* b, int32_t C, float* out,
+                                       void* out_h2, int32_t ldh, p2w_stream_t stream) {
+    return stem_launch(prec, xyzr, n, w, b, C, out, out_h2, ldh, stream, true);
 }
 
 // One wave per output row: the row's neighbours, their inverse-square-distance weights and the denominator are

@@ -1896,7 +1896,7 @@ __global__ __launch_bounds__(512, 2) void sa_conv16s_kernel(const float* __restr
 __global__ __launch_bounds__(256) void sa_edge_meta_kernel(const float4* __restrict__ xyzr, const int* __restrict__ idx, const int* __restrict__ batch_dst,
                                     const float* __restrict__ sf, const int* __restrict__ nbr, const int* __restrict__ deg, int kw,
                                     int M, int n_src, int ldp4, int G, const int* __restrict__ list, const int* __restrict__ n_list_dev,
-                                    int* __restrict__ meta_j, float4* __restrict__ meta_g, int* __restrict__ desc);
+                                    const int* __restrict__ src_row, int* __restrict__ meta_j, float4* __restrict__ meta_g, int* __restrict__ desc);
 constexpr int SA_PART_BLOCK = 1024;
 __global__ __launch_bounds__(SA_PART_BLOCK) void sa_part_count_kernel(const int* __restrict__ deg, int kw, int M, int* __restrict__ blk_small);
 __global__ __launch_bounds__(1024) void sa_part_scan_kernel(int* __restrict__ blk_small, int nblk, int M, int* __restrict__ counts);
@@ -1918,7 +1918,7 @@ static int32_t launch_sa_conv_h(const float* P, int32_t ldp, int32_t n_src, cons
                                 const float* sf, const int32_t* nbr, const int32_t* deg, int32_t kw, int32_t M,
                                 const float* w1r4, const _Float16* W2h, float wscale, int32_t C1, int32_t C2, const float* b2,
                                 const float* bn_s, const float* bn_t, float* out, int32_t ldo, _Float16* out_h2, int32_t ldh,
-                                void* ws, size_t ws_bytes, int32_t flags, hipStream_t stream) {
+                                void* ws, size_t ws_bytes, int32_t flags, hipStream_t stream, const int32_t* src_row = nullptr) {
     constexpr int KA = HCfg<PREC>::kalign;
     const int C2pad = (C2 + 255) / 256 * 256, C1pad = (C1 + KA - 1) / KA * KA;
     // LDS tables (layer-1 geometry weights, per-column epilogue parameters) and 32-bit offsets: edge rows, P rows in float4 units
@@ -1938,7 +1938,7 @@ static int32_t launch_sa_conv_h(const float* P, int32_t ldp, int32_t n_src, cons
         constexpr int G = decltype(g_c)::value;
         const long rows_max = tiles_max * 32;
         sa_edge_meta_kernel<<<p2w_cdiv(rows_max, 256), 256, 0, stream>>>(x4, idx, batch_dst, sf, nbr, deg, kw, M, n_src, ldp / 4, G,
-                                                                       list, n_list_dev, meta_j, meta_g, desc);
+                                                                       list, n_list_dev, src_row, meta_j, meta_g, desc);
         const long items = p2w_cdiv(tiles_max, tpi) * nNt3;
         int grid = (int)(items < n_cu ? items : n_cu);
         if (grid >= 8) grid &= ~7;   // whole XCD rounds (see the kernel's work assignment)
@@ -1994,4 +1994,4 @@ int32_t p2w_sa_conv_h1_impl(int32_t prec, const float* P, int32_t ldp, int32_t n
                             const int32_t* batch_dst, const float* sf, const int32_t* nbr, const int32_t* deg, int32_t kw,
                             int32_t M, const float* w1r4, const _Float16* W2h, float wscale, int32_t C1, int32_t C2,
                             const float* b2, const float* bn_s, const float* bn_t, float* out, int32_t ldo, _Float16* out_h2,
-                            int32_t ldh, void* ws, size_t ws_bytes, int32_t flags, hipStream_t stream);
+                            int32_t ldh, void* ws, size_t ws_bytes, int32_t flags, hipStream_t stream, const int32_t* src_row = nullptr);

@@ -237,6 +237,9 @@ class EngineOptions:
                                   # 2 the k = 32 searches, 4 the interpolation searches (A/B: per-voxel rows are short)
     search_collect: bool = False  # k = 32 searches select by collected candidates + sorting networks (P2W_SEARCH_COLLECT) instead of sorted
                                   # insertions (A/B: 0.645 vs 0.562 ms per bench step, tools/search_ab.py)
+    fp1_cell_order: bool = False  # H path: the level-0 features live in the sampler's cell order (stem, SA1's hoisted product, FP1, head), the
+                                  # logits are scattered back, so that the last interpolation's coarse rows and SA1's P rows come from L2.
+                                  # Bit-identical; measured: interp_concat 0.303 -> 0.289 ms, the rest of the step +-0 -> off (tools/opt_ab.py)
     fp_hints: bool = True         # seed the k = 2 interpolation searches from the sampler's ranks (p2w_knn_hint2)
     sa_specialized: bool = False  # 256-column PointNetConv items by the wave-specialised kernel (P2W_SA_SPECIALIZED: 4 producer + 4 consumer waves)
     sa_pack: bool = True          # P2W_SA_PACK8 on the ball-query level (targets with <= 8 neighbours share an MFMA tile)
@@ -455,6 +458,12 @@ class Engine:
                 # queries are neighbours in space and only the grid rows near them are visited.  Results are unchanged.
                 sorted0, skeys0 = torch.empty((N, 4), **f32), skeys
                 self._call("index_records", L.p2w_index_records, ptr(src.xyzr), ptr(order), ptr(src.ptr), B, N, ptr(sorted0))
+                geo.order, geo.sorted0 = order, sorted0
+                geo.rows0_sorted = bool(grid_search and self.fp1_cell_order and self.prec is not None)
+                if geo.rows0_sorted:   # position of every input point in the cell order (the P row of a level-0 source point)
+                    geo.order64 = order.long()
+                    geo.inv0 = torch.empty(N, **i32)
+                    geo.inv0[geo.order64] = torch.arange(N, **i32)
                 if grid_search:
                     self._call("ball_query", L.p2w_ball_query_grid_indexed, ptr(sorted0), ptr(skeys0), ptr(src.ptr), ptr(grids[1]),
                                ptr(cstart0), ptr(src.xyzr), ptr(lv.idx), ptr(lv.ptr), B, N, res * 2, k, ptr(lv.nbr), ptr(lv.deg),
@@ -481,7 +490,9 @@ class Engine:
         for f in (2, 1, 0):
             fine, coarse = geo.levels[f], geo.levels[f + 1]
             nbr, deg = torch.empty((N, 2), **i32), torch.empty(N, **i32)
-            q, fl = (sorted0, SEARCH_Q_ROW_IN_W) if f == 0 else (fine.xyzr, 0)
+            # level 0 queries run over the cell-sorted copy; their result rows go to the points' own rows (row in .w) - or stay in
+            # cell order when the feature phase keeps level 0 in that order (fp1_cell_order)
+            q, fl = (sorted0, 0 if getattr(geo, "rows0_sorted", False) else SEARCH_Q_ROW_IN_W) if f == 0 else (fine.xyzr, 0)
             if grid_search:
                 hint = None
                 if ranks.get(f) is not None:   # both of a point's two nearest coarse points are within its cell
@@ -498,6 +509,8 @@ class Engine:
             geo.fp_nbr[f] = (nbr, deg)
         aux0 += list(ckeys.values()) + list(grids.values()) + [t for t in ranks.values() if t is not None]
         aux0 += [t for t in list(cstart.values()) + [cstart0] if t is not None]
+        if getattr(geo, "rows0_sorted", False):
+            aux0 += [geo.inv0, geo.order64]
         geo.aux = list(bbox.values()) + aux0
         geo.counts_dev = torch.cat([torch.stack([geo.levels[l].ptr[B] for l in (1, 2, 3)]), status])
         geo.counts_host = torch.empty(6, dtype=torch.int32, pin_memory=True)
@@ -572,8 +585,17 @@ class Engine:
         pitch = [pad8(F3 + Fs[f]) for f in range(4)]
         xh = [hcol(cat[f], F3) for f in range(4)]   # H features of level f = the skip columns of its FP module's rows
         x0 = new(N, Cw)
-        self._call("stem", L.p2w_stem_h2, prec, ptr(lv[0].xyzr), N, ptr(w.stem_w), ptr(w.stem_b), Cw, ptr(x0), ptr(xh[0]),
-                   pitch[0])
+        # Level 0 in the sampler's CELL ORDER (fp1_cell_order): the H rows of the input points' features - the skip columns of FP1's rows,
+        # the A operand of SA1's hoisted product - are row p = the p-th point of the cell-sorted order, so are FP1's rows, its MLP, the head;
+        # the logits are scattered back at the end.  Spatial neighbours are then memory neighbours: the last interpolation's two coarse
+        # rows per point and SA1's P rows come from L2.  The fp32 stem features (data.x, model.py:228) stay in input order.
+        sorted0 = bool(getattr(geo, "rows0_sorted", False))
+        if sorted0:
+            self._call("stem", L.p2w_stem_h2_indexed, prec, ptr(geo.sorted0), N, ptr(w.stem_w), ptr(w.stem_b), Cw, ptr(x0), ptr(xh[0]),
+                       pitch[0])
+        else:
+            self._call("stem", L.p2w_stem_h2, prec, ptr(lv[0].xyzr), N, ptr(w.stem_w), ptr(w.stem_b), Cw, ptr(x0), ptr(xh[0]),
+                       pitch[0])
         self.stem_out = x0
         if keep is not None:
             keep["stem"] = x0
@@ -597,10 +619,10 @@ class Engine:
             meta = torch.empty(int(L.p2w_sa_conv_h_ws_bytes(M, sa_flags)) + 65536, dtype=torch.uint8, device=dev)   # per-edge (j, normalised offset) scratch (+ room for diagnostics)
             if keep is not None:
                 keep[f"sa{l}_module.ws"] = meta
-            self._call("sa_conv", L.p2w_sa_conv_h, prec, ptr(P), C1p, src.n, ptr(src.xyzr), ptr(dst.idx), ptr(dst.batch),
+            self._call("sa_conv", L.p2w_sa_conv_h_rows, prec, ptr(P), C1p, src.n, ptr(src.xyzr), ptr(dst.idx), ptr(dst.batch),
                        ptr(geo.sf), ptr(dst.nbr), ptr(dst.deg), geo.k, M, ptr(p["w1r4"]), ptr(p["W2"].w16),
                        p["W2"].wscale, C1, C2, ptr(p["b2"]), ptr(p["bn_s"]), ptr(p["bn_t"]), ptr(conv), C2, ptr(convh),
-                       pad8(C2), ptr(meta), meta.numel(), sa_flags)
+                       pad8(C2), ptr(meta), meta.numel(), sa_flags, ptr(geo.inv0) if (l == 1 and sorted0) else None)
             # fp32 form of the level's output: level 3 feeds cat(x, pos) of the global module; otherwise only on request
             out = new(M, C2) if (keep is not None or l == 3) else None
             # residual block in row chunks: the two 4F-wide intermediates of a chunk (2 x chunk x 4F x 4 B) are written
@@ -659,10 +681,12 @@ class Engine:
         y, y_xyzr = g, zeros_c
         logits = torch.empty(N, dtype=torch.float32, device=dev) if w.num_classes == 1 else None
         o_multi = new(N, w.num_classes) if w.num_classes != 1 else None
+        logits_out = logits
         for fl in (4, 3, 2, 1):
             fine = lv[fl - 1]
             m, Fc, cf, ld = fine.n, y.shape[1], cat[fl - 1], pitch[fl - 1]
             nbr, deg, kw = (nbr4, deg4, 1) if fl == 4 else (*geo.fp_nbr[fl - 1], 2)
+            fine_xyzr = geo.sorted0 if (fl == 1 and sorted0) else fine.xyzr   # FP1's rows (and fp_nbr[0]'s) are in cell order then
             l0, l1 = w.fp[fl]
             chunk = self.res_chunk_rows if self.res_chunk_rows > 0 else m
             chunk = max(256, min(m, pick_chunk(m, chunk * 512 // (Fc + Fs[fl - 1]), max(1, l0.N // 256)) if self.chunk_pick
@@ -691,7 +715,7 @@ class Engine:
                 a, yh, hws, hdh = bf["a"], bf["yh"], bf["hws"], bf["hdh"]
                 with torch.cuda.stream(st):
                     # the interpolated part only (skip = NULL): the skip columns of these rows were written by their producer
-                    self._call("interp_concat", L.p2w_interp_concat_h2, prec, ptr(y), Fc, ptr(y_xyzr), ptr(fine.xyzr[r0:]),
+                    self._call("interp_concat", L.p2w_interp_concat_h2, prec, ptr(y), Fc, ptr(y_xyzr), ptr(fine_xyzr[r0:]),
                                ptr(nbr[r0:]), ptr(deg[r0:]), kw, None, 0, mm, ptr(cf[r0:]), ld)
                     self._gemm_h2("gemm_mlp", cf[r0:], ld, mm, l0, out_h2=a, ldh_o=pad8(l0.N))
                     self._gemm_h2("gemm_mlp", a, pad8(l0.N), mm, l1, out_f32=None if b is None else b[r0:], ldo=l1.N,
@@ -713,7 +737,20 @@ class Engine:
                 cur.wait_event(done)
             y, y_xyzr = b, fine.xyzr
             if keep is not None:
+                if fl == 1 and sorted0 and b is not None:   # rows back in input order for whoever asked
+                    bo = torch.empty_like(b)
+                    bo[geo.order64] = b
+                    b = bo
                 keep[f"fp{fl}_module.out"] = b
+        if sorted0:   # cell order -> input order (one row per point: 4 B, or num_classes x 4 B)
+            if w.num_classes == 1:
+                logits_out = torch.empty_like(logits)
+                logits_out[geo.order64] = logits
+                logits = logits_out
+            else:
+                om = torch.empty_like(o_multi)
+                om[geo.order64] = o_multi
+                o_multi = om
         if w.num_classes != 1:
             logits = o_multi.t()
         return torch.squeeze(logits)

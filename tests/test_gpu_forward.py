@@ -170,6 +170,39 @@ def test_packed_pointnetconv_is_bit_identical(precision):
         assert bool(torch.isfinite(a).all()) and torch.equal(a, b)
 
 
+@pytest.mark.parametrize("option", ["fp1_cell_order", "search_collect", "sa_specialized"])
+@pytest.mark.parametrize("precision", ["f16x3", "fp16"])
+def test_round4_engine_switches_keep_the_logits(option, precision):
+    """The round-4 A/B switches give the default path's results: `fp1_cell_order` (level-0 features in the sampler's cell order,
+    logits scattered back: rows are only re-arranged) and `search_collect` (k = 32 selection by collected candidates + sorting
+    networks) bit for bit; `sa_specialized` (wave-specialised PointNetConv with 16x16x32 MFMA tiles: another k order inside a
+    slab) within the parity bar of the default - on ragged batches with tiny voxels, through forward and through Net.stream."""
+    from pointstowood_amd import Net
+    batches = [synth.collate([synth.uniform_voxel(2.0, 6000, 91, True), synth.uniform_voxel(2.0, 900, 92, False)]),
+               synth.collate([synth.uniform_voxel(2.0, 3, 94, True), synth.uniform_voxel(1.0, 4000, 95, True),
+                              synth.uniform_voxel(4.0, 2000, 96, False), synth.uniform_voxel(2.0, 40, 97, True)]),
+               synth.collate([synth.surface_voxel(2.0, 12000, 98, False)])]
+    sd = weights.synth_state_dict(1, 32, seed=4)
+
+    def mk(b):
+        d = _D()
+        d.pos, d.batch, d.reflectance, d.sf = b["pos"].cuda(), b["batch"].cuda(), b["reflectance"].cuda(), b["sf"].cuda()
+        return d
+    outs = {}
+    for on in (False, True):
+        net = Net(num_classes=1, C=32, k=32, precision=precision, **{option: on})
+        net.load_state_dict(sd, strict=True)
+        net = net.cuda().eval()
+        outs[on] = [net(mk(b)).clone() for b in batches] + [o.clone() for o in net.stream(mk(b) for b in batches)]
+    torch.cuda.synchronize()
+    for a, b in zip(outs[True], outs[False]):
+        assert bool(torch.isfinite(a).all()) and a.shape == b.shape
+        if option == "sa_specialized" and precision == "f16x3":
+            assert (a - b).abs().max() <= 2e-4 and (torch.sigmoid(a) - torch.sigmoid(b)).abs().max() <= 5e-5
+        else:
+            assert torch.equal(a, b)
+
+
 def test_stream_pipeline_equals_sequential_forward():
     """Net.stream (geometry of batch i+1 overlapped with features of batch i on a second HIP stream) must return
     bit-identical logits to one forward per batch, in order."""
@@ -403,6 +436,10 @@ def test_forward_fuzz_against_live_oracle(seed):
         n = geo.levels[f].n
         ours = nbr[:n].cpu().long().clone()
         ours[torch.arange(2)[None, :] >= deg[:n].cpu().long()[:, None]] = -1
+        if f == 0 and getattr(geo, "rows0_sorted", False):   # level 0's rows are kept in the sampler's cell order (fp1_cell_order)
+            unsorted = torch.empty_like(ours)
+            unsorted[geo.order[:n].cpu().long()] = ours
+            ours = unsorted
         assert torch.equal(ours, _fp_neighbours_expected(geo, f)), f"interpolation neighbours of level {f}"
     assert torch.isfinite(got).all()
     assert bool(((got.cpu() - ref).abs() <= 4e-4 + 2e-5 * ref.abs()).all())   # (logits of tiny voxels reach +-60)
