@@ -137,6 +137,11 @@ __global__ __launch_bounds__(256) void rs_scan_add_kernel(int* __restrict__ hist
     if (i < len) hist[i] += tsum[i >> 12];
 }
 
+// One digit pass over a 4096-key tile.  The tile's pairs are read ONCE into registers (16 per thread, coalesced), ranked with the
+// ballot scheme of the header comment into their position in the tile's digit-sorted order, parked there in LDS, and written out in
+// that order: the keys of one digit leave the workgroup as one contiguous run of the destination (16 keys = 128 bytes on average)
+// instead of ~50 partial segments per wave instruction (round 4: the direct scatter moved 32 B per pair at 0.84 TB/s and was
+// 1.3 - 2.8 x slower than rocPRIM at plot scale, tools/sort_bench.py).
 __global__ __launch_bounds__(RS_BLOCK) void rs_scatter_kernel(const unsigned long long* __restrict__ kin, const unsigned long long* __restrict__ kout,
                                                               const unsigned long long* __restrict__ ktmp, unsigned long long* __restrict__ kout_w,
                                                               unsigned long long* __restrict__ ktmp_w, const int* __restrict__ vin,
@@ -144,7 +149,12 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_scatter_kernel(const unsigned lon
                                                               int* __restrict__ vout_w, int* __restrict__ vtmp_w,
                                                               const int* __restrict__ n_dev, int n_bound, int pass,
                                                               const RsCtl* __restrict__ ctl, int nblk, const int* __restrict__ hist) {
-    __shared__ int cnt[4][RS_RADIX];    // digits per wave quarter of the tile, then the running destination offsets
+    constexpr int PER = RS_TILE / 4 / 64;               // 64-key chunks per wave (a wave owns 1024 consecutive keys)
+    __shared__ int cnt[4][RS_RADIX];                    // digits per wave quarter of the tile, then the running tile-local offsets
+    __shared__ int gbase[RS_RADIX];                     // destination of the tile's first key of digit d, minus its tile-local position
+    __shared__ int wsum[4];
+    __shared__ unsigned long long skey[RS_TILE];        // the tile in digit order
+    __shared__ int sval[RS_TILE];
     if (pass >= rs_passes(ctl)) return;
     const int n = rs_count(n_dev, n_bound);
     const long long t0 = (long long)blockIdx.x * RS_TILE;
@@ -159,23 +169,38 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_scatter_kernel(const unsigned lon
     for (int w = 0; w < 4; ++w) cnt[w][threadIdx.x] = 0;
     __syncthreads();
     const long long w0 = t0 + (long long)wave * (RS_TILE / 4);
-    for (int c = 0; c < RS_TILE / 4 / 64; ++c) {
-        const long long i = w0 + c * 64 + lane;
-        if (i < n) atomicAdd(&cnt[wave][(int)((ks[i] >> shift) & 255ull)], 1);
-    }
-    __syncthreads();
-    {   // thread d: destination of digit d's first element of every wave quarter
-        int run = hist[threadIdx.x * nblk + blockIdx.x];
+    unsigned long long key[PER];
+    int val[PER];
 #pragma unroll
-        for (int w = 0; w < 4; ++w) { const int c = cnt[w][threadIdx.x]; cnt[w][threadIdx.x] = run; run += c; }
-    }
-    __syncthreads();
-    for (int c = 0; c < RS_TILE / 4 / 64; ++c) {
+    for (int c = 0; c < PER; ++c) {
         const long long i = w0 + c * 64 + lane;
         const bool valid = i < n;
-        const unsigned long long key = valid ? ks[i] : 0ull;
-        const int val = valid ? (vs ? vs[i] : (int)i) : 0;
-        const int d = (int)((key >> shift) & 255ull);
+        key[c] = valid ? ks[i] : ~0ull;
+        val[c] = valid ? (vs ? vs[i] : (int)i) : 0;
+        if (valid) atomicAdd(&cnt[wave][(int)((key[c] >> shift) & 255ull)], 1);
+    }
+    __syncthreads();
+    {   // thread d: the tile's keys of digit d start at tile position (exclusive scan of the tile's digit counts) and at `hist` globally
+        int c[4], tc = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { c[w] = cnt[w][threadIdx.x]; tc += c[w]; }
+        int inc = tc;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int before = 0;
+        for (int w = 0; w < wave; ++w) before += wsum[w];
+        int run = before + inc - tc;                    // tile-local start of digit threadIdx.x
+        gbase[threadIdx.x] = hist[threadIdx.x * nblk + blockIdx.x] - run;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { cnt[w][threadIdx.x] = run; run += c[w]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < PER; ++c) {
+        const bool valid = w0 + c * 64 + lane < n;
+        const int d = (int)((key[c] >> shift) & 255ull);
         unsigned long long peers = __ballot(valid);
         if (!peers) break;                                   // (whole chunks past the end: wave-uniform)
 #pragma unroll
@@ -187,10 +212,18 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_scatter_kernel(const unsigned lon
             const int rank = __popcll(peers & ((1ull << lane) - 1ull));
             const int base = cnt[wave][d];                   // read by every lane of the group before its first lane advances it:
             const int pos = base + rank;                     // LDS operations of one wave execute in program order
-            kd[pos] = key;
-            vd[pos] = val;
+            skey[pos] = key[c];
+            sval[pos] = val[c];
             if (rank == 0) cnt[wave][d] = base + __popcll(peers);
         }
+    }
+    __syncthreads();
+    const int tile_n = (int)(n - t0 < RS_TILE ? n - t0 : RS_TILE);
+    for (int p = threadIdx.x; p < tile_n; p += RS_BLOCK) {
+        const unsigned long long k = skey[p];
+        const int dst = gbase[(int)((k >> shift) & 255ull)] + p;
+        kd[dst] = k;
+        vd[dst] = sval[p];
     }
 }
 
