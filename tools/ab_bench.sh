@@ -1,6 +1,8 @@
 #!/bin/bash
 # Same-box A/B of two source trees (this one vs ab_old/): alternate short bench runs, print ms/step and the kernel classes.
-# usage: tools/ab_bench.sh [rounds] [extra bench args for both]     (ab_old/ = `git archive <commit> | tar -x -C ab_old`, built)
+# usage: tools/ab_bench.sh [rounds] [extra bench args for both]     (ab_old/ = `git archive <commit> | tar -x -C ab_old`, built;
+# a TEMPORARY export made just before the gpurun call - it is git-ignored and pytest-ignored - and deleted after it.  For kernel
+# variants of the SAME tree prefer tools/build_variant.sh + the *_ab.py tools: no second tree needed)
 rounds=${1:-3}; shift
 for r in $(seq 1 $rounds); do
   for t in . ab_old; do

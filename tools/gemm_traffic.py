@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-launch fabric traffic of the GEMM class against one pass over each launch's operands (diagnostic).
 
-    python tools/gemm_traffic.py gpurun_out/prof_r3_f16x3 [gpurun_out/gemm_list.json]
+    python tools/gemm_traffic.py gpurun_out/prof_r4_f16x3 [gpurun_out/gemm_list.json]
 
 Takes the LAST forward of the profiled sequential bench (the profiled step: batch 0, the batch tools/gemm_list.py logs) from the
 FETCH_SIZE and WRITE_SIZE passes of tools/profile_round.sh and prints, launch by launch, counter bytes (FETCH x 2 + WRITE, KiB -> B)
