@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Every GEMM launch of one sequential forward on the bench batch with its own HIP-event bracket: shape, time and algorithmic
 TFLOP/s under the library's tile choice (flags 0) and with each tile forced (P2W_GEMM_TILE_128 = 1, P2W_GEMM_TILE_256 = 2).
-Median of 5 forwards per setting.   python tools/gemm_launches.py"""
+Median of 5 forwards per setting.   python tools/gemm_launches.py [B points_per_voxel]"""
 import os, statistics, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,7 +10,11 @@ from pointstowood_amd import Net, synthetic_weights as weights
 from pointstowood_amd import engine as eng_mod
 
 dev = torch.device("cuda")
-data = bench.make_batch(0, dev, 0)
+if len(sys.argv) > 2:   # B points_per_voxel: a small batch instead of the bench batch
+    from pointstowood_amd import synthetic_voxels as synth
+    data = bench.device_feed([synth.uniform_voxel(2.0, int(sys.argv[2]), 100 + i, False) for i in range(int(sys.argv[1]))], dev)
+else:
+    data = bench.make_batch(0, dev, 0)
 E = eng_mod.Engine
 orig = E._gemm_h2
 shapes = []
@@ -24,7 +28,8 @@ def spy(self, name, A, ldh_a, M, lin, *a, **kw):
 
 E._gemm_h2 = spy
 res = {}
-for flags in (0, 1, 2):
+FLAGSETS = (0, 1, 2)   # library's choice, forced 128 x 128, forced 256 x 256
+for flags in FLAGSETS:
     net = Net(num_classes=1, C=32, k=32, gemm_flags=flags)
     net.load_state_dict(weights.synth_state_dict(1, 32, seed=0), strict=True)
     net = net.to(dev).eval()
@@ -42,16 +47,15 @@ for flags in (0, 1, 2):
     res[flags] = ([statistics.median(r[i] for r in runs) for i in range(len(runs[0]))], list(shapes))
     del net
 t0, sh = res[0]
-print(f"{'launch':11s} {'M':>7s} {'K':>5s} {'N':>5s} | {'default us':>10s} {'TF':>6s} | {'128^2 us':>9s} {'256^2 us':>9s}")
-tot = [0.0, 0.0, 0.0]
+print(f"{'launch':11s} {'M':>7s} {'K':>5s} {'N':>5s} | {'default us':>10s} {'TF':>6s} | {'128^2':>7s} {'256^2':>7s}")
+tot = [0.0] * len(FLAGSETS)
 n_sh = len(sh)
 for i in range(len(t0)):
     name, M, K, N = sh[i] if i < n_sh else ("head", data.pos.shape[0], 512, 512)
     tf = 2.0 * M * K * N / (t0[i] * 1e-6) / 1e12
-    t1 = res[1][0][i] if i < len(res[1][0]) else float("nan")
-    t2 = res[2][0][i] if i < len(res[2][0]) else float("nan")
-    for j, t in enumerate((t0[i], t1, t2)):
+    ts = [res[f][0][i] if i < len(res[f][0]) else float("nan") for f in FLAGSETS]
+    for j, t in enumerate(ts):
         tot[j] += t
-    mark = " <-128" if abs(t0[i] - t1) < abs(t0[i] - t2) else ""
-    print(f"{name:11s} {M:7d} {K:5d} {N:5d} | {t0[i]:10.1f} {tf:6.0f} | {t1:9.1f} {t2:9.1f}{mark}")
-print("sum (us): default %.0f, forced 128^2 %.0f, forced 256^2 %.0f, best per launch %.0f" % (tot[0], tot[1], tot[2], sum(min(a, b, c) for a, b, c in zip(res[0][0], res[1][0], res[2][0]))))
+    mark = " <-128" if abs(ts[0] - ts[1]) < abs(ts[0] - ts[2]) else ""
+    print(f"{name:11s} {M:7d} {K:5d} {N:5d} | {ts[0]:10.1f} {tf:6.0f} | {ts[1]:7.1f} {ts[2]:7.1f}{mark}")
+print("sum (us): " + ", ".join(f"flags {f}: {t:.0f}" for f, t in zip(FLAGSETS, tot)) + ", best per launch %.0f" % sum(min(res[f][0][i] for f in FLAGSETS) for i in range(len(t0))))
