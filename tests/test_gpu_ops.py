@@ -409,10 +409,14 @@ def test_c_abi_rejects_bad_arguments():
     from pointstowood_amd._lib import lib, ptr, stream
     x = torch.zeros(16, 4, device="cuda")
     p = torch.tensor([0, 16], dtype=torch.int32, device="cuda")
-    n = torch.zeros(16, 100, dtype=torch.int32, device="cuda")
+    n = torch.zeros(16, 101, dtype=torch.int32, device="cuda")
     d = torch.zeros(16, dtype=torch.int32, device="cuda")
     L = lib()
-    assert L.p2w_knn(ptr(x), ptr(p), ptr(x), None, ptr(p), 1, 16, 100, ptr(n), ptr(d), None, 0, stream()) == -1   # k > 64
+    assert L.p2w_knn(ptr(x), ptr(p), ptr(x), None, ptr(p), 1, 16, 101, ptr(n), ptr(d), None, 0, stream()) == -1   # k > 100 (P2W_MAX_K_WIDE)
+    assert L.p2w_knn(ptr(x), ptr(p), ptr(x), None, ptr(p), 1, 16, 100, ptr(n), ptr(d), None, 0, stream()) == 0    # 65 .. 100: the wide path
+    g8 = torch.zeros(8, dtype=torch.int64, device="cuda")
+    k64 = torch.zeros(16, dtype=torch.int64, device="cuda")
+    assert L.p2w_knn_grid(ptr(x), ptr(k64), ptr(p), ptr(g8), ptr(x), None, ptr(p), 1, 16, 65, ptr(n), ptr(d), None, 0, stream()) == -1   # grid searches: k <= 64
     assert L.p2w_knn(None, ptr(p), ptr(x), None, ptr(p), 1, 16, 8, ptr(n), ptr(d), None, 0, stream()) == -2       # NULL
     assert L.p2w_knn(x.data_ptr() + 4, ptr(p), ptr(x), None, ptr(p), 1, 16, 8, ptr(n), ptr(d), None, 0, stream()) == -3  # alignment
     assert b"NULL" in L.p2w_strerror(-2)
