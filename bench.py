@@ -638,6 +638,8 @@ def main():
                        "gather": args.gather,
                        "pipeline": ("HIP streams: geometry(i+1) || features(i), features alternating over "
                                     f"{net.engine_options.feature_streams} high-priority streams") if args.pipeline else "sequential"},
+            "timing_note": f"timed region {dt:.2f} s ({args.steps} steps) right after {args.warmup} warm-up steps: a cold-clock number; box-to-box spread of this "
+                           "line is +-3-5 % (DVFS), same-box A/Bs are in docs/LAB_NOTES.md",
             "end_to_end_tflops_algorithmic": 2.0 * total_macs * args.steps / dt / 1e12,
             "pcie_inclusive": pcie,
             "roofline": {"bound": "mfma", "kernel": kname.get(dom, dom), "achieved": achieved, "peak": peak,
