@@ -359,7 +359,7 @@ class Engine:
     def _table_cells(self, level, B, N):
         """Table capacity (entries) for the sampler of `level`, 0 = use the sort.  Provision: B voxels x the cells of a 2.3 m cube
         at that resolution (+ margin), times the level's growth factor (x 8 after every overflow, i.e. twice the extent per
-        axis, while it fits TABLE_CELLS_MAX).  The kernels clear, scan and compact only the part of the table the batch's real
+        axis; a batch for which that does not fit TABLE_CELLS_MAX takes the sort).  The kernels clear, scan and compact only the part of the table the batch's real
         grid uses, so a generous capacity costs (almost) nothing - what costs is the GRID: it grows with the number of voxels,
         the sort with the number of points.  Many small voxels (B in the hundreds, a few hundred points each) mean tens of
         millions of cells for half a million points, so the table is only taken while the grid of B nominal voxels has at
@@ -372,10 +372,10 @@ class Engine:
         per_voxel = (int(2.3 / SA_RES[level]) + 3) ** 3
         if B * per_voxel > self.table_cells_per_point * max(N, 1):
             return 0
-        scale = self._table_scale[level]
-        while scale > 1 and B * per_voxel * scale > self.TABLE_CELLS_MAX:
-            scale //= 8
-        cells = B * per_voxel * scale
+        # the growth factor this level has needed so far (x 8 per overflow).  If a table of that extent does not fit for THIS batch's
+        # voxel count, take the sort: a smaller table is the one that already overflowed (round 4: a 67-voxel batch of 4 m plot
+        # voxels shrank the factor back to 1, overflowed, and paid a discarded geometry pass + the sort on every forward)
+        cells = B * per_voxel * self._table_scale[level]
         return cells if cells <= self.TABLE_CELLS_MAX else 0
 
     def _table_workspace(self, n, cells, device):
