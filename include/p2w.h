@@ -223,6 +223,19 @@ size_t p2w_cell_starts_ws_bytes(int64_t n_cells);
 int32_t p2w_cell_starts(const uint64_t* keys_sorted, int32_t n, int64_t n_cells, int32_t* table_out, void* ws, size_t ws_bytes,
                         p2w_stream_t stream);
 
+/* Exact fp64 re-ranking of a grid kNN result - the neighbour sets of the reference's KD-tree (predicter.py:136-137: pykdtree over
+ * the float64 `classified_pc` of :205, float64 queries), which the fp32 searches above can miss where two candidates' distances
+ * differ by less than an fp32 rounding.  cand_sorted[nc][3]: the candidates' float64 coordinates in the cell-sorted order of
+ * `grid` (p2w_voxel_sample's order_out); cand_index[p] = the index the result reports for sorted position p, cand_pos = its
+ * inverse; keys_sorted / cell_start (optional) / grid: as p2w_knn_grid_indexed; (ox, oy, oz): the offset that was subtracted
+ * from the float64 coordinates to make the fp32 ones the grid was built on; q[m][3]: float64 queries.  nbr[m, k] / deg[m]: in
+ * = any k candidates per query (the fp32 result; deg < k only where fewer than k candidates exist), out = the k nearest in
+ * float64, ascending (squared distance = ((dx^2 + dy^2) + dz^2), candidate index).  k <= P2W_MAX_K. */
+int32_t p2w_knn_refine_f64(const double* cand_sorted, const int32_t* cand_index, const int32_t* cand_pos,
+                           const uint64_t* keys_sorted, const int32_t* cell_start, const p2w_grid* grid, double ox, double oy,
+                           double oz, const double* q, int32_t m, int32_t nc, int32_t k, int32_t* nbr, int32_t* deg,
+                           p2w_stream_t stream);
+
 /* PointCloudClassifier.compute_labels (predicter.py:112-127) over a neighbour table nbr[n,k] (indices into pred /
  * prob, deg[i] valid entries): pwood_out = median of the neighbours' probabilities (np.median: mean of the two middle
  * values for an even count); label_out: any_wood != 1 -> 1 if any neighbour's prediction > any_wood else 0;
@@ -308,12 +321,12 @@ int32_t p2w_packed_dims_h(int32_t prec, int32_t N, int32_t K, int32_t* N_pad, in
 #define P2W_GEMM_ORDER_ROWS 8    /* tile order: an XCD owns whole row tiles (W re-read from its L2) */
 #define P2W_GEMM_ORDER_COLS 16   /* tile order: an XCD owns a slice of column tiles (A streamed per slice) */
 #define P2W_GEMM_RESIDUAL_H 32   /* epi->residual is an H tensor of the launch's precision (epi->ldr = its row pitch ldh), not fp32 */
+#define P2W_GEMM_STREAMK 64      /* p2w_gemm_h2_sk: run the rows behind the whole chip rounds as a split-K tail even where the cost model says no */
+#define P2W_GEMM_NO_STREAMK 128  /* p2w_gemm_h2_sk: never (= p2w_gemm_h2) */
 /* flags of p2w_sa_conv_h (0 = let the library choose the work-item shape by C2) */
 #define P2W_SA_ITEM_256 1        /* 4 targets x 256 output columns per work item */
 #define P2W_SA_ITEM_128 2        /* 8 targets x 128 output columns per work item */
 #define P2W_SA_PACK8 4           /* targets with <= 8 neighbours share a 32-row MFMA tile four at a time (sparse ball-query levels) */
-#define P2W_SA_SPECIALIZED 8     /* 256-column items by the wave-specialised kernel: 4 producer waves (gather, layer-1 correction, A rows,
-                                    W2 DMA) + 4 consumer waves (MFMAs on 128 x 64 wave tiles, epilogue); same results */
 /* bits 16..23 of `flags` of p2w_gemm_h2 / p2w_sa_conv_h: profiling ablations, honoured only by diagnostic builds
  * (-DP2W_GEMM_ABLATE / -DP2W_SA_ABLATE); production builds ignore them.
  * bits 8..15 of `flags` of p2w_gemm_h2: scheduling experiments (tools/gemm_desync.py; results unchanged): bits 8..13 = start
@@ -327,6 +340,17 @@ int32_t p2w_packed_dims_h(int32_t prec, int32_t N, int32_t K, int32_t* N_pad, in
 int32_t p2w_gemm_h2(int32_t prec, const void* A_h, int32_t ldh_a, const void* Wh, float wscale, int32_t M, int32_t N,
                     int32_t K, const p2w_epilogue* epi, float* out_f32, int32_t ldo, void* out_h, int32_t ldh_o,
                     int32_t flags, p2w_stream_t stream);
+/* p2w_gemm_h2 with a caller-owned workspace (the ABI never allocates): the library may then run the rows that do not fill a whole
+ * round of the chip's workgroup slots as a second launch - plainly, or as a SPLIT-K tail: each 128 x 128 tile's K range cut into S
+ * pieces that run side by side (raw fp32 partial tiles in `ws`) + a fix-up pass that adds a tile's pieces in ascending K order
+ * (deterministic) and runs the same epilogue.  What a launch takes is decided from (M, N, K) alone, so equal calls give equal
+ * bits; results differ from p2w_gemm_h2's in the last fp32 bits only (the K range is summed in pieces).  ws: 16-byte aligned,
+ * p2w_gemm_h2_sk_ws_bytes() bytes (32 MiB on a 256-CU chip) make every plan possible (a smaller one narrows the choice, ws = NULL
+ * is p2w_gemm_h2); it must not be shared by launches that may run concurrently (one per stream). */
+size_t p2w_gemm_h2_sk_ws_bytes(void);
+int32_t p2w_gemm_h2_sk(int32_t prec, const void* A_h, int32_t ldh_a, const void* Wh, float wscale, int32_t M, int32_t N,
+                       int32_t K, const p2w_epilogue* epi, float* out_f32, int32_t ldo, void* out_h, int32_t ldh_o,
+                       void* ws, size_t ws_bytes, int32_t flags, p2w_stream_t stream);
 /* conv1 + BN + ReLU + conv2 for ONE output channel (model.py:241-243) as one operator: out[i] = dot(epilogue(A_h[i,:] * W^T), dot_w) +
  * dot_b.  The [M, N] intermediate never reaches HBM: the GEMM's epilogue leaves one partial sum per row and 64-column slice in
  * ws, a finishing pass adds the slices in a fixed order (deterministic).  epi->residual is not supported (P2W_EUNSUPPORTED).

@@ -26,7 +26,8 @@ SEARCH_X_INDEX_IN_W, SEARCH_Q_ROW_IN_W, SEARCH_BOX, SEARCH_COLLECT = 1, 2, 4, 8 
 PREC_F16X3, PREC_F16, PREC_BF16 = 0, 1, 2                      # include/p2w.h P2W_PREC_*
 PREC_OF = {"f16x3": PREC_F16X3, "fp16": PREC_F16, "bf16": PREC_BF16}
 GEMM_TILE_128, GEMM_TILE_256, GEMM_GENERIC_EPI, GEMM_ORDER_ROWS, GEMM_ORDER_COLS, GEMM_RESIDUAL_H = 1, 2, 4, 8, 16, 32   # P2W_GEMM_*
-SA_ITEM_256, SA_ITEM_128, SA_PACK8, SA_SPECIALIZED = 1, 2, 4, 8                                                       # P2W_SA_*
+GEMM_STREAMK, GEMM_NO_STREAMK = 64, 128
+SA_ITEM_256, SA_ITEM_128, SA_PACK8 = 1, 2, 4                                                       # P2W_SA_*
 
 SIGNATURES = {
     "p2w_version": (_i32, []),
@@ -55,6 +56,7 @@ SIGNATURES = {
     "p2w_sort_pairs_u64": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _sz, _vp]),
     "p2w_key_runs_ws_bytes": (_sz, [_i32]),
     "p2w_key_runs": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "p2w_knn_refine_f64": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_double, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "p2w_cell_starts_ws_bytes": (_sz, [C.c_int64]),
     "p2w_cell_starts": (_i32, [_vp, _i32, C.c_int64, _vp, _vp, _sz, _vp]),
     "p2w_vote": (_i32, [_vp, _vp, _i32, _vp, _vp, _i32, _f32, _vp, _vp, _vp]),
@@ -67,6 +69,8 @@ SIGNATURES = {
                            _vp, _i32, _vp]),
     "p2w_packed_dims_h": (_i32, [_i32, _i32, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
     "p2w_gemm_h2": (_i32, [_i32, _vp, _i32, _vp, _f32, _i32, _i32, _i32, C.POINTER(Epilogue), _vp, _i32, _vp, _i32, _i32, _vp]),
+    "p2w_gemm_h2_sk_ws_bytes": (_sz, []),
+    "p2w_gemm_h2_sk": (_i32, [_i32, _vp, _i32, _vp, _f32, _i32, _i32, _i32, C.POINTER(Epilogue), _vp, _i32, _vp, _i32, _vp, _sz, _i32, _vp]),
     "p2w_gemm_h2_rowdot_ws_bytes": (_sz, [_i32, _i32]),
     "p2w_gemm_h2_rowdot": (_i32, [_i32, _vp, _i32, _vp, _f32, _i32, _i32, _i32, C.POINTER(Epilogue), _vp, _f32, _vp, _vp, _sz, _i32, _vp]),
     "p2w_sa_conv_h_ws_bytes": (_sz, [_i32, _i32]),

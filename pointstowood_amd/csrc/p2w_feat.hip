@@ -333,10 +333,12 @@ extern "C" int32_t p2w_sa_conv(const float* P, int32_t ldp, const float* xyzr_sr
 // H family entry points: argument checks here, kernels in p2w_hgemm.h (f16x3 instantiated in this file, the
 // single-plane precisions in p2w_feat_h1.hip)
 // ------------------------------------------------------------------------------------------------
-extern "C" int32_t p2w_gemm_h2(int32_t prec, const void* A_h, int32_t ldh_a, const void* Wh, float wscale, int32_t M, int32_t N,
+static int32_t gemm_h2_checked(int32_t prec, const void* A_h, int32_t ldh_a, const void* Wh, float wscale, int32_t M, int32_t N,
                                int32_t K, const p2w_epilogue* epi, float* out_f32, int32_t ldo, void* out_h, int32_t ldh_o,
-                               int32_t flags, p2w_stream_t stream) {
+                               void* ws, size_t ws_bytes, int32_t flags, p2w_stream_t stream) {
     if (prec < P2W_PREC_F16X3 || prec > P2W_PREC_BF16) return P2W_EINVAL;
+    if (ws) P2W_CHECK_ALIGN16(ws);
+    if ((flags & P2W_GEMM_STREAMK) && (flags & P2W_GEMM_NO_STREAMK)) return P2W_EINVAL;
     if (M == 0) return P2W_OK;
     P2W_CHECK_PTR(A_h); P2W_CHECK_PTR(Wh);
     if (!out_f32 && !out_h) return P2W_ENULL;
@@ -362,9 +364,22 @@ extern "C" int32_t p2w_gemm_h2(int32_t prec, const void* A_h, int32_t ldh_a, con
     const _Float16* Wp = static_cast<const _Float16*>(Wh);
     if (prec == P2W_PREC_F16X3)
         return launch_gemm_h<0>(Ah, ldh_a, Wp, wscale, M, N, K, ep, out_f32, ldo, static_cast<_Float16*>(out_h), ldh_o, flags,
-                                p2w_s(stream));
+                                p2w_s(stream), nullptr, nullptr, 0, static_cast<float*>(ws), ws_bytes);
     return p2w_gemm_h1_impl(prec, Ah, ldh_a, Wp, wscale, M, N, K, ep, out_f32, ldo, static_cast<_Float16*>(out_h), ldh_o, flags,
-                            p2w_s(stream));
+                            p2w_s(stream), nullptr, nullptr, 0, static_cast<float*>(ws), ws_bytes);
+}
+extern "C" int32_t p2w_gemm_h2(int32_t prec, const void* A_h, int32_t ldh_a, const void* Wh, float wscale, int32_t M, int32_t N,
+                               int32_t K, const p2w_epilogue* epi, float* out_f32, int32_t ldo, void* out_h, int32_t ldh_o,
+                               int32_t flags, p2w_stream_t stream) {
+    return gemm_h2_checked(prec, A_h, ldh_a, Wh, wscale, M, N, K, epi, out_f32, ldo, out_h, ldh_o, nullptr, 0, flags, stream);
+}
+// workspace of the split-K tail: one 128 x 128 fp32 piece per workgroup of the tail launch (at most two per CU)
+extern "C" size_t p2w_gemm_h2_sk_ws_bytes(void) { return (size_t)2 * p2w_cu_count() * 128 * 128 * sizeof(float); }
+extern "C" int32_t p2w_gemm_h2_sk(int32_t prec, const void* A_h, int32_t ldh_a, const void* Wh, float wscale, int32_t M, int32_t N,
+                                  int32_t K, const p2w_epilogue* epi, float* out_f32, int32_t ldo, void* out_h, int32_t ldh_o,
+                                  void* ws, size_t ws_bytes, int32_t flags, p2w_stream_t stream) {
+    if (!ws && ws_bytes) return P2W_ENULL;
+    return gemm_h2_checked(prec, A_h, ldh_a, Wh, wscale, M, N, K, epi, out_f32, ldo, out_h, ldh_o, ws, ws_bytes, flags, stream);
 }
 
 // conv1 + BN + ReLU + conv2 with one output channel (model.py:241-243) without the [M, N] intermediate: the GEMM's epilogue

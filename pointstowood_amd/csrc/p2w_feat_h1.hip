@@ -6,10 +6,11 @@
 
 int32_t p2w_gemm_h1_impl(int32_t prec, const _Float16* Ah, int32_t ldh_a, const _Float16* Wp, float wscale, int32_t M, int32_t N,
                          int32_t K, const EpiArgs& ep, float* out_f32, int32_t ldo, _Float16* out_h2, int32_t ldh_o,
-                         int32_t flags, hipStream_t stream, const float* dotw, float* part, int32_t ldpart) {
+                         int32_t flags, hipStream_t stream, const float* dotw, float* part, int32_t ldpart, float* skws,
+                         size_t skws_bytes) {
     if (prec == P2W_PREC_F16)
-        return launch_gemm_h<1>(Ah, ldh_a, Wp, wscale, M, N, K, ep, out_f32, ldo, out_h2, ldh_o, flags, stream, dotw, part, ldpart);
-    return launch_gemm_h<2>(Ah, ldh_a, Wp, wscale, M, N, K, ep, out_f32, ldo, out_h2, ldh_o, flags, stream, dotw, part, ldpart);
+        return launch_gemm_h<1>(Ah, ldh_a, Wp, wscale, M, N, K, ep, out_f32, ldo, out_h2, ldh_o, flags, stream, dotw, part, ldpart, skws, skws_bytes);
+    return launch_gemm_h<2>(Ah, ldh_a, Wp, wscale, M, N, K, ep, out_f32, ldo, out_h2, ldh_o, flags, stream, dotw, part, ldpart, skws, skws_bytes);
 }
 
 int32_t p2w_sa_conv_h1_impl(int32_t prec, const float* P, int32_t ldp, int32_t n_src, const float* xyzr_src, const int32_t* idx,

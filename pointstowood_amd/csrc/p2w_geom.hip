@@ -2136,6 +2136,160 @@ extern "C" int32_t p2w_vote(const int32_t* nbr, const int32_t* deg, int32_t k, c
     return P2W_LAUNCH_STATUS();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Exact fp64 re-ranking of a kNN result: the back-projection's neighbour sets as the reference's KD-tree finds them
+// (predicter.py:136-137: KDTree over the float64 `classified_pc`, queried with float64 originals - distances are fp64).
+// The grid search above measures in fp32 on plot-local coordinates, so candidates whose fp64 distances differ by less than an
+// fp32 rounding can swap at the k-th place.  Any k candidates bound the true k-th distance from above: with R2 = the largest
+// fp64 distance of the fp32 result's members, the true k nearest all lie within R2.  One wave per query gathers every
+// candidate within R2 (fp64 distance, ((dx^2 + dy^2) + dz^2) rounded like the CPU KD-trees' loops) from the grid rows the
+// ball touches - normally k + a few - and ranks them by (distance, candidate index): the first k, in that order, replace
+// the result.  More than RF_CAP candidates within R2 (piles of coincident points): the k smallest are extracted one by
+// one by repeated scans instead (slow, exact).
+// ------------------------------------------------------------------------------------------------
+constexpr int RF_CAP = 128;
+__global__ __launch_bounds__(256) void knn_refine_kernel(const double* __restrict__ cs, const int* __restrict__ cidx,
+                                                         const int* __restrict__ inv, const unsigned long long* __restrict__ keys,
+                                                         const int* __restrict__ cell_start, const p2w_grid* __restrict__ gridp,
+                                                         double ox, double oy, double oz, const double* __restrict__ q, int m, int nc,
+                                                         int k, int* __restrict__ nbr, int* __restrict__ deg) {
+    __shared__ double s_d[4][RF_CAP];
+    __shared__ int s_i[4][RF_CAP];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int qi = blockIdx.x * 4 + w;
+    if (qi >= m) return;                                  // (no workgroup barrier below: waves are independent)
+    const int n_in = min(deg[qi], k);
+    if (n_in <= 0) return;
+    const double qx = q[3 * (size_t)qi], qy = q[3 * (size_t)qi + 1], qz = q[3 * (size_t)qi + 2];
+    auto d2 = [&](const double* c) {
+        const double dx = qx - c[0], dy = qy - c[1], dz = qz - c[2];
+        return (dx * dx + dy * dy) + dz * dz;
+    };
+    auto wmax = [](double v) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+        return v;
+    };
+    double dl = -1.0;
+    int jl = -1;
+    if (lane < n_in) {
+        jl = nbr[(size_t)qi * k + lane];
+        dl = d2(cs + 3 * (size_t)inv[jl]);
+    }
+    double* sd = s_d[w];
+    int* si = s_i[w];
+    int T = 0;
+    if (n_in < k) {   // fewer candidates than k exist: the result holds all of them, only their order is at stake
+        if (lane < n_in) { sd[lane] = dl; si[lane] = jl; }
+        T = n_in;
+    }
+    const double R2 = wmax(dl);
+    const p2w_grid g = *gridp;
+    int lo_c[3], hi_c[3];
+    {
+        const double R = sqrt(R2) * (1.0 + 1e-12) + 1e-300;
+        const double ql[3] = {qx - ox - (double)g.lo[0], qy - oy - (double)g.lo[1], qz - oz - (double)g.lo[2]};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            // cells were taken from fp32 local coordinates by fp32 arithmetic: allow for both roundings (in cells)
+            const double mrg = 1e-6 + 2.4e-7 * (double)g.dims[a];
+            const double top = (double)(g.dims[a] - 1);
+            lo_c[a] = (int)fmin(fmax(floor((ql[a] - R) / (double)g.res - mrg), 0.0), top);
+            hi_c[a] = (int)fmin(fmax(floor((ql[a] + R) / (double)g.res + mrg), 0.0), top);
+        }
+    }
+    const int ny = hi_c[1] - lo_c[1] + 1, nz = hi_c[2] - lo_c[2] + 1;
+    const long long rows = (long long)ny * nz;
+    auto start = [&](unsigned long long key) {
+        return cell_start ? cell_start[key] : lower_bound_key(keys, 0, nc, key);
+    };
+    // visit(p, d): every candidate position p of the rows the ball touches, lanes in lockstep; returns nothing
+    auto scan = [&](auto&& visit) {
+        for (long long t0 = 0; t0 < rows; t0 += 64) {
+            const long long t = t0 + lane;
+            int a = 0, b = 0;
+            if (t < rows) {
+                const long long cy = lo_c[1] + t % ny, cz = lo_c[2] + t / ny;
+                const unsigned long long base = (unsigned long long)((cz * g.dims[1] + cy) * g.dims[0]);
+                a = start(base + lo_c[0]);
+                b = start(base + hi_c[0] + 1);
+            }
+            int len = b - a;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) len = max(len, __shfl_xor(len, off));
+            for (int s = 0; s < len; ++s) {
+                const int p = a + s;
+                const bool act = p < b;
+                const double d = act ? d2(cs + 3 * (size_t)p) : INFINITY;
+                visit(p, d, act);
+            }
+        }
+    };
+    if (n_in >= k) {
+        scan([&](int p, double d, bool act) {
+            const bool hit = act && d <= R2;
+            const unsigned long long bal = __ballot(hit);
+            if (hit) {
+                const int slot = T + __popcll(bal & ((1ull << lane) - 1ull));
+                if (slot < RF_CAP) { sd[slot] = d; si[slot] = cidx[p]; }
+            }
+            T += __popcll(bal);
+        });
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (T <= RF_CAP) {
+        for (int e = lane; e < T; e += 64) {
+            const double de = sd[e];
+            const int ie = si[e];
+            int rank = 0;
+            for (int f = 0; f < T; ++f) {
+                const double df = sd[f];
+                const int jf = si[f];
+                rank += (df < de || (df == de && jf < ie)) ? 1 : 0;
+            }
+            if (rank < k) nbr[(size_t)qi * k + rank] = ie;
+        }
+        if (lane == 0) deg[qi] = min(T, k);
+        return;
+    }
+    // overflow: the k smallest (distance, index) pairs one after the other
+    double pd = -1.0;
+    int pi = -1;
+    for (int r = 0; r < k; ++r) {
+        double bd = INFINITY;
+        int bi = 0x7fffffff;
+        scan([&](int p, double d, bool act) {
+            if (!act || d > R2) return;
+            const int i = cidx[p];
+            if (!(d > pd || (d == pd && i > pi))) return;       // not behind the previous pick
+            if (d < bd || (d == bd && i < bi)) { bd = d; bi = i; }
+        });
+        double md = bd;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) md = fmin(md, __shfl_xor(md, off));
+        int mi = bd == md ? bi : 0x7fffffff;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) mi = min(mi, __shfl_xor(mi, off));
+        if (lane == 0) nbr[(size_t)qi * k + r] = mi;
+        pd = md; pi = mi;
+    }
+    if (lane == 0) deg[qi] = k;
+}
+
+extern "C" int32_t p2w_knn_refine_f64(const double* cand_sorted, const int32_t* cand_index, const int32_t* cand_pos,
+                                      const uint64_t* keys_sorted, const int32_t* cell_start, const p2w_grid* grid, double ox, double oy,
+                                      double oz, const double* q, int32_t m, int32_t nc, int32_t k, int32_t* nbr, int32_t* deg,
+                                      p2w_stream_t stream) {
+    if (m == 0 || nc == 0) return P2W_OK;
+    P2W_CHECK_PTR(cand_sorted); P2W_CHECK_PTR(cand_index); P2W_CHECK_PTR(cand_pos); P2W_CHECK_PTR(keys_sorted); P2W_CHECK_PTR(grid);
+    P2W_CHECK_PTR(q); P2W_CHECK_PTR(nbr); P2W_CHECK_PTR(deg);
+    if (m < 0 || nc < 0 || k <= 0 || k > P2W_MAX_K) return P2W_EINVAL;
+    knn_refine_kernel<<<p2w_cdiv(m, 4), 256, 0, p2w_s(stream)>>>(cand_sorted, cand_index, cand_pos,
+                                                                reinterpret_cast<const unsigned long long*>(keys_sorted), cell_start, grid,
+                                                                ox, oy, oz, q, m, nc, k, nbr, deg);
+    return P2W_LAUNCH_STATUS();
+}
+
 __global__ __launch_bounds__(256) void fill_batch_nbr_kernel(const int* __restrict__ batch, int m, int* __restrict__ nbr,
                                                              int* __restrict__ deg) {
     const int i = blockIdx.x * 256 + threadIdx.x;

@@ -754,18 +754,20 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void gemm_h2g_kernel(const _Float1
 // ONE in-order counter on gfx950): that barrier waits with a COUNTED vmcnt - the DMA is older than every store of the
 // epilogue, so "at most n outstanding" with n <= the number of stores behind it means the DMA has landed.
 // ------------------------------------------------------------------------------------------------
-template <int PREC, int WR, int WC, int RT, int CT, bool DOTK = false>
-__global__ __launch_bounds__(64 * WR * WC, 2) void gemm_hp_kernel(const _Float16* __restrict__ A, int ldh_a,
-                                                               const _Float16* __restrict__ Wh, float wscale, int M, int N,
-                                                               int Kpad, int nMt, int nNt, int nvb, EpiArgs ep, OutArgs o, int ef,
-                                                               int tmode, int stagger) {
+// SK = the split-K tail form (gemm_hp_sk_kernel below): a workgroup runs ONE piece - the K slabs [j nslab / S, (j + 1) nslab / S)
+// of one tile of a (tail) row range - and leaves it as RAW fp32 accumulators in `skws`; gemm_hp_skfix_kernel adds a tile's S
+// pieces in a fixed order and runs the epilogue.  Same stage image, DMA, fragment reads and MFMAs.  Pieces are numbered
+// split-major (piece = j * tiles + tile) and dealt to the XCDs in contiguous blocks, so the workgroups that share an L2 run
+// neighbouring tiles over the SAME K range side by side: a slab of A or W fetched by one is an L2 hit for the others (pieces of
+// one tile side by side - the stream-K order - share nothing: measured fabric-bound at 2.2 us per slab instead of 1.1).
+// `nvb` carries the tile count, `stagger` the split count S.
+template <int PREC, int WR, int WC, int RT, int CT, bool DOTK, bool SK>
+__device__ __forceinline__ void gemm_hp_body(const _Float16* __restrict__ A, int ldh_a, const _Float16* __restrict__ Wh, float wscale,
+                                             int M, int N, int Kpad, int nMt, int nNt, int nvb, const EpiArgs& ep, const OutArgs& o,
+                                             int ef, int tmode, int stagger, float* __restrict__ skws) {
     constexpr int KS = HCfg<PREC>::kslab;
     constexpr int BM = 32 * RT * WR, BN = 32 * CT * WC, NW = WR * WC;
     constexpr int A_CH = 8 * BM, STAGE_CH = A_CH + 8 * BN;
-    if (stagger > 0 && ((blockIdx.x >> 3) & 1)) {   // start stagger (100 MHz ticks): every other workgroup of an XCD starts late
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)stagger) __builtin_amdgcn_s_sleep(16);
-    }
     constexpr bool HALF = NW == 8;                        // 8-wave tile: waves 0..3 issue the whole stage (see gemm_h2g_kernel)
     constexpr int NWI = HALF ? NW / 2 : NW;
     constexpr int NI = STAGE_CH / 64 / NWI;
@@ -781,8 +783,26 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void gemm_hp_kernel(const _Float16
         }
         return false;
     };
+    const int nslab = Kpad / KS;
     int L = blockIdx.x, mt, nt;
-    if (!next_tile(L, mt, nt)) return;
+    int sk_s0 = 0, sk_s1 = 0, sk_piece = 0;   // SK: this workgroup's slab range and piece number
+    if constexpr (SK) {
+        const int S = stagger, P = nvb * S, per_xcd = (P + 7) >> 3;
+        const int w = blockIdx.x >> 3;
+        sk_piece = (blockIdx.x & 7) * per_xcd + w;
+        if (w >= per_xcd || sk_piece >= P) return;
+        const int j = sk_piece / nvb, r = sk_piece - j * nvb;
+        sk_s0 = (int)((long long)j * nslab / S);
+        sk_s1 = (int)((long long)(j + 1) * nslab / S);
+        if (sk_s0 >= sk_s1) return;              // (S <= nslab: never; the fix-up skips empty pieces the same way)
+        mt = r / nNt; nt = r - mt * nNt;
+    } else {
+        if (stagger > 0 && ((blockIdx.x >> 3) & 1)) {   // start stagger (100 MHz ticks): every other workgroup of an XCD starts late
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)stagger) __builtin_amdgcn_s_sleep(16);
+        }
+        if (!next_tile(L, mt, nt)) return;
+    }
 
     const _Float16* src[NI];
     auto setup_src = [&](int mt_, int nt_) {   // per-lane DMA sources of a tile (LDS image: gemm_h2g_kernel)
@@ -823,11 +843,10 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void gemm_hp_kernel(const _Float16
         const int rb = BM + wc * 32 * CT + 16 * t + r16;
         offB[t] = (rb * 8 + (kg ^ ((rb >> 1) & 7))) * 16;
     }
-    const int nslab = Kpad / KS;
     setup_src(mt, nt);
     if (issuer) {
 #pragma unroll
-        for (int i = 0; i < NI; ++i) issue_piece(i, 0, 0);
+        for (int i = 0; i < NI; ++i) issue_piece(i, 0, SK ? sk_s0 * 64 : 0);
     }
     int gs = 0;        // slabs done by this workgroup: stage of the current slab = gs & 1
     bool landed = false;   // the DMA of the slab about to start has been waited for already (behind the previous tile's epilogue)
@@ -893,6 +912,20 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void gemm_hp_kernel(const _Float16
         }
         ++gs;
     };
+    if constexpr (SK) {
+#pragma unroll
+        for (int i = 0; i < RT16; ++i)
+#pragma unroll
+            for (int j = 0; j < CT16; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int s = sk_s0; s + 1 < sk_s1; ++s) slab(s, std::false_type{}, 0, 0);
+        slab(sk_s1 - 1, std::true_type{}, mt, nt);   // (behind the last slab: a replay of this tile's slab 0 nobody reads)
+        // raw accumulators in register order
+        f32x4* dst = reinterpret_cast<f32x4*>(skws) + (size_t)sk_piece * (size_t)(BM * BN / 4) + tid;
+#pragma unroll
+        for (int i = 0; i < RT16; ++i)
+#pragma unroll
+            for (int j = 0; j < CT16; ++j) dst[(i * CT16 + j) * (64 * NW)] = acc[i][j];
+    } else {
     while (true) {
         int Ln = L + gridDim.x, mtn = mt, ntn = nt;
         const bool more = next_tile(Ln, mtn, ntn);
@@ -908,14 +941,61 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void gemm_hp_kernel(const _Float16
         if (!more) break;
         L = Ln; mt = mtn; nt = ntn;
     }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the replayed stage behind the last tile
+}
+
+template <int PREC, int WR, int WC, int RT, int CT, bool DOTK = false>
+__global__ __launch_bounds__(64 * WR * WC, 2) void gemm_hp_kernel(const _Float16* __restrict__ A, int ldh_a,
+                                                               const _Float16* __restrict__ Wh, float wscale, int M, int N,
+                                                               int Kpad, int nMt, int nNt, int nvb, EpiArgs ep, OutArgs o, int ef,
+                                                               int tmode, int stagger) {
+    gemm_hp_body<PREC, WR, WC, RT, CT, DOTK, false>(A, ldh_a, Wh, wscale, M, N, Kpad, nMt, nNt, nvb, ep, o, ef, tmode, stagger, nullptr);
+}
+
+// Split-K tail (see gemm_hp_body): A = first row of the tail range, M = its rows; tiles are numbered row-major (tile r: row
+// tile r / nNt, column tile r % nNt); grid = 8 * ceil(tiles * S / 8) workgroups.
+template <int PREC, int WR, int WC, int RT, int CT>
+__global__ __launch_bounds__(64 * WR * WC, 2) void gemm_hp_sk_kernel(const _Float16* __restrict__ A, int ldh_a,
+                                                                  const _Float16* __restrict__ Wh, int M, int Kpad, int nNt,
+                                                                  int tiles, int S, float* __restrict__ skws) {
+    const EpiArgs ep = {};
+    const OutArgs o = {};
+    gemm_hp_body<PREC, WR, WC, RT, CT, false, true>(A, ldh_a, Wh, 1.f, M, 0, Kpad, 0, nNt, tiles, ep, o, 0, 0, S, skws);
+}
+
+// The fix-up behind gemm_hp_sk_kernel: one workgroup (of the GEMM's shape) per tail tile adds the tile's S pieces in ascending
+// K order - a fixed order: results do not depend on timing - and runs the GEMM's epilogue on the sums.
+template <int PREC, int WR, int WC, int RT, int CT>
+__global__ __launch_bounds__(64 * WR * WC) void gemm_hp_skfix_kernel(const float* __restrict__ skws, int tiles, int S, int nslab, int nNt,
+                                                                      float wscale, int M, int N, EpiArgs ep, OutArgs o, int ef) {
+    constexpr int BM = 32 * RT * WR, BN = 32 * CT * WC, NW = WR * WC, RT16 = 2 * RT, CT16 = 2 * CT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wave / WC, wc = wave % WC;
+    const int r = blockIdx.x;
+    f32x4 acc[RT16][CT16];
+#pragma unroll
+    for (int i = 0; i < RT16; ++i)
+#pragma unroll
+        for (int j = 0; j < CT16; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < S; ++j) {
+        if ((int)((long long)j * nslab / S) >= (int)((long long)(j + 1) * nslab / S)) continue;   // an empty piece was never written
+        const f32x4* src = reinterpret_cast<const f32x4*>(skws) + (size_t)(j * tiles + r) * (size_t)(BM * BN / 4) + tid;
+#pragma unroll
+        for (int i = 0; i < RT16; ++i)
+#pragma unroll
+            for (int jj = 0; jj < CT16; ++jj) acc[i][jj] += src[(i * CT16 + jj) * (64 * NW)];
+    }
+    const int mt = r / nNt, nt = r - mt * nNt;
+    gemm_epilogue_dispatch16<PREC, RT16, CT16, false, false>(acc, ep, wscale, mt * BM + wr * 32 * RT, nt * BN + wc * 32 * CT, lane, M, N, o, ef);
 }
 
 // host side of p2w_gemm_h2 for one precision (argument checks that do not depend on it are done by the caller)
 template <int PREC>
 static int32_t launch_gemm_h(const _Float16* Ah, int32_t ldh_a, const _Float16* Wp, float wscale, int32_t M, int32_t N, int32_t K,
                              const EpiArgs& ep, float* out_f32, int32_t ldo, _Float16* out_h2, int32_t ldh_o, int32_t flags,
-                             hipStream_t stream, const float* dotw = nullptr, float* part = nullptr, int32_t ldpart = 0) {
+                             hipStream_t stream, const float* dotw = nullptr, float* part = nullptr, int32_t ldpart = 0,
+                             float* skws = nullptr, size_t skws_bytes = 0, int sk_S = 0) {
     constexpr int KA = HCfg<PREC>::kalign;
     const int Npad = (N + 255) / 256 * 256, Kpad = (K + KA - 1) / KA * KA;
     if ((ldh_a % KA) != 0 || ldh_a < Kpad) return P2W_EINVAL;     // K padding must exist (and be zero) in A as well
@@ -928,15 +1008,89 @@ static int32_t launch_gemm_h(const _Float16* Ah, int32_t ldh_a, const _Float16* 
     // whole rounds of the chip, from 3/4 of one round up (per-launch A/B over the network's GEMMs: 207 tiles on
     // 256 CUs still win by 8 %, 340 of 512 or N = 640 padded to 768 lose by 10-25 %)
     const int n_cu = p2w_cu_count();
-    const long tiles256 = (long)p2w_cdiv(M, 256) * (Npad / 256);
-    const long rounds = (tiles256 + n_cu - 1) / n_cu;
-    const bool fills = tiles256 * 100 >= rounds * n_cu * 78;
-    bool big = N >= 256 && (N % 256) == 0 && tiles256 * 4 >= 3 * n_cu && fills;
-    // (a rule that also took long-K layers with only half a round of 256-tiles to the large tile paid off with one workgroup
-    // per tile and 32x32x16 MFMAs; with persistent workgroups on 16x16x32 the small tile wins there: M = 32768, K = 1024,
-    // N = 256: 48 vs 68 us; M = 17506, K = 2048, N = 512: 113 vs 130 us)
-    if (flags & P2W_GEMM_TILE_256) big = true;
-    if (flags & P2W_GEMM_TILE_128) big = false;
+    auto pick_big = [&](int rows) {
+        const long tiles256 = (long)p2w_cdiv(rows, 256) * (Npad / 256);
+        const long rounds = (tiles256 + n_cu - 1) / n_cu;
+        const bool fills = tiles256 * 100 >= rounds * n_cu * 78;
+        bool b = N >= 256 && (N % 256) == 0 && tiles256 * 4 >= 3 * n_cu && fills;
+        // (a rule that also took long-K layers with only half a round of 256-tiles to the large tile paid off with one workgroup
+        // per tile and 32x32x16 MFMAs; with persistent workgroups on 16x16x32 the small tile wins there: M = 32768, K = 1024,
+        // N = 256: 48 vs 68 us; M = 17506, K = 2048, N = 512: 113 vs 130 us)
+        if (flags & P2W_GEMM_TILE_256) b = true;
+        if (flags & P2W_GEMM_TILE_128) b = false;
+        return b;
+    };
+    const bool big = pick_big(M);
+    // Tail plan (needs the caller's workspace).  A launch whose tiles do not fill whole rounds of the chip's workgroup slots pays a
+    // whole round for the last, partial one (M = 17506, N = K = 2048: 552 tiles of 256 x 256 = 2.16 rounds on 256 CUs cost 3).
+    // With a workspace the rows of the WHOLE rounds run as one launch and the remaining rows as a second one: either plainly (on
+    // the tile the rule above picks for so few rows) or as a SPLIT-K tail - 128 x 128 tiles, each tile's K range cut into S pieces
+    // that run side by side (gemm_hp_sk_kernel: raw fp32 pieces in the workspace) + a fix-up launch (gemm_hp_skfix_kernel: pieces
+    // added in a fixed order, the same epilogue code).  The choice is a cost model over measured slab times - a function of the
+    // shape alone, so equal calls give equal bits.
+    if (sk_S == 0 && skws && !dotw && !(flags & P2W_GEMM_NO_STREAMK)) {
+        const int nslab = Kpad / HCfg<PREC>::kslab;
+        // per-slab times (us) of a workgroup, measured (tools/gemm_sk_ab.py, tools/gemm_launches.py): 128 x 128 tile alone on its
+        // CU / two per CU, 256 x 256 tile (one per CU)
+        const double f = PREC == 0 ? 1.0 : 0.7, ts1 = 0.9 * f, ts2 = 1.65 * f, tsb = 2.25 * f;
+        auto t_small = [&](long tiles) { return tiles > n_cu ? ts2 : ts1; };
+        // one launch on the rule's tile: the whole rounds + the partial one (whose workgroups have their CUs to themselves)
+        auto one_launch = [&](bool b, int rows) {
+            const long T = b ? (long)p2w_cdiv(rows, 256) * (Npad / 256) : (long)p2w_cdiv(rows, 128) * p2w_cdiv(N, 128);
+            const long G = b ? n_cu : 2 * n_cu, qq = T / G, R = T % G;
+            return (double)nslab * ((double)qq * (b ? tsb : ts2) + (R ? (b ? tsb : t_small(R)) : 0.0));
+        };
+        double best_cost = one_launch(big, M);
+        int best_mode = 0, best_rows_full = 0, best_S = 0;
+        bool best_big = big, sk_big = big;
+        double sk_cost = 1e30;
+        int sk_rows_full = 0, sk_S_best = 0;
+        const size_t piece_b = (size_t)128 * 128 * 4;
+        for (int cand = 0; cand < 2; ++cand) {   // tile of the whole rounds: 256 x 256 (where N allows it), 128 x 128
+            const bool b = cand == 0;
+            if (b && !(N >= 256 && (N % 256) == 0)) continue;
+            if ((flags & P2W_GEMM_TILE_256) && !b) continue;
+            if ((flags & P2W_GEMM_TILE_128) && b) continue;
+            const int BMm = b ? 256 : 128, G_m = n_cu * (b ? 1 : 2);
+            const int nNt_m = b ? Npad / 256 : p2w_cdiv(N, 128), nMt_m = p2w_cdiv(M, BMm);
+            const long T = (long)nMt_m * nNt_m, q = T / G_m;
+            const int mt_full = (int)((q * G_m) / nNt_m);          // row tiles of the whole rounds
+            if ((long)mt_full * nNt_m >= T) continue;               // no partial round
+            if (q == 0 && b != big) continue;                       // (nothing but a tail: one candidate is enough)
+            const int rows_full = mt_full * BMm, m_t = M - rows_full;
+            const double main_t = (double)q * nslab * (b ? tsb : ts2) + (q > 0 ? 4.0 : 0.0);
+            const long T_t = (long)p2w_cdiv(m_t, 128) * p2w_cdiv(N, 128);
+            if (q > 0) {   // whole rounds + a plain second launch (on the tile the rule picks for so few rows)
+                const double c = main_t + one_launch(pick_big(m_t), m_t);
+                if (c < 0.95 * best_cost) { best_cost = c; best_mode = 1; best_rows_full = rows_full; best_big = b; best_S = 0; }
+            }
+            for (int S = 2; S <= nslab && T_t * S <= 2 * n_cu; ++S) {   // ... + a split-K tail
+                if ((size_t)(T_t * S) * piece_b > skws_bytes) break;
+                const double c = main_t + (double)((nslab + S - 1) / S) * ts1 + 10.0 + (double)(T_t * S) * piece_b * 2.0 / 2.5e6;   // (pieces share their L2: the uncontended slab time holds)
+                if (c < sk_cost) { sk_cost = c; sk_rows_full = rows_full; sk_big = b; sk_S_best = S; }
+            }
+        }
+        if (sk_S_best > 0 && (sk_cost < 0.9 * best_cost || (flags & P2W_GEMM_STREAMK))) {
+            best_mode = 2; best_rows_full = sk_rows_full; best_big = sk_big; best_S = sk_S_best;
+        }
+        if (best_mode != 0) {
+            constexpr int PL = HCfg<PREC>::planes;
+            const int fl = (flags & ~(P2W_GEMM_STREAMK | P2W_GEMM_TILE_128 | P2W_GEMM_TILE_256)) | P2W_GEMM_NO_STREAMK;
+            const int rows_full = best_rows_full, m_t = M - rows_full;
+            if (rows_full > 0) {
+                const int32_t rc = launch_gemm_h<PREC>(Ah, ldh_a, Wp, wscale, rows_full, N, K, ep, out_f32, ldo, out_h2, ldh_o,
+                                                       fl | (best_big ? P2W_GEMM_TILE_256 : P2W_GEMM_TILE_128), stream);
+                if (rc != P2W_OK) return rc;
+            }
+            const size_t r0 = (size_t)rows_full;
+            EpiArgs ept = ep;
+            if (ept.residual) ept.residual += r0 * ep.ldr;
+            if (ept.res_h) ept.res_h += r0 * PL * ep.ldr;
+            return launch_gemm_h<PREC>(Ah + r0 * PL * ldh_a, ldh_a, Wp, wscale, m_t, N, K, ept, out_f32 ? out_f32 + r0 * ldo : nullptr, ldo,
+                                       out_h2 ? out_h2 + r0 * PL * ldh_o : nullptr, ldh_o, fl, stream, nullptr, nullptr, 0,
+                                       best_mode == 2 ? skws : nullptr, skws_bytes, best_mode == 2 ? best_S : 0);
+        }
+    }
     // epilogue class for the specialised interior-tile path (0 = generic); needs 32-bit element offsets
 #ifdef P2W_GEMM_STAMP
     const bool use_s1 = false;   // ep.sh1 carries the stamp buffer
@@ -1005,7 +1159,11 @@ static int32_t launch_gemm_h(const _Float16* Ah, int32_t ldh_a, const _Float16* 
         if (g >= 8) g &= ~7;
         return g;
     };
-    if (big) {
+    if (sk_S > 0) {   // this call IS a split-K tail (planned above)
+        const int nslab = Kpad / HCfg<PREC>::kslab, nNt1 = p2w_cdiv(N, 128), T_t = p2w_cdiv(M, 128) * nNt1;
+        gemm_hp_sk_kernel<PREC, 2, 2, 2, 2><<<8 * p2w_cdiv(T_t * sk_S, 8), 256, 0, stream>>>(Ah, ldh_a, Wp, M, Kpad, nNt1, T_t, sk_S, skws);
+        gemm_hp_skfix_kernel<PREC, 2, 2, 2, 2><<<T_t, 256, 0, stream>>>(skws, T_t, sk_S, nslab, nNt1, wscale, M, N, ep, o, ef);
+    } else if (big) {
         const int nMt = p2w_cdiv(M, 256), nNt2 = Npad / 256;
         const int tm = pick_mode(nNt2, nMt, 1), nvb = tile_grid(nMt, nNt2, tm);
         if (dotw) gemm_hp_kernel<PREC, 2, 4, 4, 2, true><<<pgrid(nvb, 1), 512, 0, stream>>>(Ah, ldh_a, Wp, wscale, M, N, Kpad, nMt, nNt2, nvb, ep, o, ef, tm, stagger);
@@ -1509,388 +1667,6 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
 #endif
 }
 
-// ------------------------------------------------------------------------------------------------
-// Wave-specialised form of the kernel above (round 4; P2W_SA_SPECIALIZED): same items (4 tiles x 256 columns), same LDS image
-// of a slab, same metadata, same epilogue - but the 8 waves no longer all do everything:
-//   waves 0..3 = PRODUCERS: metadata + P-row gather (global loads, three slabs ahead, in registers), the layer-1 correction +
-//                ReLU + hi/lo split on the VALU, A rows -> LDS (2 rows x 8 k per thread and slab), and the whole W2 DMA;
-//   waves 4..7 = CONSUMERS: fragment reads + MFMAs on a 128-row x 64-column wave tile (all four row tiles of the item against
-//                the wave's quarter of the columns: 128 accumulator registers, which no wave could spare beside the producer's
-//                state) and the item's epilogue.
-// One producer and one consumer share a SIMD.  A consumer never executes a vector memory load, so no `vmcnt` wait and no
-// producer VALU instruction stands in the MFMA stream, and a B fragment read serves four MFMA row tiles instead of two.
-// The producers' memory operations are ALL inline asm with hand-counted `s_waitcnt vmcnt(n)` (hipcc drains to vmcnt(0) around
-// LDS-DMA and at every register rotation of a software pipeline; a producer's iteration is 560 cycles of VALU work, so any
-// such drain would make the memory latency - 1.1 us from issue to landing for the DMA under load - the length of a slab):
-// per slab a producer thread issues, in this order, 2 metadata index loads (slab g+4), 8 DMA pieces (slab g+2 of W2, into a
-// ring of THREE B stages), 4 P-row loads (slab g+3) and 2 metadata vector loads (slab g+3) = 16 operations, and the three waits
-// of an iteration are "all but the newest 24 / 32 / 22" (derivation at the waits).  Register sets rotate by the slab number
-// modulo 3 (gathered values, metadata vectors) and 2 (metadata indices), the stages by modulo 2 (A) and 3 (B): the loop body is
-// instantiated for the 6 phases, no register is ever copied.  LDS: 2 x 16 KiB (A) + 3 x 32 KiB (B) + 20 KiB of tables.
-// One s_barrier per slab: at barrier g the consumers have finished slab g-1 and slab g is complete in A stage g & 1 / B stage g % 3.
-// ------------------------------------------------------------------------------------------------
-typedef float v4f __attribute__((ext_vector_type(4)));
-template <int PREC, int G>
-__global__ __launch_bounds__(512, 2) void sa_conv16s_kernel(const float* __restrict__ P, int ldp, const int* __restrict__ meta_j,
-                                                            const float4* __restrict__ meta_g, const int* __restrict__ desc,
-                                                            const int* __restrict__ tiles_dev, int M, const float* __restrict__ w1r4, int C1, int C1pad,
-                                                            const _Float16* __restrict__ W2h, float wscale, int C2,
-                                                            int nMt_, int nNt, const float* __restrict__ b2,
-                                                            const float* __restrict__ bn_s, const float* __restrict__ bn_t,
-                                                            float* __restrict__ out, int ldo, _Float16* __restrict__ out_h2, int ldh, int dbg_) {
-    // dbg (profiling ablations, -DP2W_SA_ABLATE builds only; wrong results): 2 no W2 DMA, 4 no MFMA, 16 no P gather, 8 no producer VALU
-#ifdef P2W_SA_ABLATE
-    const int dbg = dbg_;
-#else
-    constexpr int dbg = 0;
-    (void)dbg_;
-#endif
-    constexpr int NP = HCfg<PREC>::planes;
-    constexpr int BN = 256, BM = 128, RT = 4, NR = 2;      // consumer: RT row tiles x 2 column tiles; producer: NR rows per thread
-    constexpr int GPT = 32 / G;
-    if (tiles_dev) M = *tiles_dev;
-    const int nMt = tiles_dev ? (M + BM / 32 - 1) / (BM / 32) : nMt_;
-    if (M <= 0) return;
-    constexpr int A_CH = 4 * NP * BM, B_CH = 4 * NP * BN;   // 16-byte chunks of an A / a B stage
-    constexpr int NI = B_CH / 64 / 4;                        // W2 DMA pieces (1 KiB) per producer wave and slab
-    __shared__ __attribute__((aligned(16))) char S[(2 * A_CH + 3 * B_CH) * 16 + 4 * 512 * 4 + 3 * SA_EPI_COLS * 4];   // ONE object (see above)
-    float* const Wr = reinterpret_cast<float*>(S + (2 * A_CH + 3 * B_CH) * 16);
-    float* const Ep = Wr + 4 * 512;
-    const int tid = threadIdx.x, lane = tid & 63;
-    for (int i = tid; i < 4 * C1pad; i += 512) Wr[i] = w1r4[i];
-    for (int i = tid; i < C2; i += 512) { Ep[i] = b2[i]; Ep[SA_EPI_COLS + i] = bn_s[i]; Ep[2 * SA_EPI_COLS + i] = bn_t[i]; }
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nitems = nMt * nNt, nslab = C1pad / H_BK;
-    int first, stride, limit;   // XCD-aware work assignment, as above
-    if ((gridDim.x & 7) == 0) {
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per = gridDim.x >> 3;
-        const int chunk = (nitems + 7) >> 3;
-        first = xcd * chunk + slot; stride = per; limit = min((xcd + 1) * chunk, nitems);
-    } else {
-        first = blockIdx.x; stride = gridDim.x; limit = nitems;
-    }
-    if (first >= limit) return;
-    const int my_items = (limit - first + stride - 1) / stride;
-    const int total = my_items * nslab;
-    auto item_mt = [&](int it) { return (first + it * stride) / nNt; };
-    auto item_nt = [&](int it) { return (first + it * stride) % nNt; };
-    constexpr int RCH = 4 * NP;
-    auto img = [](int row, int chunk) { return (row * RCH + (NP == 2 ? (chunk ^ ((row >> 1) & 7)) : (chunk ^ ((row >> 2) & 3)))) * 16; };
-    struct Cur { int it, s, mt, nt; };   // a slab: its item, its number within the item, the item's row / column tile (past the end: the last one)
-    auto nxt = [&](Cur c) {
-        if (++c.s == nslab) {
-            c.s = 0; ++c.it;
-            const int itc = min(c.it, my_items - 1);
-            c.mt = item_mt(itc); c.nt = item_nt(itc);
-        }
-        return c;
-    };
-    auto k_of = [&](Cur c) { return (c.it < my_items ? c.s : nslab - 1) * H_BK; };
-    const unsigned lds_base = (unsigned)(uintptr_t)(lds_vp)S;
-    __syncthreads();   // Wr / Ep staged
-
-    if (wave < 4) {
-        // ------------------------------------------------ producers ------------------------------------------------
-        const int prow = tid >> 2, pq = tid & 3;   // rows prow, prow + 64 of the item; 8 k values (one 16-byte chunk per plane)
-        const unsigned a_dst = lds_base + (unsigned)img(prow, pq);
-        const _Float16* bsrc[NI];                  // per-lane source of the wave's DMA pieces (item and slab offsets are added at issue)
-        unsigned bdst[NI];
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int g2 = wave + 4 * i;
-            const int row = (NP == 2 ? 8 : 16) * g2 + (lane >> (NP == 2 ? 3 : 2));
-            const int c = NP == 2 ? ((lane & 7) ^ ((row >> 1) & 7)) : ((lane & 3) ^ ((row >> 2) & 3));
-            bsrc[i] = W2h + (size_t)row * (NP * C1pad) + 8 * c;
-            bdst[i] = lds_base + (unsigned)(2 * A_CH + g2 * 64) * 16u;
-        }
-        constexpr int KADV = NP == 2 ? 2 : 1;
-        auto dma = [&](int bstage, Cur c) {        // W2 slab of `c` -> B stage `bstage` (8 x 1 KiB per wave)
-            const size_t off = (size_t)c.nt * BN * NP * C1pad + (size_t)(KADV * k_of(c));
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
-                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-                             :: "v"(bsrc[i] + off), "s"(bdst[i] + (unsigned)bstage * (B_CH * 16u)) : "m0", "memory");
-        };
-        const int last_row = M * 32 - 1;
-        auto rows_of = [&](Cur c, int u) { return min(c.mt * BM + prow + 64 * u, last_row); };
-        int js[2][NR];        // metadata index (P row offset in float4 units) of the thread's rows, slab s -> js[s & 1]
-        v4f gs[3][NR];        // metadata vector (normalised offset, reflectance), slab s -> gs[s % 3]
-        v4f vs[3][NR][2];     // gathered P values, slab s -> vs[s % 3]
-        auto load_j = [&](int set, Cur c) {
-#pragma unroll
-            for (int u = 0; u < NR; ++u) asm volatile("global_load_dword %0, %1, off" : "=&v"(js[set][u]) : "v"(meta_j + rows_of(c, u)) : "memory");
-        };
-        auto load_g = [&](int set, Cur c) {
-#pragma unroll
-            for (int u = 0; u < NR; ++u) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(gs[set][u]) : "v"(meta_g + rows_of(c, u)) : "memory");
-        };
-        auto gather = [&](int set, int jset, Cur c) {   // unconditional (empty slots point at P's zero row)
-            const unsigned k4 = (unsigned)(k_of(c) >> 2) + 2u * pq;
-#pragma unroll
-            for (int u = 0; u < NR; ++u) {
-                const float4* p = reinterpret_cast<const float4*>(P) + ((unsigned)js[jset][u] + k4);
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(vs[set][u][0]) : "v"(p) : "memory");
-                asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=&v"(vs[set][u][1]) : "v"(p) : "memory");
-            }
-        };
-        auto produce = [&](int astage, int set, Cur c) {   // A rows of slab `c` from vs[set], gs[set] -> A stage `astage`
-            const int k = k_of(c) + 8 * pq;
-            float4 w[2][4];
-#pragma unroll
-            for (int half = 0; half < 2; ++half)
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) w[half][cc] = *reinterpret_cast<const float4*>(&Wr[cc * C1pad + k + 4 * half]);
-#pragma unroll
-            for (int u = 0; u < NR; ++u) {
-                const v4f rg = gs[set][u];
-                unsigned hiw[4], low[4];
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const float4 wx = w[half][0], wy = w[half][1], wz = w[half][2], wf = w[half][3];
-                    const v4f p = vs[set][u][half];
-                    // two k values per instruction (v_pk_fma_f32): the producers' VALU work stands in the consumers' MFMA issue slots
-                    const fpair g0 = {rg[0], rg[0]}, g1 = {rg[1], rg[1]}, g2 = {rg[2], rg[2]}, g3 = {rg[3], rg[3]};
-                    fpair a = {p[0], p[1]}, b = {p[2], p[3]};
-                    a = __builtin_elementwise_fma(g0, fpair{wx.x, wx.y}, a); b = __builtin_elementwise_fma(g0, fpair{wx.z, wx.w}, b);
-                    a = __builtin_elementwise_fma(g1, fpair{wy.x, wy.y}, a); b = __builtin_elementwise_fma(g1, fpair{wy.z, wy.w}, b);
-                    a = __builtin_elementwise_fma(g2, fpair{wz.x, wz.y}, a); b = __builtin_elementwise_fma(g2, fpair{wz.z, wz.w}, b);
-                    a = __builtin_elementwise_fma(g3, fpair{wf.x, wf.y}, a); b = __builtin_elementwise_fma(g3, fpair{wf.z, wf.w}, b);
-                    float v[4] = {fmaxf(a[0], 0.f), fmaxf(a[1], 0.f), fmaxf(b[0], 0.f), fmaxf(b[1], 0.f)};
-                    if constexpr (PREC == 0) {
-                        unsigned h01, l01, h23, l23;
-                        split_pair(v[0], v[1], h01, l01);
-                        split_pair(v[2], v[3], h23, l23);
-                        hiw[2 * half] = h01; hiw[2 * half + 1] = h23;
-                        low[2 * half] = l01; low[2 * half + 1] = l23;
-                    } else {
-                        hiw[2 * half] = pack_pair<PREC>(v[0], v[1]); hiw[2 * half + 1] = pack_pair<PREC>(v[2], v[3]);
-                    }
-                }
-                const unsigned sa = a_dst + (unsigned)astage * (A_CH * 16u) + (unsigned)(u * 64 * RCH * 16);
-                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-                const u32x4 hv = {hiw[0], hiw[1], hiw[2], hiw[3]};
-                asm volatile("ds_write_b128 %0, %1" :: "v"(sa), "v"(hv) : "memory");
-                if constexpr (PREC == 0) {
-                    const u32x4 lv = {low[0], low[1], low[2], low[3]};
-                    asm volatile("ds_write_b128 %0, %1" :: "v"(sa ^ 64u), "v"(lv) : "memory");
-                }
-            }
-        };
-        // `s_waitcnt vmcnt(n)` that the compiler must keep in front of every use of the named register set (one lambda per count:
-        // the count is an assembler immediate, and asm operands cannot name captured variables inside a generic lambda)
-#define P2W_WAIT_J(NAME, N) auto NAME = [&](int set) { asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(js[set][0]), "+v"(js[set][1]) :: "memory"); }
-#define P2W_WAIT_V(NAME, N) auto NAME = [&](int set) { \
-            asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(vs[set][0][0]), "+v"(vs[set][0][1]), "+v"(vs[set][1][0]), "+v"(vs[set][1][1]), \
-                                                    "+v"(gs[set][0]), "+v"(gs[set][1]) :: "memory"); }
-        // operations per iteration: 2 + NI + 4 + 2 = 16 (f16x3: NI = 8 DMA pieces) or 12 (single plane: NI = 4)
-        static_assert(NI == 8 || NI == 4, "the hand-counted waits below are written for 8 or 4 DMA pieces per wave and slab");
-        P2W_WAIT_J(wait_j0, 0);
-        P2W_WAIT_J(wait_j24, 24);   // NI = 8: (8 + 4 + 2) of the previous iteration + (2 + 8) of this one
-        P2W_WAIT_J(wait_j16, 16);   // NI = 4: (4 + 4 + 2) + (2 + 4)
-        P2W_WAIT_V(wait_v0, 0);
-        P2W_WAIT_V(wait_v32, 32);   // NI = 8: 16 + 16
-        P2W_WAIT_V(wait_v24, 24);   // NI = 4: 12 + 12
-#undef P2W_WAIT_J
-#undef P2W_WAIT_V
-        auto wait_dma = [&]() {     // NI = 8: (4 + 2) + 16 = 22; NI = 4: (4 + 2) + 12 = 18
-            if constexpr (NI == 8) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-        };
-        auto wait_lds = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
-        auto dummy_loads = [&](int n) {   // ablation builds: n loads of one hot line, so that the operation count of an iteration stays 16
-            int sink;
-            for (int i = 0; i < n; ++i) asm volatile("global_load_dword %0, %1, off" : "=&v"(sink) : "v"(meta_j) : "memory");
-        };
-        // cursors of slabs g+1 .. g+4 (c[0] = slab g+1)
-        Cur c[4];
-        c[0] = nxt(Cur{0, 0, item_mt(0), item_nt(0)});
-        c[1] = nxt(c[0]); c[2] = nxt(c[1]); c[3] = nxt(c[2]);
-        {   // prologue (synchronous): slab 0 complete in A stage 0 / B stage 0, B(1) landed, slabs 1 and 2 gathered, indices of slab 3
-            const Cur s0 = {0, 0, item_mt(0), item_nt(0)};
-            load_j(0, s0); load_j(1, c[0]);
-            wait_j0(0); wait_j0(1);
-            gather(0, 0, s0); load_g(0, s0);
-            gather(1, 1, c[0]); load_g(1, c[0]);
-            load_j(0, c[1]);
-            wait_j0(0);
-            gather(2, 0, c[1]); load_g(2, c[1]);
-            load_j(1, c[2]);                      // slab 3 -> js[1]
-            dma(0, s0); dma(1, c[0]);
-            wait_v0(0); wait_v0(1); wait_v0(2); wait_j0(1);
-            produce(0, 0, s0);
-        }
-        // iteration g, phase ph = g % 6: slab numbers modulo 2 / 3 are compile-time functions of ph
-        auto step = [&](auto ph_, int g) -> bool {
-            constexpr int ph = decltype(ph_)::value;
-            if (g >= total) return false;
-            wait_lds();                                            // this wave's ds_writes of A(g)
-            __builtin_amdgcn_s_barrier();                          // slab g complete for the consumers; stages of slab g-1 free
-            load_j((ph + 4) & 1, c[3]);                            // 2: indices of slab g+4
-            if (!(dbg & 2)) dma((ph + 2) % 3, c[1]);               // 8: W2 of slab g+2
-            else dummy_loads(NI);                                  // (ablation: the hand-counted waits need the operations' number)
-            // indices of slab g+3: issued first in iteration g-1; newer: 14 of that iteration + the 10 above
-            if constexpr (NI == 8) wait_j24((ph + 3) & 1); else wait_j16((ph + 3) & 1);
-            if (!(dbg & 16)) gather(ph % 3, (ph + 3) & 1, c[2]);   // 4: P rows of slab g+3 (set (g+3) % 3 = g % 3)
-            else dummy_loads(2 * NR);
-            load_g(ph % 3, c[2]);                                  // 2: metadata vectors of slab g+3
-            // values + vectors of slab g+1: the last 6 operations of iteration g-2; newer: 16 + 16
-            if constexpr (NI == 8) wait_v32((ph + 1) % 3); else wait_v24((ph + 1) % 3);
-            if (!(dbg & 8)) produce((ph + 1) & 1, (ph + 1) % 3, c[0]);   // A rows of slab g+1
-            // W2 of slab g+1: operations 3..10 of iteration g-1; newer: 6 of that iteration + 16
-            wait_dma();
-            c[0] = c[1]; c[1] = c[2]; c[2] = c[3]; c[3] = nxt(c[3]);
-            return true;
-        };
-        for (int g = 0;; g += 6) {
-            if (!step(std::integral_constant<int, 0>{}, g)) break;
-            if (!step(std::integral_constant<int, 1>{}, g + 1)) break;
-            if (!step(std::integral_constant<int, 2>{}, g + 2)) break;
-            if (!step(std::integral_constant<int, 3>{}, g + 3)) break;
-            if (!step(std::integral_constant<int, 4>{}, g + 4)) break;
-            if (!step(std::integral_constant<int, 5>{}, g + 5)) break;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing of this wave may still be landing in LDS when the workgroup retires
-        return;
-    }
-
-    // ---------------------------------------------------- consumers ----------------------------------------------------
-    // MFMA shape v_mfma_f32_16x16x32: one instruction contracts the slab's whole 32 k of a 16 x 16 tile (lane = row l & 15, k octet
-    // l >> 4: a 16-byte chunk of the row's plane, the GEMM kernel's fragment).  Same MACs per cycle as 32x32x16; a timing-only
-    // substitution promised -11 % on this kernel (the shorter instruction leaves the producer's VALU work more issue slots), the
-    // real re-tiling with its epilogue gave -3 %: 1.83 ms against 1.88 ms with 32x32x16 tiles and 1.72 - 1.80 ms for the 8-wave
-    // kernel above, which therefore stays the default (DESIGN.md "PointNetConv: what the wave-specialised kernel showed").
-    const int cw = wave - 4;                       // the wave's quarter of the item's 256 columns
-    const int r16 = lane & 15, kg = lane >> 4;
-    constexpr int RT16 = 8, CT16 = 4;              // 16-row tiles of the item's 128 rows, 16-column tiles of the wave's 64 columns
-    int offA[RT16], offB[CT16];                    // plane 0; the lo plane (f16x3) is ^ 64
-#pragma unroll
-    for (int t = 0; t < RT16; ++t) offA[t] = img(16 * t + r16, kg);
-#pragma unroll
-    for (int t = 0; t < CT16; ++t) offB[t] = 2 * A_CH * 16 + img(cw * 64 + 16 * t + r16, kg);
-    f32x4 acc[RT16][CT16];
-#pragma unroll
-    for (int i = 0; i < RT16; ++i)
-#pragma unroll
-        for (int j = 0; j < CT16; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    struct Degs { int d[RT][GPT]; };
-    auto load_deg = [&](int mt_, Degs& e) {
-#pragma unroll
-        for (int i = 0; i < RT; ++i)
-#pragma unroll
-            for (int q = 0; q < GPT; ++q) e.d[i][q] = desc[min(mt_ * (BM / 32) + i, M - 1) * GPT + q];
-    };
-    Cur c0 = {0, 0, item_mt(0), item_nt(0)}, c1 = nxt(c0);
-    Degs dg_;
-    load_deg(c0.mt, dg_);
-    int b3 = 0;                                    // g % 3
-    for (int g = 0; g < total; ++g) {
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_s_barrier();             // slab g is complete in A stage g & 1 / B stage g % 3
-        asm volatile("" ::: "memory");
-        Degs dg_n;
-        load_deg(c1.mt, dg_n);                    // descriptors of slab g+1's item (wave-uniform: scalar loads)
-        const char* sa_ = S + (size_t)(g & 1) * (A_CH * 16);
-        const char* sb_ = S + (size_t)b3 * (B_CH * 16);
-        b3 = b3 == 2 ? 0 : b3 + 1;
-        h8 af[NP][RT16], bf[NP][CT16];
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-#pragma unroll
-            for (int t = 0; t < CT16; ++t) bf[p][t] = *reinterpret_cast<const h8*>(sb_ + (offB[t] ^ (p << 6)));
-#pragma unroll
-            for (int t = 0; t < RT16; ++t) af[p][t] = *reinterpret_cast<const h8*>(sa_ + (offA[t] ^ (p << 6)));
-        }
-        if (!(dbg & 4)) {
-            // product-major order: the three MFMAs into one accumulator tile are 32 instructions apart
-            if constexpr (PREC == 0) {
-#pragma unroll
-                for (int i = 0; i < RT16; ++i)
-#pragma unroll
-                    for (int j = 0; j < CT16; ++j) acc[i][j] = h_mfma16<PREC>(af[1][i], bf[0][j], acc[i][j]);
-#pragma unroll
-                for (int i = 0; i < RT16; ++i)
-#pragma unroll
-                    for (int j = 0; j < CT16; ++j) acc[i][j] = h_mfma16<PREC>(af[0][i], bf[1][j], acc[i][j]);
-            }
-#pragma unroll
-            for (int i = 0; i < RT16; ++i)
-#pragma unroll
-                for (int j = 0; j < CT16; ++j) acc[i][j] = h_mfma16<PREC>(af[0][i], bf[0][j], acc[i][j]);
-        } else {
-#pragma unroll
-            for (int p = 0; p < NP; ++p) {
-#pragma unroll
-                for (int t = 0; t < RT16; ++t) asm volatile("" :: "v"(af[p][t]));
-#pragma unroll
-                for (int t = 0; t < CT16; ++t) asm volatile("" :: "v"(bf[p][t]));
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < RT; ++i)
-#pragma unroll
-            for (int q = 0; q < GPT; ++q) asm volatile("" : "+v"(dg_n.d[i][q]));
-        if (c0.s == nslab - 1) {   // item finished: reduce over the neighbour slots, store, start the next accumulation
-            // layer-2 bias + ReLU + BN affine and the max over a target's valid neighbour slots, as sa_epilogue_regs (monotone
-            // transform: the extremum of the raw accumulators is transformed once per column), for 16 x 16 accumulator tiles:
-            // lane l holds column l & 15 and rows 4 (l >> 4) + 0..3 of a tile; a 32-row tile (one target, or four targets of
-            // 8 slots with P2W_SA_PACK8) is two of them.
-            const int n0 = c0.nt * BN + cw * 64;
-#pragma unroll
-            for (int j = 0; j < CT16; ++j) {
-                const int col = n0 + 16 * j + r16;
-                const int colc = min(col, C2 - 1);
-                const float bias = Ep[colc], bs = Ep[SA_EPI_COLS + colc], bt = Ep[2 * SA_EPI_COLS + colc];
-                const bool cv = col < C2;
-                const float sgn = bs < 0.f ? -1.f : 1.f;
-#pragma unroll
-                for (int t = 0; t < RT; ++t) {
-#pragma unroll
-                    for (int q = 0; q < GPT; ++q) {
-                        const int dsc = (c0.mt * (BM / 32) + t >= M) ? -1 : __builtin_amdgcn_readfirstlane(dg_.d[t][q]);
-                        if (dsc < 0) continue;   // wave-uniform
-                        const int tgt = dsc >> 6, d = dsc & 63;
-                        float ext = -INFINITY;
-                        bool store_lane;
-                        if constexpr (G == 32) {
-#pragma unroll
-                            for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-                                for (int rr = 0; rr < 4; ++rr)
-                                    if (16 * hh + 4 * kg + rr < d) ext = fmaxf(ext, sgn * acc[2 * t + hh][j][rr]);
-                            const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(ext), __float_as_uint(ext), false, false);
-                            ext = fmaxf(__uint_as_float(s16[0]), __uint_as_float(s16[1]));
-                            const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(ext), __float_as_uint(ext), false, false);
-                            ext = fmaxf(__uint_as_float(s32[0]), __uint_as_float(s32[1]));
-                            store_lane = kg == 0;
-                        } else {   // rows 8 q .. 8 q + 7 of the 32-row tile: 16-row tile q >> 1, lane groups 2 (q & 1) and 2 (q & 1) + 1
-                            const bool mine = (kg >> 1) == (q & 1);
-#pragma unroll
-                            for (int rr = 0; rr < 4; ++rr)
-                                if (mine && 4 * (kg & 1) + rr < d) ext = fmaxf(ext, sgn * acc[2 * t + (q >> 1)][j][rr]);
-                            const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(ext), __float_as_uint(ext), false, false);
-                            ext = fmaxf(__uint_as_float(s16[0]), __uint_as_float(s16[1]));
-                            store_lane = kg == 2 * (q & 1);
-                        }
-                        float vmax = fmaf(fmaxf(fmaf(sgn * ext, wscale, bias), 0.f), bs, bt);
-                        if (d == 0 || !cv) vmax = 0.f;   // rows without neighbours; pad columns of an H row stay zero
-                        if (cv && store_lane && out) out[(size_t)tgt * ldo + col] = vmax;
-                        if (out_h2) {   // lanes (2p, 2p+1) hold adjacent columns: the even lane stores both as one word per plane
-                            const float nb = __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(vmax), 0xB1, 0xf, 0xf, false));
-                            if (store_lane && (lane & 1) == 0 && col < ldh) h_store2<PREC>(out_h2, ldh, tgt, col, vmax, nb);
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < RT16; ++i)
-#pragma unroll
-                for (int j = 0; j < CT16; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        dg_ = dg_n;
-        c0 = c1; c1 = nxt(c1);
-    }
-}
 
 // pre-pass kernels (p2w_feat.hip)
 __global__ __launch_bounds__(256) void sa_edge_meta_kernel(const float4* __restrict__ xyzr, const int* __restrict__ idx, const int* __restrict__ batch_dst,
@@ -1943,11 +1719,7 @@ static int32_t launch_sa_conv_h(const float* P, int32_t ldp, int32_t n_src, cons
         int grid = (int)(items < n_cu ? items : n_cu);
         if (grid >= 8) grid &= ~7;   // whole XCD rounds (see the kernel's work assignment)
         const int nMt3 = (int)p2w_cdiv(tiles_max, tpi);
-        if (wide && (flags & P2W_SA_SPECIALIZED))
-            sa_conv16s_kernel<PREC, G><<<grid, 512, 0, stream>>>(
-                P, ldp, meta_j, meta_g, desc, tiles_dev, (int)tiles_max, w1r4, C1, C1pad, W2h, wscale, C2, nMt3, nNt3, b2, bn_s, bn_t,
-                out, ldo, out_h2, ldh, sadbg);
-        else if (wide)
+        if (wide)
             sa_conv16p_kernel<PREC, 256, 2, G><<<grid, 512, 0, stream>>>(
                 P, ldp, meta_j, meta_g, desc, tiles_dev, (int)tiles_max, w1r4, C1, C1pad, W2h, (size_t)C2pad * C1pad, wscale, C2, nMt3,
                 nNt3, b2, bn_s, bn_t, out, ldo, out_h2, ldh, sadbg);
@@ -1989,7 +1761,8 @@ static int32_t launch_sa_conv_h(const float* P, int32_t ldp, int32_t n_src, cons
 // entry points of the single-plane family (defined in p2w_feat_h1.hip, called by the extern "C" dispatchers)
 int32_t p2w_gemm_h1_impl(int32_t prec, const _Float16* Ah, int32_t ldh_a, const _Float16* Wp, float wscale, int32_t M, int32_t N,
                          int32_t K, const EpiArgs& ep, float* out_f32, int32_t ldo, _Float16* out_h2, int32_t ldh_o,
-                         int32_t flags, hipStream_t stream, const float* dotw = nullptr, float* part = nullptr, int32_t ldpart = 0);
+                         int32_t flags, hipStream_t stream, const float* dotw = nullptr, float* part = nullptr, int32_t ldpart = 0,
+                         float* skws = nullptr, size_t skws_bytes = 0);
 int32_t p2w_sa_conv_h1_impl(int32_t prec, const float* P, int32_t ldp, int32_t n_src, const float* xyzr_src, const int32_t* idx,
                             const int32_t* batch_dst, const float* sf, const int32_t* nbr, const int32_t* deg, int32_t kw,
                             int32_t M, const float* w1r4, const _Float16* W2h, float wscale, int32_t C1, int32_t C2,

@@ -24,7 +24,7 @@ from dataclasses import dataclass, field, fields
 import torch
 
 from . import _lib
-from ._lib import GEMM_RESIDUAL_H, PREC_F16X3, PREC_OF, SA_PACK8, SA_SPECIALIZED, SEARCH_BOX, SEARCH_COLLECT, SEARCH_Q_ROW_IN_W, SEARCH_X_INDEX_IN_W, Epilogue, check, lib, ptr
+from ._lib import GEMM_RESIDUAL_H, PREC_F16X3, PREC_OF, SA_PACK8, SEARCH_BOX, SEARCH_COLLECT, SEARCH_Q_ROW_IN_W, SEARCH_X_INDEX_IN_W, Epilogue, check, lib, ptr
 
 BN_EPS = 1e-5
 SA_RES = (0.04, 0.08, 0.16)  # model.py:210-212
@@ -241,7 +241,6 @@ class EngineOptions:
                                   # logits are scattered back, so that the last interpolation's coarse rows and SA1's P rows come from L2.
                                   # Bit-identical; measured: interp_concat 0.303 -> 0.289 ms, the rest of the step +-0 -> off (tools/opt_ab.py)
     fp_hints: bool = True         # seed the k = 2 interpolation searches from the sampler's ranks (p2w_knn_hint2)
-    sa_specialized: bool = False  # 256-column PointNetConv items by the wave-specialised kernel (P2W_SA_SPECIALIZED: 4 producer + 4 consumer waves)
     sa_pack: bool = True          # P2W_SA_PACK8 on the ball-query level (targets with <= 8 neighbours share an MFMA tile)
     chunk_pick: bool = True       # fill-aware row-chunk sizes (pick_chunk); False: the plain budget
     chunk_full_rounds: bool = True   # a residual-block level whose tiles fill its last chip round badly: whole rounds first, rest after
@@ -256,6 +255,9 @@ class EngineOptions:
     feat_priority: int = -1
     res_priority: int = -1        # ... and of the second chunk-chain stream (part of the feature phase)
     gemm_flags: int = 0           # P2W_GEMM_* bits of include/p2w.h passed to every p2w_gemm_h2 call (A/B runs)
+    gemm_stream_k: bool = True    # GEMMs run through p2w_gemm_h2_sk with a per-stream workspace: rows that do not fill a whole chip round
+                                  # run as a stream-K tail where the library's cost model says it pays (then a level is ONE chunk:
+                                  # chunk_full_rounds does not apply)
     sa_flags: int = 0             # P2W_SA_ITEM_* bits passed to p2w_sa_conv_h (A/B runs)
 
     def __post_init__(self):
@@ -552,8 +554,24 @@ class Engine:
                  residual_h=False):
         ep = Epilogue(ptr(lin.bias), ptr(lin.sc0), ptr(lin.sh0), ptr(lin.sc1), ptr(lin.sh1), ptr(residual), ldr,
                       lin.relu0, lin.relu1, lin.relu2, lin.relu_final)
+        flags = self.gemm_flags | (GEMM_RESIDUAL_H if residual_h else 0)
+        if self.gemm_stream_k:
+            ws = self._sk_workspace(A.device)
+            self._call(name, lib().p2w_gemm_h2_sk, self.prec, ptr(A), ldh_a, ptr(lin.w16), lin.wscale, M, lin.N, lin.K, C.byref(ep),
+                       ptr(out_f32), ldo, ptr(out_h2), ldh_o, ptr(ws), ws.numel(), flags)
+            return
         self._call(name, lib().p2w_gemm_h2, self.prec, ptr(A), ldh_a, ptr(lin.w16), lin.wscale, M, lin.N, lin.K, C.byref(ep),
-                   ptr(out_f32), ldo, ptr(out_h2), ldh_o, self.gemm_flags | (GEMM_RESIDUAL_H if residual_h else 0))
+                   ptr(out_f32), ldo, ptr(out_h2), ldh_o, flags)
+
+    def _sk_workspace(self, dev):
+        """The stream-K workspace of the CURRENT stream (launches on different streams may overlap, so each stream that runs
+        GEMMs owns one; allocated once, p2w_gemm_h2_sk_ws_bytes() = 32 MiB on a 256-CU chip)."""
+        pool = self.__dict__.setdefault("_sk_ws", {})
+        key = _lib.stream()
+        ws = pool.get(key)
+        if ws is None:
+            ws = pool[key] = torch.empty(int(lib().p2w_gemm_h2_sk_ws_bytes()), dtype=torch.uint8, device=dev)
+        return ws
 
     def _features_h2(self, geo: Geometry, keep: dict | None = None):
         """H pipeline (f16x3 / fp16 / bf16): every GEMM operand is an H tensor (16-bit planes: fp16 hi/lo for f16x3, one
@@ -615,7 +633,7 @@ class Engine:
             convh = newh(M, C2)
             # level 1 is the ball query: on sparse input most targets have few neighbours, and those with <= 8 share an MFMA
             # tile four at a time (P2W_SA_PACK8); the kNN levels always fill their 32 slots
-            sa_flags = self.sa_flags | (SA_PACK8 if (l == 1 and self.sa_pack) else 0) | (SA_SPECIALIZED if self.sa_specialized else 0)
+            sa_flags = self.sa_flags | (SA_PACK8 if (l == 1 and self.sa_pack) else 0)
             meta = torch.empty(int(L.p2w_sa_conv_h_ws_bytes(M, sa_flags)) + 65536, dtype=torch.uint8, device=dev)   # per-edge (j, normalised offset) scratch (+ room for diagnostics)
             if keep is not None:
                 keep[f"sa{l}_module.ws"] = meta
@@ -628,7 +646,7 @@ class Engine:
             # residual block in row chunks: the two 4F-wide intermediates of a chunk (2 x chunk x 4F x 4 B) are written
             # and re-read while they still sit in the 256 MiB Infinity Cache instead of round-tripping HBM
             chunk = self.res_chunk_rows if self.res_chunk_rows > 0 else M
-            chunk = max(256, min(M, pick_chunk(M, chunk * 512 // E, E // 256, full_rounds=self.chunk_full_rounds) if self.chunk_pick
+            chunk = max(256, min(M, pick_chunk(M, chunk * 512 // E, E // 256, full_rounds=self.chunk_full_rounds and not self.gemm_stream_k) if self.chunk_pick
                                  else (chunk * 512 // E) // 256 * 256))   # ~same bytes per chunk at every level
             # Chunks are independent chains of four GEMMs; alternating them between two streams lets the tiles of one
             # chain fill the CUs the other leaves idle at its wave tails (a 1122-row tail chunk at level 3 otherwise

@@ -97,11 +97,12 @@ def segment_plot(pc, model, grid_sizes=(2.0, 4.0), min_pts: int = 128, max_pts: 
     for logits in model.stream(feed()):
         d = pending.popleft()
         prob.append(torch.sigmoid(torch.nan_to_num(logits)).reshape(-1))                 # predicter.py:197-199
-        xyz.append(d.pos + d.local_shift.view(-1, 3)[d.batch])                             # predicter.py:211
+        # predicter.py:203-211: the un-shifted coordinates are float64 sums of the float32 position and shift
+        xyz.append(d.pos.to(torch.float64) + d.local_shift.view(-1, 3)[d.batch].to(torch.float64))
     if xyz:
-        cls = torch.cat([torch.cat(xyz), torch.cat(prob)[:, None]], 1)
+        cls = torch.cat([torch.cat(xyz), torch.cat(prob)[:, None].to(torch.float64)], 1)
     else:
-        cls = torch.zeros((0, 4), dtype=torch.float32, device=dev)
+        cls = torch.zeros((0, 4), dtype=torch.float64, device=dev)
     if world > 1:
         cls = gather_rows(cls, dist)
         # the gather returns rank-major rows; put them back into batch order, the order a single process classifies in: the
@@ -113,14 +114,14 @@ def segment_plot(pc, model, grid_sizes=(2.0, 4.0), min_pts: int = 128, max_pts: 
         if off != cls.shape[0]:
             raise RuntimeError(f"gathered {cls.shape[0]} classified points, the batch plan holds {off}")
         cls = torch.cat([cls[start[b]: start[b] + batch_rows[b]] for b in range(len(batch_rows))]) if batch_rows else cls
-    cls_xyz, cls_prob = cls[:, :3].contiguous(), cls[:, 3].contiguous()
+    cls_xyz, cls_prob = cls[:, :3].contiguous(), cls[:, 3].to(torch.float32).contiguous()
     cls_pred = (cls_prob >= is_wood).to(torch.float32)                                       # predicter.py:200
     if stats is not None:
         _sync(dev)
         stats["classify_s"], t0 = time.perf_counter() - t0, time.perf_counter()
         stats["classified_points"] = int(cls_prob.numel())
     q0, q1 = slice_for_rank(n, rank, world)
-    label, pwood = collect_predictions(cls_xyz, cls_pred, cls_prob, pc[q0:q1, :3].to(torch.float32), any_wood=any_wood)
+    label, pwood = collect_predictions(cls_xyz, cls_pred, cls_prob, pc[q0:q1, :3], any_wood=any_wood)   # (float64 KD-tree semantics)
     if world > 1:
         both = gather_rows(torch.stack([label, pwood], 1), dist)
         label, pwood = both[:, 0].contiguous(), both[:, 1].contiguous()

@@ -169,19 +169,23 @@ def classify_batch(model, data, is_wood: float, device):
     logits = torch.nan_to_num(model(data))
     probs = torch.sigmoid(logits).reshape(-1)
     preds = (probs >= is_wood).to(torch.int64)
+    return _rows(data, preds, probs).cpu().numpy()
+
+
+def _rows(data, preds, probs):
+    """[n, 5] float64 = (un-shifted xyz, prediction, probability) as predicter.py:203-211 builds them: numpy's concatenate of
+    float32 positions, int64 predictions and float32 probabilities is float64, and the shift is added to THAT array - the
+    un-shifted coordinates are the float64 sums of two float32 values, not their float32 sums."""
     shift = data.local_shift.reshape(-1, 3)[data.batch.long()]
-    xyz = data.pos[:, :3] + shift
-    out = torch.cat([xyz, preds[:, None].to(xyz.dtype), probs[:, None].to(xyz.dtype)], dim=1)
-    return out.cpu().numpy()
+    xyz = data.pos[:, :3].to(torch.float64) + shift.to(torch.float64)
+    return torch.cat([xyz, preds[:, None].to(torch.float64), probs[:, None].to(torch.float64)], dim=1)
 
 
 def _consume(logits, data, is_wood: float):
     """The post-processing of one batch (predicter.py:197-211) on the device: [n, 5] = un-shifted xyz, prediction, probability."""
     probs = torch.sigmoid(torch.nan_to_num(logits)).reshape(-1)
     preds = (probs >= is_wood).to(torch.int64)
-    shift = data.local_shift.reshape(-1, 3)[data.batch.long()]
-    xyz = data.pos[:, :3] + shift
-    return torch.cat([xyz, preds[:, None].to(xyz.dtype), probs[:, None].to(xyz.dtype)], dim=1)
+    return _rows(data, preds, probs)
 
 
 def classify(model, loader, is_wood: float = 0.5, device="cuda"):
@@ -199,9 +203,9 @@ def classify(model, loader, is_wood: float = 0.5, device="cuda"):
         with torch.no_grad():
             for logits in model.stream(feed()):
                 outs.append(_consume(logits, held.pop(0), is_wood))
-        return torch.cat(outs).cpu().numpy() if outs else np.zeros((0, 5), dtype=np.float32)
+        return torch.cat(outs).cpu().numpy() if outs else np.zeros((0, 5), dtype=np.float64)
     outs = [classify_batch(model, data, is_wood, device) for data in loader]
-    return np.vstack(outs) if outs else np.zeros((0, 5), dtype=np.float32)
+    return np.vstack(outs) if outs else np.zeros((0, 5), dtype=np.float64)
 
 
 def classify_sharded(model, dataset, batches, is_wood, device, dist):
@@ -218,7 +222,7 @@ def classify_sharded(model, dataset, batches, is_wood, device, dist):
         data = Batch.from_data_list([dataset[i] for i in batches[bid]])
         mine.append(classify_batch(model, data, is_wood, device))
         rows_of[bid] = mine[-1].shape[0]
-    local = torch.from_numpy(np.vstack(mine) if mine else np.zeros((0, 5), dtype=np.float32)).to(device)
+    local = torch.from_numpy(np.vstack(mine) if mine else np.zeros((0, 5), dtype=np.float64)).to(device)
     rows_of = rows_of.to(device)
     dist.all_reduce(rows_of)                           # every batch has exactly one owner: the sum is its row count
     rows_of = [int(c) for c in rows_of.cpu()]
@@ -234,4 +238,4 @@ def classify_sharded(model, dataset, batches, is_wood, device, dist):
             where[bid] = (r, off, rows_of[bid])
             off += rows_of[bid]
     ordered = [out[where[b][0]][where[b][1]: where[b][1] + where[b][2]] for b in range(len(batches))]
-    return torch.cat(ordered).cpu().numpy() if ordered else np.zeros((0, 5), dtype=np.float32)
+    return torch.cat(ordered).cpu().numpy() if ordered else np.zeros((0, 5), dtype=np.float64)

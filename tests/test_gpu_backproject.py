@@ -67,19 +67,71 @@ def test_collect_predictions_exact_on_lattice_coordinates(any_wood):
     assert np.array_equal(pw.cpu().numpy()[untied], ref[untied, 1].astype(np.float32))
 
 
-def test_collect_predictions_general_coordinates_and_chunks():
-    """Arbitrary fp32 coordinates: the fp32 search may swap candidates whose fp64 distances differ by < 1 ulp(fp32);
-    agreement must be essentially total, and chunked == unchunked exactly."""
-    from pointstowood_amd.backproject import collect_predictions
-    cls, pred, prob, q = _scene(80000, 30000, 5)
-    classification = np.concatenate([cls.astype(np.float64), pred[:, None], prob[:, None]], 1)
-    ref = OB.collect_predictions(classification, q, 1.0)
-    t = [torch.from_numpy(a).cuda() for a in (cls, pred, prob, q)]
-    lab, pw = collect_predictions(*t)
-    lab2, pw2 = collect_predictions(*t, chunk=7000, cell=0.17)
-    assert torch.equal(lab, lab2) and torch.equal(pw, pw2)         # exact search: grid cell / chunking cannot matter
-    assert (lab.cpu().numpy() == ref[:, 0]).mean() > 0.9995
-    assert (np.abs(pw.cpu().numpy() - ref[:, 1]) < 1e-6).mean() > 0.999
+def _twin_scene(offset, seed=5, n_cls=40000, n_q=30000):
+    """Arbitrary float64 coordinates the way a plot produces them: every classified point occurs twice (the two voxel grid
+    sizes), the copies a rounding apart (each is the float64 sum of a float32 position and a float32 shift,
+    predicter.py:211), at a survey-grade offset.  float32 cannot tell the copies apart; float64 can."""
+    cls, pred, prob, q = _scene(n_cls, n_q, seed)
+    g = np.random.default_rng(seed + 100)
+    base = cls.astype(np.float64) + np.asarray(offset, dtype=np.float64)
+    twin = base + g.standard_normal(base.shape) * 2e-7
+    cls64 = np.concatenate([base, twin])
+    perm = g.permutation(len(cls64))
+    cls64 = cls64[perm]
+    prob2 = np.concatenate([prob, g.random(n_cls).astype(np.float32)])[perm]
+    pred2 = (prob2 >= 0.5).astype(np.float32)
+    q64 = q.astype(np.float64) + np.asarray(offset, dtype=np.float64) + g.standard_normal(q.shape) * 1e-4
+    return cls64, pred2, prob2, q64
+
+
+@pytest.mark.parametrize("offset", [(0.0, 0.0, 0.0), (5.0e5, 6.2e6, 100.0)])
+@pytest.mark.parametrize("any_wood", [1.0, 0.5])
+def test_collect_predictions_general_coordinates_and_chunks(offset, any_wood):
+    """Arbitrary float64 coordinates, near-coincident copies, a 5e5 / 6e6 m offset: the neighbour SETS are the float64
+    KD-tree's (predicter.py:136-137) wherever the k-th and (k + 1)-th float64 distances differ - label and pwood EQUAL
+    there, not 'mostly' - and chunking / cell size cannot matter."""
+    from scipy.spatial import cKDTree
+    from pointstowood_amd.backproject import collect_predictions, neighbours
+    cls64, pred, prob, q64 = _twin_scene(offset)
+    k = 64 if any_wood == 1 else 32
+    classification = np.concatenate([cls64, pred[:, None].astype(np.float64), prob[:, None].astype(np.float64)], 1)
+    ref = OB.collect_predictions(classification, q64, any_wood)
+    d, ref_idx = cKDTree(cls64).query(q64, k=k + 1)
+    untied = d[:, k - 1] < d[:, k]
+    assert untied.mean() > 0.99
+    t = [torch.from_numpy(a).cuda() for a in (cls64, pred, prob, q64)]
+    lab, pw = collect_predictions(*t, any_wood=any_wood)
+    lab2, pw2 = collect_predictions(*t, any_wood=any_wood, chunk=7000, cell=0.17)
+    assert torch.equal(lab, lab2) and torch.equal(pw, pw2)
+    assert np.array_equal(lab.cpu().numpy()[untied], ref[untied, 0].astype(np.float32))
+    assert np.array_equal(pw.cpu().numpy()[untied], ref[untied, 1].astype(np.float32))
+    # the index sets themselves, and their order (ascending float64 distance)
+    got = np.full((len(q64), k), -1, dtype=np.int64)
+    for rows, nbr, deg in neighbours(t[0], t[3], k, chunk=11000):
+        assert bool((deg == k).all())
+        got[rows.cpu().numpy()] = nbr.cpu().numpy()
+    strict = untied & (np.diff(d[:, :k], axis=1) > 0).all(1)            # no ties inside the set either: the order is unique
+    assert np.array_equal(np.sort(got[untied], 1), np.sort(ref_idx[untied, :k], 1))
+    assert np.array_equal(got[strict], ref_idx[strict, :k])
+
+
+def test_refine_survives_piles_of_coincident_points():
+    """More candidates inside the fp32 result's bound than the refinement's list holds (300 exact copies of one point): the
+    one-by-one extraction takes over; ties go to the lower index."""
+    from pointstowood_amd.backproject import neighbours
+    g = np.random.default_rng(1)
+    cls = g.random((5000, 3)) * 4.0
+    cls[1000:1300] = cls[1000]                                   # a pile of 300 coincident points
+    q = np.concatenate([cls[1000][None] + 1e-3, g.random((200, 3)) * 4.0])
+    t = [torch.from_numpy(a).cuda() for a in (cls, q)]
+    got = np.zeros((len(q), 64), dtype=np.int64)
+    for rows, nbr, deg in neighbours(t[0], t[1], 64):
+        got[rows.cpu().numpy()] = nbr.cpu().numpy()
+    d = ((q[:, None, :] - cls[None, :, :]) ** 2)
+    d2 = (d[:, :, 0] + d[:, :, 1]) + d[:, :, 2]
+    want = np.lexsort((np.broadcast_to(np.arange(len(cls)), d2.shape), d2), axis=1)[:, :64]
+    assert np.array_equal(got, want)
+    assert np.array_equal(got[0], np.arange(1000, 1064))
 
 
 def test_fewer_classified_points_than_k():

@@ -170,13 +170,14 @@ def test_packed_pointnetconv_is_bit_identical(precision):
         assert bool(torch.isfinite(a).all()) and torch.equal(a, b)
 
 
-@pytest.mark.parametrize("option", ["fp1_cell_order", "search_collect", "sa_specialized"])
+@pytest.mark.parametrize("option", ["fp1_cell_order", "search_collect", "gemm_stream_k"])
 @pytest.mark.parametrize("precision", ["f16x3", "fp16"])
-def test_round4_engine_switches_keep_the_logits(option, precision):
-    """The round-4 A/B switches give the default path's results: `fp1_cell_order` (level-0 features in the sampler's cell order,
-    logits scattered back: rows are only re-arranged) and `search_collect` (k = 32 selection by collected candidates + sorting
-    networks) bit for bit; `sa_specialized` (wave-specialised PointNetConv with 16x16x32 MFMA tiles: another k order inside a
-    slab) within the parity bar of the default - on ragged batches with tiny voxels, through forward and through Net.stream."""
+def test_engine_switches_keep_the_logits(option, precision):
+    """The A/B switches give the default path's results: `fp1_cell_order` (level-0 features in the sampler's cell order, logits
+    scattered back: rows are only re-arranged) and `search_collect` (k = 32 selection by collected candidates + sorting
+    networks) bit for bit; `gemm_stream_k` (GEMM rows behind the whole chip rounds as a split-K tail: a tail tile's K range is
+    summed in pieces) within the last fp32 bits of the accumulators, far inside the parity bar - on ragged batches with tiny
+    voxels, through forward and through Net.stream."""
     from pointstowood_amd import Net
     batches = [synth.collate([synth.uniform_voxel(2.0, 6000, 91, True), synth.uniform_voxel(2.0, 900, 92, False)]),
                synth.collate([synth.uniform_voxel(2.0, 3, 94, True), synth.uniform_voxel(1.0, 4000, 95, True),
@@ -197,8 +198,9 @@ def test_round4_engine_switches_keep_the_logits(option, precision):
     torch.cuda.synchronize()
     for a, b in zip(outs[True], outs[False]):
         assert bool(torch.isfinite(a).all()) and a.shape == b.shape
-        if option == "sa_specialized" and precision == "f16x3":
-            assert (a - b).abs().max() <= 2e-4 and (torch.sigmoid(a) - torch.sigmoid(b)).abs().max() <= 5e-5
+        if option == "gemm_stream_k":
+            lim = 5e-5 if precision == "f16x3" else 2e-2    # (fp16: an H value one rounding apart moves a logit by ~1e-3)
+            assert (a - b).abs().max() <= lim
         else:
             assert torch.equal(a, b)
 

@@ -215,6 +215,66 @@ def test_gemm_h_epilogue(prec, M, N, K, flags):
 
 
 @pytest.mark.parametrize("prec", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K,flags", [(300, 200, 100, 64), (1000, 512, 516, 64), (2100, 130, 1024, 64), (5, 512, 2048, 64),
+                                         (70000, 512, 512, 64), (70000, 512, 512, 64 | 2), (17506, 2048, 2048, 0), (1122, 2048, 2048, 0),
+                                         (33000, 256, 1024, 64 | 2)])
+def test_gemm_h_stream_k_tail(prec, M, N, K, flags):
+    """p2w_gemm_h2_sk: the rows behind the whole chip rounds as a stream-K tail (forced with P2W_GEMM_STREAMK = 64, or the
+    library's own choice on the two level-3 shapes of the bench batch) - full epilogue, H residual in f16x3, fp32 + H outputs
+    into wider rows - against fp64 and against p2w_gemm_h2; twice with the same bits (the fix-up adds the pieces in a fixed order)."""
+    import ctypes as C
+    from pointstowood_amd._lib import Epilogue, check, lib, ptr, stream
+    L = lib()
+    g = torch.Generator().manual_seed(M + N + K)
+    Kc = (K + 3) // 4 * 4
+    A = torch.randn(M, Kc, generator=g)
+    A[:, K:] = 0
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    vec = lambda: torch.randn(N, generator=g)
+    bias, s0, t0 = vec(), vec(), vec()
+    Rf = torch.randn(M, (N + 3) // 4 * 4, generator=g)
+    Rf[:, N:] = 0
+    dW, wscale, Kp = _pack_h(W, prec)
+    ka = 32 if prec == 0 else 64
+    planes = 2 if prec == 0 else 1
+    ldh_a = (Kc + 4 + ka - 1) // ka * ka
+    Ah = _to_h(A, prec, ldh_a)
+    ldr = (Rf.shape[1] + 4 + ka - 1) // ka * ka
+    Rh = _to_h(Rf, prec, ldr)
+    R = _from_h(Rh, prec, ldr)[:, :N]
+    db, ds0, dt0 = bias.cuda(), s0.cuda(), t0.cuda()
+    ep = Epilogue(ptr(db), ptr(ds0), ptr(dt0), None, None, ptr(Rh), ldr, 1, 0, 0, 1)
+    ldo, ldh_o = N + 6, (N + ka - 1) // ka * ka + ka
+    ws = torch.empty(int(L.p2w_gemm_h2_sk_ws_bytes()), dtype=torch.uint8, device="cuda")
+
+    def run(sk):
+        out = torch.zeros((M, ldo), device="cuda")
+        outh = torch.zeros((M, planes * ldh_o), dtype=Ah.dtype, device="cuda")
+        if sk:
+            check(L.p2w_gemm_h2_sk(prec, ptr(Ah), ldh_a, ptr(dW), wscale, M, N, K, C.byref(ep), ptr(out), ldo, ptr(outh), ldh_o,
+                                   ptr(ws), ws.numel(), flags | 32, stream()))
+        else:
+            check(L.p2w_gemm_h2(prec, ptr(Ah), ldh_a, ptr(dW), wscale, M, N, K, C.byref(ep), ptr(out), ldo, ptr(outh), ldh_o,
+                                (flags & ~64) | 32, stream()))
+        return out, outh
+    o1, h1 = run(True)
+    o2, h2 = run(True)
+    o0, h0 = run(False)
+    assert torch.equal(o1, o2) and torch.equal(h1, h2)
+    v = torch.relu(A[:, :K].double() @ W.double().t() + bias.double()) * s0.double() + t0.double()
+    v = torch.relu(v + R)
+    scale = max(1.0, v.abs().max().item())
+    assert (o1[:, :N].cpu().double() - v).abs().max().item() <= H_TOL[prec] * scale
+    assert float(o1[:, N:].abs().max()) == 0.0                      # nothing written beyond the N output columns
+    assert (o1 - o0).abs().max().item() <= 4e-6 * scale * (K / 512) ** 0.5 + 1e-7   # the K range summed in pieces: last fp32 bits only
+    hv = _from_h(h1, prec, ldh_o)
+    assert (hv[:, :N] - o1[:, :N].cpu().double()).abs().max().item() <= (2e-6 if prec == 0 else 1e-3 if prec == 1 else 8e-3) * scale
+    pad_to = (N + ka - 1) // ka * ka
+    assert float(hv[:, N:pad_to].abs().max() if pad_to > N else 0.0) == 0.0
+    assert float(hv[:, pad_to:].abs().max()) == 0.0                 # columns beyond the launch's own stay untouched
+
+
+@pytest.mark.parametrize("prec", [0, 1, 2])
 @pytest.mark.parametrize("M,N,K,flags", [(1000, 512, 512, 0), (5, 512, 512, 0), (777, 100, 36, 0), (2049, 512, 64, 2), (2049, 512, 64, 1),
                                          (300, 130, 200, 0), (4096, 256, 128, 2), (32768, 512, 512, 0), (70000, 512, 512, 0),
                                          (70000, 512, 512, 1)])

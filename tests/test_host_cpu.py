@@ -509,7 +509,7 @@ def _cpu_collect(cls_xyz, cls_pred, cls_prob, query_xyz, any_wood=1.0, k=1):
     if cls_xyz.shape[0] == 0 or query_xyz.shape[0] == 0:
         z = torch.zeros(query_xyz.shape[0])
         return z, z.clone()
-    j = torch.cat([torch.cdist(q, cls_xyz).argmin(dim=1) for q in query_xyz.split(4096)])
+    j = torch.cat([torch.cdist(q.to(torch.float64), cls_xyz.to(torch.float64)).argmin(dim=1) for q in query_xyz.split(4096)])
     return cls_pred[j].clone(), cls_prob[j].clone()
 
 
