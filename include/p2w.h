@@ -267,10 +267,18 @@ typedef struct p2w_epilogue {
     const float* residual; /* [M, ldr] or NULL */
     int32_t ldr;
     int32_t relu0, relu1, relu2, relu_final;
+    uint32_t* range;     /* NULL, or TWO device words the H-family GEMMs (p2w_gemm_h2 / _sk / _rowdot) report the launch's range in
+                            (the caller zeroes them; p2w_gemm ignores it): range[0] is set to 1 if an epilogue value lies beyond
+                            +-P2W_RANGE_HI (or is NaN), range[1] if one lies beyond +-P2W_RANGE_LO.  It is the range watch of the
+                            split-fp16 arithmetic: past 65504 an H value has lost its low part, and a tensor WITHOUT a value of
+                            ordinary size has lost it to fp16's subnormal floor (2^-24 absolute) */
 } p2w_epilogue;
 
+#define P2W_RANGE_HI 6.0e4f
+#define P2W_RANGE_LO 0.03125f
+
 /* Packed weight: Wp[N_pad][K_pad] fp32, row n = output channel, k contiguous, zero padded
- * (K_pad = round_up(K, 32), N_pad = round_up(N, 128)); see p2w_packed_dims. */
+ * (K_pad = round_up(K, 32), N_pad = round_up(N, 256)); see p2w_packed_dims. */
 void p2w_packed_dims(int32_t N, int32_t K, int32_t* N_pad, int32_t* K_pad);
 
 /* out[M,N] = epilogue(A[M,K] * W^T): Linear / 1x1 Conv1d + folded BatchNorm / depthwise affines +
@@ -378,18 +386,21 @@ int32_t p2w_sa_conv_h_rows(int32_t prec, const float* P, int32_t ldp, int32_t n_
                            const int32_t* batch_dst, const float* sf, const int32_t* nbr, const int32_t* deg, int32_t kw,
                            int32_t M, const float* w1r4, const void* W2h, float wscale, int32_t C1, int32_t C2,
                            const float* b2, const float* bn_s, const float* bn_t, float* out, int32_t ldo, void* out_h,
-                           int32_t ldh, void* ws, size_t ws_bytes, int32_t flags, const int32_t* src_row, p2w_stream_t stream);
+                           int32_t ldh, void* ws, size_t ws_bytes, int32_t flags, const int32_t* src_row, uint32_t* range,
+                           p2w_stream_t stream);
 /* The small kernels writing H (and fp32 where given): stem (model.py:208,228), knn_interpolate + cat (:149-151),
  * cat(x, pos) (:135).  For the stem and the interpolation `ldh` is the row pitch as in p2w_gemm_h2: they write their columns
  * (C, resp. Fc + Fs) plus the zero pad to the next K-slab boundary and leave the rest of a wider row alone (p2w_interp_concat_h2
  * with skip = NULL, Fs = 0 writes only the interpolated part of a row whose skip columns another producer has written). */
+/* range (p2w_stem_h2, p2w_stem_h2_indexed, p2w_sa_conv_h_rows; NULL = off): the range watch of p2w_epilogue.range - a device
+ * pair of words (over, seen) the launch sets to 1 (the caller zeroes them). */
 int32_t p2w_stem_h2(int32_t prec, const float* xyzr, int32_t n, const float* w, const float* b, int32_t C, float* out,
-                    void* out_h, int32_t ldh, p2w_stream_t stream);
+                    void* out_h, int32_t ldh, uint32_t* range, p2w_stream_t stream);
 /* ... for records that come in another order (p2w_index_records: e.g. the sampler's cell order) and carry their own row as the
  * int32 in .w: the fp32 row of record i is out[.w], its H row is out_h[i] (model.py:228 stores the stem features on the batch in
  * input order; the H copy feeds the GEMMs in the records' order). */
 int32_t p2w_stem_h2_indexed(int32_t prec, const float* xyzr, int32_t n, const float* w, const float* b, int32_t C, float* out,
-                            void* out_h, int32_t ldh, p2w_stream_t stream);
+                            void* out_h, int32_t ldh, uint32_t* range, p2w_stream_t stream);
 int32_t p2w_interp_concat_h2(int32_t prec, const float* xc, int32_t Fc, const float* xyzr_c, const float* xyzr_f,
                              const int32_t* nbr, const int32_t* deg, int32_t kw, const float* skip, int32_t Fs, int32_t m,
                              void* out_h, int32_t ldh, p2w_stream_t stream);

@@ -14,6 +14,53 @@ import torch
 
 from . import ops
 
+CELL_NONFINITE = (1 << 63) - 1   # P2W_CELL_NONFINITE of include/p2w.h
+
+
+def cells_nd(P, size):
+    """PyG voxel_grid(P, size) with batch=None: every column of P is binned with the same cell size (the arithmetic of
+    ``ops.voxel_grid``).  Rows with a non-finite value stay out of the column minima / maxima and get the key CELL_NONFINITE
+    (like the product's p2w_cells_nd: the reference's own grid on such input is the integer cast of a NaN, i.e. undefined)."""
+    n = P.shape[0]
+    Pb = torch.cat([P, torch.zeros((n, 1), dtype=P.dtype, device=P.device)], dim=1)
+    S = torch.cat([torch.full((P.shape[1],), float(size), dtype=P.dtype, device=P.device),
+                   torch.ones(1, dtype=P.dtype, device=P.device)])
+    fin = torch.isfinite(Pb)
+    row_ok = fin.all(dim=1)
+    inf = torch.full_like(Pb, float("inf"))
+    ok2 = row_ok[:, None].expand_as(Pb)
+    lo, hi = torch.where(ok2, Pb, inf).min(dim=0).values, torch.where(ok2, Pb, -inf).max(dim=0).values
+    cnt = ((hi - lo) / S).to(torch.long) + 1
+    stride = torch.ones_like(cnt)
+    stride[1:] = torch.cumprod(cnt, 0)[:-1]
+    Pb = torch.where(ok2, Pb, lo[None].expand_as(Pb))
+    cell = (((Pb - lo[None]) / S[None]).to(torch.long) * stride[None]).sum(dim=1)
+    return torch.where(row_ok, cell, torch.full_like(cell, CELL_NONFINITE))
+
+
+class TensorBackend:
+    """Tensor-operation restatement of the two sorting steps of the product's voxeliser (``pointstowood_amd.preprocessing.HipBackend``):
+    what the GPU tests compare the HIP kernels with, and the stand-in the CPU tests of the host-side logic (samplers, sharding over
+    gloo) put into ``preprocessing.backend`` - the product itself has no tensor path."""
+
+    @staticmethod
+    def grid_segments(P, size, min_pts):
+        """(order, starts, counts): stable argsort of the cell ids, start and length of every run with >= min_pts points."""
+        cell = cells_nd(P, size)
+        order = torch.argsort(cell, stable=True)          # points of a voxel keep their original relative order
+        cell_sorted = cell[order]
+        _, counts = torch.unique_consecutive(cell_sorted, return_counts=True)
+        starts = torch.cumsum(counts, 0) - counts
+        keep = (counts >= min_pts).nonzero(as_tuple=True)[0]
+        starts, counts = starts[keep], counts[keep]
+        if starts.numel() and int(cell_sorted[starts[-1]]) == CELL_NONFINITE:   # rows with a non-finite value belong to no voxel
+            starts, counts = starts[:-1], counts[:-1]
+        return order, starts, counts
+
+    @staticmethod
+    def argsort_f32(x):
+        return torch.argsort(x, stable=True)
+
 
 def ground(pos):
     x, y, z = pos[:, 0].contiguous(), pos[:, 1].contiguous(), pos[:, 2].contiguous()

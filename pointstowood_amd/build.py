@@ -84,7 +84,8 @@ def _build_locked(objdir: str, verbose: bool) -> str:
         with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
             objs = list(ex.map(cc, SOURCES))
         tmp = LIB + tag + ".tmp"
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp, *objs]
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", f"-Wl,--version-script={os.path.join(CSRC, 'p2w_exports.map')}",
+               "-o", tmp, *objs]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr}")

@@ -353,7 +353,7 @@ static int32_t gemm_h2_checked(int32_t prec, const void* A_h, int32_t ldh_a, con
         if ((epi->sc0 && !epi->sh0) || (epi->sc1 && !epi->sh1)) return P2W_ENULL;
         if (epi->residual && epi->ldr < N) return P2W_EINVAL;
         ep = {epi->bias, epi->sc0, epi->sh0, epi->sc1, epi->sh1, epi->residual,
-              epi->ldr, epi->relu0, epi->relu1, epi->relu2, epi->relu_final, nullptr};
+              epi->ldr, epi->relu0, epi->relu1, epi->relu2, epi->relu_final, nullptr, epi->range};
         if ((flags & P2W_GEMM_RESIDUAL_H) && epi->residual) {   // the residual is an H tensor of this precision, ldr its row pitch
             if ((epi->ldr & 7) || (reinterpret_cast<uintptr_t>(epi->residual) & 15u)) return P2W_EALIGN;
             ep.res_h = reinterpret_cast<const _Float16*>(epi->residual);
@@ -411,7 +411,7 @@ extern "C" int32_t p2w_gemm_h2_rowdot(int32_t prec, const void* A_h, int32_t ldh
     if (epi) {
         if ((epi->sc0 && !epi->sh0) || (epi->sc1 && !epi->sh1)) return P2W_ENULL;
         if (epi->residual) return P2W_EUNSUPPORTED;
-        ep = {epi->bias, epi->sc0, epi->sh0, epi->sc1, epi->sh1, nullptr, 0, epi->relu0, epi->relu1, epi->relu2, epi->relu_final, nullptr};
+        ep = {epi->bias, epi->sc0, epi->sh0, epi->sc1, epi->sh1, nullptr, 0, epi->relu0, epi->relu1, epi->relu2, epi->relu_final, nullptr, epi->range};
     }
     const _Float16* Ah = static_cast<const _Float16*>(A_h);
     const _Float16* Wp = static_cast<const _Float16*>(Wh);
@@ -521,7 +521,7 @@ extern "C" int32_t p2w_sa_conv_h_rows(int32_t prec, const float* P, int32_t ldp,
                                  int32_t kw, int32_t M, const float* w1r4, const void* W2h, float wscale, int32_t C1,
                                  int32_t C2, const float* b2, const float* bn_s, const float* bn_t, float* out,
                                  int32_t ldo, void* out_h, int32_t ldh, void* ws, size_t ws_bytes, int32_t flags,
-                                 const int32_t* src_row, p2w_stream_t stream) {
+                                 const int32_t* src_row, uint32_t* range, p2w_stream_t stream) {
     if (prec < P2W_PREC_F16X3 || prec > P2W_PREC_BF16) return P2W_EINVAL;
     if (M == 0) return P2W_OK;
     P2W_CHECK_PTR(P); P2W_CHECK_PTR(xyzr_src); P2W_CHECK_PTR(idx); P2W_CHECK_PTR(batch_dst); P2W_CHECK_PTR(sf);
@@ -535,9 +535,9 @@ extern "C" int32_t p2w_sa_conv_h_rows(int32_t prec, const float* P, int32_t ldp,
     const _Float16* W2 = static_cast<const _Float16*>(W2h);
     if (prec == P2W_PREC_F16X3)
         return launch_sa_conv_h<0>(P, ldp, n_src, xyzr_src, idx, batch_dst, sf, nbr, deg, kw, M, w1r4, W2, wscale, C1, C2, b2, bn_s, bn_t,
-                                   out, ldo, static_cast<_Float16*>(out_h), ldh, ws, ws_bytes, flags, p2w_s(stream), src_row);
+                                   out, ldo, static_cast<_Float16*>(out_h), ldh, ws, ws_bytes, flags, p2w_s(stream), src_row, range);
     return p2w_sa_conv_h1_impl(prec, P, ldp, n_src, xyzr_src, idx, batch_dst, sf, nbr, deg, kw, M, w1r4, W2, wscale, C1, C2, b2, bn_s,
-                               bn_t, out, ldo, static_cast<_Float16*>(out_h), ldh, ws, ws_bytes, flags, p2w_s(stream), src_row);
+                               bn_t, out, ldo, static_cast<_Float16*>(out_h), ldh, ws, ws_bytes, flags, p2w_s(stream), src_row, range);
 }
 
 extern "C" int32_t p2w_sa_conv_h(int32_t prec, const float* P, int32_t ldp, int32_t n_src, const float* xyzr_src, const int32_t* idx,
@@ -547,7 +547,7 @@ extern "C" int32_t p2w_sa_conv_h(int32_t prec, const float* P, int32_t ldp, int3
                                  int32_t ldo, void* out_h, int32_t ldh, void* ws, size_t ws_bytes, int32_t flags,
                                  p2w_stream_t stream) {
     return p2w_sa_conv_h_rows(prec, P, ldp, n_src, xyzr_src, idx, batch_dst, sf, nbr, deg, kw, M, w1r4, W2h, wscale, C1, C2, b2, bn_s, bn_t,
-                              out, ldo, out_h, ldh, ws, ws_bytes, flags, nullptr, stream);
+                              out, ldo, out_h, ldh, ws, ws_bytes, flags, nullptr, nullptr, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -571,28 +571,32 @@ __device__ __forceinline__ void store4(const OutArgs& o, size_t row, int c, cons
 // the H output to the record's position (p2w_stem_h2_indexed)
 template <int PREC, bool INDEXED = false>
 __global__ __launch_bounds__(256) void stem_kernel(const float4* __restrict__ xyzr, int n, const float* __restrict__ w,
-                                                   const float* __restrict__ b, int C, int q4, OutArgs o) {
+                                                   const float* __restrict__ b, int C, int q4, OutArgs o, unsigned* __restrict__ range) {
     const long g = (long)blockIdx.x * 256 + threadIdx.x;  // one thread per (row, 4 channels incl. zero padding)
-    if (g >= (long)n * q4) return;
-    const int row = (int)(g / q4), c0 = (int)(g % q4) * 4;
-    const float4 p = xyzr[row];
-    float v[4];
+    float amax = 0.f;
+    if (g < (long)n * q4) {
+        const int row = (int)(g / q4), c0 = (int)(g % q4) * 4;
+        const float4 p = xyzr[row];
+        float v[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int c = c0 + e;
-        v[e] = (c < C) ? fmaxf(fmaf(p.z, w[c * 3 + 2], fmaf(p.y, w[c * 3 + 1], fmaf(p.x, w[c * 3 + 0], b[c]))), 0.f) : 0.f;
+        for (int e = 0; e < 4; ++e) {
+            const int c = c0 + e;
+            v[e] = (c < C) ? fmaxf(fmaf(p.z, w[c * 3 + 2], fmaf(p.y, w[c * 3 + 1], fmaf(p.x, w[c * 3 + 0], b[c]))), 0.f) : 0.f;
+        }
+        amax = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));   // (ReLU outputs: >= 0)
+        if constexpr (INDEXED) {
+            if (o.f32 && c0 < o.ldo) *reinterpret_cast<float4*>(&o.f32[(size_t)__float_as_int(p.w) * o.ldo + c0]) = make_float4(v[0], v[1], v[2], v[3]);
+            if (o.h2 && c0 < o.hcols) h_store4<PREC>(o.h2, o.ldh, (size_t)row, c0, v);
+        } else {
+            store4<PREC>(o, (size_t)row, c0, v);
+        }
     }
-    if constexpr (INDEXED) {
-        if (o.f32 && c0 < o.ldo) *reinterpret_cast<float4*>(&o.f32[(size_t)__float_as_int(p.w) * o.ldo + c0]) = make_float4(v[0], v[1], v[2], v[3]);
-        if (o.h2 && c0 < o.hcols) h_store4<PREC>(o.h2, o.ldh, (size_t)row, c0, v);
-    } else {
-        store4<PREC>(o, (size_t)row, c0, v);
-    }
+    if (range) range_commit_max(range, amax, threadIdx.x & 63);
 }
 
 
 static int32_t stem_launch(int32_t prec, const float* xyzr, int32_t n, const float* w, const float* b, int32_t C, float* out,
-                           void* out_h2, int32_t ldh, p2w_stream_t stream, bool indexed = false) {
+                           void* out_h2, int32_t ldh, p2w_stream_t stream, bool indexed = false, uint32_t* range = nullptr) {
     if (prec < P2W_PREC_F16X3 || prec > P2W_PREC_BF16) return P2W_EINVAL;
     if (n == 0) return P2W_OK;
     P2W_CHECK_PTR(xyzr); P2W_CHECK_PTR(w); P2W_CHECK_PTR(b); P2W_CHECK_ALIGN16(xyzr);
@@ -605,13 +609,13 @@ static int32_t stem_launch(int32_t prec, const float* xyzr, int32_t n, const flo
     if (indexed) {
         const int grid = p2w_cdiv((long)n * q4, 256);
         const float4* x4 = reinterpret_cast<const float4*>(xyzr);
-        if (prec == P2W_PREC_F16) stem_kernel<1, true><<<grid, 256, 0, p2w_s(stream)>>>(x4, n, w, b, C, q4, o);
-        else if (prec == P2W_PREC_BF16) stem_kernel<2, true><<<grid, 256, 0, p2w_s(stream)>>>(x4, n, w, b, C, q4, o);
-        else stem_kernel<0, true><<<grid, 256, 0, p2w_s(stream)>>>(x4, n, w, b, C, q4, o);
+        if (prec == P2W_PREC_F16) stem_kernel<1, true><<<grid, 256, 0, p2w_s(stream)>>>(x4, n, w, b, C, q4, o, range);
+        else if (prec == P2W_PREC_BF16) stem_kernel<2, true><<<grid, 256, 0, p2w_s(stream)>>>(x4, n, w, b, C, q4, o, range);
+        else stem_kernel<0, true><<<grid, 256, 0, p2w_s(stream)>>>(x4, n, w, b, C, q4, o, range);
         return P2W_LAUNCH_STATUS();
     }
     P2W_LAUNCH_PREC(prec, stem_kernel, p2w_cdiv((long)n * q4, 256), 256, p2w_s(stream), reinterpret_cast<const float4*>(xyzr), n, w, b,
-                    C, q4, o);
+                    C, q4, o, range);
     return P2W_LAUNCH_STATUS();
 }
 extern "C" int32_t p2w_stem(const float* xyzr, int32_t n, const float* w, const float* b, int32_t C, float* out,
@@ -620,12 +624,12 @@ extern "C" int32_t p2w_stem(const float* xyzr, int32_t n, const float* w, const 
     return stem_launch(P2W_PREC_F16X3, xyzr, n, w, b, C, out, nullptr, 0, stream);
 }
 extern "C" int32_t p2w_stem_h2(int32_t prec, const float* xyzr, int32_t n, const float* w, const float* b, int32_t C, float* out,
-                               void* out_h2, int32_t ldh, p2w_stream_t stream) {
-    return stem_launch(prec, xyzr, n, w, b, C, out, out_h2, ldh, stream);
+                               void* out_h2, int32_t ldh, uint32_t* range, p2w_stream_t stream) {
+    return stem_launch(prec, xyzr, n, w, b, C, out, out_h2, ldh, stream, false, range);
 }
 extern "C" int32_t p2w_stem_h2_indexed(int32_t prec, const float* xyzr, int32_t n, const float* w, const float* b, int32_t C, float* out,
-                                       void* out_h2, int32_t ldh, p2w_stream_t stream) {
-    return stem_launch(prec, xyzr, n, w, b, C, out, out_h2, ldh, stream, true);
+                                       void* out_h2, int32_t ldh, uint32_t* range, p2w_stream_t stream) {
+    return stem_launch(prec, xyzr, n, w, b, C, out, out_h2, ldh, stream, true, range);
 }
 
 // One wave per output row: the row's neighbours, their inverse-square-distance weights and the denominator are
@@ -868,7 +872,7 @@ extern "C" int32_t p2w_rowdot(const float* x, int32_t ldx, int32_t F, const floa
 }
 
 // ------------------------------------------------------------------------------------------------
-extern "C" int32_t p2w_version(void) { return 300; }
+extern "C" int32_t p2w_version(void) { return 500; }
 
 extern "C" const char* p2w_strerror(int32_t code) {
     switch (code) {

@@ -17,10 +17,11 @@ int32_t p2w_sa_conv_h1_impl(int32_t prec, const float* P, int32_t ldp, int32_t n
                             const int32_t* batch_dst, const float* sf, const int32_t* nbr, const int32_t* deg, int32_t kw,
                             int32_t M, const float* w1r4, const _Float16* W2h, float wscale, int32_t C1, int32_t C2,
                             const float* b2, const float* bn_s, const float* bn_t, float* out, int32_t ldo, _Float16* out_h2,
-                            int32_t ldh, void* ws, size_t ws_bytes, int32_t flags, hipStream_t stream, const int32_t* src_row) {
+                            int32_t ldh, void* ws, size_t ws_bytes, int32_t flags, hipStream_t stream, const int32_t* src_row,
+                            unsigned* range) {
     if (prec == P2W_PREC_F16)
         return launch_sa_conv_h<1>(P, ldp, n_src, xyzr_src, idx, batch_dst, sf, nbr, deg, kw, M, w1r4, W2h, wscale, C1, C2, b2, bn_s, bn_t,
-                                   out, ldo, out_h2, ldh, ws, ws_bytes, flags, stream, src_row);
+                                   out, ldo, out_h2, ldh, ws, ws_bytes, flags, stream, src_row, range);
     return launch_sa_conv_h<2>(P, ldp, n_src, xyzr_src, idx, batch_dst, sf, nbr, deg, kw, M, w1r4, W2h, wscale, C1, C2, b2, bn_s, bn_t,
-                               out, ldo, out_h2, ldh, ws, ws_bytes, flags, stream, src_row);
+                               out, ldo, out_h2, ldh, ws, ws_bytes, flags, stream, src_row, range);
 }

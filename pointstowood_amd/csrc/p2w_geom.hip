@@ -1919,22 +1919,35 @@ __global__ void vc_init_kernel(VcHeader* h) {
 __global__ __launch_bounds__(256) void vc_minmax_kernel(const float* __restrict__ P, int n, int D, int ld, VcHeader* h) {
     __shared__ float red[4][2 * VC_MAXD];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int d = 0; d < D; ++d) {
-        float lo = INFINITY, hi = -INFINITY;
-        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-            const float v = P[i * ld + d];
-            if (isfinite(v)) { lo = fminf(lo, v); hi = fmaxf(hi, v); }   // non-finite values take no part in the grid (see vc_cells_kernel)
-        }
+    float lo[VC_MAXD], hi[VC_MAXD];
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) { lo = fminf(lo, __shfl_xor(lo, off)); hi = fmaxf(hi, __shfl_xor(hi, off)); }
-        if (lane == 0) { red[wave][2 * d] = lo; red[wave][2 * d + 1] = hi; }
+    for (int d = 0; d < VC_MAXD; ++d) { lo[d] = INFINITY; hi[d] = -INFINITY; }
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float v[VC_MAXD];
+        bool ok = true;
+#pragma unroll
+        for (int d = 0; d < VC_MAXD; ++d) {
+            v[d] = d < D ? P[i * ld + d] : 0.f;
+            ok = ok && isfinite(v[d]);
+        }
+        if (ok) {   // a ROW with a non-finite value takes no part in the grid (see vc_cells_kernel): none of its columns does
+#pragma unroll
+            for (int d = 0; d < VC_MAXD; ++d) { lo[d] = fminf(lo[d], v[d]); hi[d] = fmaxf(hi[d], v[d]); }
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < VC_MAXD; ++d) {
+        float a = lo[d], b = hi[d];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { a = fminf(a, __shfl_xor(a, off)); b = fmaxf(b, __shfl_xor(b, off)); }
+        if (lane == 0) { red[wave][2 * d] = a; red[wave][2 * d + 1] = b; }
     }
     __syncthreads();
     if (threadIdx.x < D) {
         const int d = threadIdx.x;
-        float lo = red[0][2 * d], hi = red[0][2 * d + 1];
-        for (int w = 1; w < 4; ++w) { lo = fminf(lo, red[w][2 * d]); hi = fmaxf(hi, red[w][2 * d + 1]); }
-        atomicMin(&h->lo[d], f2ord(lo)); atomicMax(&h->hi[d], f2ord(hi));
+        float a = red[0][2 * d], b = red[0][2 * d + 1];
+        for (int w = 1; w < 4; ++w) { a = fminf(a, red[w][2 * d]); b = fmaxf(b, red[w][2 * d + 1]); }
+        atomicMin(&h->lo[d], f2ord(a)); atomicMax(&h->hi[d], f2ord(b));
     }
 }
 // PyG voxel_grid(P, size) with batch = None: sum_d trunc((P_d - lo_d) / size) * stride_d, strides = running products of
@@ -1942,7 +1955,7 @@ __global__ __launch_bounds__(256) void vc_minmax_kernel(const float* __restrict_
 // Rows with a non-finite value: the reference's min / max propagate a NaN into the grid origin and every cell id of the plot
 // becomes the cast of a NaN (undefined); here such rows stay out of the minima / maxima and get the dedicated key
 // P2W_CELL_NONFINITE (INT64_MAX: they sort last as a run of their own, which the voxeliser drops) - defined behaviour on both
-// the HIP and the tensor path (preprocessing._cells), identical to the reference on finite input.
+// the HIP path and its tensor restatement (oracle/preprocess.py cells_nd), identical to the reference on finite input.
 __global__ __launch_bounds__(256) void vc_cells_kernel(const float* __restrict__ P, int n, int D, int ld, float size,
                                                        const VcHeader* __restrict__ h, long long* __restrict__ cell) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;

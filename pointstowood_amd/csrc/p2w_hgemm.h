@@ -172,7 +172,21 @@ struct EpiArgs {
     const float *bias, *sc0, *sh0, *sc1, *sh1, *residual;
     int ldr, relu0, relu1, relu2, relu_final;
     const _Float16* res_h;   // P2W_GEMM_RESIDUAL_H: the residual as an H tensor of the launch's precision (row pitch ldr) instead of fp32
+    unsigned* range;         // optional range watch (p2w_epilogue.range)
 };
+// The wave's range report: a plain store of 1 into the launch's OVER / SEEN word.  Every writer of a word writes the same value,
+// so no atomic and no look-before-write is needed (both were tried: an atomic OR behind a look through the vector L1 never sees
+// the other CUs' bits and drains the epilogue's stores, +14 us per GEMM launch; a scalar glc look serialises at ~25 ns per wave).
+__device__ __forceinline__ void range_commit(unsigned* __restrict__ dst, bool over, bool seen, int lane) {
+    if (lane == 0) {
+        if (over) dst[0] = 1u;
+        if (seen) dst[1] = 1u;
+    }
+}
+// ... from a per-lane maximum of |value|
+__device__ __forceinline__ void range_commit_max(unsigned* __restrict__ dst, float m, int lane) {
+    range_commit(dst, __ballot(!(m <= P2W_RANGE_HI)) != 0ull, __ballot(m > P2W_RANGE_LO) != 0ull, lane);
+}
 // value of two adjacent columns (col even) of H row `row`: the inverse of h_store2
 template <int PREC>
 __device__ __forceinline__ fpair h_load2(const _Float16* __restrict__ base, unsigned ldh, unsigned row, unsigned col) {
@@ -437,6 +451,8 @@ __device__ __forceinline__ void gemm_epilogue_16(const f32x4 (&acc)[RT16][CT16],
         if (RES) load_res(rcur, 0);
     }
     float dot4[4] = {0.f, 0.f, 0.f, 0.f};
+    // range watch (ep.range): wave-uniform masks in scalar registers - this kernel has no vector register to spare
+    unsigned long long r_over = 0ull, r_seen = 0ull;
 #pragma unroll
     for (int st = 0; st < NSTEP; ++st) {
         const int it = st >> 2, reg = st & 3;
@@ -455,6 +471,11 @@ __device__ __forceinline__ void gemm_epilogue_16(const f32x4 (&acc)[RT16][CT16],
             for (int jq = 0; jq < JQ; ++jq) {
                 const float va = value(acc[it][2 * jq][reg], bias[jq][0], s0[jq][0], t0[jq][0], s1[jq][0], t1[jq][0], rcur[jq][0]);
                 const float vb = value(acc[it][2 * jq + 1][reg], bias[jq][1], s0[jq][1], t0[jq][1], s1[jq][1], t1[jq][1], rcur[jq][1]);
+                {
+                    const float m2 = fmaxf(fabsf(va), fabsf(vb));
+                    r_over |= __ballot(!(m2 <= P2W_RANGE_HI));
+                    r_seen |= __ballot(m2 > P2W_RANGE_LO);
+                }
                 if (DOT) dsum = fmaf(vb, dw[jq][1], fmaf(va, dw[jq][0], dsum));
                 if (OF) *reinterpret_cast<fpair*>(fp + 32 * jq) = fpair{va, vb};
                 if (OH) {
@@ -494,6 +515,11 @@ __device__ __forceinline__ void gemm_epilogue_16(const f32x4 (&acc)[RT16][CT16],
                         if (!cv) v[e] = 0.f;                       // pad columns of an H row must be zero
                         if (OF && cv) o.f32[(size_t)row * o.ldo + c + e] = v[e];
                     }
+                    {
+                        const float m2 = fmaxf(fabsf(v[0]), fabsf(v[1]));
+                        r_over |= __ballot(!(m2 <= P2W_RANGE_HI));
+                        r_seen |= __ballot(m2 > P2W_RANGE_LO);
+                    }
                     if (DOT) dsum = fmaf(v[1], dw[jq][1], fmaf(v[0], dw[jq][0], dsum));
                     if (OH && c < o.hcols) h_store2<PREC>(o.h2, o.ldh, row, c, v[0], v[1]);
                 }
@@ -504,6 +530,7 @@ __device__ __forceinline__ void gemm_epilogue_16(const f32x4 (&acc)[RT16][CT16],
             }
         }
     }
+    if (ep.range) range_commit(ep.range, r_over != 0ull, r_seen != 0ull, lane);   // (wave-uniform branch)
 }
 
 template <int PREC, int RT16, int CT16, bool WAIT_OLDER = false, bool DOTK = false>
@@ -1202,7 +1229,7 @@ template <int RT, int GPT> struct SaEpiRegs { float bias[2], s[2], t[2]; int dsc
 template <int PREC, int RT, int G>   // RT 32-row tiles per wave, G rows (neighbour slots) per target
 __device__ __forceinline__ void sa_epilogue_regs(const f32x16 (&acc)[RT][2], float wscale, int n0, int wc, int lane,
                                                  const SaEpiRegs<RT, 32 / G>& e, int C2, float* __restrict__ out, int ldo,
-                                                 _Float16* __restrict__ out_h2, int ldh) {
+                                                 _Float16* __restrict__ out_h2, int ldh, float& amax) {
     static_assert(G == 32 || G == 8, "one or four targets per 32-row tile");
     constexpr int GPT = 32 / G;
     const int h = lane >> 5;
@@ -1254,6 +1281,7 @@ __device__ __forceinline__ void sa_epilogue_regs(const f32x16 (&acc)[RT][2], flo
                 }
                 float vmax = fmaf(fmaxf(fmaf(sgn * ext, wscale, e.bias[j]), 0.f), e.s[j], e.t[j]);
                 if (d == 0 || !cv) vmax = 0.f;   // rows without neighbours; pad columns of an H row stay zero
+                amax = fmaxf(amax, fabsf(vmax));
                 if (cv && h == 0 && out) out[(size_t)tgt * ldo + col] = vmax;
                 if (out_h2) {  // lanes (2p, 2p+1) hold adjacent columns: the even lane stores both as one word per plane
                     const float nb = __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(vmax), 0xB1, 0xf, 0xf, false));
@@ -1276,7 +1304,7 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
                                                             int nMt_, int nNt, const float* __restrict__ b2,
                                                             const float* __restrict__ bn_s, const float* __restrict__ bn_t,
                                                             float* __restrict__ out, int ldo, _Float16* __restrict__ out_h2,
-                                                            int ldh, int dbg_) {
+                                                            int ldh, int dbg_, unsigned* __restrict__ range) {
     // dbg (profiling ablations, -DP2W_SA_ABLATE builds only): 1 no epilogue, 2 no W2 DMA after the first, 4 no MFMA,
     // 32 layer-1 weights of slab 0 in every slab, 64 fragments always from stage 0, 128 no barrier,
     // 8 no producer, 16 no P gather
@@ -1509,6 +1537,7 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
     };
     Degs dg_;
     load_deg(c0.mt, dg_);   // item 0; later items' counts arrive one iteration ahead (dg_n)
+    float amax = 0.f;       // range watch: max |output| of this wave's items, committed once at the end
 #ifdef P2W_SA_STAMP
     unsigned long long t_wait = 0, t_epi = 0, t_mma = 0, t_ld = 0;
     const unsigned long long t_start = p2w_stamp();
@@ -1643,7 +1672,7 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
                 for (int i = 0; i < RT; ++i)
 #pragma unroll
                     for (int q = 0; q < GPT; ++q) e.dsc[i][q] = (c0.mt * (BM / 32) + wr * RT + i >= M) ? -1 : dg_.d[i][q];
-                sa_epilogue_regs<PREC, RT, G>(acc, wscale, c0.nt * BN, wc, lane, e, C2, out, ldo, out_h2, ldh);
+                sa_epilogue_regs<PREC, RT, G>(acc, wscale, c0.nt * BN, wc, lane, e, C2, out, ldo, out_h2, ldh, amax);
             }
 #pragma unroll
             for (int i = 0; i < RT; ++i)
@@ -1659,6 +1688,7 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
         va = vb; ma = mb; mb = mc; dg_ = dg_n;
         c0 = c1; c1 = c2; c2 = c3; c3 = nxt(c3);
     }
+    if (range) range_commit_max(range, amax, lane);
 #ifdef P2W_SA_STAMP
     if (lane == 0 && (wave == 0 || wave == 4) && blockIdx.x < 256) {   // stamp buffer: the 64 KiB behind the tile descriptors
         unsigned long long* sb = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(const_cast<int*>(desc) + (size_t)M * GPT) + 64) + (blockIdx.x * 2 + (wave ? 1 : 0)) * 8;
@@ -1694,7 +1724,8 @@ static int32_t launch_sa_conv_h(const float* P, int32_t ldp, int32_t n_src, cons
                                 const float* sf, const int32_t* nbr, const int32_t* deg, int32_t kw, int32_t M,
                                 const float* w1r4, const _Float16* W2h, float wscale, int32_t C1, int32_t C2, const float* b2,
                                 const float* bn_s, const float* bn_t, float* out, int32_t ldo, _Float16* out_h2, int32_t ldh,
-                                void* ws, size_t ws_bytes, int32_t flags, hipStream_t stream, const int32_t* src_row = nullptr) {
+                                void* ws, size_t ws_bytes, int32_t flags, hipStream_t stream, const int32_t* src_row = nullptr,
+                                unsigned* range = nullptr) {
     constexpr int KA = HCfg<PREC>::kalign;
     const int C2pad = (C2 + 255) / 256 * 256, C1pad = (C1 + KA - 1) / KA * KA;
     // LDS tables (layer-1 geometry weights, per-column epilogue parameters) and 32-bit offsets: edge rows, P rows in float4 units
@@ -1722,11 +1753,11 @@ static int32_t launch_sa_conv_h(const float* P, int32_t ldp, int32_t n_src, cons
         if (wide)
             sa_conv16p_kernel<PREC, 256, 2, G><<<grid, 512, 0, stream>>>(
                 P, ldp, meta_j, meta_g, desc, tiles_dev, (int)tiles_max, w1r4, C1, C1pad, W2h, (size_t)C2pad * C1pad, wscale, C2, nMt3,
-                nNt3, b2, bn_s, bn_t, out, ldo, out_h2, ldh, sadbg);
+                nNt3, b2, bn_s, bn_t, out, ldo, out_h2, ldh, sadbg, range);
         else
             sa_conv16p_kernel<PREC, 128, 2, G><<<grid, 512, 0, stream>>>(
                 P, ldp, meta_j, meta_g, desc, tiles_dev, (int)tiles_max, w1r4, C1, C1pad, W2h, (size_t)C2pad * C1pad, wscale, C2, nMt3,
-                nNt3, b2, bn_s, bn_t, out, ldo, out_h2, ldh, sadbg);
+                nNt3, b2, bn_s, bn_t, out, ldo, out_h2, ldh, sadbg, range);
     };
     char* w = static_cast<char*>(ws);
     if (!(flags & P2W_SA_PACK8)) {
@@ -1767,4 +1798,5 @@ int32_t p2w_sa_conv_h1_impl(int32_t prec, const float* P, int32_t ldp, int32_t n
                             const int32_t* batch_dst, const float* sf, const int32_t* nbr, const int32_t* deg, int32_t kw,
                             int32_t M, const float* w1r4, const _Float16* W2h, float wscale, int32_t C1, int32_t C2,
                             const float* b2, const float* bn_s, const float* bn_t, float* out, int32_t ldo, _Float16* out_h2,
-                            int32_t ldh, void* ws, size_t ws_bytes, int32_t flags, hipStream_t stream, const int32_t* src_row = nullptr);
+                            int32_t ldh, void* ws, size_t ws_bytes, int32_t flags, hipStream_t stream, const int32_t* src_row = nullptr,
+                            unsigned* range = nullptr);

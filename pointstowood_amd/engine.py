@@ -111,6 +111,7 @@ class PackedWeights:
                 "F_in": f_in, "C1": C1, "C2": C2,
                 "hoist": pack(W1[:, :f_in], bias=b1),               # P = x_src W1x^T + b1
                 "w1r4": f32(w1r4),
+                "w1r_bound": float(w1r4.abs().sum(dim=0).max()),   # |layer-1 correction| <= this (|normalised offset|, |reflectance| <= 1)
                 "W2": pack(W2), "b2": f32(b2), "bn_s": f32(s2), "bn_t": f32(t2),
             }
             # InvertedResidualBlock (model.py:46-85) as 4 GEMMs
@@ -255,6 +256,11 @@ class EngineOptions:
     feat_priority: int = -1
     res_priority: int = -1        # ... and of the second chunk-chain stream (part of the feature phase)
     gemm_flags: int = 0           # P2W_GEMM_* bits of include/p2w.h passed to every p2w_gemm_h2 call (A/B runs)
+    range_guard: bool = True      # f16x3: every stem / PointNetConv / GEMM launch reports whether an output lay beyond +-6e4 (the hi plane
+                                  # saturates at 65504) and whether any lay above 2^-5 (a tensor without one has its lo plane on fp16's
+                                  # subnormal floor); a forward with such a layer is recomputed on the fp32 MFMA path (Engine.fallback, set
+                                  # by Net) instead of returning silently degraded logits.  (fp16 / bf16 are throughput modes whose
+                                  # error is reported, not bounded: no watch.)
     gemm_stream_k: bool = True    # GEMMs run through p2w_gemm_h2_sk with a per-stream workspace: rows that do not fill a whole chip round
                                   # run as a stream-K tail where the library's cost model says it pays (then a level is ONE chunk:
                                   # chunk_full_rounds does not apply)
@@ -294,6 +300,13 @@ class Engine:
         self._table_scale = [1, 1, 1]   # per level: grows by 8 (up to TABLE_SCALE_MAX) after an overflow
         self._table_rest = [0, 0, 0]    # per level: batches the table sits out after overflowing at its largest scale
         self._ws_t = None
+        self._range = None        # range watch of the feature phase being enqueued: (layer names, device floats)
+        self.fallback = None      # callable(geo, keep) -> logits on an arithmetic without the range limit (Net: the fp32 engine)
+        self.range_fallbacks = 0  # forwards recomputed because a layer left the 16-bit planes' range
+        # the fused PointNetConv adds its layer-1 correction (|.| <= w1r_bound) to the hoisted product INSIDE the kernel: weights that
+        # could push a product that passed the watch over fp16's maximum are a violation by themselves
+        self._static_range = [(f"sa{l}.layer1", f"geometry weights up to {weights.sa[l - 1]['w1r_bound']:.3g}") for l in (1, 2, 3)
+                              if self.prec == PREC_F16X3 and self.options.range_guard and weights.sa[l - 1].get("w1r_bound", 0.0) > self.W1R_LIMIT]
         self.events = None  # set to a list to record (name, start, end) events per launch
         self.events_grouped = False   # True: (name, start, end, launches) per run of consecutive same-name launches
         self._open = None
@@ -546,14 +559,82 @@ class Engine:
 
     # -- phase 2 ------------------------------------------------------------------------------
     def features(self, geo: Geometry, keep: dict | None = None):
+        """Enqueues the feature phase on the current stream.  With the range guard on, ``geo.watch`` then holds the phase's range
+        report (in flight on the same stream: ``checked`` evaluates it once the phase has finished)."""
         if self.prec is not None:
-            return self._features_h2(geo, keep)
+            self._range_begin(geo.sf.device)
+            logits = self._features_h2(geo, keep)
+            geo.watch = self._range_end()
+            return logits
+        geo.watch = None
         return self._features_fp32(geo, keep)
 
+    def checked(self, geo: Geometry, logits, keep: dict | None = None):
+        """The range guard's verdict on a FINISHED feature phase (the caller has waited for it): `logits`, or - when a layer's
+        outputs left the range the 16-bit planes carry - the logits of ``fallback`` (the fp32 MFMA engine) on the same geometry,
+        enqueued on the current stream.  Silent saturation is never an outcome: without a fallback the forward raises."""
+        bad = self.range_violations(getattr(geo, "watch", None))
+        if not bad:
+            return logits
+        what = "; ".join(f"{n}: {v}" for n, v in bad[:4])
+        if self.fallback is None:
+            raise RuntimeError(f"precision {self.precision!r}: activations outside the range of the 16-bit planes ({what}); "
+                               "use precision='fp32'")
+        if self.range_fallbacks == 0:
+            import warnings
+            warnings.warn(f"pointstowood_amd: precision {self.precision!r} cannot carry this checkpoint's activations ({what}): such "
+                          "batches are recomputed on the fp32 MFMA path (about 4x slower)")
+        self.range_fallbacks += 1
+        return self.fallback(geo, keep)
+
+    # -- range watch (EngineOptions.range_guard) -------------------------------------------------------------
+    RANGE_SLOTS = 64
+    RANGE_HI, RANGE_LO = 6.0e4, 2.0 ** -5  # the thresholds behind the two bits (P2W_RANGE_HI / _LO)
+    W1R_LIMIT = 65504.0 - 6.0e4            # room the PointNetConv's layer-1 correction has above a hoisted product that passed the watch
+
+    def _watch(self, layer, rows=1):
+        """Device address of the range-watch word of `layer` (one per layer of the forward in flight), or None (guard off, or a
+        launch without rows: it reports nothing)."""
+        w = self._range
+        if w is None or layer is None or rows <= 0:
+            return None
+        names, buf = w
+        if layer not in names:
+            if len(names) >= self.RANGE_SLOTS:
+                return None
+            names.append(layer)
+        return buf.data_ptr() + 8 * names.index(layer)   # two words per layer: (over, seen)
+
+    def _range_begin(self, dev):
+        self._range = ([], torch.zeros(2 * self.RANGE_SLOTS, dtype=torch.int32, device=dev)) if (self.range_guard and self.prec == PREC_F16X3) else None
+
+    def _range_end(self):
+        """(layer names, device words, pinned host copy in flight on the current stream) of the forward just enqueued."""
+        w, self._range = self._range, None
+        if w is None:
+            return None
+        host = torch.empty(2 * self.RANGE_SLOTS, dtype=torch.int32, pin_memory=True)
+        host.copy_(w[1], non_blocking=True)
+        return w[0], w[1], host
+
+    def range_violations(self, watch):
+        """Layers of a FINISHED forward whose outputs left the range the 16-bit planes carry: [(layer, what)]."""
+        if watch is None:
+            return []
+        names, _, host = watch
+        bad = list(self._static_range)
+        flags = host[: 2 * len(names)].tolist()
+        for i, n in enumerate(names):
+            if flags[2 * i]:
+                bad.append((n, f"values beyond +-{self.RANGE_HI:g} (or NaN)"))
+            elif not flags[2 * i + 1]:
+                bad.append((n, f"no value above {self.RANGE_LO:g}"))
+        return bad
+
     def _gemm_h2(self, name, A, ldh_a, M, lin: Linear, out_f32=None, ldo=0, out_h2=None, ldh_o=0, residual=None, ldr=0,
-                 residual_h=False):
+                 residual_h=False, watch=None):
         ep = Epilogue(ptr(lin.bias), ptr(lin.sc0), ptr(lin.sh0), ptr(lin.sc1), ptr(lin.sh1), ptr(residual), ldr,
-                      lin.relu0, lin.relu1, lin.relu2, lin.relu_final)
+                      lin.relu0, lin.relu1, lin.relu2, lin.relu_final, self._watch(watch, M))
         flags = self.gemm_flags | (GEMM_RESIDUAL_H if residual_h else 0)
         if self.gemm_stream_k:
             ws = self._sk_workspace(A.device)
@@ -610,10 +691,10 @@ class Engine:
         sorted0 = bool(getattr(geo, "rows0_sorted", False))
         if sorted0:
             self._call("stem", L.p2w_stem_h2_indexed, prec, ptr(geo.sorted0), N, ptr(w.stem_w), ptr(w.stem_b), Cw, ptr(x0), ptr(xh[0]),
-                       pitch[0])
+                       pitch[0], self._watch("stem", N))
         else:
             self._call("stem", L.p2w_stem_h2, prec, ptr(lv[0].xyzr), N, ptr(w.stem_w), ptr(w.stem_b), Cw, ptr(x0), ptr(xh[0]),
-                       pitch[0])
+                       pitch[0], self._watch("stem", N))
         self.stem_out = x0
         if keep is not None:
             keep["stem"] = x0
@@ -628,7 +709,7 @@ class Engine:
             P[src.n].zero_()
             if C1p != C1:
                 P[:, C1:].zero_()
-            self._gemm_h2("gemm_hoist", xh[l - 1], pitch[l - 1], src.n, p["hoist"], out_f32=P, ldo=C1p)
+            self._gemm_h2("gemm_hoist", xh[l - 1], pitch[l - 1], src.n, p["hoist"], out_f32=P, ldo=C1p, watch=f"hoist{l}")
             conv = new(M, C2) if (keep is not None or not res_h) else None
             convh = newh(M, C2)
             # level 1 is the ball query: on sparse input most targets have few neighbours, and those with <= 8 share an MFMA
@@ -640,7 +721,7 @@ class Engine:
             self._call("sa_conv", L.p2w_sa_conv_h_rows, prec, ptr(P), C1p, src.n, ptr(src.xyzr), ptr(dst.idx), ptr(dst.batch),
                        ptr(geo.sf), ptr(dst.nbr), ptr(dst.deg), geo.k, M, ptr(p["w1r4"]), ptr(p["W2"].w16),
                        p["W2"].wscale, C1, C2, ptr(p["b2"]), ptr(p["bn_s"]), ptr(p["bn_t"]), ptr(conv), C2, ptr(convh),
-                       pad8(C2), ptr(meta), meta.numel(), sa_flags, ptr(geo.inv0) if (l == 1 and sorted0) else None)
+                       pad8(C2), ptr(meta), meta.numel(), sa_flags, ptr(geo.inv0) if (l == 1 and sorted0) else None, self._watch(f"sa{l}", M))
             # fp32 form of the level's output: level 3 feeds cat(x, pos) of the global module; otherwise only on request
             out = new(M, C2) if (keep is not None or l == 3) else None
             # residual block in row chunks: the two 4F-wide intermediates of a chunk (2 x chunk x 4F x 4 B) are written
@@ -664,12 +745,13 @@ class Engine:
                 m = min(chunk, M - r0)
                 (e1, e2), st = bufs[ci % len(lanes)], lanes[ci % len(lanes)]
                 with torch.cuda.stream(st):
-                    self._gemm_h2("gemm_res", convh[r0:], pad8(C2), m, p["g1"], out_h2=e1, ldh_o=pad8(E))
-                    self._gemm_h2("gemm_res", e1, pad8(E), m, p["g2"], out_h2=e2, ldh_o=pad8(E))
-                    self._gemm_h2("gemm_res", e2, pad8(E), m, p["g3"], out_h2=e1, ldh_o=pad8(E))
+                    self._gemm_h2("gemm_res", convh[r0:], pad8(C2), m, p["g1"], out_h2=e1, ldh_o=pad8(E), watch=f"res{l}.1")
+                    self._gemm_h2("gemm_res", e1, pad8(E), m, p["g2"], out_h2=e2, ldh_o=pad8(E), watch=f"res{l}.2")
+                    self._gemm_h2("gemm_res", e2, pad8(E), m, p["g3"], out_h2=e1, ldh_o=pad8(E), watch=f"res{l}.3")
                     self._gemm_h2("gemm_res", e1, pad8(E), m, p["g4"], out_f32=None if out is None else out[r0:], ldo=C2,
                                   out_h2=xh[l][r0:], ldh_o=pitch[l],
-                                  residual=convh[r0:] if res_h else conv[r0:], ldr=pad8(C2) if res_h else C2, residual_h=res_h)
+                                  residual=convh[r0:] if res_h else conv[r0:], ldr=pad8(C2) if res_h else C2, residual_h=res_h,
+                                  watch=f"res{l}.4")
             if nst > 1:   # join: everything after this level (and the buffers' reuse) is ordered behind both chains
                 done = torch.cuda.Event()
                 done.record(side)
@@ -683,8 +765,8 @@ class Engine:
         cat_g = newh(M3, F3 + 4)
         self._call("concat_xyz", L.p2w_concat_xyz_h2, prec, ptr(x3), F3, ptr(lv[3].xyzr), M3, ptr(cat_g), pad8(F3 + 4))
         h1, h2 = newh(M3, F3), new(M3, F3)
-        self._gemm_h2("gemm_mlp", cat_g, pad8(F3 + 4), M3, w.sa4[0], out_h2=h1, ldh_o=pad8(F3))
-        self._gemm_h2("gemm_mlp", h1, pad8(F3), M3, w.sa4[1], out_f32=h2, ldo=F3)
+        self._gemm_h2("gemm_mlp", cat_g, pad8(F3 + 4), M3, w.sa4[0], out_h2=h1, ldh_o=pad8(F3), watch="sa4.0")
+        self._gemm_h2("gemm_mlp", h1, pad8(F3), M3, w.sa4[1], out_f32=h2, ldo=F3, watch="sa4.1")
         g = new(B, F3)
         self._call("segment_max", L.p2w_segment_max, ptr(h2), F3, F3, ptr(lv[3].ptr), B, ptr(g))
         if keep is not None:
@@ -735,9 +817,9 @@ class Engine:
                     # the interpolated part only (skip = NULL): the skip columns of these rows were written by their producer
                     self._call("interp_concat", L.p2w_interp_concat_h2, prec, ptr(y), Fc, ptr(y_xyzr), ptr(fine_xyzr[r0:]),
                                ptr(nbr[r0:]), ptr(deg[r0:]), kw, None, 0, mm, ptr(cf[r0:]), ld)
-                    self._gemm_h2("gemm_mlp", cf[r0:], ld, mm, l0, out_h2=a, ldh_o=pad8(l0.N))
+                    self._gemm_h2("gemm_mlp", cf[r0:], ld, mm, l0, out_h2=a, ldh_o=pad8(l0.N), watch=f"fp{fl}.0")
                     self._gemm_h2("gemm_mlp", a, pad8(l0.N), mm, l1, out_f32=None if b is None else b[r0:], ldo=l1.N,
-                                  out_h2=yh, ldh_o=pad8(l1.N))
+                                  out_h2=yh, ldh_o=pad8(l1.N), watch=f"fp{fl}.1")
                     if fl == 1:   # head (model.py:241-243) on the same chunk
                         if one:
                             lin = w.head1
@@ -747,7 +829,7 @@ class Engine:
                                        lin.K, C.byref(ep), ptr(w.head2_w), float(w.head2_b[0]), ptr(logits[r0:]), ptr(hws),
                                        hws.numel(), self.gemm_flags)
                         else:   # multi-class head: conv2 is one more (narrow) GEMM over the H form of conv1's output
-                            self._gemm_h2("gemm_mlp", yh, pad8(F3), mm, w.head1, out_h2=hdh, ldh_o=pad8(F3))
+                            self._gemm_h2("gemm_mlp", yh, pad8(F3), mm, w.head1, out_h2=hdh, ldh_o=pad8(F3), watch="head1")
                             self._gemm_h2("gemm_mlp", hdh, pad8(F3), mm, w.head2, out_f32=o_multi[r0:], ldo=w.num_classes)
             if nst > 1:   # join
                 done = torch.cuda.Event()
@@ -852,7 +934,11 @@ class Engine:
             keep["geometry"] = geo
             if keep.get("geometry_only"):   # profiling: the level sizes are wanted, the fp32 copies of the level features are not
                 keep = None
-        return self.features(geo, keep)
+        logits = self.features(geo, keep)
+        if geo.watch is not None:   # the range guard needs the finished phase: one more host wait per forward (Net.stream hides it)
+            torch.cuda.current_stream().synchronize()
+            logits = self.checked(geo, logits, keep)
+        return logits
 
     # -- two-stream software pipeline over a sequence of batches ---------------------------------------------
     def forward_stream(self, inputs):
@@ -888,12 +974,32 @@ class Engine:
             geo.aux = list(geo.aux) + list(args)   # ... and they stay alive until this batch's features were launched
             return geo
 
+        def finish(logits, ev, g, fs):
+            """Hand a batch's logits to the caller's stream; with the range guard, after the host has seen the phase finish and
+            its range report (the next batch's phase is already queued behind it, so the GPU does not idle meanwhile)."""
+            if g.watch is not None:
+                if ev is not None:
+                    ev.synchronize()
+                else:
+                    cur_stream.synchronize()
+                if self.range_violations(g.watch):
+                    with torch.cuda.stream(fs):
+                        logits = self.checked(g, logits, None)
+                        if ev is not None:
+                            ev = torch.cuda.Event()
+                            ev.record()
+                    if ev is not None:
+                        logits.record_stream(cur_stream)
+            if ev is not None:
+                cur_stream.wait_event(ev)
+            return logits
+
         it = iter(inputs)
         nxt = next(it, None)
         if nxt is None:
             return
         geo = launch_geometry(nxt)
-        pending = []   # (logits, done event) of batches whose features are in flight, oldest first
+        pending = []   # (logits, done event, geometry, feature stream) of batches whose features are in flight, oldest first
         i = 0
         while geo is not None:
             nxt = next(it, None)
@@ -913,15 +1019,10 @@ class Engine:
                     ev = torch.cuda.Event()
                     ev.record()
                 logits.record_stream(cur_stream)
-            pending.append((logits, ev))
+            pending.append((logits, ev, geo, fs))
             if len(pending) >= len(f_streams):
-                out, e = pending.pop(0)
-                if e is not None:
-                    cur_stream.wait_event(e)
-                yield out
+                yield finish(*pending.pop(0))
             geo = geo_next
             i += 1
-        for out, e in pending:
-            if e is not None:
-                cur_stream.wait_event(e)
-            yield out
+        for item in pending:
+            yield finish(*item)

@@ -98,6 +98,7 @@ class Net(torch.nn.Module):
                 node.register_parameter(leaf, torch.nn.Parameter(self._init(shape, kind), requires_grad=False))
         self._packed = None
         self._engine = None
+        self._fb_engine = None   # fp32 engine of the range guard's fallback (built on first use)
         self.eval()
 
     @staticmethod
@@ -117,16 +118,28 @@ class Net(torch.nn.Module):
 
     # -- weight packing -------------------------------------------------------------------------
     def _apply(self, fn, *a, **kw):
-        self._packed = None
+        self._packed = self._fb_engine = None
         return super()._apply(fn, *a, **kw)
 
     def load_state_dict(self, *a, **kw):
-        self._packed = None
+        self._packed = self._fb_engine = None
         return super().load_state_dict(*a, **kw)
 
     def repack(self):
         """Call after mutating parameters in place."""
-        self._packed = None
+        self._packed = self._fb_engine = None
+
+    def _range_fallback(self, geo, keep):
+        """The feature phase of `geo` on the fp32 MFMA path: what the range guard (EngineOptions.range_guard) runs instead when a
+        layer's activations do not fit the 16-bit planes of f16x3 / fp16 / bf16 (a checkpoint whose BatchNorm scales push them
+        beyond +-6e4 or under fp16's subnormal floor).  The geometry is precision-independent and is reused."""
+        if getattr(geo, "rows0_sorted", False):
+            raise RuntimeError("range fallback: not available with fp1_cell_order=True (the fp32 path keeps level 0 in input order)")
+        dev = geo.sf.device
+        if self._fb_engine is None or self._fb_engine.w.device != dev:
+            packed = PackedWeights(self.state_dict(), self.C, self.num_classes, dev, "fp32")
+            self._fb_engine = Engine(packed, k=self.k, precision="fp32", options=self.engine_options)
+        return self._fb_engine.features(geo, keep)
 
     def _ensure_packed(self, device):
         if self._packed is None or self._packed.device != device or self._packed.precision != self.precision:
@@ -134,6 +147,7 @@ class Net(torch.nn.Module):
             self._engine = Engine(self._packed, k=self.k, precision=self.precision, options=self.engine_options)
         if self._engine.k != self.k or self._engine.precision != self.precision or self._engine.options is not self.engine_options:
             self._engine = Engine(self._packed, k=self.k, precision=self.precision, options=self.engine_options)
+        self._engine.fallback = self._range_fallback if self.precision != "fp32" else None
         return self._engine
 
     # -- forward --------------------------------------------------------------------------------

@@ -12,11 +12,11 @@ ids per grid size, voxels are contiguous segments of the sorted order.
   ..., n_z - so voxels are also split by height above ground); ``mode="xyz"`` bins over x, y, z only.
 
 The grid step (cell ids over all columns, the stable argsort that groups the points of a voxel, the runs with at least
-``min_pts`` points) runs on hand-written HIP kernels behind the C ABI when the points are on the GPU: ``p2w_cells_nd``,
-``p2w_sort_pairs_u64`` (radix sort), ``p2w_key_runs``.  The same step in tensor operations (``_grid_segments_torch``) serves
-points that live on the host (the CPU tests of the host-side logic); both give identical voxels, rows with non-finite values
-included (they belong to no voxel; tested on the GPU).  Ground
-normalisation and the reflectance quantile transform are cheap tensor code on whatever device the points are on.
+``min_pts`` points) and the reflectance ranking run on hand-written HIP kernels behind the C ABI: ``p2w_cells_nd``,
+``p2w_sort_pairs_u64`` (radix sort), ``p2w_key_runs``.  There is no second path: points on the host are refused like
+everywhere else in the package.  (The CPU tests of the host-side logic around the voxeliser - samplers, sharding - swap
+``backend`` for ``oracle.preprocess.TensorBackend``, the tensor-operation restatement of the two steps that the GPU tests
+compare the kernels with.)  Ground normalisation and the quantile transform themselves are elementwise tensor code.
 """
 from __future__ import annotations
 
@@ -31,42 +31,23 @@ def ground_normalise(pos, resolution: float = 5.0):
     xb = torch.arange(float(x.min()), float(x.max()) + resolution, resolution).to(pos.device)
     yb = torch.arange(float(y.min()), float(y.max()) + resolution, resolution).to(pos.device)
     gi = torch.bucketize(x, xb) * len(yb) + torch.bucketize(y, yb)
-    _, inv = torch.unique(gi, return_inverse=True)
-    zmin = torch.full((int(inv.max()) + 1,), float("inf"), device=pos.device).scatter_reduce(0, inv, z, reduce="amin")
-    return torch.cat((pos, (z - zmin[inv]).view(-1, 1)), dim=1)
+    # per-cell minimum straight into a dense table of the (few hundred) 5 m cells: the reference's torch.unique only renumbers them
+    zmin = torch.full(((len(xb) + 1) * len(yb) + 1,), float("inf"), device=pos.device).scatter_reduce(0, gi, z, reduce="amin")
+    return torch.cat((pos, (z - zmin[gi]).view(-1, 1)), dim=1)
 
 
 def quantile_normalize_reflectance(refl):
     if torch.isnan(refl).any():
         raise ValueError("Input reflectance tensor contains NaN values.")
-    _, indices = torch.sort(refl, stable=True)
-    ranks = torch.argsort(indices, stable=True)
+    order = backend.argsort_f32(refl)                     # stable ascending (ties keep their input order)
+    ranks = torch.empty_like(order)
+    ranks[order] = torch.arange(order.numel(), dtype=order.dtype, device=order.device)   # = argsort(order): the inverse permutation
     q = torch.clamp((ranks.float() + 1) / (len(ranks) + 1), 1e-7, 1 - 1e-7)
     n = torch.erfinv(2 * q - 1) * torch.sqrt(torch.tensor(2.0, device=refl.device))
     return 2 * (n - n.min()) / (n.max() - n.min()) - 1
 
 
 CELL_NONFINITE = (1 << 63) - 1   # P2W_CELL_NONFINITE of include/p2w.h
-
-
-def _cells(P, size):
-    """PyG voxel_grid(P, size) with batch=None: every column of P is binned with the same cell size.  Rows with a non-finite
-    value stay out of the column minima / maxima and get the key CELL_NONFINITE (like p2w_cells_nd: the reference's own
-    grid on such input is the integer cast of a NaN, i.e. undefined); on finite input this is the reference's arithmetic."""
-    n = P.shape[0]
-    Pb = torch.cat([P, torch.zeros((n, 1), dtype=P.dtype, device=P.device)], dim=1)
-    S = torch.cat([torch.full((P.shape[1],), float(size), dtype=P.dtype, device=P.device),
-                   torch.ones(1, dtype=P.dtype, device=P.device)])
-    fin = torch.isfinite(Pb)
-    row_ok = fin.all(dim=1)
-    inf = torch.full_like(Pb, float("inf"))
-    lo, hi = torch.where(fin, Pb, inf).min(dim=0).values, torch.where(fin, Pb, -inf).max(dim=0).values
-    cnt = ((hi - lo) / S).to(torch.long) + 1
-    stride = torch.ones_like(cnt)
-    stride[1:] = torch.cumprod(cnt, 0)[:-1]
-    Pb = torch.where(row_ok[:, None], Pb, lo[None].expand_as(Pb))
-    cell = (((Pb - lo[None]) / S[None]).to(torch.long) * stride[None]).sum(dim=1)
-    return torch.where(row_ok, cell, torch.full_like(cell, CELL_NONFINITE))
 
 
 def _drop_nonfinite_run(cell_sorted, starts, counts):
@@ -76,37 +57,50 @@ def _drop_nonfinite_run(cell_sorted, starts, counts):
     return starts, counts
 
 
-def _grid_segments_torch(P, size, min_pts):
-    """(order, starts, counts): stable argsort of the cell ids, start and length of every run with >= min_pts points."""
-    cell = _cells(P, size)
-    order = torch.argsort(cell, stable=True)          # points of a voxel keep their original relative order
-    cell_sorted = cell[order]
-    _, counts = torch.unique_consecutive(cell_sorted, return_counts=True)
-    starts = torch.cumsum(counts, 0) - counts
-    keep = (counts >= min_pts).nonzero(as_tuple=True)[0]
-    return (order, *_drop_nonfinite_run(cell_sorted, starts[keep], counts[keep]))
+class HipBackend:
+    """The voxeliser's two sorting steps on libp2w_gfx950.so (the product path; GPU tensors only)."""
+
+    @staticmethod
+    def grid_segments(P, size, min_pts):
+        """(order, starts, counts): stable argsort of the cell ids of PyG voxel_grid(P, size) over every column, start and length of
+        every run with >= min_pts points: p2w_cells_nd -> p2w_sort_pairs_u64 (stable radix argsort) -> p2w_key_runs."""
+        _lib.require_cuda(P)
+        L, ptr, stream, check = _lib.lib(), _lib.ptr, _lib.stream, _lib.check
+        P = P.contiguous()
+        n, D = P.shape
+        dev = P.device
+        if D > 16:
+            raise ValueError("the voxeliser bins at most 16 columns")
+        u8 = lambda nbytes: torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
+        cell, cell_sorted = torch.empty(n, dtype=torch.int64, device=dev), torch.empty(n, dtype=torch.int64, device=dev)
+        order = torch.empty(n, dtype=torch.int32, device=dev)
+        ws = u8(max(L.p2w_sort_pairs_u64_ws_bytes(n), L.p2w_key_runs_ws_bytes(n)))
+        check(L.p2w_cells_nd(ptr(P), n, D, D, float(size), ptr(cell), ptr(ws), ws.numel(), stream()), "p2w_cells_nd")
+        check(L.p2w_sort_pairs_u64(ptr(cell), ptr(cell_sorted), None, ptr(order), n, ptr(ws), ws.numel(), stream()), "p2w_sort_pairs_u64")
+        starts, counts = torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.int32, device=dev)
+        n_out = torch.zeros(1, dtype=torch.int32, device=dev)
+        check(L.p2w_key_runs(ptr(cell_sorted), n, int(min_pts), ptr(starts), ptr(counts), ptr(n_out), ptr(ws), ws.numel(), stream()),
+              "p2w_key_runs")
+        k = int(n_out)                                     # the one host sync of a grid size
+        return (order.long(), *_drop_nonfinite_run(cell_sorted, starts[:k].long(), counts[:k].long()))
+
+    @staticmethod
+    def argsort_f32(x):
+        """Stable ascending argsort of a float32 vector (no NaN; -0.0 == +0.0 as in torch.sort) on p2w_sort_pairs_u64: the values'
+        bit patterns made order-preserving (sign bit flipped for positives, all bits for negatives) are the radix sort's keys."""
+        _lib.require_cuda(x)
+        L, ptr, stream, check = _lib.lib(), _lib.ptr, _lib.stream, _lib.check
+        n = x.numel()
+        bits = (x.to(torch.float32).reshape(-1) + 0.0).contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+        keys = torch.where(bits >= 0x80000000, 0xFFFFFFFF - bits, bits + 0x80000000).contiguous()
+        keys_sorted = torch.empty_like(keys)
+        order = torch.empty(n, dtype=torch.int32, device=x.device)
+        ws = torch.empty(max(int(L.p2w_sort_pairs_u64_ws_bytes(n)), 256), dtype=torch.uint8, device=x.device)
+        check(L.p2w_sort_pairs_u64(ptr(keys), ptr(keys_sorted), None, ptr(order), n, ptr(ws), ws.numel(), stream()), "p2w_sort_pairs_u64")
+        return order.long()
 
 
-def _grid_segments_hip(P, size, min_pts):
-    """The same through libp2w_gfx950.so: p2w_cells_nd -> p2w_sort_pairs_u64 (stable radix argsort) -> p2w_key_runs."""
-    L, ptr, stream, check = _lib.lib(), _lib.ptr, _lib.stream, _lib.check
-    P = P.contiguous()
-    n, D = P.shape
-    dev = P.device
-    if D > 16:
-        raise ValueError("the voxeliser bins at most 16 columns")
-    u8 = lambda nbytes: torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
-    cell, cell_sorted = torch.empty(n, dtype=torch.int64, device=dev), torch.empty(n, dtype=torch.int64, device=dev)
-    order = torch.empty(n, dtype=torch.int32, device=dev)
-    ws = u8(max(L.p2w_sort_pairs_u64_ws_bytes(n), L.p2w_key_runs_ws_bytes(n)))
-    check(L.p2w_cells_nd(ptr(P), n, D, D, float(size), ptr(cell), ptr(ws), ws.numel(), stream()), "p2w_cells_nd")
-    check(L.p2w_sort_pairs_u64(ptr(cell), ptr(cell_sorted), None, ptr(order), n, ptr(ws), ws.numel(), stream()), "p2w_sort_pairs_u64")
-    starts, counts = torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.int32, device=dev)
-    n_out = torch.zeros(1, dtype=torch.int32, device=dev)
-    check(L.p2w_key_runs(ptr(cell_sorted), n, int(min_pts), ptr(starts), ptr(counts), ptr(n_out), ptr(ws), ws.numel(), stream()),
-          "p2w_key_runs")
-    k = int(n_out)                                     # the one host sync of a grid size
-    return (order.long(), *_drop_nonfinite_run(cell_sorted, starts[:k].long(), counts[:k].long()))
+backend = HipBackend   # (tests of the host-side logic on the CPU put oracle.preprocess.TensorBackend here)
 
 
 def voxelise(pc, grid_sizes=(2.0, 4.0), min_pts: int = 128, max_pts: int = 16384, mode: str = "compat", generator=None,
@@ -124,10 +118,9 @@ def voxelise(pc, grid_sizes=(2.0, 4.0), min_pts: int = 128, max_pts: int = 16384
     if refl_on:
         pos[:, 3] = quantile_normalize_reflectance(pos[:, 3].reshape(-1))
     weight = (pos[:, 3] - pos[:, 3].min() + 1e-8) if refl_on else None
-    segments = _grid_segments_hip if pos.is_cuda else _grid_segments_torch
     voxels = []
     for size in grid_sizes:
-        order, starts, counts = segments(pos if mode == "compat" else pos[:, :3], size, min_pts)
+        order, starts, counts = backend.grid_segments(pos if mode == "compat" else pos[:, :3], size, min_pts)
         # One gather puts every voxel's rows next to each other; a voxel that needs neither the max_pts sampling nor
         # the NaN-row filter (almost all of them) is then just a VIEW of that tensor: no per-voxel kernels, one sync.
         gathered = pos[order]

@@ -25,3 +25,17 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture
+def tensor_backend():
+    """Puts the oracle's tensor-operation restatement of the voxeliser's two sorting steps into ``preprocessing.backend`` for tests of
+    the HOST-SIDE logic that run without a GPU (samplers, sharding over gloo).  The product's own backend is the HIP library and
+    refuses host tensors."""
+    from oracle import preprocess as OP
+    from pointstowood_amd import preprocessing as PP
+    old, PP.backend = PP.backend, OP.TensorBackend
+    try:
+        yield OP.TensorBackend
+    finally:
+        PP.backend = old

@@ -53,6 +53,9 @@ def main():
         torch.set_num_threads(1)
         net = _FakeNet()
         pipeline.collect_predictions = _fake_collect
+        from oracle import preprocess as OP                    # the CPU stand-in of the voxeliser's HIP grid step
+        from pointstowood_amd import preprocessing
+        preprocessing.backend = OP.TensorBackend
         budget = dict(max_points=20000, max_voxels=16)
     else:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

@@ -235,7 +235,70 @@ def test_stream_pipeline_equals_sequential_forward():
         net2 = net2.cuda().eval()
         got = [o.clone() for o in net2.stream(mk(b) for b in many)]
         torch.cuda.synchronize()
-        assert len(got) == 11 and all(torch.equal(a, seq[i % 4]) for i, a in enumerate(got)), kw
+        own = [net2(mk(b)).clone() for b in batches]       # (another chunking plans other split-K tails: last fp32 bits may differ
+        assert len(got) == 11 and all(torch.equal(a, own[i % 4]) for i, a in enumerate(got)), kw   # from `seq`, never from `own`)
+        assert all((a - seq[i % 4]).abs().max() <= 2e-4 for i, a in enumerate(got)), kw
+
+
+def _rescaled(sd, spots, s):
+    """`sd` with the activations at `spots` multiplied by s and the consuming weights divided by s: the same function (ReLU and
+    the eval-mode BatchNorm / depthwise affines are positively homogeneous), but the tensors BETWEEN the two GEMMs are s times
+    as large - what a checkpoint with extreme BatchNorm scales does to an arithmetic with a limited range."""
+    out = {k: v.clone() for k, v in sd.items()}
+    for kind, p in spots:
+        if kind == "dsc":      # residual block: second depthwise-separable conv - its BN + ReLU output is the pointwise conv's input
+            out[p + ".depthwise_bn.weight"] *= s
+            out[p + ".depthwise_bn.bias"] *= s
+            out[p + ".pointwise_conv.weight"] /= s
+        else:                  # MLP (model.py:198-202): layer 0 = Lin + ReLU, its output is layer 1's input
+            out[p + ".0.0.weight"] *= s
+            out[p + ".0.0.bias"] *= s
+            out[p + ".1.0.weight"] /= s
+    return out
+
+
+@pytest.mark.parametrize("scale", [1.0e6, 1.0e-7])
+def test_range_guard_recomputes_what_f16x3_cannot_carry(scale):
+    """A recipe checkpoint whose intermediate activations sit at 1e6 (the fp16 hi plane saturates at 65504) or at 1e-7 (both
+    planes on fp16's subnormal floor): the forward must still meet the parity bar against the fp32 oracle - the range watch
+    sees the layer, the batch is recomputed on the fp32 MFMA path, a warning says so - through forward and through Net.stream;
+    an ordinary checkpoint never takes the fallback.  Without the guard the same checkpoint is silently wrong."""
+    import warnings
+    from pointstowood_amd import Net
+    sd0 = weights.synth_state_dict(1, 8, seed=3)
+    spots = [("dsc", "sa2_module.residual_block.conv.3"), ("mlp", "fp2_module.NN")]
+    sd = _rescaled(sd0, spots, scale)
+    vox = [synth.uniform_voxel(2.0, 3000, 31, True), synth.uniform_voxel(2.0, 1200, 32, False)]
+    b = synth.collate(vox)
+    ref = onet.forward(sd, b["pos"].clone(), b["batch"], b["reflectance"], b["sf"], k=32)
+    ref0 = onet.forward(sd0, b["pos"].clone(), b["batch"], b["reflectance"], b["sf"], k=32)
+    assert (ref - ref0).abs().max() < 2e-4           # the rescaled checkpoint IS the same function
+
+    def mk():
+        d = _D()
+        d.pos, d.batch, d.reflectance, d.sf = b["pos"].cuda(), b["batch"].cuda(), b["reflectance"].cuda(), b["sf"].cuda()
+        return d
+    net = Net(num_classes=1, C=8, k=32)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().eval()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        out = net(mk()).cpu()
+        outs = [o.cpu() for o in net.stream(mk() for _ in range(3))]
+    assert net._engine.range_fallbacks == 4 and any("fp32 MFMA path" in str(x.message) for x in w)
+    for o in [out] + outs:
+        assert (o - ref).abs().max() <= 4e-4 and (torch.sigmoid(o) - torch.sigmoid(ref)).abs().max() <= 1e-4
+    # the ordinary checkpoint stays on the f16x3 path
+    net0 = Net(num_classes=1, C=8, k=32)
+    net0.load_state_dict(sd0, strict=True)
+    net0 = net0.cuda().eval()
+    o0 = net0(mk()).cpu()
+    assert net0._engine.range_fallbacks == 0 and (o0 - ref0).abs().max() <= 4e-4
+    # ... and this is what the guard is for
+    raw = Net(num_classes=1, C=8, k=32, range_guard=False)
+    raw.load_state_dict(sd, strict=True)
+    raw = raw.cuda().eval()
+    assert (raw(mk()).cpu() - ref).abs().max() > 1e-3
 
 
 def test_predict_cli_on_a_voxel_directory(tmp_path):

@@ -395,7 +395,7 @@ def test_interp_and_stem_write_only_their_columns_of_wider_rows():
         x0 = torch.empty((m, Cw), device="cuda")
         view = wide[:, planes * (Fc + ka):]
         dw_, db_ = w_.cuda(), b_.cuda()          # (kept alive: a temporary's memory is recycled by the next allocation)
-        check(lib().p2w_stem_h2(prec, ptr(rf), m, ptr(dw_), ptr(db_), Cw, ptr(x0), ptr(view), pitch, stream()))
+        check(lib().p2w_stem_h2(prec, ptr(rf), m, ptr(dw_), ptr(db_), Cw, ptr(x0), ptr(view), pitch, None, stream()))
         sref = torch.relu(b["pos"].double() @ w_.double().t() + b_.double())
         assert (x0.cpu().double() - sref).abs().max().item() <= 1e-5
         got = _from_h(wide, prec, pitch)

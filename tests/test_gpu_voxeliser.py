@@ -81,6 +81,17 @@ def test_key_runs_filter(n, min_count):
     assert torch.equal(so[:k].cpu().long(), starts[keep]) and torch.equal(co[:k].cpu().long(), counts[keep])
 
 
+def _host_voxelise(pc, *a, **kw):
+    """The voxeliser's host-side glue over the oracle's tensor restatement of the grid step, on host tensors."""
+    from oracle import preprocess as OP
+    from pointstowood_amd import preprocessing as PP
+    old, PP.backend = PP.backend, OP.TensorBackend
+    try:
+        return PP.voxelise(pc, *a, **kw)
+    finally:
+        PP.backend = old
+
+
 @pytest.mark.parametrize("refl,mode", [(True, "compat"), (False, "compat"), (True, "xyz")])
 def test_voxelise_on_the_gpu_equals_the_tensor_path(refl, mode):
     """preprocessing.voxelise on GPU tensors (cell ids, radix argsort and run filter by the HIP kernels) gives the voxels of the
@@ -88,7 +99,7 @@ def test_voxelise_on_the_gpu_equals_the_tensor_path(refl, mode):
     from pointstowood_amd import preprocessing as PP
     from tests.test_host_cpu import _plot
     pc = _plot(n=120000, seed=5, refl=refl)
-    ref, nz_ref = PP.voxelise(pc, (2.0, 4.0), min_pts=64, max_pts=100000, mode=mode)
+    ref, nz_ref = _host_voxelise(pc, (2.0, 4.0), min_pts=64, max_pts=100000, mode=mode)
     got, nz = PP.voxelise(pc.cuda(), (2.0, 4.0), min_pts=64, max_pts=100000, mode=mode)
     assert len(got) == len(ref) and len(got) > 30
     assert (nz.cpu() - nz_ref).abs().max() <= 1e-5
@@ -103,6 +114,7 @@ def test_voxeliser_keeps_non_finite_rows_out_of_every_voxel():
     """rows with a NaN / inf value take no part in the grid (minima, maxima, cell counts) and belong to no voxel, on the
     HIP path and on the tensor path alike (P2W_CELL_NONFINITE: they sort last as a run of their own, which is dropped); the
     voxels of the finite rows are those of the same cloud without the bad rows."""
+    from oracle import preprocess as OP
     from pointstowood_amd import preprocessing as PP
     from pointstowood_amd._lib import ptr, stream
     from pointstowood_amd import synthetic_voxels as synth
@@ -115,6 +127,7 @@ def test_voxeliser_keeps_non_finite_rows_out_of_every_voxel():
     dirty[bad[:100], 0] = float("nan")
     dirty[bad[100:200], 2] = float("inf")
     dirty[bad[200:], 3] = float("-inf")
+    dirty[bad[:50], 1] = 1e30                           # (a dropped ROW's finite values must not stretch the grid either)
     # cell ids: the finite rows get the ids of the clean cloud restricted to them (same minima / maxima: the extremes are finite rows)
     keep = torch.ones(n, dtype=torch.bool)
     keep[bad] = False
@@ -122,14 +135,14 @@ def test_voxeliser_keeps_non_finite_rows_out_of_every_voxel():
     cell = torch.empty(n, dtype=torch.int64, device="cuda")
     ws = torch.empty(256, dtype=torch.uint8, device="cuda")
     assert L.p2w_cells_nd(ptr(P.cuda()), n, 4, 4, 2.0, ptr(cell), ptr(ws), ws.numel(), stream()) == 0
-    ref = PP._cells(P, 2.0)
+    ref = OP.cells_nd(P, 2.0)
     assert torch.equal(cell.cpu(), ref)
     assert bool((cell.cpu()[bad] == PP.CELL_NONFINITE).all()) and bool((cell.cpu()[keep] != PP.CELL_NONFINITE).all())
-    assert torch.equal(ref[keep], PP._cells(P[keep], 2.0))
+    assert torch.equal(ref[keep], OP.cells_nd(P[keep], 2.0))
     # whole voxeliser, ground normalisation off (its bucketize would see the NaN): GPU == host, no voxel holds a bad row
     dirty5 = torch.cat([dirty, torch.zeros(n, 1)], 1)
     vg, _ = PP.voxelise(dirty5.cuda(), (2.0, 4.0), 64, 16384, ground=False)
-    vh, _ = PP.voxelise(dirty5, (2.0, 4.0), 64, 16384, ground=False)
+    vh, _ = _host_voxelise(dirty5, (2.0, 4.0), 64, 16384, ground=False)
     assert len(vg) == len(vh) > 10
     for a, b in zip(vg, vh):   # same rows in the same order (the normalised reflectance differs in erfinv's last bits between devices)
         assert a.shape == b.shape and torch.equal(a.cpu()[:, :3], b[:, :3]) and torch.allclose(a.cpu(), b, rtol=0, atol=5e-4)

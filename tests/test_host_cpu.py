@@ -119,6 +119,105 @@ def test_c_abi_exports_every_declared_symbol():
     assert L.p2w_version() >= 100 and L.p2w_strerror(-4) == b"p2w: workspace too small"
 
 
+def _header_prototypes():
+    """name -> (return type, [parameter types]) of every function include/p2w.h declares, comments and parameter names stripped."""
+    hdr = open(os.path.join(ROOT, "include", "p2w.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", " ", hdr, flags=re.S)
+    hdr = re.sub(r"^\s*#.*$", " ", hdr, flags=re.M)
+    protos = {}
+    for m in re.finditer(r"([A-Za-z_][A-Za-z0-9_ \*]*?)\b(p2w_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*;", hdr, flags=re.S):
+        ret, name, params = m.group(1).strip(), m.group(2), m.group(3).strip()
+        types = []
+        if params and params != "void":
+            for prm in params.split(","):
+                prm = " ".join(prm.split())
+                t = re.sub(r"\b[A-Za-z_][A-Za-z0-9_]*$", "", prm).strip() if not prm.endswith("*") else prm   # drop the parameter's name
+                types.append(t.replace(" *", "*"))
+        protos[name] = (ret.replace(" *", "*"), types)
+    return protos
+
+
+def _ctype_class(t):
+    """C type of the header -> the ctypes class the binding must use."""
+    t = t.replace("const ", "").strip()
+    if t.endswith("*") or t == "p2w_stream_t":
+        return ctypes.c_char_p if t == "char*" else ctypes.c_void_p
+    return {"int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "size_t": ctypes.c_size_t, "float": ctypes.c_float,
+            "double": ctypes.c_double, "uint32_t": ctypes.c_uint32, "uint64_t": ctypes.c_uint64}[t]
+
+
+def test_binding_signatures_match_the_header_prototypes():
+    """Every prototype of include/p2w.h against pointstowood_amd/_lib.SIGNATURES: arity, return type and the class of every
+    parameter (pointer / int32 / int64 / size_t / float / double) - a drifted binding reads garbage instead of failing."""
+    protos = _header_prototypes()
+    assert set(protos) == set(_lib.SIGNATURES), set(protos) ^ set(_lib.SIGNATURES)
+    for name, (ret, params) in protos.items():
+        res, args = _lib.SIGNATURES[name]
+        want_ret = None if ret == "void" else _ctype_class(ret)
+        assert res is want_ret or (want_ret is ctypes.c_void_p and res is ctypes.c_char_p), (name, ret, res)
+        assert len(args) == len(params), (name, len(args), params)
+        for i, (a, t) in enumerate(zip(args, params)):
+            want = _ctype_class(t)
+            ok = a is want or (want is ctypes.c_void_p and isinstance(a, type) and issubclass(a, ctypes._Pointer))
+            assert ok, (name, i, t, a)
+    # the epilogue structure, field by field
+    hdr = open(os.path.join(ROOT, "include", "p2w.h")).read()
+    body = re.sub(r"/\*.*?\*/", " ", re.search(r"typedef struct p2w_epilogue \{(.*?)\} p2w_epilogue;", hdr, flags=re.S).group(1), flags=re.S)
+    fields = []
+    for decl in body.split(";"):
+        decl = " ".join(decl.split())
+        if not decl:
+            continue
+        base = decl.split(",")[0]
+        ptr = "*" in base
+        names = [n.strip().lstrip("*") for n in re.sub(r"^(const )?[a-z0-9_]+\s*\*?", "", decl, count=1).split(",")]
+        fields += [(n, ctypes.c_void_p if ptr else ctypes.c_int32) for n in names]
+    assert fields == [(n, t) for n, t in _lib.Epilogue._fields_], fields
+
+
+def test_header_compiles_as_c_and_the_library_links(tmp_path):
+    """include/p2w.h is a C header (no C++ leaks) and libp2w_gfx950.so is an ordinary shared library: a C program built with gcc
+    calls the version / error-string / packed-dimension helpers and gets the documented status from an argument error - no Python,
+    no torch, no GPU.  The library exports the p2w_* ABI and nothing else."""
+    import shutil
+    import subprocess
+    _lib.lib()
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "abi.c"
+    src.write_text('''
+#include <stdio.h>
+#include <string.h>
+#include "p2w.h"
+int main(void) {
+    int32_t np = 0, kp = 0;
+    p2w_epilogue e;
+    memset(&e, 0, sizeof e);
+    if (p2w_version() < 500) return 1;
+    if (strcmp(p2w_strerror(P2W_EWORKSPACE), "p2w: workspace too small") != 0) return 2;
+    p2w_packed_dims(100, 70, &np, &kp);
+    if (np != 256 || kp != 96) return 3;
+    if (p2w_gemm_h2(7, (const void*)16, 32, (const void*)16, 1.0f, 4, 4, 4, &e, (float*)16, 4, 0, 0, 0, 0) != P2W_EINVAL) return 4;
+    if (p2w_gemm_h2_sk_ws_bytes() == 0) return 5;
+    printf("abi ok %d %zu\\n", (int)p2w_version(), sizeof(p2w_epilogue));
+    return 0;
+}
+''')
+    exe = tmp_path / "abi"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    r = subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-x", "c", str(src), "-I", os.path.join(ROOT, "include"), "-L", libdir,
+                        "-l:libp2w_gfx950.so", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.startswith("abi ok"), (r.returncode, r.stdout, r.stderr)
+    assert int(r.stdout.split()[3]) == ctypes.sizeof(_lib.Epilogue)
+    nm = shutil.which("nm")
+    if nm:
+        syms = [l.split()[-1] for l in subprocess.run([nm, "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout.splitlines() if l.strip()]
+        assert syms and all(x.startswith("p2w_") for x in syms), [x for x in syms if not x.startswith("p2w_")][:5]
+
+
 def test_partition_is_balanced_and_deterministic():
     costs = [16384, 128, 9000, 700, 16384, 5000, 12000, 300, 8000]
     plan = partition_batches(costs, 4)
@@ -241,8 +340,15 @@ def _plot(n=60000, seed=0, refl=True):
     return torch.cat(cols, 1)
 
 
+def test_voxeliser_refuses_host_tensors():
+    """One path per stage: the product's voxeliser runs its grid step on the HIP library and refuses points on the host."""
+    from pointstowood_amd import preprocessing as PP
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        PP.voxelise(_plot(n=2000), (2.0,), min_pts=64)
+
+
 @pytest.mark.parametrize("refl", [True, False])
-def test_voxeliser_matches_reference_restatement(refl):
+def test_voxeliser_matches_reference_restatement(refl, tensor_backend):
     from oracle import preprocess as OP
     from pointstowood_amd import preprocessing as PP
     pc = _plot(refl=refl)
@@ -513,9 +619,18 @@ def _cpu_collect(cls_xyz, cls_pred, cls_prob, query_xyz, any_wood=1.0, k=1):
     return cls_pred[j].clone(), cls_prob[j].clone()
 
 
+def _cpu_stand_ins():
+    """In a spawned worker: the CPU stand-ins of the two GPU stages around the host-side logic under test."""
+    from oracle import preprocess as OP
+    from pointstowood_amd import pipeline, preprocessing
+    pipeline.collect_predictions = _cpu_collect
+    preprocessing.backend = OP.TensorBackend
+    return pipeline
+
+
 def _plot_worker(rank, world, port, max_points, q):
     import torch.distributed as dist
-    from pointstowood_amd import pipeline
+    pipeline = _cpu_stand_ins()
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(1)
@@ -529,7 +644,7 @@ def _plot_worker(rank, world, port, max_points, q):
 
 
 @pytest.mark.parametrize("world,max_points", [(4, 3000), (8, 100000)])
-def test_segment_plot_sharded_gloo_world4_and_8(world, max_points, monkeypatch):
+def test_segment_plot_sharded_gloo_world4_and_8(world, max_points, monkeypatch, tensor_backend):
     """The sharded plot flow (pipeline.segment_plot: LPT-partitioned voxel batches -> all-gather of the classified points ->
     plot slices -> all-gather of the per-point results) at world sizes 4 and 8, including ranks that get NO batch (world 8
     with one large-budget batch: seven idle ranks) and ranks whose share is one small batch: every rank must end with the
@@ -566,7 +681,7 @@ def test_segment_plot_sharded_gloo_world4_and_8(world, max_points, monkeypatch):
 
 def _budget_worker(rank, world, port, q):
     import torch.distributed as dist
-    from pointstowood_amd import pipeline
+    pipeline = _cpu_stand_ins()
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(1)
@@ -634,7 +749,7 @@ def test_gather_logits_gloo_world4_and_8_with_empty_and_tiny_ranks(counts):
     assert all(out == expect for _, out in res)
 
 
-def test_auto_cell_and_default_forward_budget(monkeypatch):
+def test_auto_cell_and_default_forward_budget(monkeypatch, tensor_backend):
     """backproject.auto_cell follows the cloud's density (denser cloud -> smaller cells, clamped); segment_plot's default
     budget is a fifth of the classified points, clamped to [262144, 2097152] (so a small plot goes through in one forward)."""
     from pointstowood_amd import pipeline
