@@ -47,7 +47,7 @@ sys.path.insert(0, ROOT)
 PEAK_TFLOPS = {"fp32": 157.3, "f16x3": 2500.0, "fp16": 2500.0, "bf16": 2500.0}
 PEAK_HBM_GBPS = 8000.0
 C, K_NBR, BATCH, NPTS = 32, 32, 8, 16384
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r4_{precision}_hbm_traffic.json")   # written by tools/profile_round.sh
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r5_{precision}_hbm_traffic.json")   # written by tools/profile_round.sh
 
 
 def parse_args(argv=None):
@@ -178,6 +178,9 @@ def search_pairs(geo):
 # 2 adds per pair (oracle/ops.py's ((dx*dx)+(dy*dy))+(dz*dz), no FMA) = 8 FLOP; the compare / insertion is not counted
 PEAK_PAIRS_PER_S = 157.3e12 / 8.0
 
+SEARCH_EVAL_FILE = os.path.join(ROOT, "profiles", "r5_search_evaluated.json")
+MFMA_BUSY_FILE = os.path.join(ROOT, "profiles", "r5_{precision}_mfma_busy.csv")
+
 KERNEL_OF = {"gemm_hoist": "gemm_kernel", "gemm_res": "gemm_kernel", "gemm_mlp": "gemm_kernel", "sa_conv": "sa_conv_kernel"}
 
 
@@ -207,6 +210,28 @@ def profile_step(net, data, reps=3):
     eng.res_streams = streams
     per = {kname: (statistics.median(r[kname][0] for r in runs), runs[0][kname][1]) for kname in runs[0]}
     return per, keep["geometry"]
+
+
+MFMA_PER_PRODUCT = {"f16x3": 3, "fp16": 1, "bf16": 1, "fp32": 1}
+
+
+def mfma_busy(precision):
+    """SQ_VALU_MFMA_BUSY_CYCLES share per GEMM instantiation from the round's committed PMC summary (separate --pmc pass of the
+    same command: tools/profile_round.sh), or None."""
+    import csv
+    try:
+        rows = list(csv.DictReader(l for l in open(MFMA_BUSY_FILE.format(precision=precision)) if not l.lstrip('"').startswith("#")))
+    except OSError:
+        return None
+    out = {}
+    for r in rows:
+        name = r.get("kernel") or r.get("Kernel_Name") or ""
+        if "gemm_hp" in name:
+            for key in ("mfma_busy_pct", "MFMA_busy_pct", "mfma_busy"):
+                if key in r:
+                    out[name[:80]] = float(r[key])
+                    break
+    return {"source": os.path.relpath(MFMA_BUSY_FILE.format(precision=precision), ROOT), "percent_by_instantiation": out} if out else None
 
 
 def cpu_model():
@@ -313,14 +338,21 @@ def measure_workload(net, data, reps=5):
     return out
 
 
-def plot_workload(net, args, device, n=10_000_000, reps=2):
+def plot_workload(args, device, n=10_000_000, reps=2):
     """BASELINE configs[3] at its stated size on this GPU: the 10 M-point synthetic forest plot through
     pipeline.segment_plot (voxelise 2 m + 4 m -> classify every voxel -> back-project with the k = 64 median vote;
-    reference predict.py:116-156, src/predicter.py:193-234, src/preprocessing.py:79-127).  One untimed run (allocator), then
-    `reps` timed ones; the stage times are those of the last run."""
+    reference predict.py:116-156, src/predicter.py:193-234, src/preprocessing.py:79-127) on a Net of its own.  One untimed run
+    (allocator), then `reps` timed ones (stage times of the last); then ONE more run with the forwards issued one after the other
+    and a HIP-event bracket per kernel class: the plot's level sizes, algorithmic FLOPs and per-class times - how efficiently the
+    plot's ragged forwards run compared with the bench batch."""
     import torch
+    from pointstowood_amd import Net
+    from pointstowood_amd import synthetic_weights as weights
     from pointstowood_amd.pipeline import segment_plot
     from pointstowood_amd.synthetic_voxels import forest_plot
+    net = Net(num_classes=1, C=C, k=K_NBR, precision=args.precision, **engine_options(args.engine_opt))
+    net.load_state_dict(weights.synth_state_dict(1, C, seed=0), strict=True)
+    net = net.to(device).eval()
     pc = forest_plot(n, side=100.0).to(device)
     gen = lambda: torch.Generator(device=device).manual_seed(0)
     segment_plot(pc, net, generator=gen())
@@ -341,7 +373,84 @@ def plot_workload(net, args, device, n=10_000_000, reps=2):
            "stages_s_last_run": {k: round(v, 4) for k, v in stats.items() if k.endswith("_s")},
            "forwards": len(stats.get("batch_points", [])), "max_points_per_forward": stats.get("max_points"),
            "outputs_ok": ok, "dtype": args.precision}
-    del pc, n_z, label, pwood
+    # efficiency: sequential forwards with per-class event brackets
+    eng = net._engine
+    macs, kmacs_tot, fwd_sizes = 0, {}, []
+    feats = eng.features
+
+    def features(geo, keep=None):
+        nonlocal macs
+        t, km, sz = algorithmic_macs(geo)
+        macs += t
+        for k_, v in km.items():
+            kmacs_tot[k_] = kmacs_tot.get(k_, 0) + v
+        fwd_sizes.append(dict(sz, voxels=geo.B))
+        return feats(geo, keep)
+    eng.features = features
+    net.stream = lambda batches: (net(b) for b in batches)     # one forward after the other on one stream: the brackets need it
+    try:
+        segment_plot(pc, net, generator=gen())                 # (untimed: this stream's allocator pool has not seen these forwards yet)
+        macs, kmacs_tot, fwd_sizes = 0, {}, []
+        eng.events, eng.events_grouped = [], True
+        st2 = {}
+        segment_plot(pc, net, generator=gen(), stats=st2)
+        eng.flush_events()
+        torch.cuda.synchronize()
+        ev = eng.events
+    finally:
+        eng.events, eng.events_grouped = None, False
+        del eng.features, net.stream
+    per = {}
+    for name, s_, e_, launches in ev:
+        kname = KERNEL_OF.get(name, name)
+        t_, n_ = per.get(kname, (0.0, 0))
+        per[kname] = (t_ + s_.elapsed_time(e_), n_ + launches)
+    cls_s = max(stats.get("classify_s", 0.0), 1e-9)
+    out["classify_tflops_algorithmic"] = round(2.0 * macs / cls_s / 1e12, 2)
+    out["algorithmic_gflop_per_plot"] = round(2.0 * macs / 1e9, 1)
+    out["sequential_profile"] = {
+        "classify_s": round(st2.get("classify_s", 0.0), 4),
+        "kernel_ms_per_plot": {k: round(v[0], 2) for k, v in sorted(per.items(), key=lambda kv: -kv[1][0])[:8]},
+        "kernel_launches_per_plot": {k: v[1] for k, v in sorted(per.items(), key=lambda kv: -kv[1][0])[:3]},
+        "note": "HIP-event brackets per run of consecutive launches of one class, forwards issued one after the other: a class' time "
+                "includes the gaps to the next class' first launch (the last search's includes the host's wait for the level sizes)",
+    }
+    for kname, m_ in kmacs_tot.items():
+        if kname in per and per[kname][0] > 0:
+            out["sequential_profile"][kname + "_tflops_algorithmic"] = round(2.0 * m_ / (per[kname][0] * 1e-3) / 1e12, 1)
+    tot = lambda key: [sum(f[key][i] for f in fwd_sizes) for i in range(3)]
+    big = max(fwd_sizes, key=lambda f: f["N"]) if fwd_sizes else None
+    out["level_sizes_total"] = {"N": sum(f["N"] for f in fwd_sizes), "M": tot("M"), "E": tot("E"), "forwards": len(fwd_sizes)} if fwd_sizes else None
+    out["level_sizes_largest_forward"] = big
+    # The same voxels through the reference's CLI surface (predict.py --voxels = predicter.classify_voxels; the voxel list in
+    # memory instead of 14 k files): host-side dataset feed + collation -> stream pipeline -> one D2H copy, against the
+    # reference-shaped loop (BalancedBatchSampler at --batch_size 8, one forward and one D2H copy per batch) on every 4th voxel.
+    try:
+        from pointstowood_amd import DataLoader, predicter
+        from pointstowood_amd.preprocessing import voxelise
+        vox, _ = voxelise(pc, (2.0, 4.0), 128, 16384, generator=gen())
+        host_vox = [v.cpu() for v in vox]
+        del vox
+        ds = predicter.VoxelDataset(host_vox)
+        predicter.classify_voxels(net, predicter.VoxelDataset(host_vox[::16]), 0.5, device)      # (allocator)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rows = predicter.classify_voxels(net, ds, 0.5, device)
+        dt_new = time.perf_counter() - t0
+        sub = predicter.VoxelDataset(host_vox[::4])
+        sampler = predicter.BalancedBatchSampler(sub, 8)
+        t0 = time.perf_counter()
+        n_old = sum(predicter.classify_batch(net, d, 0.5, device).shape[0] for d in DataLoader(sub, batch_sampler=sampler, num_workers=0))
+        dt_old = time.perf_counter() - t0
+        out["voxel_directory_cli"] = {
+            "voxels": len(ds), "points": int(rows.shape[0]), "s": round(dt_new, 3), "points_per_s": round(rows.shape[0] / dt_new, 1),
+            "path": "predicter.classify_voxels: PointBudgetSampler (262144 points per forward) -> Net.stream -> one D2H copy",
+            "batch_size_8_loop": {"voxels": len(sub), "points": int(n_old), "s": round(dt_old, 3), "points_per_s": round(n_old / dt_old, 1),
+                                  "path": "BalancedBatchSampler(8) + one classify_batch (forward + D2H) per batch: the reference's loop shape"}}
+        del rows, host_vox, ds, sub
+    except Exception as e:   # the headline line must not die on an auxiliary workload
+        out["voxel_directory_cli"] = {"error": repr(e)[:300]}
+    del pc, n_z, label, pwood, net
     torch.cuda.empty_cache()
     return out
 
@@ -361,8 +470,6 @@ def extra_workloads(net, args, device):
         ("surface B=8 x 16384 xyz-only (cylinders + blobs: ball-query cap saturated)",
          lambda: [synth.surface_voxel(2.0, NPTS, 300 + i, False) for i in range(BATCH)]),
     ]
-    if not args.no_plot_workload:
-        out["configs[3] 10 M-point plot (voxelise + classify + back-project, 1 GPU)"] = plot_workload(net, args, device)
     for name, make in cases:
         d = device_feed(make(), device)
         out[name] = dict(measure_workload(net, d), dtype=args.precision)
@@ -375,6 +482,8 @@ def extra_workloads(net, args, device):
             del net16
         del d
         torch.cuda.empty_cache()
+    if not args.no_plot_workload:   # last, and on a Net of its own: its oversized voxels must not shape the other workloads' engine state
+        out["configs[3] 10 M-point plot (voxelise + classify + back-project, 1 GPU)"] = plot_workload(args, device)
     return out
 
 
@@ -608,19 +717,38 @@ def main():
                 hbm[name] = {"algorithmic_bytes_per_step": nbytes, "ms_per_step": round(per[name][0], 4), "launches": per[name][1],
                              "achieved_GBps": round(gbps, 1), "frac_of_8TBps": round(gbps / PEAK_HBM_GBPS, 4)}
         pairs = search_pairs(geo)
-        search = {"unit": "candidate-distance evaluations/s (reference brute-force definition: queries x candidates per voxel)",
-                  "peak": PEAK_PAIRS_PER_S, "peak_note": "fp32 VALU peak 157.3 TFLOP/s / 8 FLOP per evaluation",
-                  "kernels": {}}
+        # The searches against the fp32 VALU peak: the roofline figure counts the distance evaluations the grid kernels PERFORM
+        # (profiles/r5_search_evaluated.json: counted in a -DP2W_SLAB_PROFILE build on this workload's batch 0); the reference's
+        # brute-force definition (queries x candidates per voxel) is what the kernels save, reported as a ratio, not as a fraction.
+        evaluated, ev_src = {}, None
+        try:
+            ev = json.load(open(SEARCH_EVAL_FILE))
+            evaluated, ev_src = ev.get("evaluated_pairs_per_step", {}), os.path.relpath(SEARCH_EVAL_FILE, ROOT)
+        except (OSError, ValueError):
+            pass
+        search = {"unit": "candidate-distance evaluations/s", "peak": PEAK_PAIRS_PER_S,
+                  "peak_note": "fp32 VALU peak 157.3 TFLOP/s / 8 FLOP per evaluation",
+                  "evaluated_source": ev_src, "kernels": {}}
         for name, npairs in pairs.items():
             if name in per and per[name][0] > 0:
-                rate = npairs / (per[name][0] * 1e-3)
-                search["kernels"][name] = {"pairs_per_step": npairs, "ms_per_step": round(per[name][0], 4), "launches": per[name][1],
-                                           "achieved": rate, "frac_of_valu_peak": round(rate / PEAK_PAIRS_PER_S, 4)}
+                sec = per[name][0] * 1e-3
+                k = {"ms_per_step": round(per[name][0], 4), "launches": per[name][1], "bruteforce_pairs_per_step": npairs}
+                if name in evaluated:
+                    k["evaluated_pairs_per_step"] = int(evaluated[name])
+                    k["achieved"] = evaluated[name] / sec
+                    k["frac_of_valu_peak"] = round(evaluated[name] / sec / PEAK_PAIRS_PER_S, 5)
+                    k["bruteforce_over_evaluated"] = round(npairs / max(evaluated[name], 1), 1)
+                search["kernels"][name] = k
         tot_ms = sum(v["ms_per_step"] for v in search["kernels"].values())
         if tot_ms > 0:
             search["ms_per_step"] = round(tot_ms, 4)
-            search["achieved"] = sum(pairs[k] for k in search["kernels"]) / (tot_ms * 1e-3)
-            search["frac_of_valu_peak"] = round(search["achieved"] / PEAK_PAIRS_PER_S, 4)
+            ev_tot = sum(v.get("evaluated_pairs_per_step", 0) for v in search["kernels"].values())
+            if ev_tot:
+                search["achieved"] = ev_tot / (tot_ms * 1e-3)
+                search["frac_of_valu_peak"] = round(search["achieved"] / PEAK_PAIRS_PER_S, 5)
+            search["bruteforce_pairs_per_s"] = sum(pairs[k] for k in search["kernels"]) / (tot_ms * 1e-3)
+            search["note"] = ("latency-bound kernels (VALU active 17-26 % of wave cycles, profiles/*_valu.csv): the fraction says how "
+                              "little of the chip's arithmetic the exact searches need, not how well they use it")
         notes = {"f16x3": "f16x3 issues 3 fp16 MFMAs per algorithmic product: ceiling for algorithmic FLOPs is peak/3",
                  "fp16": "one fp16 MFMA per product", "bf16": "one bf16 MFMA per product", "fp32": "exact fp32 MFMA"}
         line = {
@@ -646,7 +774,10 @@ def main():
                          "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)",
                          "traffic_bytes_per_step": traffic_step, "traffic_source": traffic_src, "note": notes[args.precision],
                          "launches_per_step": dom_launches, "kernel_ms_per_step": dom_ms,
-                         "algorithmic_gflop_per_step": 2.0 * kmacs[dom] / 1e9},
+                         "algorithmic_gflop_per_step": 2.0 * kmacs[dom] / 1e9,
+                         "executed_frac": achieved * MFMA_PER_PRODUCT[args.precision] / peak,
+                         "executed_note": "executed MFMA rate / peak = frac x MFMAs per algorithmic product",
+                         "mfma_busy": mfma_busy(args.precision)},
             "hbm_kernels": hbm,
             "search": search,
             "kernel_ms_per_step": {kname: round(v[0], 4) for kname, v in sorted(per.items(), key=lambda kv: -kv[1][0])},

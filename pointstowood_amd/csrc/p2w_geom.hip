@@ -1398,7 +1398,7 @@ __global__ __launch_bounds__(256, (MODE == 0 && SEL == 2) ? P2W_COLLECT_WAVES : 
         for (int rb = 0; rb < nrt; rb += G_MAXRUN) {
         const int n_c = build(rb);
         SLAB_STAMP(2);   // plan
-        SLAB_COUNT(8, 1); SLAB_COUNT(9, n_c); SLAB_COUNT(10, __popc(active));
+        SLAB_COUNT(8, 1); SLAB_COUNT(9, n_c); SLAB_COUNT(10, __popc(active)); SLAB_COUNT(13, (unsigned long long)n_c * __popc(active));   // 13: distance evaluations
         for (int tbase = 0; tbase < n_c; tbase += TILE) {
             __syncthreads();   // previous tile consumed
             // slots used by this tile: a power of two >= the candidates left (>= 256), so that the shuffle stays a

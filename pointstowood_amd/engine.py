@@ -299,6 +299,8 @@ class Engine:
             setattr(self, name, getattr(self.options, name))
         self._table_scale = [1, 1, 1]   # per level: grows by 8 (up to TABLE_SCALE_MAX) after an overflow
         self._table_rest = [0, 0, 0]    # per level: batches the table sits out after overflowing at its largest scale
+        self._table_probe = [False, False, False]   # per level: the table just handed out was smaller than the remembered factor (a probe)
+        self._table_probe_rest = [0, 0, 0]          # per level: oversized batches that take the sort before the next probe
         self._ws_t = None
         self._range = None        # range watch of the feature phase being enqueued: (layer names, device floats)
         self.fallback = None      # callable(geo, keep) -> logits on an arithmetic without the range limit (Net: the fp32 engine)
@@ -391,7 +393,23 @@ class Engine:
         # voxel count, take the sort: a smaller table is the one that already overflowed (round 4: a 67-voxel batch of 4 m plot
         # voxels shrank the factor back to 1, overflowed, and paid a discarded geometry pass + the sort on every forward)
         cells = B * per_voxel * self._table_scale[level]
-        return cells if cells <= self.TABLE_CELLS_MAX else 0
+        if cells <= self.TABLE_CELLS_MAX:
+            return cells
+        # The remembered extent does not fit for THIS many voxels.  The factor is one number per level, but batches differ: after a
+        # batch of 4 m plot voxels (factor 8) every later batch of many NOMINAL voxels would take the sort for the life of the engine
+        # (ADVICE r4).  So such a batch PROBES the largest smaller factor that fits - a probe that overflows costs one discarded
+        # geometry pass, is not answered by growing the factor, and silences probing for TABLE_REST batches (they take the sort).
+        if self._table_probe_rest[level] > 0:
+            self._table_probe_rest[level] -= 1
+            return 0
+        s = self._table_scale[level]
+        while s > 1 and B * per_voxel * s > self.TABLE_CELLS_MAX:
+            s //= 8
+        cells = B * per_voxel * s
+        if cells > self.TABLE_CELLS_MAX:
+            return 0
+        self._table_probe[level] = True
+        return cells
 
     def _table_workspace(self, n, cells, device):
         need = int(lib().p2w_voxel_sample_table_ws_bytes(n, cells))
@@ -421,6 +439,7 @@ class Engine:
         geo.stream = torch.cuda.current_stream()
         status = torch.zeros(3, **i32)    # per level: 1 = the table sampler's grid did not fit (results undefined)
         geo.table_levels = []
+        geo.table_probes = []      # levels whose table was handed out BELOW the remembered growth factor (see _table_cells)
         xyzr0, batch0 = torch.empty((N, 4), **f32), torch.empty(N, **i32)
         self._call("pack_xyzr", L.p2w_pack_xyzr, ptr(pos), pos.stride(0), ptr(reflectance), ptr(ptr0), B, N,
                    ptr(xyzr0), ptr(batch0))
@@ -451,7 +470,10 @@ class Engine:
             # rank of every source point's cell among the sampled level (= index of its representative): seeds the
             # interpolation searches (level 0 takes part in its sorted order, so it needs the rank per sorted position)
             ranks[l] = torch.empty(N, **i32) if (grid_search and self.fp_hints) else None
+            self._table_probe[l] = False
             cells = 0 if force_sort else self._table_cells(l, B, N)
+            if self._table_probe[l]:
+                geo.table_probes.append(l)
             if cells:
                 ws_t = self._table_workspace(N, cells, dev)
                 geo.table_levels.append(l)
@@ -543,6 +565,9 @@ class Engine:
             # downstream of the first of them is undefined.  Repeat the geometry with the sort (rare: voxels much larger than
             # 2 m), and give the table 8 x the room next time.
             for l in overflow:   # more room next time (capped); whether a batch's table is worth taking is _table_cells' decision
+                if l in getattr(geo, "table_probes", ()):   # a probe below the remembered factor failed: no growth, no probing for a while
+                    self._table_probe_rest[l] = self.TABLE_REST
+                    continue
                 if self._table_scale[l] >= self.TABLE_SCALE_MAX:
                     self._table_rest[l] = self.TABLE_REST     # no more room to give: the sort serves the next batches
                 self._table_scale[l] = min(self._table_scale[l] * 8, self.TABLE_SCALE_MAX)

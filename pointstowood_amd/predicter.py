@@ -42,6 +42,14 @@ class VoxelDataset(torch.utils.data.Dataset):
     def raw(self, index):
         return self._mem[index] if self._mem is not None else torch.load(self.keys[index])
 
+    def preload(self):
+        """Reads every voxel file once and keeps it (the reference reads each file twice: its sampler loads every voxel for its
+        length, the loader loads it again - predicter.py:28-31,78-80); returns the voxel lengths, also kept as ``lengths``."""
+        if self._mem is None:
+            self._mem = [torch.load(k) for k in self.keys]
+        self.lengths = [int(len(v)) for v in self._mem]
+        return self.lengths
+
     def __getitem__(self, index):
         pc = torch.as_tensor(self.raw(index))
         pos = pc[:, :3].to(torch.float32)
@@ -197,7 +205,7 @@ def classify(model, loader, is_wood: float = 0.5, device="cuda"):
 
         def feed():
             for data in loader:
-                d = data.to(device)
+                d = data.to(device, non_blocking=True)       # (pinned by the loader: the copy overlaps the forwards in flight)
                 held.append(d)
                 yield d
         with torch.no_grad():
@@ -206,6 +214,55 @@ def classify(model, loader, is_wood: float = 0.5, device="cuda"):
         return torch.cat(outs).cpu().numpy() if outs else np.zeros((0, 5), dtype=np.float64)
     outs = [classify_batch(model, data, is_wood, device) for data in loader]
     return np.vstack(outs) if outs else np.zeros((0, 5), dtype=np.float64)
+
+
+def classify_voxels(model, dataset, is_wood: float = 0.5, device="cuda", batch_size: int = 8, reference_sampler: bool = False,
+                    max_points: int = 262144, max_voxels: int = 256):
+    """``predict.py --voxels`` on one GPU: every voxel of ``dataset`` through the model, rows as ``classify`` returns them
+    ([n, 5] float64: un-shifted xyz, prediction, probability - predicter.py:193-213).
+
+    Default: the voxels are read once (``VoxelDataset.preload``), packed into forwards of at most ``max_points`` points
+    (``PointBudgetSampler``: every voxel exactly once, sizes the kernels are efficient at) and streamed through
+    ``Net.stream`` - geometry of the next forward beside the features of the current ones, one device-to-host copy at the end.
+    ``reference_sampler=True``: the reference's ``BalancedBatchSampler`` at ``batch_size`` voxels per forward (it draws from the
+    global numpy RNG and drops the voxels of the last incomplete batch, as there), through the same pipeline."""
+    if reference_sampler:
+        sampler = BalancedBatchSampler(dataset, batch_size, reference=True)
+    else:
+        sampler = PointBudgetSampler(dataset.preload(), max_points, max_voxels)
+    return classify(model, prefetch_batches(dataset, list(sampler), pin=torch.device(device).type == "cuda"), is_wood, device)
+
+
+def prefetch_batches(dataset, batches, pin: bool = True, workers: int = 1, ahead: int = 4):
+    """The loader of ``classify_voxels``: yields ``Batch.from_data_list([dataset[i] for i in b])`` for every b of ``batches``, in
+    order, built `ahead` batches ahead by a background thread and (``pin``) in pinned memory, so that the host-side feed - a dozen
+    small tensor operations per voxel (predicter.py:78-94) - runs beside the forwards in flight instead of between them.  The
+    worker computes with ONE intra-op thread: the operations are a few thousand elements each, and with the process-wide thread
+    count the reference's CLI sets (all cores, predict.py:79-84) each of them costs a thread-team barrier (measured on a
+    256-thread host: 0.5 ms per voxel instead of 0.1).  More than one worker thread does not pay: the per-voxel operations
+    are too small to release the interpreter lock for long (measured: 0.43 s with 1 worker, 0.97 with 2, 6.1 with 8)."""
+    import collections
+    from concurrent.futures import ThreadPoolExecutor
+
+    def init():
+        torch.set_num_threads(1)          # (per calling thread: the feed's workers only)
+
+    def build(b):
+        out = Batch.from_data_list([dataset[i] for i in b])
+        return out.pin_memory() if pin else out
+    batches = list(batches)
+    with ThreadPoolExecutor(max_workers=max(1, min(workers, len(batches))), initializer=init) as pool:
+        pending = collections.deque()
+        it = iter(batches)
+        for b in it:
+            pending.append(pool.submit(build, b))
+            if len(pending) > ahead + workers:
+                break
+        while pending:
+            yield pending.popleft().result()
+            nxt = next(it, None)
+            if nxt is not None:
+                pending.append(pool.submit(build, nxt))
 
 
 def classify_sharded(model, dataset, batches, is_wood, device, dist):

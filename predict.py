@@ -27,7 +27,7 @@ def build_parser():
     p = argparse.ArgumentParser()
     p.add_argument('--point-cloud', '-p', default=[], nargs='+', type=str, help='list of point cloud files')
     p.add_argument('--odir', type=str, default='.', help='output directory')
-    p.add_argument('--batch_size', default=8, type=int, help="voxels per forward")
+    p.add_argument('--batch_size', default=8, type=int, help="voxels per forward with --reference-sampler (the default packs forwards by a point budget)")
     p.add_argument('--num_procs', default=-1, type=int, help="Number of CPU cores you want to use.")
     p.add_argument('--resolution', type=float, default=0.01, help='Resolution to which point cloud is downsampled [m]')
     p.add_argument('--grid_size', type=float, nargs='+', default=[2.0, 4.0], help='Grid sizes for voxelization')
@@ -124,7 +124,7 @@ def main(argv=None):
         raise SystemExit('predict.py needs an MI355X: the HIP path has no CPU fallback')
 
     from pointstowood_amd import DataLoader, Net
-    from pointstowood_amd.predicter import (BalancedBatchSampler, VoxelDataset, classify_batch, classify_sharded, load_model)
+    from pointstowood_amd.predicter import (BalancedBatchSampler, VoxelDataset, classify_sharded, classify_voxels, load_model)
     # one process per GPU under `python -m torch.distributed.run --nproc-per-node N predict.py --voxels ...`: the voxel
     # batches are sharded over the ranks (predicter.classify_sharded), rank 0 writes the result
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
@@ -145,16 +145,16 @@ def main(argv=None):
     ds = VoxelDataset(args.voxels)
     if len(ds) == 0:
         raise SystemExit(f'no voxel_*.pt files in {args.voxels}')
-    sampler = BalancedBatchSampler(ds, args.batch_size, reference=args.reference_sampler)
     t0 = time.time()
     if world > 1:
+        sampler = BalancedBatchSampler(ds, args.batch_size, reference=args.reference_sampler)
         if args.reference_sampler:
             np.random.seed(0)      # the reference's sampler draws from the global numpy RNG: every rank needs the same batches
         out = classify_sharded(model, ds, [list(b) for b in sampler], args.is_wood, device, dist)
     else:
-        loader = DataLoader(ds, batch_sampler=sampler, num_workers=0, pin_memory=True)
-        outs = [classify_batch(model, data, args.is_wood, device) for data in loader]
-        out = np.vstack(outs)
+        # the reference's loop (predicter.py:193-215) through the stream pipeline: voxels read once, forwards packed by a point
+        # budget (--reference-sampler: its BalancedBatchSampler at --batch_size voxels per forward), one D2H copy at the end
+        out = classify_voxels(model, ds, args.is_wood, device, batch_size=args.batch_size, reference_sampler=args.reference_sampler)
     n = out.shape[0]
     if rank != 0:
         return out

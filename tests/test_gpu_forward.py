@@ -240,6 +240,36 @@ def test_stream_pipeline_equals_sequential_forward():
         assert all((a - seq[i % 4]).abs().max() <= 2e-4 for i, a in enumerate(got)), kw
 
 
+def test_table_sampler_recovers_after_oversized_voxels():
+    """one batch of 4 m voxels grows the table sampler's remembered extent (x 8); a later batch of MANY nominal 2 m voxels,
+    for which a table of that extent no longer fits, must not fall to the sort sampler for the life of the engine: it probes the
+    largest smaller table that fits - and gets it.  Same logits as a fresh engine either way."""
+    from pointstowood_amd import Net
+    sd = weights.synth_state_dict(1, 8, seed=2)
+
+    def mk(vox):
+        b = synth.collate(vox)
+        d = _D()
+        d.pos, d.batch, d.reflectance, d.sf = b["pos"].cuda(), b["batch"].cuda(), b["reflectance"].cuda(), b["sf"].cuda()
+        return d
+    big = [synth.uniform_voxel(4.0, 12000, 500 + i, False) for i in range(3)]
+    many = [synth.uniform_voxel(2.0, 7000, 600 + i, False) for i in range(48)]     # 48 x 216000 x 8 cells > the table's maximum
+    net = Net(num_classes=1, C=8, k=32)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().eval()
+    keep = {"geometry_only": True}
+    net(mk(big), keep=keep)
+    eng = net._engine
+    assert eng._table_scale[0] >= 8                      # the 4 m voxels overflowed the nominal level-0 table once
+    keep = {"geometry_only": True}
+    out = net(mk(many), keep=keep)
+    assert 0 in keep["geometry"].table_levels and 0 in keep["geometry"].table_probes     # level 0 ran on a (probed) table, not the sort
+    fresh = Net(num_classes=1, C=8, k=32)
+    fresh.load_state_dict(sd, strict=True)
+    fresh = fresh.cuda().eval()
+    assert torch.equal(out, fresh(mk(many)))
+
+
 def _rescaled(sd, spots, s):
     """`sd` with the activations at `spots` multiplied by s and the consuming weights divided by s: the same function (ReLU and
     the eval-mode BatchNorm / depthwise affines are positively homogeneous), but the tensors BETWEEN the two GEMMs are s times
@@ -325,10 +355,10 @@ def test_predict_cli_on_a_voxel_directory(tmp_path):
     assert out.shape == (2400, 5) and os.path.exists(tmp_path / "o" / "classified_voxels.npy")
     torch.set_num_threads(min(os.cpu_count() or 1, 16))   # predict.py sets all cores like the reference; the oracle crawls there
     # oracle: classify every voxel alone is NOT equivalent (batch-global grid origin), so rebuild the same batches
-    from pointstowood_amd.predicter import BalancedBatchSampler, VoxelDataset
+    from pointstowood_amd.predicter import PointBudgetSampler, VoxelDataset
     ds = VoxelDataset(str(vdir))
     ref_rows = []
-    for batch in BalancedBatchSampler(ds, 2):
+    for batch in PointBudgetSampler(ds.preload(), 262144, 256):      # the CLI's default: forwards packed by a point budget
         feeds = [ohost.feed(ds.raw(i)) for i in batch]
         b = synth.collate(feeds)
         logits = onet.forward(sd, b["pos"], b["batch"], b["reflectance"], b["sf"], k=32)
@@ -338,6 +368,20 @@ def test_predict_cli_on_a_voxel_directory(tmp_path):
     assert np.abs(out[:, 4] - ref[:, 4]).max() <= 1e-4              # wood probability
     far = np.abs(ref[:, 4] - 0.5) > 2e-4
     assert (out[far, 3] == ref[far, 3]).all()                        # labels (away from the decision threshold)
+    # --reference-sampler: the reference's BalancedBatchSampler (global numpy RNG, remainder dropped) through the same stream
+    # pipeline = one classify_batch per batch of that sampler under the same seed, row for row
+    from pointstowood_amd import DataLoader, Net
+    from pointstowood_amd.predicter import BalancedBatchSampler, classify_batch, load_model
+    np.random.seed(5)
+    out_ref = mod.main(["--voxels", str(vdir), "--model", str(tmp_path / "m.pth"), "--odir", str(tmp_path / "o2"),
+                        "--batch_size", "2", "--reference-sampler"])
+    net = Net(num_classes=1).cuda()
+    load_model(str(tmp_path / "m.pth"), net, "cuda")
+    net.eval()
+    np.random.seed(5)
+    loop = np.vstack([classify_batch(net, d, 0.5, "cuda")
+                      for d in DataLoader(ds, batch_sampler=BalancedBatchSampler(ds, 2, reference=True), num_workers=0)])
+    assert out_ref.shape == loop.shape and out_ref.shape[0] < 2400 and np.array_equal(out_ref, loop)   # (3 voxels, 2 per batch: one dropped)
 
 
 def test_voxeliser_on_gpu_matches_cpu_restatement():

@@ -5,7 +5,7 @@
 #                                             FETCH_SIZE / WRITE_SIZE, MFMA busy, VALU issue counters
 #   tools/profile_round.sh config2|config4|surface   the named workload, 3 sequential forwards: kernel stats, FETCH / WRITE, MFMA busy
 set -u
-TAG=${TAG:-r4}
+TAG=${TAG:-r5}
 WHAT=${1:-bench}
 PREC=${2:-f16x3}
 export TMPDIR=/tmp
