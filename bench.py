@@ -547,6 +547,9 @@ def plot_main(args, world, rank, device, dist):
 
 def main():
     args = parse_args()
+    if os.environ.get("P2W_BENCH_WATCHDOG"):   # tests: a bench that does not finish dumps every thread's stack and exits instead of hanging
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["P2W_BENCH_WATCHDOG"]), exit=True)
     if args.cpu_baseline_child:
         return cpu_baseline_child(args.cpu_baseline_child)
     world = int(os.environ.get("WORLD_SIZE", "1"))

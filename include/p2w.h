@@ -267,15 +267,19 @@ typedef struct p2w_epilogue {
     const float* residual; /* [M, ldr] or NULL */
     int32_t ldr;
     int32_t relu0, relu1, relu2, relu_final;
-    uint32_t* range;     /* NULL, or TWO device words the H-family GEMMs (p2w_gemm_h2 / _sk / _rowdot) report the launch's range in
-                            (the caller zeroes them; p2w_gemm ignores it): range[0] is set to 1 if an epilogue value lies beyond
-                            +-P2W_RANGE_HI (or is NaN), range[1] if one lies beyond +-P2W_RANGE_LO.  It is the range watch of the
-                            split-fp16 arithmetic: past 65504 an H value has lost its low part, and a tensor WITHOUT a value of
-                            ordinary size has lost it to fp16's subnormal floor (2^-24 absolute) */
+    uint32_t* range;     /* NULL, or the launch's range report (the caller zeroes it; p2w_gemm ignores it): P2W_RANGE_SLOTS word
+                            pairs, 64 words apart (P2W_RANGE_WORDS words in all; a workgroup writes the pair of its number modulo
+                            the slot count - one hot address would queue every store in one L2 channel).  Word 0 of a pair is set
+                            to 1 if an epilogue value lies beyond +-P2W_RANGE_HI (or is NaN), word 1 if one lies beyond
+                            +-P2W_RANGE_LO; the report is the OR over the slots.  It is the range watch of the split-fp16
+                            arithmetic: past 65504 an H value has lost its low part, and a tensor WITHOUT a value of ordinary
+                            size has lost it to fp16's subnormal floor (2^-24 absolute) */
 } p2w_epilogue;
 
 #define P2W_RANGE_HI 6.0e4f
 #define P2W_RANGE_LO 0.03125f
+#define P2W_RANGE_SLOTS 16
+#define P2W_RANGE_WORDS (64 * P2W_RANGE_SLOTS)
 
 /* Packed weight: Wp[N_pad][K_pad] fp32, row n = output channel, k contiguous, zero padded
  * (K_pad = round_up(K, 32), N_pad = round_up(N, 256)); see p2w_packed_dims. */
@@ -393,7 +397,7 @@ int32_t p2w_sa_conv_h_rows(int32_t prec, const float* P, int32_t ldp, int32_t n_
  * (C, resp. Fc + Fs) plus the zero pad to the next K-slab boundary and leave the rest of a wider row alone (p2w_interp_concat_h2
  * with skip = NULL, Fs = 0 writes only the interpolated part of a row whose skip columns another producer has written). */
 /* range (p2w_stem_h2, p2w_stem_h2_indexed, p2w_sa_conv_h_rows; NULL = off): the range watch of p2w_epilogue.range - a device
- * pair of words (over, seen) the launch sets to 1 (the caller zeroes them). */
+ * block of P2W_RANGE_WORDS words (the caller zeroes them). */
 int32_t p2w_stem_h2(int32_t prec, const float* xyzr, int32_t n, const float* w, const float* b, int32_t C, float* out,
                     void* out_h, int32_t ldh, uint32_t* range, p2w_stream_t stream);
 /* ... for records that come in another order (p2w_index_records: e.g. the sampler's cell order) and carry their own row as the

@@ -2161,6 +2161,7 @@ extern "C" int32_t p2w_vote(const int32_t* nbr, const int32_t* deg, int32_t k, c
 // one by repeated scans instead (slow, exact).
 // ------------------------------------------------------------------------------------------------
 constexpr int RF_CAP = 128;
+constexpr int RF_FLAT = 256;   // candidate positions of the flattened runs staged per step (per wave)
 __global__ __launch_bounds__(256) void knn_refine_kernel(const double* __restrict__ cs, const int* __restrict__ cidx,
                                                          const int* __restrict__ inv, const unsigned long long* __restrict__ keys,
                                                          const int* __restrict__ cell_start, const p2w_grid* __restrict__ gridp,
@@ -2168,6 +2169,7 @@ __global__ __launch_bounds__(256) void knn_refine_kernel(const double* __restric
                                                          int k, int* __restrict__ nbr, int* __restrict__ deg) {
     __shared__ double s_d[4][RF_CAP];
     __shared__ int s_i[4][RF_CAP];
+    __shared__ int s_f[4][RF_FLAT];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int qi = blockIdx.x * 4 + w;
     if (qi >= m) return;                                  // (no workgroup barrier below: waves are independent)
@@ -2216,7 +2218,11 @@ __global__ __launch_bounds__(256) void knn_refine_kernel(const double* __restric
     auto start = [&](unsigned long long key) {
         return cell_start ? cell_start[key] : lower_bound_key(keys, 0, nc, key);
     };
-    // visit(p, d): every candidate position p of the rows the ball touches, lanes in lockstep; returns nothing
+    // visit(p, d, act): every candidate position p of the rows the ball touches, lanes in lockstep.  A lane owns a grid row (its run
+    // [a, b) of the cell-sorted candidates); the runs are FLATTENED through a per-wave LDS list (each lane writes its run's
+    // positions behind the wave's running total), so that consecutive lanes then measure consecutive candidates of a run:
+    // 24-byte records of one run share cache lines, a lane per run fetched every line ~5 times from L2.
+    int* fl = s_f[w];
     auto scan = [&](auto&& visit) {
         for (long long t0 = 0; t0 < rows; t0 += 64) {
             const long long t = t0 + lane;
@@ -2227,14 +2233,28 @@ __global__ __launch_bounds__(256) void knn_refine_kernel(const double* __restric
                 a = start(base + lo_c[0]);
                 b = start(base + hi_c[0] + 1);
             }
-            int len = b - a;
+            const int len = b - a;
+            int pre = len;                                   // inclusive scan of the run lengths over the wave
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) len = max(len, __shfl_xor(len, off));
-            for (int s = 0; s < len; ++s) {
-                const int p = a + s;
-                const bool act = p < b;
-                const double d = act ? d2(cs + 3 * (size_t)p) : INFINITY;
-                visit(p, d, act);
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_up(pre, off);
+                if (lane >= off) pre += o;
+            }
+            const int total = __shfl(pre, 63);
+            pre -= len;                                      // exclusive: this lane's first flat index
+            for (int base_f = 0; base_f < total; base_f += RF_FLAT) {
+                // the part of every lane's run that falls into [base_f, base_f + RF_FLAT)
+                const int s_lo = max(0, base_f - pre), s_hi = min(len, base_f + RF_FLAT - pre);
+                for (int s2 = s_lo; s2 < s_hi; ++s2) fl[pre + s2 - base_f] = a + s2;
+                __builtin_amdgcn_wave_barrier();
+                const int n_f = min(RF_FLAT, total - base_f);
+                for (int f0 = 0; f0 < n_f; f0 += 64) {
+                    const bool act = f0 + lane < n_f;
+                    const int p = act ? fl[f0 + lane] : 0;
+                    const double d = act ? d2(cs + 3 * (size_t)p) : INFINITY;
+                    visit(p, d, act);
+                }
+                __builtin_amdgcn_wave_barrier();
             }
         }
     };

@@ -174,13 +174,16 @@ struct EpiArgs {
     const _Float16* res_h;   // P2W_GEMM_RESIDUAL_H: the residual as an H tensor of the launch's precision (row pitch ldr) instead of fp32
     unsigned* range;         // optional range watch (p2w_epilogue.range)
 };
-// The wave's range report: a plain store of 1 into the launch's OVER / SEEN word.  Every writer of a word writes the same value,
-// so no atomic and no look-before-write is needed (both were tried: an atomic OR behind a look through the vector L1 never sees
-// the other CUs' bits and drains the epilogue's stores, +14 us per GEMM launch; a scalar glc look serialises at ~25 ns per wave).
+// The wave's range report: a plain store of 1 into one of the launch's OVER / SEEN words.  Every writer of a word writes the same
+// value, so no atomic and no look-before-write is needed (both were tried: an atomic OR behind a look through the vector L1 never
+// sees the other CUs' bits and drains the epilogue's stores, +14 us per GEMM launch; a scalar glc look serialises at ~25 ns per
+// wave).  A launch's report is P2W_RANGE_SLOTS copies of the word pair, 256 bytes apart, the workgroup picks one by its number:
+// thousands of stores to ONE address queue up in one L2 channel (measured: +3.5 us per GEMM launch).
 __device__ __forceinline__ void range_commit(unsigned* __restrict__ dst, bool over, bool seen, int lane) {
     if (lane == 0) {
-        if (over) dst[0] = 1u;
-        if (seen) dst[1] = 1u;
+        unsigned* p = dst + (blockIdx.x & (P2W_RANGE_SLOTS - 1)) * 64;
+        if (over) p[0] = 1u;
+        if (seen) p[1] = 1u;
     }
 }
 // ... from a per-lane maximum of |value|
@@ -453,6 +456,7 @@ __device__ __forceinline__ void gemm_epilogue_16(const f32x4 (&acc)[RT16][CT16],
     float dot4[4] = {0.f, 0.f, 0.f, 0.f};
     // range watch (ep.range): wave-uniform masks in scalar registers - this kernel has no vector register to spare
     unsigned long long r_over = 0ull, r_seen = 0ull;
+    float m4 = 0.f;   // ... but for the running maximum of four row steps
 #pragma unroll
     for (int st = 0; st < NSTEP; ++st) {
         const int it = st >> 2, reg = st & 3;
@@ -471,11 +475,7 @@ __device__ __forceinline__ void gemm_epilogue_16(const f32x4 (&acc)[RT16][CT16],
             for (int jq = 0; jq < JQ; ++jq) {
                 const float va = value(acc[it][2 * jq][reg], bias[jq][0], s0[jq][0], t0[jq][0], s1[jq][0], t1[jq][0], rcur[jq][0]);
                 const float vb = value(acc[it][2 * jq + 1][reg], bias[jq][1], s0[jq][1], t0[jq][1], s1[jq][1], t1[jq][1], rcur[jq][1]);
-                {
-                    const float m2 = fmaxf(fabsf(va), fabsf(vb));
-                    r_over |= __ballot(!(m2 <= P2W_RANGE_HI));
-                    r_seen |= __ballot(m2 > P2W_RANGE_LO);
-                }
+                m4 = fmaxf(m4, fmaxf(fabsf(va), fabsf(vb)));     // (one v_max3 per column pair)
                 if (DOT) dsum = fmaf(vb, dw[jq][1], fmaf(va, dw[jq][0], dsum));
                 if (OF) *reinterpret_cast<fpair*>(fp + 32 * jq) = fpair{va, vb};
                 if (OH) {
@@ -488,6 +488,11 @@ __device__ __forceinline__ void gemm_epilogue_16(const f32x4 (&acc)[RT16][CT16],
                         *reinterpret_cast<unsigned*>(hp + 32 * jq) = pack_pair<PREC>(va, vb);
                     }
                 }
+            }
+            if (reg == 3) {   // the maximum of four row steps goes into the scalar masks: two compares per 4 x JQ column pairs
+                r_over |= __ballot(!(m4 <= P2W_RANGE_HI));
+                r_seen |= __ballot(m4 > P2W_RANGE_LO);
+                m4 = 0.f;
             }
             if (DOT) {   // the four rows of a lane (reg 0..3) are consecutive: one 16-byte store per row tile by the lanes of column 0
                 dot4[reg] = row16_sum(dsum);

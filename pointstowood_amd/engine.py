@@ -613,7 +613,8 @@ class Engine:
         return self.fallback(geo, keep)
 
     # -- range watch (EngineOptions.range_guard) -------------------------------------------------------------
-    RANGE_SLOTS = 64
+    RANGE_SLOTS = 64                       # layers of a forward
+    RANGE_WORDS = 1024                     # P2W_RANGE_WORDS: words of one launch's report (16 slots of (over, seen), 64 words apart)
     RANGE_HI, RANGE_LO = 6.0e4, 2.0 ** -5  # the thresholds behind the two bits (P2W_RANGE_HI / _LO)
     W1R_LIMIT = 65504.0 - 6.0e4            # room the PointNetConv's layer-1 correction has above a hoisted product that passed the watch
 
@@ -628,10 +629,10 @@ class Engine:
             if len(names) >= self.RANGE_SLOTS:
                 return None
             names.append(layer)
-        return buf.data_ptr() + 8 * names.index(layer)   # two words per layer: (over, seen)
+        return buf.data_ptr() + 4 * self.RANGE_WORDS * names.index(layer)   # one report block per layer
 
     def _range_begin(self, dev):
-        self._range = ([], torch.zeros(2 * self.RANGE_SLOTS, dtype=torch.int32, device=dev)) if (self.range_guard and self.prec == PREC_F16X3) else None
+        self._range = ([], torch.zeros(self.RANGE_SLOTS * self.RANGE_WORDS, dtype=torch.int32, device=dev)) if (self.range_guard and self.prec == PREC_F16X3) else None
 
     def _range_end(self):
         """(layer names, device words, pinned host copy in flight on the current stream) of the forward just enqueued."""
@@ -639,7 +640,8 @@ class Engine:
         if w is None:
             return None
         host = torch.empty(2 * self.RANGE_SLOTS, dtype=torch.int32, pin_memory=True)
-        host.copy_(w[1], non_blocking=True)
+        # OR over a layer's report slots on the device (one small reduction), then (over, seen) per layer to the host
+        host.copy_(w[1].view(self.RANGE_SLOTS, self.RANGE_WORDS // 64, 64)[:, :, :2].amax(dim=1).reshape(-1), non_blocking=True)
         return w[0], w[1], host
 
     def range_violations(self, watch):

@@ -30,7 +30,7 @@ def _free_bytes(dev):
     return torch.cuda.mem_get_info(dev)[0] if dev.type == "cuda" else None
 
 
-def default_budget(total_points: int, world: int, free, dist=None) -> int:
+def default_budget(total_points: int, world: int, free, dist=None, device=None) -> int:
     """Points per forward when the caller names no budget: a fifth of a rank's share of the classified points, between 262144
     and 2097152, within 40 % of the free device memory.  The batch list must be IDENTICAL on every rank (each rank takes its
     LPT share of it BY INDEX), so the memory cap comes from the rank with the least free memory (one all-reduce(MIN) of a
@@ -39,7 +39,10 @@ def default_budget(total_points: int, world: int, free, dist=None) -> int:
     if free is not None:
         if world > 1:
             backend = dist.get_backend() if hasattr(dist, "get_backend") else "gloo"
-            t = torch.tensor([int(free)], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+            # (the scalar lives on the device the PLOT is on - a caller that never called torch.cuda.set_device would otherwise
+            # put every rank's NCCL tensor on cuda:0 - or on the host for gloo)
+            on = (device if device is not None and torch.device(device).type == "cuda" else "cuda") if backend == "nccl" else "cpu"
+            t = torch.tensor([int(free)], dtype=torch.int64, device=on)
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             free = int(t)
         budget = max(65536, min(budget, int(0.4 * free) // BYTES_PER_POINT))
@@ -60,7 +63,8 @@ def segment_plot(pc, model, grid_sizes=(2.0, 4.0), min_pts: int = 128, max_pts: 
     ``dist`` (an initialised ``torch.distributed``, one process per GPU, every rank holding the same ``pc`` and the same
     ``generator`` state): every rank voxelises (cheap, and it makes the voxel list identical everywhere without an
     exchange), classifies its LPT share of the voxel batches, the classified points are all-gathered once, each rank
-    back-projects a contiguous slice of the plot and the slices are all-gathered: two exchanges in total."""
+    back-projects a contiguous slice of the plot and the slices are all-gathered: two data exchanges (plus, with the default
+    budget, one all-reduce of a scalar: the ranks' least free memory)."""
     dev = pc.device
     t0 = time.perf_counter()
     vox, n_z = voxelise(pc, tuple(grid_sizes), min_pts, max_pts, mode=mode, generator=generator, ground=ground)
@@ -74,7 +78,7 @@ def segment_plot(pc, model, grid_sizes=(2.0, 4.0), min_pts: int = 128, max_pts: 
     lengths = [int(v.shape[0]) for v in vox]
     world, rank = (dist.get_world_size(), dist.get_rank()) if dist is not None else (1, 0)
     if max_points is None:
-        max_points = default_budget(sum(lengths), world, _free_bytes(dev), dist)
+        max_points = default_budget(sum(lengths), world, _free_bytes(dev), dist, dev)
     if max_voxels is None:
         max_voxels = max(1, max_points // 1024)
     batches = list(PointBudgetSampler(lengths, max_points, max_voxels))

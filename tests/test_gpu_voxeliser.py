@@ -17,10 +17,13 @@ def _L():
 
 
 @pytest.mark.parametrize("n,bits,with_vals", [(1, 64, False), (63, 8, True), (4096, 16, False), (4097, 20, True), (100003, 37, False),
-                                              (1 << 20, 63, True), (300000, 0, False), (70000, 9, True)])
+                                              (1 << 20, 63, True), (300000, 0, False), (70000, 9, True),
+                                              # beyond 1 048 576 keys the histogram scan is two-level (rs_scan_tile / _sums / _add): ADVICE r4
+                                              ((1 << 20) + 1, 40, False), (5_000_011, 24, True), (5_000_011, 45, False)])
 def test_radix_sort_pairs_is_a_stable_sort(n, bits, with_vals):
     """p2w_sort_pairs_u64 == torch.sort(stable=True): keys of 0..63 significant bits (the pass count follows the data), many
-    duplicates (stability decides their order), sizes around the 4096-key tile, with given values and as an argsort."""
+    duplicates (stability decides their order), sizes around the 4096-key tile and on both sides of the two-level histogram scan's
+    threshold, with given values and as an argsort."""
     from pointstowood_amd._lib import ptr, stream
     L = _L()
     g = torch.Generator().manual_seed(n + bits)
