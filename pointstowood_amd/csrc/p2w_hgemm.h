@@ -996,30 +996,28 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void gemm_hp_sk_kernel(const _Floa
     gemm_hp_body<PREC, WR, WC, RT, CT, false, true>(A, ldh_a, Wh, 1.f, M, 0, Kpad, 0, nNt, tiles, ep, o, 0, 0, S, skws);
 }
 
-// The fix-up behind gemm_hp_sk_kernel: one workgroup (of the GEMM's shape) per tail tile adds the tile's S pieces in ascending
-// K order - a fixed order: results do not depend on timing - and runs the GEMM's epilogue on the sums.
+// The fix-up behind gemm_hp_sk_kernel: RT16 workgroups (of the GEMM's shape) per tail tile, one per 16-row block of every wave's
+// rows, add the tile's S pieces in ascending K order - a fixed order: results do not depend on timing - and run the GEMM's
+// epilogue on the sums.  (One workgroup per tile walked S x 64 KiB serially: 25 us per launch for 36 tiles x 14 pieces, twice the
+// time of the MFMA launch it finishes.)
 template <int PREC, int WR, int WC, int RT, int CT>
 __global__ __launch_bounds__(64 * WR * WC) void gemm_hp_skfix_kernel(const float* __restrict__ skws, int tiles, int S, int nslab, int nNt,
                                                                       float wscale, int M, int N, EpiArgs ep, OutArgs o, int ef) {
     constexpr int BM = 32 * RT * WR, BN = 32 * CT * WC, NW = WR * WC, RT16 = 2 * RT, CT16 = 2 * CT;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wave / WC, wc = wave % WC;
-    const int r = blockIdx.x;
-    f32x4 acc[RT16][CT16];
+    const int r = blockIdx.x / RT16, i = blockIdx.x - r * RT16;
+    f32x4 acc[1][CT16];
 #pragma unroll
-    for (int i = 0; i < RT16; ++i)
+    for (int j = 0; j < CT16; ++j) acc[0][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < S; ++p) {
+        if ((int)((long long)p * nslab / S) >= (int)((long long)(p + 1) * nslab / S)) continue;   // an empty piece was never written
+        const f32x4* src = reinterpret_cast<const f32x4*>(skws) + (size_t)(p * tiles + r) * (size_t)(BM * BN / 4) + tid;
 #pragma unroll
-        for (int j = 0; j < CT16; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int j = 0; j < S; ++j) {
-        if ((int)((long long)j * nslab / S) >= (int)((long long)(j + 1) * nslab / S)) continue;   // an empty piece was never written
-        const f32x4* src = reinterpret_cast<const f32x4*>(skws) + (size_t)(j * tiles + r) * (size_t)(BM * BN / 4) + tid;
-#pragma unroll
-        for (int i = 0; i < RT16; ++i)
-#pragma unroll
-            for (int jj = 0; jj < CT16; ++jj) acc[i][jj] += src[(i * CT16 + jj) * (64 * NW)];
+        for (int jj = 0; jj < CT16; ++jj) acc[0][jj] += src[(i * CT16 + jj) * (64 * NW)];
     }
     const int mt = r / nNt, nt = r - mt * nNt;
-    gemm_epilogue_dispatch16<PREC, RT16, CT16, false, false>(acc, ep, wscale, mt * BM + wr * 32 * RT, nt * BN + wc * 32 * CT, lane, M, N, o, ef);
+    gemm_epilogue_dispatch16<PREC, 1, CT16, false, false>(acc, ep, wscale, mt * BM + wr * 32 * RT + 16 * i, nt * BN + wc * 32 * CT, lane, M, N, o, ef);
 }
 
 // host side of p2w_gemm_h2 for one precision (argument checks that do not depend on it are done by the caller)
@@ -1066,15 +1064,18 @@ static int32_t launch_gemm_h(const _Float16* Ah, int32_t ldh_a, const _Float16* 
         // CU / two per CU, 256 x 256 tile (one per CU)
         const double f = PREC == 0 ? 1.0 : 0.7, ts1 = 0.9 * f, ts2 = 1.65 * f, tsb = 2.25 * f;
         auto t_small = [&](long tiles) { return tiles > n_cu ? ts2 : ts1; };
-        // one launch on the rule's tile: the whole rounds + the partial one (whose workgroups have their CUs to themselves)
+        // (a round of few 256 x 256 tiles runs far above the full-chip rate - clock and fabric to itself: 40 tiles 0.73 us per slab)
+        auto t_big = [&](long tiles) { return tiles >= n_cu ? tsb : (0.75 * f + (tsb - 0.75 * f) * (double)tiles / n_cu); };
+        // one launch on a given tile: the whole rounds + the partial one (whose workgroups have their CUs to themselves)
         auto one_launch = [&](bool b, int rows) {
             const long T = b ? (long)p2w_cdiv(rows, 256) * (Npad / 256) : (long)p2w_cdiv(rows, 128) * p2w_cdiv(N, 128);
             const long G = b ? n_cu : 2 * n_cu, qq = T / G, R = T % G;
-            return (double)nslab * ((double)qq * (b ? tsb : ts2) + (R ? (b ? tsb : t_small(R)) : 0.0));
+            return (double)nslab * ((double)qq * (b ? tsb : ts2) + (R ? (b ? t_big(R) : t_small(R)) : 0.0));
         };
+        const bool big_ok = N >= 256 && (N % 256) == 0;
         double best_cost = one_launch(big, M);
         int best_mode = 0, best_rows_full = 0, best_S = 0;
-        bool best_big = big, sk_big = big;
+        bool best_big = big, sk_big = big, tail_big = false;
         double sk_cost = 1e30;
         int sk_rows_full = 0, sk_S_best = 0;
         const size_t piece_b = (size_t)128 * 128 * 4;
@@ -1092,13 +1093,18 @@ static int32_t launch_gemm_h(const _Float16* Ah, int32_t ldh_a, const _Float16* 
             const int rows_full = mt_full * BMm, m_t = M - rows_full;
             const double main_t = (double)q * nslab * (b ? tsb : ts2) + (q > 0 ? 4.0 : 0.0);
             const long T_t = (long)p2w_cdiv(m_t, 128) * p2w_cdiv(N, 128);
-            if (q > 0) {   // whole rounds + a plain second launch (on the tile the rule picks for so few rows)
-                const double c = main_t + one_launch(pick_big(m_t), m_t);
-                if (c < 0.95 * best_cost) { best_cost = c; best_mode = 1; best_rows_full = rows_full; best_big = b; best_S = 0; }
+            if (q > 0) {   // whole rounds + a plain second launch, on the cheaper tile for so few rows
+                for (int tb = 0; tb < 2; ++tb) {
+                    if (tb == 1 && (!big_ok || (flags & P2W_GEMM_TILE_128))) continue;
+                    if (tb == 0 && (flags & P2W_GEMM_TILE_256)) continue;
+                    const double c = main_t + one_launch(tb == 1, m_t);
+                    if (c < 0.95 * best_cost) { best_cost = c; best_mode = 1; best_rows_full = rows_full; best_big = b; best_S = 0; tail_big = tb == 1; }
+                }
             }
             for (int S = 2; S <= nslab && T_t * S <= 2 * n_cu; ++S) {   // ... + a split-K tail
                 if ((size_t)(T_t * S) * piece_b > skws_bytes) break;
-                const double c = main_t + (double)((nslab + S - 1) / S) * ts1 + 10.0 + (double)(T_t * S) * piece_b * 2.0 / 2.5e6;   // (pieces share their L2: the uncontended slab time holds)
+                const double c = main_t + (double)((nslab + S - 1) / S) * 1.0 * f + 18.0 + (double)(T_t * S) * piece_b * 2.0 / 8.0e6;   // fitted (tools/gemm_sk_ab.py): pieces share
+                                                                                       // their L2 (~ the uncontended slab time); two more launches + the fix-up's latency ~ 18 us
                 if (c < sk_cost) { sk_cost = c; sk_rows_full = rows_full; sk_big = b; sk_S_best = S; }
             }
         }
@@ -1119,7 +1125,8 @@ static int32_t launch_gemm_h(const _Float16* Ah, int32_t ldh_a, const _Float16* 
             if (ept.residual) ept.residual += r0 * ep.ldr;
             if (ept.res_h) ept.res_h += r0 * PL * ep.ldr;
             return launch_gemm_h<PREC>(Ah + r0 * PL * ldh_a, ldh_a, Wp, wscale, m_t, N, K, ept, out_f32 ? out_f32 + r0 * ldo : nullptr, ldo,
-                                       out_h2 ? out_h2 + r0 * PL * ldh_o : nullptr, ldh_o, fl, stream, nullptr, nullptr, 0,
+                                       out_h2 ? out_h2 + r0 * PL * ldh_o : nullptr, ldh_o,
+                                       best_mode == 2 ? fl : (fl | (tail_big ? P2W_GEMM_TILE_256 : P2W_GEMM_TILE_128)), stream, nullptr, nullptr, 0,
                                        best_mode == 2 ? skws : nullptr, skws_bytes, best_mode == 2 ? best_S : 0);
         }
     }
@@ -1194,7 +1201,7 @@ static int32_t launch_gemm_h(const _Float16* Ah, int32_t ldh_a, const _Float16* 
     if (sk_S > 0) {   // this call IS a split-K tail (planned above)
         const int nslab = Kpad / HCfg<PREC>::kslab, nNt1 = p2w_cdiv(N, 128), T_t = p2w_cdiv(M, 128) * nNt1;
         gemm_hp_sk_kernel<PREC, 2, 2, 2, 2><<<8 * p2w_cdiv(T_t * sk_S, 8), 256, 0, stream>>>(Ah, ldh_a, Wp, M, Kpad, nNt1, T_t, sk_S, skws);
-        gemm_hp_skfix_kernel<PREC, 2, 2, 2, 2><<<T_t, 256, 0, stream>>>(skws, T_t, sk_S, nslab, nNt1, wscale, M, N, ep, o, ef);
+        gemm_hp_skfix_kernel<PREC, 2, 2, 2, 2><<<T_t * 4, 256, 0, stream>>>(skws, T_t, sk_S, nslab, nNt1, wscale, M, N, ep, o, ef);   // (RT16 = 4 row blocks per tile)
     } else if (big) {
         const int nMt = p2w_cdiv(M, 256), nNt2 = Npad / 256;
         const int tm = pick_mode(nNt2, nMt, 1), nvb = tile_grid(nMt, nNt2, tm);
