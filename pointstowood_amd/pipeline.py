@@ -31,11 +31,13 @@ def _free_bytes(dev):
 
 
 def default_budget(total_points: int, world: int, free, dist=None, device=None) -> int:
-    """Points per forward when the caller names no budget: a fifth of a rank's share of the classified points, between 262144
+    """Points per forward when the caller names no budget: a fifth (one process) or a tenth (sharded: the LPT plan needs enough
+    batches per rank to come out even - tools/scaling_predict.py: 6 batches per rank left 15 - 27 % between the ranks at world 8)
+    of a rank's share of the classified points, between 262144
     and 2097152, within 40 % of the free device memory.  The batch list must be IDENTICAL on every rank (each rank takes its
     LPT share of it BY INDEX), so the memory cap comes from the rank with the least free memory (one all-reduce(MIN) of a
     scalar), never from a rank's own reading."""
-    budget = min(max(total_points // (5 * world), 262144), 2097152)
+    budget = min(max(total_points // ((5 if world == 1 else 10) * world), 262144), 2097152)
     if free is not None:
         if world > 1:
             backend = dist.get_backend() if hasattr(dist, "get_backend") else "gloo"
