@@ -125,15 +125,10 @@ int32_t p2w_level_gather(const float* xyzr_src, const int32_t* idx, const int32_
  *   X_INDEX_IN_W: candidate c is reported as (and ties / "first cap" are ordered by) the int32 in xyzr_x[c].w, not c.
  *   Q_ROW_IN_W  : the results of query q are written to row (int32 in its record's .w) of nbr / deg, not row q.
  *   BOX (grid searches only): bound the gathered region in x as well - one run per grid row instead of one per z
- *   layer; for grids whose rows are much longer than a workgroup's reach (plot-scale searches).
- *   COLLECT (grid kNN, k >= 8): collect the candidates under a query's threshold (ballot compaction into a 64-entry list in
- *   LDS) and merge 64 of them at a time into the top-k list with a 64-lane sorting network, instead of one sorted insertion
- *   per admitted candidate.  Same results; on MI355X the insertions are faster (the selection is not what the kernel waits
- *   for, and the lists cost a workgroup per CU: DESIGN.md), so this is an A/B switch, not the default. */
+ *   layer; for grids whose rows are much longer than a workgroup's reach (plot-scale searches). */
 #define P2W_SEARCH_X_INDEX_IN_W 1
 #define P2W_SEARCH_Q_ROW_IN_W 2
 #define P2W_SEARCH_BOX 4
-#define P2W_SEARCH_COLLECT 8
 
 /* Ball query: torch-cluster radius(x, y, r, batch_x, batch_y, max_num_neighbors) - model.py:118.
  * Queries are x[qidx[q]] (qidx NULL = identity).  For query q of voxel b the `cap` candidates of lowest index among

@@ -22,7 +22,7 @@ class Epilogue(C.Structure):
 
 
 # name -> (restype, argtypes); must list every symbol declared in include/p2w.h
-SEARCH_X_INDEX_IN_W, SEARCH_Q_ROW_IN_W, SEARCH_BOX, SEARCH_COLLECT = 1, 2, 4, 8   # include/p2w.h P2W_SEARCH_*
+SEARCH_X_INDEX_IN_W, SEARCH_Q_ROW_IN_W, SEARCH_BOX = 1, 2, 4   # include/p2w.h P2W_SEARCH_*
 PREC_F16X3, PREC_F16, PREC_BF16 = 0, 1, 2                      # include/p2w.h P2W_PREC_*
 PREC_OF = {"f16x3": PREC_F16X3, "fp16": PREC_F16, "bf16": PREC_BF16}
 GEMM_TILE_128, GEMM_TILE_256, GEMM_GENERIC_EPI, GEMM_ORDER_ROWS, GEMM_ORDER_COLS, GEMM_RESIDUAL_H = 1, 2, 4, 8, 16, 32   # P2W_GEMM_*

@@ -20,9 +20,6 @@ from . import _lib
 from ._lib import SEARCH_BOX, SEARCH_X_INDEX_IN_W, check, lib, ptr
 
 
-EXTRA_SEARCH_FLAGS = 0   # OR-ed into the search's flags (tools/search_ab.py sets P2W_SEARCH_COLLECT for A/B runs)
-
-
 def _records(xyz: torch.Tensor) -> torch.Tensor:
     out = torch.zeros((xyz.shape[0], 4), dtype=torch.float32, device=xyz.device)
     out[:, :3] = xyz
@@ -101,7 +98,7 @@ def neighbours(cls_xyz: torch.Tensor, query_xyz: torch.Tensor, k: int, cell: flo
         nbr = torch.empty((m, k), **i32)
         deg = torch.empty(m, **i32)
         check(L.p2w_knn_grid_indexed(ptr(rec_c), ptr(skeys), ptr(ptr_c), ptr(grid), ptr(cell_start), ptr(q), None, ptr(ptr_q), 1, m, k,
-                                     ptr(nbr), ptr(deg), None, SEARCH_X_INDEX_IN_W | SEARCH_BOX | EXTRA_SEARCH_FLAGS, _lib.stream()), "knn_grid")
+                                     ptr(nbr), ptr(deg), None, SEARCH_X_INDEX_IN_W | SEARCH_BOX, _lib.stream()), "knn_grid")
         qs64 = q64[rows].contiguous()
         check(L.p2w_knn_refine_f64(ptr(cs64), ptr(order), ptr(pos_of), ptr(skeys), ptr(cell_start), ptr(grid), ox, oy, oz, ptr(qs64),
                                    m, nc, k, ptr(nbr), ptr(deg), _lib.stream()), "knn_refine_f64")

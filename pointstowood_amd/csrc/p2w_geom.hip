@@ -1044,62 +1044,6 @@ __global__ __launch_bounds__(256) void ball_kernel(const float4* __restrict__ x,
 
 
 
-// ---- wave-wide sorting network on packed (d2, index) keys -------------------------------------------------------
-// One 64-bit key per lane.  xl<M>(v): the value lane ^ M holds - DPP inside a row of 16 (quad_perm for 1 and 2, the two
-// bank-masked row shifts for 4, row_ror:8 for 8), v_permlane16_swap / v_permlane32_swap (gfx950) across rows.  The keys
-// come out of integer selects (never out of packed fp32 arithmetic: DESIGN "packed-FMA -> DPP hazard").
-template <int M>
-__device__ __forceinline__ unsigned xl(unsigned v, int lane) {
-    if constexpr (M == 1) return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xf, 0xf, false);        // quad_perm [1,0,3,2]
-    else if constexpr (M == 2) return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
-    else if constexpr (M == 4) {
-        const int t = __builtin_amdgcn_update_dpp((int)v, (int)v, 0x104, 0xf, 0x5, false);    // banks 0, 2: row_shl:4 (lane + 4)
-        return (unsigned)__builtin_amdgcn_update_dpp(t, (int)v, 0x114, 0xf, 0xA, false);      // banks 1, 3: row_shr:4 (lane - 4)
-    } else if constexpr (M == 8) return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xf, 0xf, false);   // row_ror:8
-    else if constexpr (M == 16) {
-        const auto sw = __builtin_amdgcn_permlane16_swap(v, v, false, false);
-        return (lane & 16) ? sw[0] : sw[1];
-    } else {
-        static_assert(M == 32, "xor masks 1 .. 32");
-        const auto sw = __builtin_amdgcn_permlane32_swap(v, v, false, false);
-        return (lane & 32) ? sw[0] : sw[1];
-    }
-}
-// The networks below run on NQ independent keys per lane (one per query of the wave) STAGE by stage: the exchange of query
-// j + 1 fills the wait states behind query j's DPP / permlane instructions (a single network is a chain of dependent
-// cross-lane operations, and hipcc pads every one of them with s_nop when nothing independent stands next to it).
-template <int M, int NQ>
-__device__ __forceinline__ void cx64n(unsigned long long (&v)[NQ], int lane, bool take_min) {
-    unsigned hi[NQ], lo[NQ];
-#pragma unroll
-    for (int j = 0; j < NQ; ++j) hi[j] = xl<M>((unsigned)(v[j] >> 32), lane);
-#pragma unroll
-    for (int j = 0; j < NQ; ++j) lo[j] = xl<M>((unsigned)v[j], lane);
-#pragma unroll
-    for (int j = 0; j < NQ; ++j) {
-        const unsigned long long o = ((unsigned long long)hi[j] << 32) | lo[j];
-        v[j] = ((o < v[j]) == take_min) ? o : v[j];
-    }
-}
-// bitonic merge of bitonic 64-sequences (ascending result)
-template <int NQ>
-__device__ __forceinline__ void merge64_asc(unsigned long long (&v)[NQ], int lane) {
-    cx64n<32>(v, lane, (lane & 32) == 0); cx64n<16>(v, lane, (lane & 16) == 0); cx64n<8>(v, lane, (lane & 8) == 0);
-    cx64n<4>(v, lane, (lane & 4) == 0);   cx64n<2>(v, lane, (lane & 2) == 0);   cx64n<1>(v, lane, (lane & 1) == 0);
-}
-// bitonic sort of 64 keys, DESCENDING (lane 0 ends with the largest): 21 compare-exchange stages
-template <int NQ>
-__device__ __forceinline__ void sort64_desc(unsigned long long (&v)[NQ], int lane) {
-#define P2W_CX(SIZE, M) cx64n<M>(v, lane, (((lane & (M)) == 0) == ((SIZE) == 64 ? false : ((lane & (SIZE)) != 0))))
-    P2W_CX(2, 1);
-    P2W_CX(4, 2); P2W_CX(4, 1);
-    P2W_CX(8, 4); P2W_CX(8, 2); P2W_CX(8, 1);
-    P2W_CX(16, 8); P2W_CX(16, 4); P2W_CX(16, 2); P2W_CX(16, 1);
-    P2W_CX(32, 16); P2W_CX(32, 8); P2W_CX(32, 4); P2W_CX(32, 2); P2W_CX(32, 1);
-    P2W_CX(64, 32); P2W_CX(64, 16); P2W_CX(64, 8); P2W_CX(64, 4); P2W_CX(64, 2); P2W_CX(64, 1);
-#undef P2W_CX
-}
-constexpr unsigned long long TOPK_EMPTY = 0x7f8000007fffffffull;   // (d2 = +inf, index = 0x7fffffff): an unused slot of a top-k list
 
 // ------------------------------------------------------------------------------------------------
 // grid-indexed neighbour search
@@ -1150,21 +1094,12 @@ extern "C" int32_t p2w_debug_slab_prof(unsigned long long* out, int reset) {
 #endif
 
 // MODE: 0 = kNN, 1 = ball query; TILE: candidates per LDS stage; SEL (kNN): 0 = sorted insertion from a cold start (small k),
-// 1 = counted threshold ladder + sorted insertion (k >= 8, the default), 2 = ladder + collected candidates merged by sorting
-// networks (k >= 8 with P2W_SEARCH_COLLECT; measured SLOWER than 1 on MI355X - DESIGN.md "Searches" - and kept for A/B runs);
+// 1 = counted threshold ladder + sorted insertion (k >= 8).  (Round 4 also carried SEL = 2 - candidates collected per query and
+// merged by 64-lane sorting networks: exact, 15 % slower, removed in round 5; docs/LAB_NOTES.md.)
 // BOX: the gathered region is also bounded in x (one run per grid row instead of one per z layer) - for grids whose
 // rows are much longer than a workgroup's reach (plot-scale searches); per-voxel searches gather whole rows.
-#ifndef P2W_COLLECT_WAVES
-#define P2W_COLLECT_WAVES 3   // waves per SIMD the collecting kernel is compiled for (its LDS allows three workgroups per CU)
-#endif
-#ifndef P2W_FLUSH_NQ
-#define P2W_FLUSH_NQ 4        // sorting networks in flight in a flush
-#endif
-#ifndef P2W_COLLECT_TILE
-#define P2W_COLLECT_TILE 2048   // candidates per LDS stage of the collecting kernel
-#endif
 template <int MODE, int TILE, int SEL, bool BOX>
-__global__ __launch_bounds__(256, (MODE == 0 && SEL == 2) ? P2W_COLLECT_WAVES : 1) void slab_search_kernel(const float4* __restrict__ x, const unsigned long long* __restrict__ keys,
+__global__ __launch_bounds__(256, 1) void slab_search_kernel(const float4* __restrict__ x, const unsigned long long* __restrict__ keys,
                                                           const int* __restrict__ ptr_x, const p2w_grid* __restrict__ grid,
                                                           const float4* __restrict__ xq, const int* __restrict__ qidx,
                                                           const int* __restrict__ ptr_q, int B, int k, float r, float r2,
@@ -1175,11 +1110,7 @@ __global__ __launch_bounds__(256, (MODE == 0 && SEL == 2) ? P2W_COLLECT_WAVES : 
     __shared__ int run_pre[G_MAXRUN + 1];
     __shared__ int wsum[4];
     __shared__ float wred[4][8];
-    // SEL == 2: candidates under a query's threshold are COLLECTED (ballot-compacted into the query's pending list, up to 64
-    // packed (d2, index) keys) and merged into its sorted top-k list by ONE sorting network per 64 of them, instead of one
-    // sorted insertion (~15 dependent cross-lane instructions) per candidate: see the scan and flush_all below
-    constexpr bool LADDER = SEL >= 1, COLLECT = MODE == 0 && SEL == 2;
-    __shared__ unsigned long long pend[COLLECT ? 4 : 1][COLLECT ? S_QPW : 1][COLLECT ? 64 : 1];
+    constexpr bool LADDER = SEL >= 1;
     int b, q0, q1;
     if (!search_tile(ptr_q, B, blockIdx.x, &b, &q0, &q1)) return;
     const int c0 = ptr_x[b], c1 = ptr_x[b + 1];
@@ -1202,14 +1133,13 @@ __global__ __launch_bounds__(256, (MODE == 0 && SEL == 2) ? P2W_COLLECT_WAVES : 
     UQuery uq[S_QPW];
     float best_d[S_QPW], thr[S_QPW];
     int best_i[S_QPW], cnt[S_QPW];
-    int pc[S_QPW];          // COLLECT: keys in the query's pending list (wave-uniform)
     unsigned active = 0u;   // queries of this wave whose result is not final yet
     float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY, zmin = INFINITY, zmax = -INFINITY;
     float hmax = 0.f, hinted = (MODE == 0 && hint) ? 1.f : 0.f;   // largest hint / every query of the workgroup has one
 #pragma unroll
     for (int j = 0; j < S_QPW; ++j) {
         uq[j] = load_query(xq, qidx, qw + j, q1);
-        best_d[j] = INFINITY; best_i[j] = 0x7fffffff; cnt[j] = 0; pc[j] = 0;
+        best_d[j] = INFINITY; best_i[j] = 0x7fffffff; cnt[j] = 0;
         thr[j] = MODE == 0 ? INFINITY : __int_as_float(0x7fffffff);   // ball: thr holds the index threshold's bits
         if (uq[j].valid) {
             active |= 1u << j;
@@ -1239,36 +1169,6 @@ __global__ __launch_bounds__(256, (MODE == 0 && SEL == 2) ? P2W_COLLECT_WAVES : 
     const bool in_k = lane < k;
     const int total = c1 - c0;
     SLAB_STAMP(0);   // setup
-    // COLLECT: merge every query's pending keys into its top-k list (ascending across lanes 0 .. k-1, TOPK_EMPTY beyond): sort
-    // the pending keys descending (21 stages), the lane-wise minimum with the ascending list is a bitonic sequence of the 64
-    // smallest keys of both, 6 merge stages sort it; lanes >= k are cut off and the threshold drops to the k-th distance.
-    // Exactly the list the insertions built: the k smallest (d2, index) keys seen so far, ties by index.
-    auto flush_all = [&]() {
-        constexpr int NQ = P2W_FLUSH_NQ;   // networks in flight (all eight at once spill: 16 key registers + 16 in exchange per network set)
-#pragma unroll
-        for (int h = 0; h < S_QPW / NQ; ++h) {
-            unsigned long long pk[NQ];
-#pragma unroll
-            for (int j = 0; j < NQ; ++j)
-                pk[j] = lane < pc[NQ * h + j] ? pend[COLLECT ? wave : 0][COLLECT ? NQ * h + j : 0][COLLECT ? lane : 0] : TOPK_EMPTY;
-            sort64_desc(pk, lane);
-#pragma unroll
-            for (int j = 0; j < NQ; ++j) {
-                const unsigned long long bk = ((unsigned long long)__float_as_uint(best_d[NQ * h + j]) << 32) | (unsigned)best_i[NQ * h + j];
-                pk[j] = pk[j] < bk ? pk[j] : bk;
-            }
-            merge64_asc(pk, lane);
-#pragma unroll
-            for (int j = 0; j < NQ; ++j) {
-                const int q = NQ * h + j;
-                const unsigned long long v = in_k ? pk[j] : TOPK_EMPTY;
-                best_d[q] = __uint_as_float((unsigned)(v >> 32));
-                best_i[q] = (int)(unsigned)v;
-                thr[q] = fminf(thr[q], rdlane(best_d[q], k - 1));   // slot k-1 is +inf until k keys are kept
-                pc[q] = 0;
-            }
-        }
-    };
     // The region is the cell box "bounding box of the queries grown by rho" (all of x unless BOX).  region() moves the
     // target box n* (never shrinking below the scanned box o*) and returns the number of runs that are NEW relative to
     // the scanned box; build(rb) fills the LDS run table with runs rb .. rb+G_MAXRUN-1 of them and returns how many
@@ -1390,7 +1290,7 @@ __global__ __launch_bounds__(256, (MODE == 0 && SEL == 2) ? P2W_COLLECT_WAVES : 
 #pragma unroll
             for (int j = 0; j < S_QPW; ++j) {
                 if ((active >> j) & 1u) {
-                    best_d[j] = INFINITY; best_i[j] = 0x7fffffff; cnt[j] = 0; pc[j] = 0;
+                    best_d[j] = INFINITY; best_i[j] = 0x7fffffff; cnt[j] = 0;
                     thr[j] = MODE == 0 ? INFINITY : __int_as_float(0x7fffffff);
                 }
             }
@@ -1476,41 +1376,7 @@ __global__ __launch_bounds__(256, (MODE == 0 && SEL == 2) ? P2W_COLLECT_WAVES : 
                 }
             }
             SLAB_STAMP(6);   // (ladder, when taken; else ~0)
-            if (MODE == 0 && COLLECT) {
-                // One flush site for the whole kernel (interleaved sorting networks: ~2000 instructions): a virtual chunk behind
-                // the tile's last one merges every query's pending keys.  A chunk whose admissions do not fit its query's list
-                // is presented again after a forced flush - an empty list takes any chunk (64 lanes), so nothing is ever
-                // dropped and no input (all points equal) can stall it.
-                const int nch = tsz >> 6;
-                bool force = false;
-#pragma unroll 1
-                for (int ch = 0; ch <= nch; ++ch) {   // (a rolled loop: unrolled over several chunks the compiler computes all their
-                    const bool last = ch == nch;      //  distances up front and the kernel needs 190 registers)
-                    unsigned done = last ? 0xffu : 0u;   // bit j: this chunk was presented to query j
-                    float4 c = make_float4(INFINITY, INFINITY, INFINITY, __int_as_float(0x7fffffff));
-                    if (!last) c = cand[ch * 64 + lane];
-                    for (;;) {
-                        if (force || last) { SLAB_STAMP(4); flush_all(); SLAB_STAMP(7); SLAB_COUNT(12, 1); }
-                        if (last) break;
-                        force = false;
-#pragma unroll
-                        for (int j = 0; j < S_QPW; ++j) {
-                            if (!((active >> j) & 1u) || ((done >> j) & 1u)) continue;   // wave-uniform
-                            const float d = p2w_d2(uq[j].x, uq[j].y, uq[j].z, c.x, c.y, c.z);
-                            const unsigned long long m = __ballot(d <= thr[j]);
-                            const int n = __popcll(m);
-                            if (pc[j] + n > 64) { force = true; continue; }
-                            done |= 1u << j;
-                            if (n == 0) continue;
-                            const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(c.w);
-                            const int slot = pc[j] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                            if ((m >> lane) & 1ull) pend[COLLECT ? wave : 0][COLLECT ? j : 0][COLLECT ? slot : 0] = key;
-                            pc[j] += n;
-                        }
-                        if (!force) break;
-                    }
-                }
-            } else if (MODE == 0) {
+            if (MODE == 0) {
                 for (int gr = 0; gr < (tsz >> 8); ++gr) {
                     float4 c[4];
 #pragma unroll
@@ -1600,7 +1466,7 @@ __global__ __launch_bounds__(256, (MODE == 0 && SEL == 2) ? P2W_COLLECT_WAVES : 
                 oXlo = 0; oXhi = -1; oYlo = 0; oYhi = -1; oZlo = 0; oZhi = -1;
 #pragma unroll
                 for (int j = 0; j < S_QPW; ++j)
-                    if ((active >> j) & 1u) { best_d[j] = INFINITY; best_i[j] = 0x7fffffff; thr[j] = INFINITY; pc[j] = 0; }
+                    if ((active >> j) & 1u) { best_d[j] = INFINITY; best_i[j] = 0x7fffffff; thr[j] = INFINITY; }
             }
         }
         // which queries are final?  k-th distance <= distance to the nearest face of the scanned region
@@ -1745,7 +1611,7 @@ extern "C" int32_t p2w_ball_query(const float* xyzr_x, const int32_t* ptr_x, con
 static int32_t grid_args(const uint64_t* keys, const p2w_grid* grid, int32_t flags) {
     P2W_CHECK_PTR(keys); P2W_CHECK_PTR(grid);
     if ((reinterpret_cast<uintptr_t>(keys) & 7u) || (reinterpret_cast<uintptr_t>(grid) & 7u)) return P2W_EALIGN;
-    if (flags & ~(P2W_SEARCH_X_INDEX_IN_W | P2W_SEARCH_Q_ROW_IN_W | P2W_SEARCH_BOX | P2W_SEARCH_COLLECT)) return P2W_EINVAL;
+    if (flags & ~(P2W_SEARCH_X_INDEX_IN_W | P2W_SEARCH_Q_ROW_IN_W | P2W_SEARCH_BOX)) return P2W_EINVAL;
     return P2W_OK;
 }
 
@@ -1758,11 +1624,8 @@ extern "C" int32_t p2w_knn_grid_indexed(const float* xyzr_x, const uint64_t* key
     if (st != P2W_OK) return st;
     if ((st = grid_args(keys_x, grid, flags)) != P2W_OK) return st;
     const int grid_dim = p2w_cdiv(m_bound, S_QT) + B;
-    const bool col = (flags & P2W_SEARCH_COLLECT) != 0;
-    auto* kern = (flags & P2W_SEARCH_BOX) ? ((k >= 8) ? (col ? slab_search_kernel<0, P2W_COLLECT_TILE, 2, true> : slab_search_kernel<0, 2048, 1, true>)
-                                                      : slab_search_kernel<0, 1024, 0, true>)
-                                          : ((k >= 8) ? (col ? slab_search_kernel<0, P2W_COLLECT_TILE, 2, false> : slab_search_kernel<0, 2048, 1, false>)
-                                                      : slab_search_kernel<0, 1024, 0, false>);
+    auto* kern = (flags & P2W_SEARCH_BOX) ? ((k >= 8) ? slab_search_kernel<0, 2048, 1, true> : slab_search_kernel<0, 1024, 0, true>)
+                                          : ((k >= 8) ? slab_search_kernel<0, 2048, 1, false> : slab_search_kernel<0, 1024, 0, false>);
     kern<<<grid_dim, 256, 0, p2w_s(stream)>>>(
         reinterpret_cast<const float4*>(xyzr_x), reinterpret_cast<const unsigned long long*>(keys_x), ptr_x, grid,
         reinterpret_cast<const float4*>(xyzr_q), qidx, ptr_q, B, k, 0.f, 0.f, nbr, deg, flags, hint, cell_start);

@@ -16,7 +16,8 @@
 #include "p2w_common.h"
 
 constexpr int RS_BLOCK = 256, RS_TILE = 4096, RS_RADIX = 256;
-constexpr int RS_SCAN_ONE = 65536;   // histogram tables up to this many entries are scanned by one workgroup (8 rounds)
+constexpr int RS_SCAN_ONE = 8192;    // histogram tables up to this many entries (131 k keys) are scanned by one workgroup in one round; above, two levels (a lone
+                                     // workgroup walks 65 536 entries in 169 us - per digit pass: 0.2 s of the 10 M-point plot's sampler sorts)
 
 struct RsCtl { unsigned long long orv; int pad[2]; };   // OR of all keys (-> number of passes), zeroed by the host call
 

@@ -24,7 +24,7 @@ from dataclasses import dataclass, field, fields
 import torch
 
 from . import _lib
-from ._lib import GEMM_RESIDUAL_H, PREC_F16X3, PREC_OF, SA_PACK8, SEARCH_BOX, SEARCH_COLLECT, SEARCH_Q_ROW_IN_W, SEARCH_X_INDEX_IN_W, Epilogue, check, lib, ptr
+from ._lib import GEMM_RESIDUAL_H, PREC_F16X3, PREC_OF, SA_PACK8, SEARCH_BOX, SEARCH_Q_ROW_IN_W, SEARCH_X_INDEX_IN_W, Epilogue, check, lib, ptr
 
 BN_EPS = 1e-5
 SA_RES = (0.04, 0.08, 0.16)  # model.py:210-212
@@ -236,8 +236,6 @@ class EngineOptions:
     search_index: bool = True     # grid searches look candidate runs up in the table sampler's cell -> position tables (else bisect)
     search_box: int = 0           # bit mask: grid searches bounded in x too (P2W_SEARCH_BOX: one run per grid row): 1 ball query,
                                   # 2 the k = 32 searches, 4 the interpolation searches (A/B: per-voxel rows are short)
-    search_collect: bool = False  # k = 32 searches select by collected candidates + sorting networks (P2W_SEARCH_COLLECT) instead of sorted
-                                  # insertions (A/B: 0.645 vs 0.562 ms per bench step, tools/search_ab.py)
     fp1_cell_order: bool = False  # H path: the level-0 features live in the sampler's cell order (stem, SA1's hoisted product, FP1, head), the
                                   # logits are scattered back, so that the last interpolation's coarse rows and SA1's P rows come from L2.
                                   # Bit-identical; measured: interp_concat 0.303 -> 0.289 ms, the rest of the step +-0 -> off (tools/opt_ab.py)
@@ -516,7 +514,7 @@ class Engine:
                 self._call("knn", L.p2w_knn_grid_indexed, ptr(src.xyzr), ptr(ckeys[l]), ptr(src.ptr), ptr(grids[l]), ptr(cstart.get(l)),
                            ptr(src.xyzr),
                            ptr(lv.idx), ptr(lv.ptr), B, N, k, ptr(lv.nbr), ptr(lv.deg), None,
-                           (SEARCH_BOX if self.search_box & 2 else 0) | (SEARCH_COLLECT if self.search_collect else 0))
+                           (SEARCH_BOX if self.search_box & 2 else 0))
             else:
                 self._call("knn", L.p2w_knn, ptr(src.xyzr), ptr(src.ptr), ptr(src.xyzr), ptr(lv.idx), ptr(lv.ptr), B, N,
                            k, ptr(lv.nbr), ptr(lv.deg), ptr(boxes(l)), 0)

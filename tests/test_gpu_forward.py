@@ -170,12 +170,11 @@ def test_packed_pointnetconv_is_bit_identical(precision):
         assert bool(torch.isfinite(a).all()) and torch.equal(a, b)
 
 
-@pytest.mark.parametrize("option", ["fp1_cell_order", "search_collect", "gemm_stream_k"])
+@pytest.mark.parametrize("option", ["fp1_cell_order", "gemm_stream_k"])
 @pytest.mark.parametrize("precision", ["f16x3", "fp16"])
 def test_engine_switches_keep_the_logits(option, precision):
     """The A/B switches give the default path's results: `fp1_cell_order` (level-0 features in the sampler's cell order, logits
-    scattered back: rows are only re-arranged) and `search_collect` (k = 32 selection by collected candidates + sorting
-    networks) bit for bit; `gemm_stream_k` (GEMM rows behind the whole chip rounds as a split-K tail: a tail tile's K range is
+    scattered back: rows are only re-arranged) bit for bit; `gemm_stream_k` (GEMM rows behind the whole chip rounds as a split-K tail: a tail tile's K range is
     summed in pieces) within the last fp32 bits of the accumulators, far inside the parity bar - on ragged batches with tiny
     voxels, through forward and through Net.stream."""
     from pointstowood_amd import Net

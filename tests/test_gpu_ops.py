@@ -825,13 +825,12 @@ def test_knn_grid_matches_brute_force_subset_queries(sizes, k, res2, surface, bo
 @pytest.mark.parametrize("sizes,k,surface,dup", [([5000], 32, False, False), ([3000, 33, 9000], 32, True, False), ([16384], 8, False, False),
                                                  ([2000, 16384], 64, True, False), ([4000], 32, False, True), ([70], 64, False, True)])
 @pytest.mark.parametrize("box", [0, 4])
-def test_knn_grid_collect_selection_equals_insertion(sizes, k, surface, dup, box):
-    """P2W_SEARCH_COLLECT (candidates under the threshold collected in LDS and merged 64 at a time by a wave-wide sorting
-    network) gives the neighbour tables of the default per-candidate sorted insertion, bit for bit - k = 8 .. 64, voxels with
-    fewer points than k, and clouds of exact duplicates (more admissions than a pending list holds: the forced-flush path)."""
-    from pointstowood_amd._lib import SEARCH_COLLECT, ptr, stream
+def test_knn_grid_on_duplicates_and_short_voxels_equals_brute_force(sizes, k, surface, dup, box):
+    """The grid kNN's threshold ladder + sorted insertions against the brute-force kernel, bit for bit - k = 8 .. 64, voxels with
+    fewer points than k, and clouds of exact duplicates (every distance a four-fold (d2, index) tie: only the index order decides)."""
+    from pointstowood_amd._lib import ptr, stream
     b = _batch(sizes, seed=43, surface=surface)
-    if dup:   # a quarter of the points, each four times: massive (d2, index) ties, lists overflow inside one chunk
+    if dup:   # a quarter of the points, each four times
         pos = b["pos"].clone()
         o = 0
         for n in sizes:
@@ -844,11 +843,15 @@ def test_knn_grid_collect_selection_equals_insertion(sizes, k, surface, dup, box
     coarse, _ = _level1(s)
     m1 = s["m"]
     out = []
-    for fl in (0, SEARCH_COLLECT):
+    for grid in (True, False):
         nbr = torch.full((m1, k), -7, dtype=torch.int32, device="cuda")
         deg = torch.full((m1,), -7, dtype=torch.int32, device="cuda")
-        assert L.p2w_knn_grid(ptr(coarse), ptr(s["ckeys"]), ptr(s["ptr_out"]), ptr(s["grid"]), ptr(coarse), None, ptr(s["ptr_out"]),
-                              B, m1, k, ptr(nbr), ptr(deg), None, box | fl, stream()) == 0
+        if grid:
+            st = L.p2w_knn_grid(ptr(coarse), ptr(s["ckeys"]), ptr(s["ptr_out"]), ptr(s["grid"]), ptr(coarse), None, ptr(s["ptr_out"]),
+                                B, m1, k, ptr(nbr), ptr(deg), None, box, stream())
+        else:
+            st = L.p2w_knn(ptr(coarse), ptr(s["ptr_out"]), ptr(coarse), None, ptr(s["ptr_out"]), B, m1, k, ptr(nbr), ptr(deg), None, 0, stream())
+        assert st == 0
         out.append((nbr.cpu(), deg.cpu()))
     assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][0], out[1][0])
     assert int(out[0][1].min()) >= 1 and bool((out[0][0][:, 0] == torch.arange(m1)).all() or dup)   # self first (unique points)

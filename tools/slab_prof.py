@@ -18,11 +18,10 @@ if "--json" in sys.argv:   # also write {kernel class: distance evaluations per 
     del sys.argv[i:i + 2]
 if len(sys.argv) > 1:      # a library built with -DP2W_SLAB_PROFILE (tools/build_variant.sh prof "-DP2W_SLAB_PROFILE")
     _libmod.LIB_PATH = os.path.abspath(sys.argv[1])
-COLLECT = len(sys.argv) > 2 and sys.argv[2] == "collect"
 evaluated = {}
 
 dev = torch.device("cuda", 0)
-net = Net(num_classes=1, C=bench.C, k=bench.K_NBR, search_collect=COLLECT).to(dev).eval()
+net = Net(num_classes=1, C=bench.C, k=bench.K_NBR).to(dev).eval()
 net.load_state_dict(weights.synth_state_dict(1, bench.C, seed=0), strict=True)
 net = net.to(dev)
 data = bench.make_batch(0, dev)

@@ -7,7 +7,7 @@ import torch
 from pointstowood_amd._lib import lib, ptr, stream
 
 L = lib()
-for n in (1_000_000, 5_000_000, 19_000_000):
+for n in (200_000, 1_000_000, 5_000_000, 19_000_000):
     for bits in (24, 40, 63):
         g = torch.Generator(device="cuda").manual_seed(n + bits)
         keys = torch.randint(0, 2 ** min(bits, 62), (n,), generator=g, dtype=torch.int64, device="cuda")
