@@ -389,7 +389,7 @@ __device__ __forceinline__ int w_stage_row16(int rho) {
 }
 template <int PREC, int RT16, int CT16, int EF, bool DOTK = false>   // DOTK: the row-dot kernel (the plain kernel compiles none of it)
 __device__ __forceinline__ void gemm_epilogue_16(const f32x4 (&acc)[RT16][CT16], const EpiArgs& ep, float wscale, int row0, int col0,
-                                                 int lane, int M, int N, const OutArgs& o) {
+                                                 int lane, int M, int N, const OutArgs& o, bool seen_report = true) {
     static_assert(CT16 % 2 == 0, "column tiles come in interleaved pairs");
     constexpr bool GEN = EF < 0;
     constexpr int JQ = CT16 / 2, NSTEP = RT16 * 4;
@@ -475,7 +475,9 @@ __device__ __forceinline__ void gemm_epilogue_16(const f32x4 (&acc)[RT16][CT16],
             for (int jq = 0; jq < JQ; ++jq) {
                 const float va = value(acc[it][2 * jq][reg], bias[jq][0], s0[jq][0], t0[jq][0], s1[jq][0], t1[jq][0], rcur[jq][0]);
                 const float vb = value(acc[it][2 * jq + 1][reg], bias[jq][1], s0[jq][1], t0[jq][1], s1[jq][1], t1[jq][1], rcur[jq][1]);
+#if !defined(P2W_RANGE_AB) || P2W_RANGE_AB < 3   // (diagnostic builds, tools/range_watch_ab.py: 1 no compares, 2 no stores, 3 no tracking)
                 m4 = fmaxf(m4, fmaxf(fabsf(va), fabsf(vb)));     // (one v_max3 per column pair)
+#endif
                 if (DOT) dsum = fmaf(vb, dw[jq][1], fmaf(va, dw[jq][0], dsum));
                 if (OF) *reinterpret_cast<fpair*>(fp + 32 * jq) = fpair{va, vb};
                 if (OH) {
@@ -489,11 +491,15 @@ __device__ __forceinline__ void gemm_epilogue_16(const f32x4 (&acc)[RT16][CT16],
                     }
                 }
             }
+#if !defined(P2W_RANGE_AB) || P2W_RANGE_AB == 2
             if (reg == 3) {   // the maximum of four row steps goes into the scalar masks: two compares per 4 x JQ column pairs
                 r_over |= __ballot(!(m4 <= P2W_RANGE_HI));
                 r_seen |= __ballot(m4 > P2W_RANGE_LO);
                 m4 = 0.f;
             }
+#elif P2W_RANGE_AB == 1
+            if (reg == 3) { asm volatile("" :: "v"(m4)); m4 = 0.f; }
+#endif
             if (DOT) {   // the four rows of a lane (reg 0..3) are consecutive: one 16-byte store per row tile by the lanes of column 0
                 dot4[reg] = row16_sum(dsum);
                 if (reg == 3 && c16 == 0)
@@ -535,24 +541,30 @@ __device__ __forceinline__ void gemm_epilogue_16(const f32x4 (&acc)[RT16][CT16],
             }
         }
     }
-    if (ep.range) range_commit(ep.range, r_over != 0ull, r_seen != 0ull, lane);   // (wave-uniform branch)
+#if !defined(P2W_RANGE_AB) || P2W_RANGE_AB == 1
+    // (wave-uniform branch.  OVER is reported by every tile; SEEN - "the tensor has values of ordinary size", true of nearly every
+    // wave - only where the caller asks for it: a persistent workgroup's FIRST tile.  The report stores were the watch's whole
+    // cost: 8 000 of them per launch +0.1 ms on the class, the tracking and the compares nothing - tools/range_watch_ab.py)
+    if (ep.range) range_commit(ep.range, r_over != 0ull, seen_report && r_seen != 0ull, lane);
+#endif
 }
 
 template <int PREC, int RT16, int CT16, bool WAIT_OLDER = false, bool DOTK = false>
 __device__ __forceinline__ void gemm_epilogue_dispatch16(const f32x4 (&acc)[RT16][CT16], const EpiArgs& ep, float wscale, int row0,
-                                                         int col0, int lane, int M, int N, const OutArgs& o, int ef) {
+                                                         int col0, int lane, int M, int N, const OutArgs& o, int ef,
+                                                         bool seen_report = true) {
     const bool full = (row0 + 16 * RT16 <= M) && (col0 + 16 * CT16 <= N) && ef != 0;
     if (full) {
         if constexpr (DOTK) {   // the row-dot kernel: one specialised class (bias + ReLU, the head: model.py:241-243), the rest generic
             if (ef == 513) {
-                gemm_epilogue_16<PREC, RT16, CT16, 513, true>(acc, ep, wscale, row0, col0, lane, M, N, o);
+                gemm_epilogue_16<PREC, RT16, CT16, 513, true>(acc, ep, wscale, row0, col0, lane, M, N, o, seen_report);
                 if constexpr (WAIT_OLDER) __builtin_amdgcn_s_waitcnt(p2w_vmcnt_imm(RT16 < 63 ? RT16 : 63));
                 return;
             }
         } else
         switch (ef) {
 #define P2W_EPI_CASE(E) case E: { \
-            gemm_epilogue_16<PREC, RT16, CT16, E>(acc, ep, wscale, row0, col0, lane, M, N, o); \
+            gemm_epilogue_16<PREC, RT16, CT16, E>(acc, ep, wscale, row0, col0, lane, M, N, o, seen_report); \
             constexpr int n_st = RT16 * 4 * (CT16 / 2) * (((E) & 128 ? 1 : 0) + ((E) & 256 ? (PREC == 0 ? 2 : 1) : 0)) ; \
             if constexpr (WAIT_OLDER) __builtin_amdgcn_s_waitcnt(p2w_vmcnt_imm(n_st < 63 ? n_st : 63)); \
             return; }
@@ -565,7 +577,7 @@ __device__ __forceinline__ void gemm_epilogue_dispatch16(const f32x4 (&acc)[RT16
             default: break;
         }
     }
-    gemm_epilogue_16<PREC, RT16, CT16, -1, DOTK>(acc, ep, wscale, row0, col0, lane, M, N, o);
+    gemm_epilogue_16<PREC, RT16, CT16, -1, DOTK>(acc, ep, wscale, row0, col0, lane, M, N, o, seen_report);
     if constexpr (WAIT_OLDER) __builtin_amdgcn_s_waitcnt(p2w_vmcnt_imm(0));
 }
 
@@ -968,7 +980,8 @@ __device__ __forceinline__ void gemm_hp_body(const _Float16* __restrict__ A, int
             for (int j = 0; j < CT16; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int s = 0; s + 1 < nslab; ++s) slab(s, std::false_type{}, 0, 0);
         slab(nslab - 1, std::true_type{}, mtn, ntn);
-        gemm_epilogue_dispatch16<PREC, RT16, CT16, true, DOTK>(acc, ep, wscale, mt * BM + wr * 32 * RT, nt * BN + wc * 32 * CT, lane, M, N, o, ef);
+        gemm_epilogue_dispatch16<PREC, RT16, CT16, true, DOTK>(acc, ep, wscale, mt * BM + wr * 32 * RT, nt * BN + wc * 32 * CT, lane, M, N, o, ef,
+                                                               gs == nslab && wave == 0);   // (range watch: SEEN from wave 0 of the workgroup's first tile)
         landed = true;
         if (!more) break;
         L = Ln; mt = mtn; nt = ntn;

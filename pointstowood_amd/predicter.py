@@ -196,10 +196,11 @@ def _consume(logits, data, is_wood: float):
     return _rows(data, preds, probs)
 
 
-def classify(model, loader, is_wood: float = 0.5, device="cuda"):
+def classify(model, loader, is_wood: float = 0.5, device="cuda", counts: list | None = None):
     """The reference's inference loop (predicter.py:193-213).  A model with a ``stream`` method (``pointstowood_amd.Net``) on a GPU
     gets the batches through its software pipeline (geometry of the next batch beside the features of the current ones, no
-    device-to-host copy between batches); the rows and their order are those of one ``classify_batch`` per batch."""
+    device-to-host copy between batches); the rows and their order are those of one ``classify_batch`` per batch.
+    ``counts`` (a list, optional) receives the row count of every batch."""
     if hasattr(model, "stream") and torch.device(device).type == "cuda":
         held, outs = [], []
 
@@ -211,8 +212,12 @@ def classify(model, loader, is_wood: float = 0.5, device="cuda"):
         with torch.no_grad():
             for logits in model.stream(feed()):
                 outs.append(_consume(logits, held.pop(0), is_wood))
+        if counts is not None:
+            counts.extend(int(o.shape[0]) for o in outs)
         return torch.cat(outs).cpu().numpy() if outs else np.zeros((0, 5), dtype=np.float64)
     outs = [classify_batch(model, data, is_wood, device) for data in loader]
+    if counts is not None:
+        counts.extend(int(o.shape[0]) for o in outs)
     return np.vstack(outs) if outs else np.zeros((0, 5), dtype=np.float64)
 
 
@@ -274,12 +279,13 @@ def classify_sharded(model, dataset, batches, is_wood, device, dist):
     lengths = getattr(dataset, "lengths", None)
     costs = [sum(batch_cost(lengths[i]) if lengths is not None else 1.0 for i in b) for b in batches]
     plan = partition_batches(costs, world)
-    mine, rows_of = [], torch.zeros(len(batches), dtype=torch.int64)
-    for bid in plan[rank]:
-        data = Batch.from_data_list([dataset[i] for i in batches[bid]])
-        mine.append(classify_batch(model, data, is_wood, device))
-        rows_of[bid] = mine[-1].shape[0]
-    local = torch.from_numpy(np.vstack(mine) if mine else np.zeros((0, 5), dtype=np.float64)).to(device)
+    # this rank's share through the same pipeline as one process (background feed -> Net.stream -> one D2H copy)
+    rows_of, got = torch.zeros(len(batches), dtype=torch.int64), []
+    on_gpu = torch.device(device).type == "cuda"
+    mine = classify(model, prefetch_batches(dataset, [batches[bid] for bid in plan[rank]], pin=on_gpu), is_wood, device, counts=got)
+    for bid, c in zip(plan[rank], got):
+        rows_of[bid] = c
+    local = torch.from_numpy(mine).to(device)
     rows_of = rows_of.to(device)
     dist.all_reduce(rows_of)                           # every batch has exactly one owner: the sum is its row count
     rows_of = [int(c) for c in rows_of.cpu()]
