@@ -330,6 +330,7 @@ def measure_workload(net, data, reps=5):
     n = int(data.pos.shape[0])
     top = sorted(per.items(), key=lambda kv: -kv[1][0])[:3]
     out = {"points": n, "voxels": int(data.sf.numel()), "steps": reps, "ms_per_batch": round(dt * 1e3, 3),
+           "range_fallbacks": int(getattr(net._engine, "range_fallbacks", 0)),
            "points_per_s": round(n / dt, 1), "end_to_end_tflops_algorithmic": round(2.0 * total_macs / dt / 1e12, 2),
            "level_sizes": sizes, "kernel_ms_top3": {k: round(v[0], 3) for k, v in top}}
     for kname, macs in kmacs.items():
@@ -372,7 +373,7 @@ def plot_workload(args, device, n=10_000_000, reps=2):
            "classified_points_per_s": round(stats.get("classified_points", 0) / max(stats.get("classify_s", 1e-9), 1e-9), 1),
            "stages_s_last_run": {k: round(v, 4) for k, v in stats.items() if k.endswith("_s")},
            "forwards": len(stats.get("batch_points", [])), "max_points_per_forward": stats.get("max_points"),
-           "outputs_ok": ok, "dtype": args.precision}
+           "outputs_ok": ok, "dtype": args.precision, "range_fallbacks": int(getattr(net._engine, "range_fallbacks", 0))}
     # efficiency: sequential forwards with per-class event brackets
     eng = net._engine
     macs, kmacs_tot, fwd_sizes = 0, {}, []
@@ -784,6 +785,9 @@ def main():
             "hbm_kernels": hbm,
             "search": search,
             "kernel_ms_per_step": {kname: round(v[0], 4) for kname, v in sorted(per.items(), key=lambda kv: -kv[1][0])},
+            # forwards the f16x3 range guard recomputed on the fp32 MFMA path (0 on this benchmark: a non-zero count would mean the
+            # timed steps were not f16x3 steps)
+            "range_fallbacks": int(getattr(net._engine, "range_fallbacks", 0)),
         }
         if rank_stats is not None:
             line["ranks"] = rank_stats
