@@ -269,6 +269,13 @@ typedef struct p2w_epilogue {
                             +-P2W_RANGE_LO; the report is the OR over the slots.  It is the range watch of the split-fp16
                             arithmetic: past 65504 an H value has lost its low part, and a tensor WITHOUT a value of ordinary
                             size has lost it to fp16's subnormal floor (2^-24 absolute) */
+    const void* interp;  /* NULL, or [M] records {int32 n0, int32 n1, float a0, float a1} (p2w_interp_weights; 16-byte aligned):
+                            p2w_gemm_h2 / _sk add to output row r not residual[r] but a0 * residual[n0] + a1 * residual[n1] - the
+                            rows of a COARSER level's fp32 matrix `residual` [interp_rows, ldr] interpolated on the fly (an FP
+                            module's layer 0 by linearity: relu(W [interp(y) | skip] + b) = relu(W_s skip + b + interp(W_i y)),
+                            model.py:149-153).  128 x 128 tile only (P2W_GEMM_TILE_256 is ignored); with P2W_GEMM_RESIDUAL_H: P2W_EUNSUPPORTED;
+                            p2w_gemm and p2w_gemm_h2_rowdot ignore it */
+    int32_t interp_rows; /* rows of `residual` when `interp` is given: every n0, n1 lies below it */
 } p2w_epilogue;
 
 #define P2W_RANGE_HI 6.0e4f
@@ -403,6 +410,10 @@ int32_t p2w_stem_h2_indexed(int32_t prec, const float* xyzr, int32_t n, const fl
 int32_t p2w_interp_concat_h2(int32_t prec, const float* xc, int32_t Fc, const float* xyzr_c, const float* xyzr_f,
                              const int32_t* nbr, const int32_t* deg, int32_t kw, const float* skip, int32_t Fs, int32_t m,
                              void* out_h, int32_t ldh, p2w_stream_t stream);
+/* knn_interpolate's weights alone (model.py:149, kw <= 2), for p2w_epilogue.interp: records[q] = {n0, n1, a0, a1}, a_s = w_s /
+ * (w_0 + w_1), w_s = 1 / max(d2, 1e-16); a row with one neighbour gets {n0, n0, 1, 0}.  kw > 2: P2W_EUNSUPPORTED. */
+int32_t p2w_interp_weights(const float* xyzr_c, const float* xyzr_f, const int32_t* nbr, const int32_t* deg, int32_t kw, int32_t m,
+                           void* records, p2w_stream_t stream);
 int32_t p2w_concat_xyz_h2(int32_t prec, const float* x, int32_t F, const float* xyzr, int32_t m, void* out_h, int32_t ldh,
                           p2w_stream_t stream);
 

@@ -18,7 +18,8 @@ _vp, _i32, _f32, _sz = C.c_void_p, C.c_int32, C.c_float, C.c_size_t
 
 class Epilogue(C.Structure):
     _fields_ = [("bias", _vp), ("sc0", _vp), ("sh0", _vp), ("sc1", _vp), ("sh1", _vp), ("residual", _vp),
-                ("ldr", _i32), ("relu0", _i32), ("relu1", _i32), ("relu2", _i32), ("relu_final", _i32), ("range", _vp)]
+                ("ldr", _i32), ("relu0", _i32), ("relu1", _i32), ("relu2", _i32), ("relu_final", _i32), ("range", _vp),
+                ("interp", _vp), ("interp_rows", _i32)]
 
 
 # name -> (restype, argtypes); must list every symbol declared in include/p2w.h
@@ -81,6 +82,7 @@ SIGNATURES = {
     "p2w_sa_conv_h_rows": (_i32, [_i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _f32, _i32, _i32, _vp, _vp,
                                   _vp, _vp, _i32, _vp, _i32, _vp, _sz, _i32, _vp, _vp, _vp]),
     "p2w_interp_concat_h2": (_i32, [_i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _i32, _vp]),
+    "p2w_interp_weights": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
     "p2w_concat_xyz_h2": (_i32, [_i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp]),
     "p2w_interp_concat": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _i32, _vp]),
     "p2w_concat_xyz": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _vp]),

@@ -353,7 +353,14 @@ static int32_t gemm_h2_checked(int32_t prec, const void* A_h, int32_t ldh_a, con
         if ((epi->sc0 && !epi->sh0) || (epi->sc1 && !epi->sh1)) return P2W_ENULL;
         if (epi->residual && epi->ldr < N) return P2W_EINVAL;
         ep = {epi->bias, epi->sc0, epi->sh0, epi->sc1, epi->sh1, epi->residual,
-              epi->ldr, epi->relu0, epi->relu1, epi->relu2, epi->relu_final, nullptr, epi->range};
+              epi->ldr, epi->relu0, epi->relu1, epi->relu2, epi->relu_final, nullptr, epi->range, nullptr};
+        if (epi->interp) {   // the residual's rows are interpolated from the [interp_rows, ldr] matrix `residual`
+            if (!epi->residual) return P2W_ENULL;
+            if (flags & P2W_GEMM_RESIDUAL_H) return P2W_EUNSUPPORTED;
+            if (reinterpret_cast<uintptr_t>(epi->interp) & 15u) return P2W_EALIGN;
+            if (epi->interp_rows <= 0 || (size_t)epi->interp_rows * (size_t)epi->ldr >= ((size_t)1 << 31)) return P2W_EINVAL;   // (32-bit element offsets)
+            ep.imeta = static_cast<const int4*>(epi->interp);
+        }
         if ((flags & P2W_GEMM_RESIDUAL_H) && epi->residual) {   // the residual is an H tensor of this precision, ldr its row pitch
             if ((epi->ldr & 7) || (reinterpret_cast<uintptr_t>(epi->residual) & 15u)) return P2W_EALIGN;
             ep.res_h = reinterpret_cast<const _Float16*>(epi->residual);
@@ -411,7 +418,7 @@ extern "C" int32_t p2w_gemm_h2_rowdot(int32_t prec, const void* A_h, int32_t ldh
     if (epi) {
         if ((epi->sc0 && !epi->sh0) || (epi->sc1 && !epi->sh1)) return P2W_ENULL;
         if (epi->residual) return P2W_EUNSUPPORTED;
-        ep = {epi->bias, epi->sc0, epi->sh0, epi->sc1, epi->sh1, nullptr, 0, epi->relu0, epi->relu1, epi->relu2, epi->relu_final, nullptr, epi->range};
+        ep = {epi->bias, epi->sc0, epi->sh0, epi->sc1, epi->sh1, nullptr, 0, epi->relu0, epi->relu1, epi->relu2, epi->relu_final, nullptr, epi->range, nullptr};
     }
     const _Float16* Ah = static_cast<const _Float16*>(A_h);
     const _Float16* Wp = static_cast<const _Float16*>(Wh);
@@ -756,6 +763,41 @@ extern "C" int32_t p2w_interp_concat_h2(int32_t prec, const float* xc, int32_t F
                                         int32_t m, void* out_h2, int32_t ldh, p2w_stream_t stream) {
     P2W_CHECK_PTR(out_h2);
     return interp_launch(prec, xc, Fc, xyzr_c, xyzr_f, nbr, deg, kw, skip, Fs, m, nullptr, 0, out_h2, ldh, stream);
+}
+
+// knn_interpolate's weights as one record per fine row (k <= 2): {n0, n1, a0, a1} with a_s = w_s / (w_0 + w_1), w_s as in
+// interp_concat_kernel (1 / max(d2, 1e-16), d2 = (dx dx + dy dy) + dz dz in fp32).  A row with one neighbour: {n0, n0, 1, 0}.
+__global__ __launch_bounds__(256) void interp_weights_kernel(const float4* __restrict__ xyzr_c, const float4* __restrict__ xyzr_f,
+                                                             const int* __restrict__ nbr, const int* __restrict__ deg, int kw, int m,
+                                                             int4* __restrict__ rec) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= m) return;
+    const int d = min(deg[q], kw);
+    const float4 pf = xyzr_f[q];
+    int js[2] = {0, 0};
+    float ws[2] = {0.f, 0.f};
+    for (int s = 0; s < d && s < 2; ++s) {
+        const int j = nbr[(size_t)q * kw + s];
+        const float4 pc = xyzr_c[j];
+        const float dx = pc.x - pf.x, dy = pc.y - pf.y, dz = pc.z - pf.z;
+        const float d2 = ((dx * dx) + (dy * dy)) + (dz * dz);
+        js[s] = j; ws[s] = 1.0f / fmaxf(d2, 1e-16f);
+    }
+    if (d < 2) js[1] = js[0];
+    const float den = ws[0] + ws[1];
+    const float a0 = d > 0 ? ws[0] / den : 0.f, a1 = d > 1 ? ws[1] / den : 0.f;
+    rec[q] = make_int4(js[0], js[1], __float_as_int(a0), __float_as_int(a1));
+}
+extern "C" int32_t p2w_interp_weights(const float* xyzr_c, const float* xyzr_f, const int32_t* nbr, const int32_t* deg, int32_t kw,
+                                      int32_t m, void* records, p2w_stream_t stream) {
+    if (m == 0) return P2W_OK;
+    P2W_CHECK_PTR(xyzr_c); P2W_CHECK_PTR(xyzr_f); P2W_CHECK_PTR(nbr); P2W_CHECK_PTR(deg); P2W_CHECK_PTR(records);
+    P2W_CHECK_ALIGN16(xyzr_c); P2W_CHECK_ALIGN16(xyzr_f); P2W_CHECK_ALIGN16(records);
+    if (m < 0 || kw <= 0) return P2W_EINVAL;
+    if (kw > 2) return P2W_EUNSUPPORTED;
+    interp_weights_kernel<<<p2w_cdiv(m, 256), 256, 0, p2w_s(stream)>>>(reinterpret_cast<const float4*>(xyzr_c), reinterpret_cast<const float4*>(xyzr_f),
+                                                                         nbr, deg, kw, m, static_cast<int4*>(records));
+    return P2W_LAUNCH_STATUS();
 }
 
 template <int PREC>

@@ -168,11 +168,15 @@ static inline int p2w_cu_count() {
 // ------------------------------------------------------------------------------------------------
 // epilogues
 // ------------------------------------------------------------------------------------------------
+#ifndef P2W_INTERP_DEPTH
+#define P2W_INTERP_DEPTH 2   // steps of source rows in flight in the interpolated-residual epilogue
+#endif
 struct EpiArgs {
     const float *bias, *sc0, *sh0, *sc1, *sh1, *residual;
     int ldr, relu0, relu1, relu2, relu_final;
     const _Float16* res_h;   // P2W_GEMM_RESIDUAL_H: the residual as an H tensor of the launch's precision (row pitch ldr) instead of fp32
     unsigned* range;         // optional range watch (p2w_epilogue.range)
+    const int4* imeta;       // p2w_epilogue.interp: row r's residual = a0 * residual[n0] + a1 * residual[n1] (rows of pitch ldr), {n0, n1, a0, a1} = imeta[r]
 };
 // The wave's range report: a plain store of 1 into one of the launch's OVER / SEEN words.  Every writer of a word writes the same
 // value, so no atomic and no look-before-write is needed (both were tried: an atomic OR behind a look through the vector L1 never
@@ -400,6 +404,9 @@ __device__ __forceinline__ void gemm_epilogue_16(const f32x4 (&acc)[RT16][CT16],
     const bool RF = GEN ? ep.relu_final != 0 : (EF & 64) != 0, OF = GEN ? o.f32 != nullptr : (EF & 128) != 0;
     const bool OH = GEN ? o.h2 != nullptr : (EF & 256) != 0;
     const bool RH = RES && (GEN ? ep.res_h != nullptr : (EF & 1024) != 0);   // the residual is an H tensor
+    // ... or interpolated from the rows of a coarser level (ep.imeta).  Not in the 256 x 256 kernel: it has no register to spare
+    constexpr bool RI_OK = !DOTK && RT16 <= 4;
+    const bool RI = RI_OK && RES && (GEN ? ep.imeta != nullptr : (EF & 2048) != 0);
     const bool DOT = DOTK && (GEN ? o.dotw != nullptr : (EF & 512) != 0);   // row . dotw partials instead of (or beside) the stores
     const int c16 = lane & 15, kg = lane >> 4;
     const int cb = col0 + 2 * c16;   // even column of pair 0; pair jq: + 32 jq
@@ -438,6 +445,23 @@ __device__ __forceinline__ void gemm_epilogue_16(const f32x4 (&acc)[RT16][CT16],
         return v;
     };
     fpair rcur[JQ], rnxt[JQ];
+    // interpolated residual: a ring of RI_D steps' raw source rows (two dependent gathers - record, then the rows it names -
+    // each issued ahead of its use: the record of step st + RI_D + 1 and the rows of step st + RI_D during step st; what bounds
+    // these launches is gather bytes in flight per CU, not arithmetic)
+    constexpr int RI_D = RI_OK ? (P2W_INTERP_DEPTH < NSTEP ? P2W_INTERP_DEPTH : NSTEP) : 1;
+    fpair z0r[RI_D][RI_OK ? JQ : 1], z1r[RI_D][RI_OK ? JQ : 1];
+    float a0r[RI_D], a1r[RI_D];
+    int4 m_nxt = make_int4(0, 0, 0, 0);
+    auto load_zrows = [&](int slot, const int4& mt) {
+        const float* p0 = ep.residual + ((unsigned)mt.x * (unsigned)ep.ldr + (unsigned)cb);
+        const float* p1 = ep.residual + ((unsigned)mt.y * (unsigned)ep.ldr + (unsigned)cb);
+#pragma unroll
+        for (int jq = 0; jq < (RI_OK ? JQ : 1); ++jq) {
+            z0r[slot][jq] = *reinterpret_cast<const fpair*>(p0 + 32 * jq);
+            z1r[slot][jq] = *reinterpret_cast<const fpair*>(p1 + 32 * jq);
+        }
+        a0r[slot] = __int_as_float(mt.z); a1r[slot] = __int_as_float(mt.w);
+    };
     auto load_res = [&](fpair (&dst)[JQ], int st) {   // specialised path only
         if (RH) {
 #pragma unroll
@@ -451,7 +475,17 @@ __device__ __forceinline__ void gemm_epilogue_16(const f32x4 (&acc)[RT16][CT16],
 #pragma unroll
     for (int jq = 0; jq < JQ; ++jq) { rcur[jq] = fpair{0.f, 0.f}; rnxt[jq] = fpair{0.f, 0.f}; }
     if constexpr (!GEN) {
-        if (RES) load_res(rcur, 0);
+        if constexpr (RI_OK) {
+            if (RI) {
+                int4 m0[RI_D];
+#pragma unroll
+                for (int d = 0; d < RI_D; ++d) m0[d] = ep.imeta[row_of(d)];
+                if (RI_D < NSTEP) m_nxt = ep.imeta[row_of(RI_D)];
+#pragma unroll
+                for (int d = 0; d < RI_D; ++d) load_zrows(d, m0[d]);
+            }
+        }
+        if (RES && !RI) load_res(rcur, 0);
     }
     float dot4[4] = {0.f, 0.f, 0.f, 0.f};
     // range watch (ep.range): wave-uniform masks in scalar registers - this kernel has no vector register to spare
@@ -462,7 +496,19 @@ __device__ __forceinline__ void gemm_epilogue_16(const f32x4 (&acc)[RT16][CT16],
         const int it = st >> 2, reg = st & 3;
         const int row = row_of(st);
         if constexpr (!GEN) {
-            if (RES && st + 1 < NSTEP) load_res(rnxt, st + 1);
+            if constexpr (RI_OK) {
+                if (RI) {
+#pragma unroll
+                    for (int jq = 0; jq < JQ; ++jq)
+                        rcur[jq] = fpair{fmaf(a1r[st % RI_D], z1r[st % RI_D][jq][0], a0r[st % RI_D] * z0r[st % RI_D][jq][0]),
+                                         fmaf(a1r[st % RI_D], z1r[st % RI_D][jq][1], a0r[st % RI_D] * z0r[st % RI_D][jq][1])};
+                    if (st + RI_D < NSTEP) {
+                        load_zrows(st % RI_D, m_nxt);
+                        if (st + RI_D + 1 < NSTEP) m_nxt = ep.imeta[row_of(st + RI_D + 1)];
+                    }
+                }
+            }
+            if (RES && !RI && st + 1 < NSTEP) load_res(rnxt, st + 1);
             __builtin_amdgcn_sched_barrier(0);
             float* fp = OF ? o.f32 + ((unsigned)row * (unsigned)o.ldo + (unsigned)cb) : nullptr;
             _Float16* hp = nullptr;
@@ -506,13 +552,17 @@ __device__ __forceinline__ void gemm_epilogue_16(const f32x4 (&acc)[RT16][CT16],
                     *reinterpret_cast<float4*>(o.part + ((unsigned)(col0 >> 6) * (unsigned)o.ldpart + (unsigned)(row - 3))) =
                         make_float4(dot4[0], dot4[1], dot4[2], dot4[3]);
             }
-            if (RES) {
+            if (RES && !RI) {
 #pragma unroll
                 for (int jq = 0; jq < JQ; ++jq) rcur[jq] = rnxt[jq];
             }
         } else {
             float dsum = 0.f;
             if (row < M) {
+                int4 mt = make_int4(0, 0, 0, 0);
+                if constexpr (RI_OK) {
+                    if (RI) mt = ep.imeta[row];
+                }
 #pragma unroll
                 for (int jq = 0; jq < JQ; ++jq) {
                     const int c = cb + 32 * jq;
@@ -521,7 +571,8 @@ __device__ __forceinline__ void gemm_epilogue_16(const f32x4 (&acc)[RT16][CT16],
                     for (int e = 0; e < 2; ++e) {
                         const bool cv = c + e < N;
                         float res = 0.f;
-                        if (RES && cv) res = RH ? h_load2<PREC>(ep.res_h, (unsigned)ep.ldr, (unsigned)row, (unsigned)c)[e] : ep.residual[(size_t)row * ep.ldr + c + e];
+                        if (RI && cv) res = fmaf(__int_as_float(mt.w), ep.residual[(size_t)mt.y * ep.ldr + c + e], __int_as_float(mt.z) * ep.residual[(size_t)mt.x * ep.ldr + c + e]);
+                        else if (RES && cv) res = RH ? h_load2<PREC>(ep.res_h, (unsigned)ep.ldr, (unsigned)row, (unsigned)c)[e] : ep.residual[(size_t)row * ep.ldr + c + e];
                         v[e] = value(acc[it][2 * jq + e][reg], bias[jq][e], s0[jq][e], t0[jq][e], s1[jq][e], t1[jq][e], res);
                         if (!cv) v[e] = 0.f;                       // pad columns of an H row must be zero
                         if (OF && cv) o.f32[(size_t)row * o.ldo + c + e] = v[e];
@@ -574,6 +625,16 @@ __device__ __forceinline__ void gemm_epilogue_dispatch16(const f32x4 (&acc)[RT16
             // modes) / H output, residual read from the H tensor the block's first layer consumed (1376, + fp32 output 1504: f16x3)
             P2W_EPI_CASE(480) P2W_EPI_CASE(1376) P2W_EPI_CASE(1504)
 #undef P2W_EPI_CASE
+            // bias + interpolated residual + ReLU, H output: an FP module's layer 0 on the skip columns, the coarse level's product
+            // interpolated in (engine.py fp_hoist).  128 x 128 tile (and the split-K fix-up) only
+            case 2400:
+                if constexpr (!DOTK && RT16 <= 4) {
+                    gemm_epilogue_16<PREC, RT16, CT16, 2400>(acc, ep, wscale, row0, col0, lane, M, N, o, seen_report);
+                    constexpr int n_st = RT16 * 4 * (CT16 / 2) * (PREC == 0 ? 2 : 1);
+                    if constexpr (WAIT_OLDER) __builtin_amdgcn_s_waitcnt(p2w_vmcnt_imm(n_st < 63 ? n_st : 63));
+                    return;
+                }
+                break;
             default: break;
         }
     }
@@ -1041,6 +1102,7 @@ static int32_t launch_gemm_h(const _Float16* Ah, int32_t ldh_a, const _Float16* 
                              float* skws = nullptr, size_t skws_bytes = 0, int sk_S = 0) {
     constexpr int KA = HCfg<PREC>::kalign;
     const int Npad = (N + 255) / 256 * 256, Kpad = (K + KA - 1) / KA * KA;
+    if (ep.imeta) flags = (flags & ~P2W_GEMM_TILE_256) | P2W_GEMM_TILE_128;   // the interpolated residual lives in the 128 x 128 kernel only
     if ((ldh_a % KA) != 0 || ldh_a < Kpad) return P2W_EINVAL;     // K padding must exist (and be zero) in A as well
     if (out_h2 && (ldh_o & 7)) return P2W_EINVAL;
     const int hcols = ldh_o < (N + KA - 1) / KA * KA ? ldh_o : (N + KA - 1) / KA * KA;   // outputs + zero pad to the K-slab boundary
@@ -1135,7 +1197,8 @@ static int32_t launch_gemm_h(const _Float16* Ah, int32_t ldh_a, const _Float16* 
             }
             const size_t r0 = (size_t)rows_full;
             EpiArgs ept = ep;
-            if (ept.residual) ept.residual += r0 * ep.ldr;
+            if (ept.imeta) ept.imeta += r0;                       // (the interpolated residual's rows are named by the records)
+            else if (ept.residual) ept.residual += r0 * ep.ldr;
             if (ept.res_h) ept.res_h += r0 * PL * ep.ldr;
             return launch_gemm_h<PREC>(Ah + r0 * PL * ldh_a, ldh_a, Wp, wscale, m_t, N, K, ept, out_f32 ? out_f32 + r0 * ldo : nullptr, ldo,
                                        out_h2 ? out_h2 + r0 * PL * ldh_o : nullptr, ldh_o,
@@ -1151,9 +1214,9 @@ static int32_t launch_gemm_h(const _Float16* Ah, int32_t ldh_a, const _Float16* 
 #endif
     int ef = (ep.relu0 ? 1 : 0) | (ep.sc0 ? 2 : 0) | (ep.relu1 ? 4 : 0) | (use_s1 ? 8 : 0) | (ep.relu2 ? 16 : 0) |
              ((ep.residual || ep.res_h) ? 32 : 0) | (ep.relu_final ? 64 : 0) | (out_f32 ? 128 : 0) | (out_h2 ? 256 : 0) | (dotw ? 512 : 0) |
-             (ep.res_h ? 1024 : 0);
+             (ep.res_h ? 1024 : 0) | (ep.imeta ? 2048 : 0);
     const size_t lim = (size_t)1 << 31;
-    if ((size_t)M * (size_t)(ldo > 2 * ldh_o ? ldo : 2 * ldh_o) >= lim || ((ep.residual || ep.res_h) && (size_t)M * (size_t)ep.ldr * (ep.res_h ? 2 : 1) >= lim) ||
+    if ((size_t)M * (size_t)(ldo > 2 * ldh_o ? ldo : 2 * ldh_o) >= lim || ((ep.residual || ep.res_h) && !ep.imeta && (size_t)M * (size_t)ep.ldr * (ep.res_h ? 2 : 1) >= lim) ||
         (N & 1) || (flags & P2W_GEMM_GENERIC_EPI))
         ef = 0;
     // the specialised epilogue moves column PAIRS (float2 / one H word per lane): even pitches, 8-byte aligned vectors

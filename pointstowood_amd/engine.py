@@ -138,6 +138,16 @@ class PackedWeights:
             f_in = C2
         self.sa4 = self._mlp2(sd, "sa4_module.NN", pack)
         self.fp = {l: self._mlp2(sd, f"fp{l}_module.NN", pack) for l in (4, 3, 2, 1)}
+        # layer 0 of an FP module (model.py:149-153) is linear up to its ReLU and knn_interpolate is a convex combination of coarse rows:
+        #   relu(W [interp(y) | skip] + b) = relu(interp(W_i y) + W_s skip + b)
+        # so W_i can be applied to the COARSE rows (a fifth of the fine ones at level 3 of the bench batch) and its output
+        # interpolated - inside the epilogue of the GEMM over the skip columns (p2w_epilogue.interp), so the interpolated rows
+        # never exist in HBM (EngineOptions.fp_hoist): (W_i without bias / activation, W_s with the bias, ReLU behind the sum)
+        self.fp_split = {}
+        for l in (4, 3, 2, 1):
+            W0, b0 = sd[f"fp{l}_module.NN.0.0.weight"], sd[f"fp{l}_module.NN.0.0.bias"]
+            Fc = self.sa4[1].N if l == 4 else self.fp[l + 1][1].N      # width of the coarse level's features
+            self.fp_split[l] = (pack(W0[:, :Fc]), pack(W0[:, Fc:], bias=b0, relu_final=1))
         sn, tn = _bn_affine(sd, "norm")
         self.head1 = pack(sd["conv1.weight"][:, :, 0].double() * sn[:, None],
                           bias=sn * sd["conv1.bias"].double() + tn, relu0=1)
@@ -254,6 +264,12 @@ class EngineOptions:
     feat_priority: int = -1
     res_priority: int = -1        # ... and of the second chunk-chain stream (part of the feature phase)
     gemm_flags: int = 0           # P2W_GEMM_* bits of include/p2w.h passed to every p2w_gemm_h2 call (A/B runs)
+    fp_hoist: bool = True         # FP modules whose coarse level has at most fp_hoist_ratio of the fine level's rows: layer 0's interpolated half runs on
+                                  # the coarse rows and its OUTPUT is interpolated inside the epilogue of the GEMM over the skip columns
+                                  # (fewer MACs - level 3 of the bench batch has 17 506 coarse rows for 81 683 fine ones - and the
+                                  # interpolated rows are neither written nor re-read); same function, logits move in the last bits
+    fp_hoist_ratio: float = 0.5   # ... coarse rows / fine rows up to which a module takes that route (at 2/3 the gathers of the epilogue cost
+                                  # what the saved interpolation kernel did: level 2 of the bench batch, tools/interp_epi_ab.py)
     range_guard: bool = True      # f16x3: every stem / PointNetConv / GEMM launch reports whether an output lay beyond +-6e4 (the hi plane
                                   # saturates at 65504) and whether any lay above 2^-5 (a tensor without one has its lo plane on fp16's
                                   # subnormal floor); a forward with such a layer is recomputed on the fp32 MFMA path (Engine.fallback, set
@@ -657,9 +673,10 @@ class Engine:
         return bad
 
     def _gemm_h2(self, name, A, ldh_a, M, lin: Linear, out_f32=None, ldo=0, out_h2=None, ldh_o=0, residual=None, ldr=0,
-                 residual_h=False, watch=None):
+                 residual_h=False, watch=None, interp=None):
         ep = Epilogue(ptr(lin.bias), ptr(lin.sc0), ptr(lin.sh0), ptr(lin.sc1), ptr(lin.sh1), ptr(residual), ldr,
-                      lin.relu0, lin.relu1, lin.relu2, lin.relu_final, self._watch(watch, M))
+                      lin.relu0, lin.relu1, lin.relu2, lin.relu_final, self._watch(watch, M),
+                      ptr(interp), 0 if interp is None else residual.shape[0])
         flags = self.gemm_flags | (GEMM_RESIDUAL_H if residual_h else 0)
         if self.gemm_stream_k:
             ws = self._sk_workspace(A.device)
@@ -803,7 +820,7 @@ class Engine:
         zeros_c = torch.zeros((B, 4), dtype=torch.float32, device=dev)
         # Row-chunked chains: interpolate -> MLP layer 0 -> MLP layer 1 (-> head for fp1) run chunk by chunk so the wide
         # intermediates of a chunk are consumed out of the Infinity Cache (same trick as the residual blocks).
-        y, y_xyzr = g, zeros_c
+        y, y_xyzr, y_h = g, zeros_c, None      # coarse features (fp32), their positions, their H form (where the next module hoists)
         logits = torch.empty(N, dtype=torch.float32, device=dev) if w.num_classes == 1 else None
         o_multi = new(N, w.num_classes) if w.num_classes != 1 else None
         logits_out = logits
@@ -813,6 +830,25 @@ class Engine:
             nbr, deg, kw = (nbr4, deg4, 1) if fl == 4 else (*geo.fp_nbr[fl - 1], 2)
             fine_xyzr = geo.sorted0 if (fl == 1 and sorted0) else fine.xyzr   # FP1's rows (and fp_nbr[0]'s) are in cell order then
             l0, l1 = w.fp[fl]
+            # layer 0's interpolated half on the coarse rows (PackedWeights.fp_split)?  This module: the previous one left the H
+            # form of its output; the next one: this module's output must leave one
+            hoists = lambda rows_c, rows_f: bool(self.fp_hoist and 0 < rows_c <= self.fp_hoist_ratio * rows_f)
+            Mx = y.shape[0]
+            hoist = hoists(Mx, m)
+            next_hoist = fl >= 2 and hoists(m, lv[fl - 2].n)
+            if hoist:
+                li, ls = w.fp_split[fl]
+                if y_h is None:      # (module 4: the pooled rows have no H form yet)
+                    y_h = newh(Mx, Fc + 4)
+                    self._call("concat_xyz", L.p2w_concat_xyz_h2, prec, ptr(y), Fc, ptr(y_xyzr), Mx, ptr(y_h), pad8(Fc + 4))
+                    y_ld = pad8(Fc + 4)
+                else:
+                    y_ld = pad8(Fc)
+                Z = new(Mx, l0.N)
+                self._gemm_h2("gemm_mlp", y_h, y_ld, Mx, li, out_f32=Z, ldo=l0.N)
+                rec = torch.empty((m, 4), dtype=torch.int32, device=dev)
+                self._call("interp_concat", L.p2w_interp_weights, ptr(y_xyzr), ptr(fine_xyzr), ptr(nbr), ptr(deg), kw, m, ptr(rec))
+            yh_full = newh(m, l1.N) if next_hoist else None
             chunk = self.res_chunk_rows if self.res_chunk_rows > 0 else m
             chunk = max(256, min(m, pick_chunk(m, chunk * 512 // (Fc + Fs[fl - 1]), max(1, l0.N // 256)) if self.chunk_pick
                                  else (chunk * 512 // (Fc + Fs[fl - 1])) // 256 * 256))
@@ -839,10 +875,16 @@ class Engine:
                 bf, st = bufs[ci % len(lanes)], lanes[ci % len(lanes)]
                 a, yh, hws, hdh = bf["a"], bf["yh"], bf["hws"], bf["hdh"]
                 with torch.cuda.stream(st):
-                    # the interpolated part only (skip = NULL): the skip columns of these rows were written by their producer
-                    self._call("interp_concat", L.p2w_interp_concat_h2, prec, ptr(y), Fc, ptr(y_xyzr), ptr(fine_xyzr[r0:]),
-                               ptr(nbr[r0:]), ptr(deg[r0:]), kw, None, 0, mm, ptr(cf[r0:]), ld)
-                    self._gemm_h2("gemm_mlp", cf[r0:], ld, mm, l0, out_h2=a, ldh_o=pad8(l0.N), watch=f"fp{fl}.0")
+                    if hoist:   # relu(W_s skip + b + interp(W_i y)): the interpolation of Z's rows happens in the epilogue
+                        self._gemm_h2("gemm_mlp", xh[fl - 1][r0:], ld, mm, ls, out_h2=a, ldh_o=pad8(l0.N), residual=Z, ldr=l0.N,
+                                      interp=rec[r0:], watch=f"fp{fl}.0")
+                    else:
+                        # the interpolated part only (skip = NULL): the skip columns of these rows were written by their producer
+                        self._call("interp_concat", L.p2w_interp_concat_h2, prec, ptr(y), Fc, ptr(y_xyzr), ptr(fine_xyzr[r0:]),
+                                   ptr(nbr[r0:]), ptr(deg[r0:]), kw, None, 0, mm, ptr(cf[r0:]), ld)
+                        self._gemm_h2("gemm_mlp", cf[r0:], ld, mm, l0, out_h2=a, ldh_o=pad8(l0.N), watch=f"fp{fl}.0")
+                    if yh_full is not None:
+                        yh = yh_full[r0:]
                     self._gemm_h2("gemm_mlp", a, pad8(l0.N), mm, l1, out_f32=None if b is None else b[r0:], ldo=l1.N,
                                   out_h2=yh, ldh_o=pad8(l1.N), watch=f"fp{fl}.1")
                     if fl == 1:   # head (model.py:241-243) on the same chunk
@@ -860,7 +902,7 @@ class Engine:
                 done = torch.cuda.Event()
                 done.record(side)
                 cur.wait_event(done)
-            y, y_xyzr = b, fine.xyzr
+            y, y_xyzr, y_h = b, fine.xyzr, yh_full
             if keep is not None:
                 if fl == 1 and sorted0 and b is not None:   # rows back in input order for whoever asked
                     bo = torch.empty_like(b)

@@ -274,6 +274,71 @@ def test_gemm_h_stream_k_tail(prec, M, N, K, flags):
     assert float(hv[:, pad_to:].abs().max()) == 0.0                 # columns beyond the launch's own stay untouched
 
 
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("M,Mx,N,K,kw,sk", [(3000, 700, 640, 256, 2, 0), (81683, 17506, 640, 256, 2, 0), (70000, 20000, 512, 128, 2, 1),
+                                            (17506, 9, 768, 512, 1, 1), (517, 40, 130, 32, 2, 0), (2100, 300, 130, 1024, 2, 1)])
+def test_gemm_h_interpolated_residual(prec, M, Mx, N, K, kw, sk):
+    """An FP module's layer 0 by linearity (model.py:149-153): relu(W_s skip + b + knn_interpolate(Z)) with the interpolation of
+    the coarse level's rows Z done in the GEMM's epilogue (p2w_epilogue.interp, records from p2w_interp_weights) == the same GEMM
+    with the interpolated rows given as an fp32 residual (p2w_interp_concat) to fp32 rounding, and == fp64; interior and edge
+    tiles, one and two neighbours, rows with fewer neighbours than kw, plain launches and the split-K planner's row ranges."""
+    import ctypes as C
+    from pointstowood_amd._lib import Epilogue, check, lib, ptr, stream
+    L = lib()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    bias = torch.randn(N, generator=g)
+    Z = torch.randn(Mx, N, generator=g)
+    pc, pf = torch.rand(Mx, 4, generator=g), torch.rand(M, 4, generator=g)
+    nbr = torch.randint(0, Mx, (M, kw), generator=g, dtype=torch.int32)
+    deg = torch.full((M,), kw, dtype=torch.int32)
+    deg[::7] = 1                                                            # fewer neighbours than kw
+    pf[::11, :3] = pc[nbr[::11, 0].long(), :3]                              # a fine point ON its first neighbour (w = 1e16)
+    dW, wscale, Kp = _pack_h(W, prec)
+    ka, planes = (32, 2) if prec == 0 else (64, 1)
+    ldh_a = (K + 4 + ka - 1) // ka * ka
+    Ah = _to_h(A, prec, ldh_a)
+    dZ, dpc, dpf, dn, dd, db = Z.cuda(), pc.cuda(), pf.cuda(), nbr.cuda(), deg.cuda(), bias.cuda()
+    rec = torch.empty((M, 4), dtype=torch.int32, device="cuda")
+    check(L.p2w_interp_weights(ptr(dpc), ptr(dpf), ptr(dn), ptr(dd), kw, M, ptr(rec), stream()))
+    r = rec.cpu()
+    a = r[:, 2:].contiguous().view(torch.float32)
+    assert torch.equal(r[:, 0], nbr[:, 0]) and bool((r[:, 1] == torch.where(deg >= 2, nbr[:, kw - 1], nbr[:, 0])).all())
+    assert float((a.sum(1) - 1).abs().max()) <= 2e-7 and bool((a[deg < 2, 1] == 0).all())
+    R = torch.empty((M, N), device="cuda")
+    check(L.p2w_interp_concat(ptr(dZ), N, ptr(dpc), ptr(dpf), ptr(dn), ptr(dd), kw, None, 0, M, ptr(R), N, stream()))
+    ldh_o = (N + ka - 1) // ka * ka
+    ws = torch.empty(int(L.p2w_gemm_h2_sk_ws_bytes()), dtype=torch.uint8, device="cuda")
+
+    def run(ep, flags=0):
+        outh = torch.zeros((M, planes * ldh_o), dtype=Ah.dtype, device="cuda")
+        if sk:
+            check(L.p2w_gemm_h2_sk(prec, ptr(Ah), ldh_a, ptr(dW), wscale, M, N, K, C.byref(ep), None, 0, ptr(outh), ldh_o, ptr(ws),
+                                   ws.numel(), flags, stream()))
+        else:
+            check(L.p2w_gemm_h2(prec, ptr(Ah), ldh_a, ptr(dW), wscale, M, N, K, C.byref(ep), None, 0, ptr(outh), ldh_o, flags, stream()))
+        return _from_h(outh, prec, ldh_o)
+    fused = run(Epilogue(ptr(db), None, None, None, None, ptr(dZ), N, 0, 0, 0, 1, None, ptr(rec), Mx))
+    plain = run(Epilogue(ptr(db), None, None, None, None, ptr(R), N, 0, 0, 0, 1))
+    generic = run(Epilogue(ptr(db), None, None, None, None, ptr(dZ), N, 0, 0, 0, 1, None, ptr(rec), Mx), flags=4)
+    Ad = _from_h(Ah, prec, ldh_a)[:, :K]
+    v = torch.relu(Ad @ W.double().t() + bias.double() + R.cpu().double())
+    scale = max(1.0, v.abs().max().item())
+    tol = H_TOL[prec] * scale + (0 if prec == 0 else 2e-3 * scale)          # (H output of one plane: its own rounding)
+    assert (fused[:, :N] - v).abs().max().item() <= tol
+    assert (fused - plain).abs().max().item() <= (4e-6 if prec == 0 else 2e-3) * scale
+    assert (fused - generic).abs().max().item() <= (4e-6 if prec == 0 else 2e-3) * scale
+    assert float(fused[:, N:].abs().max() if ldh_o > N else 0.0) == 0.0
+    # what the boundary refuses: an H residual, records without rows (a forced 256 x 256 tile is ignored)
+    ep = Epilogue(ptr(db), None, None, None, None, ptr(dZ), N, 0, 0, 0, 1, None, ptr(rec), Mx)
+    outh = torch.zeros((M, planes * ldh_o), dtype=Ah.dtype, device="cuda")
+    assert L.p2w_gemm_h2(prec, ptr(Ah), ldh_a, ptr(dW), wscale, M, N, K, C.byref(ep), None, 0, ptr(outh), ldh_o, 32, stream()) == -5
+    assert torch.equal(run(ep, flags=2), fused)
+    ep0 = Epilogue(ptr(db), None, None, None, None, ptr(dZ), N, 0, 0, 0, 1, None, ptr(rec), 0)
+    assert L.p2w_gemm_h2(prec, ptr(Ah), ldh_a, ptr(dW), wscale, M, N, K, C.byref(ep0), None, 0, ptr(outh), ldh_o, 0, stream()) == -1
+
+
 @pytest.mark.parametrize("prec", [0, 1, 2])
 @pytest.mark.parametrize("M,N,K,flags", [(1000, 512, 512, 0), (5, 512, 512, 0), (777, 100, 36, 0), (2049, 512, 64, 2), (2049, 512, 64, 1),
                                          (300, 130, 200, 0), (4096, 256, 128, 2), (32768, 512, 512, 0), (70000, 512, 512, 0),
