@@ -24,7 +24,7 @@ inside the timed region either way.  Rank 0 prints ONE JSON line.
 ``roofline`` is measured live: after the timed regions one extra, sequential step is run with HIP
 events around every run of consecutive launches of one kernel class (on the launch stream) and the
 dominant kernel's algorithmic FLOPs are divided by its measured time; ``traffic`` comes from the
-committed rocprofv3 PMC summary of the same command (``profiles/r4_<precision>_hbm_traffic.json``).
+committed rocprofv3 PMC summary of the same command (``profiles/r5_<precision>_hbm_traffic.json``).
 ``hbm_kernels`` gives the memory-bound kernels' algorithmic bytes / measured time
 against the 8 TB/s HBM peak.  ``cpu_baseline`` times the CPU oracle (``oracle/net.py``, a port of
 the reference forward pinned to the reference's own outputs) on a bounded sample of batch 0.
@@ -146,8 +146,21 @@ def algorithmic_macs(geo):
     return total, {"gemm_kernel": gemm, "sa_conv_kernel": sa}, dict(N=N, M=[M1, M2, M3], E=E)
 
 
-def algorithmic_bytes(geo):
-    """SURVEY.md 8(d) algorithmic bytes of the memory-bound kernels (fp32 features, int32 indices, each datum once)."""
+def hoist_saved_macs(geo, opts):
+    """MACs the engine does NOT execute where an FP module's layer 0 runs its interpolated half on the coarse rows
+    (EngineOptions.fp_hoist: relu(W [interp(y) | skip] + b) = relu(W_s skip + b + interp(W_i y))): Fc x N0 x (fine - coarse rows)
+    per module that takes the route.  The ALGORITHMIC figure (algorithmic_macs) stays the reference formulation's."""
+    if not getattr(opts, "fp_hoist", False):
+        return 0
+    rows = [geo.B] + [geo.levels[l].n for l in (3, 2, 1, 0)]          # coarse of fp4, fp3, fp2, fp1, then N
+    n0 = [24 * C, 20 * C, 16 * C, 16 * C]                             # layer 0's outputs: fp4..fp1 (model.py:226-233)
+    return sum(16 * C * n0[i] * (rows[i + 1] - rows[i]) for i in range(4) if 0 < rows[i] <= opts.fp_hoist_ratio * rows[i + 1])
+
+
+def algorithmic_bytes(geo, opts=None):
+    """SURVEY.md 8(d) algorithmic bytes of the memory-bound kernels (fp32 features, int32 indices, each datum once).  The
+    interpolation class counts the FP modules that RUN the interpolation kernel; one that takes the fp_hoist route interpolates
+    inside its GEMM's epilogue and leaves this class only its weight records (positions in, 16 B per fine row out)."""
     N, B = geo.N, geo.B
     M = [N] + [geo.levels[l].n for l in (1, 2, 3)]
     Fc = [16 * C, 16 * C, 16 * C, 16 * C]   # width of the interpolated (coarse) features entering fp4, fp3, fp2, fp1
@@ -159,7 +172,9 @@ def algorithmic_bytes(geo):
     # kNN-interp2 per FP level: 4 F Mx + 12 (Mx + My) + 4 F My   (x = coarse, y = fine)
     coarse = [B, M[3], M[2], M[1]]
     fine = [M[3], M[2], M[1], M[0]]
-    out["interp_concat"] = sum(4 * Fc[i] * coarse[i] + 12 * (coarse[i] + fine[i]) + 4 * Fc[i] * fine[i] for i in range(4))
+    hoisted = [bool(opts is not None and opts.fp_hoist and 0 < coarse[i] <= opts.fp_hoist_ratio * fine[i]) for i in range(4)]
+    out["interp_concat"] = sum((12 * (coarse[i] + fine[i]) + 16 * fine[i]) if hoisted[i] else
+                               (4 * Fc[i] * coarse[i] + 12 * (coarse[i] + fine[i]) + 4 * Fc[i] * fine[i]) for i in range(4))
     return out
 
 
@@ -697,6 +712,7 @@ def main():
         dom = max(kmacs, key=lambda kname: per[kname][0])
         dom_ms, dom_launches = per[dom]
         achieved = 2.0 * kmacs[dom] / (dom_ms * 1e-3) / 1e12
+        saved = hoist_saved_macs(geo, net.engine_options) if dom == "gemm_kernel" else 0
         pts = world * args.steps * BATCH * NPTS
         h = args.precision != "fp32"
         kname = {"gemm_kernel": (f"gemm_hp_kernel<{args.precision}> (persistent; 256x256 and 128x128 tile instantiations, all launches)"
@@ -713,7 +729,7 @@ def main():
                 traffic_src = os.path.relpath(tfile, ROOT)
         except (OSError, ValueError, KeyError):
             pass
-        abytes = algorithmic_bytes(geo)
+        abytes = algorithmic_bytes(geo, net.engine_options)
         hbm = {}
         for name, nbytes in abytes.items():
             if name in per and per[name][0] > 0:
@@ -779,8 +795,10 @@ def main():
                          "traffic_bytes_per_step": traffic_step, "traffic_source": traffic_src, "note": notes[args.precision],
                          "launches_per_step": dom_launches, "kernel_ms_per_step": dom_ms,
                          "algorithmic_gflop_per_step": 2.0 * kmacs[dom] / 1e9,
-                         "executed_frac": achieved * MFMA_PER_PRODUCT[args.precision] / peak,
-                         "executed_note": "executed MFMA rate / peak = frac x MFMAs per algorithmic product",
+                         "executed_gflop_per_step": 2.0 * (kmacs[dom] - saved) / 1e9,
+                         "executed_frac": 2.0 * (kmacs[dom] - saved) / (dom_ms * 1e-3) / 1e12 * MFMA_PER_PRODUCT[args.precision] / peak,
+                         "executed_note": "executed MFMA rate / peak: the products the kernels really issue (the FP modules' layer 0 "
+                                          "runs its interpolated half on the coarse rows: fewer than the reference formulation's) x MFMAs per product",
                          "mfma_busy": mfma_busy(args.precision)},
             "hbm_kernels": hbm,
             "search": search,

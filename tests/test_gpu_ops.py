@@ -276,7 +276,7 @@ def test_gemm_h_stream_k_tail(prec, M, N, K, flags):
 
 @pytest.mark.parametrize("prec", [0, 1])
 @pytest.mark.parametrize("M,Mx,N,K,kw,sk", [(3000, 700, 640, 256, 2, 0), (81683, 17506, 640, 256, 2, 0), (70000, 20000, 512, 128, 2, 1),
-                                            (17506, 9, 768, 512, 1, 1), (517, 40, 130, 32, 2, 0), (2100, 300, 130, 1024, 2, 1)])
+                                            (17506, 9, 768, 512, 1, 1), (517, 40, 132, 32, 2, 0), (2100, 300, 132, 1024, 2, 1)])
 def test_gemm_h_interpolated_residual(prec, M, Mx, N, K, kw, sk):
     """An FP module's layer 0 by linearity (model.py:149-153): relu(W_s skip + b + knn_interpolate(Z)) with the interpolation of
     the coarse level's rows Z done in the GEMM's epilogue (p2w_epilogue.interp, records from p2w_interp_weights) == the same GEMM
