@@ -171,13 +171,14 @@ def test_packed_pointnetconv_is_bit_identical(precision):
         assert bool(torch.isfinite(a).all()) and torch.equal(a, b)
 
 
-@pytest.mark.parametrize("option", ["fp1_cell_order", "gemm_stream_k", "fp_hoist"])
+@pytest.mark.parametrize("option", ["fp1_cell_order", "gemm_stream_k", "fp_hoist", "fp_hoist_everywhere"])
 @pytest.mark.parametrize("precision", ["f16x3", "fp16"])
 def test_engine_switches_keep_the_logits(option, precision):
     """The A/B switches give the default path's results: `fp1_cell_order` (level-0 features in the sampler's cell order, logits
     scattered back: rows are only re-arranged) bit for bit; `gemm_stream_k` (GEMM rows behind the whole chip rounds as a split-K tail: a tail tile's K range is
-    summed in pieces) within the last fp32 bits of the accumulators, far inside the parity bar - on ragged batches with tiny
-    voxels, through forward and through Net.stream."""
+    summed in pieces) and `fp_hoist` (an FP module's layer 0 on the coarse rows, interpolation in the GEMM's epilogue; "everywhere":
+    all four modules take the route, FP1 on rows in cell order) within the last fp32 bits of the accumulators, far inside the
+    parity bar - on ragged batches with tiny voxels, through forward and through Net.stream."""
     from pointstowood_amd import Net
     batches = [synth.collate([synth.uniform_voxel(2.0, 6000, 91, True), synth.uniform_voxel(2.0, 900, 92, False)]),
                synth.collate([synth.uniform_voxel(2.0, 3, 94, True), synth.uniform_voxel(1.0, 4000, 95, True),
@@ -191,14 +192,15 @@ def test_engine_switches_keep_the_logits(option, precision):
         return d
     outs = {}
     for on in (False, True):
-        net = Net(num_classes=1, C=32, k=32, precision=precision, **{option: on})
+        kw = dict(fp_hoist=on, fp_hoist_ratio=1.0, fp1_cell_order=True) if option == "fp_hoist_everywhere" else {option: on}
+        net = Net(num_classes=1, C=32, k=32, precision=precision, **kw)
         net.load_state_dict(sd, strict=True)
         net = net.cuda().eval()
         outs[on] = [net(mk(b)).clone() for b in batches] + [o.clone() for o in net.stream(mk(b) for b in batches)]
     torch.cuda.synchronize()
     for a, b in zip(outs[True], outs[False]):
         assert bool(torch.isfinite(a).all()) and a.shape == b.shape
-        if option in ("gemm_stream_k", "fp_hoist"):   # (fp_hoist: the same function with the interpolation behind the coarse GEMM)
+        if option in ("gemm_stream_k", "fp_hoist", "fp_hoist_everywhere"):   # (fp_hoist: the same function with the interpolation behind the coarse GEMM)
             lim = 6e-5 if precision == "f16x3" else 6e-2    # (fp16: an H value one rounding apart moves a logit by ~1e-3 .. 1e-2)
             assert (a - b).abs().max() <= lim
         else:
