@@ -274,7 +274,7 @@ typedef struct p2w_epilogue {
                             rows of a COARSER level's fp32 matrix `residual` [interp_rows, ldr] interpolated on the fly (an FP
                             module's layer 0 by linearity: relu(W [interp(y) | skip] + b) = relu(W_s skip + b + interp(W_i y)),
                             model.py:149-153).  128 x 128 tile only (P2W_GEMM_TILE_256 is ignored); with P2W_GEMM_RESIDUAL_H: P2W_EUNSUPPORTED;
-                            p2w_gemm and p2w_gemm_h2_rowdot ignore it */
+                            p2w_gemm and p2w_gemm_h2_rowdot refuse it (P2W_EUNSUPPORTED) */
     int32_t interp_rows; /* rows of `residual` when `interp` is given: every n0, n1 lies below it */
 } p2w_epilogue;
 

@@ -153,6 +153,7 @@ extern "C" int32_t p2w_gemm(const float* A, int32_t lda, const float* Wp, int32_
     if (epi) {
         if ((epi->sc0 && !epi->sh0) || (epi->sc1 && !epi->sh1)) return P2W_ENULL;
         if (epi->residual && epi->ldr < N) return P2W_EINVAL;
+        if (epi->interp) return P2W_EUNSUPPORTED;   // (the interpolated residual is p2w_gemm_h2's)
         ep = {epi->bias, epi->sc0, epi->sh0, epi->sc1, epi->sh1, epi->residual,
               epi->ldr, epi->relu0, epi->relu1, epi->relu2, epi->relu_final, nullptr};
     }
@@ -417,7 +418,7 @@ extern "C" int32_t p2w_gemm_h2_rowdot(int32_t prec, const void* A_h, int32_t ldh
     EpiArgs ep = {};
     if (epi) {
         if ((epi->sc0 && !epi->sh0) || (epi->sc1 && !epi->sh1)) return P2W_ENULL;
-        if (epi->residual) return P2W_EUNSUPPORTED;
+        if (epi->residual || epi->interp) return P2W_EUNSUPPORTED;
         ep = {epi->bias, epi->sc0, epi->sh0, epi->sc1, epi->sh1, nullptr, 0, epi->relu0, epi->relu1, epi->relu2, epi->relu_final, nullptr, epi->range, nullptr};
     }
     const _Float16* Ah = static_cast<const _Float16*>(A_h);

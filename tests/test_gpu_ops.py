@@ -335,6 +335,8 @@ def test_gemm_h_interpolated_residual(prec, M, Mx, N, K, kw, sk):
     outh = torch.zeros((M, planes * ldh_o), dtype=Ah.dtype, device="cuda")
     assert L.p2w_gemm_h2(prec, ptr(Ah), ldh_a, ptr(dW), wscale, M, N, K, C.byref(ep), None, 0, ptr(outh), ldh_o, 32, stream()) == -5
     assert torch.equal(run(ep, flags=2), fused)
+    o32 = torch.empty((M, N), device="cuda")          # the fp32 engine does not interpolate: refused, never a read beyond Z's rows
+    assert L.p2w_gemm(ptr(R), N, ptr(R), M, N, 4, C.byref(ep), ptr(o32), N, stream()) == -5
     ep0 = Epilogue(ptr(db), None, None, None, None, ptr(dZ), N, 0, 0, 0, 1, None, ptr(rec), 0)
     assert L.p2w_gemm_h2(prec, ptr(Ah), ldh_a, ptr(dW), wscale, M, N, K, C.byref(ep0), None, 0, ptr(outh), ldh_o, 0, stream()) == -1
 
