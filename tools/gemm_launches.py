@@ -1,9 +1,16 @@
 #!/usr/bin/env python3
 """Every GEMM launch of one sequential forward on the bench batch with its own HIP-event bracket: shape, time and algorithmic
 TFLOP/s under the library's tile choice (flags 0) and with each tile forced (P2W_GEMM_TILE_128 = 1, P2W_GEMM_TILE_256 = 2).
-Median of 5 forwards per setting.   python tools/gemm_launches.py [B points_per_voxel]"""
+Median of 5 forwards per setting.   python tools/gemm_launches.py [variant.so] [B points_per_voxel]"""
 import os, statistics, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pointstowood_amd import _lib as _libmod
+VARIANT = None
+if len(sys.argv) > 1 and sys.argv[1].endswith(".so"):   # a variant library (tools/build_variant.sh): the library's choice only
+    VARIANT = sys.argv.pop(1)
+    _libmod.LIB_PATH = os.path.abspath(VARIANT)
+    from pointstowood_amd import build as _b
+    _b._stale = lambda: False
 import torch
 import bench
 from pointstowood_amd import Net, synthetic_weights as weights
@@ -28,7 +35,7 @@ def spy(self, name, A, ldh_a, M, lin, *a, **kw):
 
 E._gemm_h2 = spy
 res = {}
-FLAGSETS = (0, 1, 2)   # library's choice, forced 128 x 128, forced 256 x 256
+FLAGSETS = (0, 0, 0) if VARIANT else (0, 1, 2)   # library's choice, forced 128 x 128, forced 256 x 256 (a variant library: three times the library's choice)
 for flags in FLAGSETS:
     net = Net(num_classes=1, C=32, k=32, gemm_flags=flags)
     net.load_state_dict(weights.synth_state_dict(1, 32, seed=0), strict=True)
