@@ -337,6 +337,9 @@ int32_t p2w_packed_dims_h(int32_t prec, int32_t N, int32_t K, int32_t* N_pad, in
 #define P2W_GEMM_RESIDUAL_H 32   /* epi->residual is an H tensor of the launch's precision (epi->ldr = its row pitch ldh), not fp32 */
 #define P2W_GEMM_STREAMK 64      /* p2w_gemm_h2_sk: run the rows behind the whole chip rounds as a split-K tail even where the cost model says no */
 #define P2W_GEMM_NO_STREAMK 128  /* p2w_gemm_h2_sk: never (= p2w_gemm_h2) */
+#define P2W_GEMM_TILE_64 (1 << 24)  /* force the 64 x 128 workgroup tile (three workgroups per CU; the library takes it for short-K launches
+                                       with one or two column tiles or a mostly empty last round of 128 x 128 tiles) */
+#define P2W_GEMM_NO_TILE_64 (1 << 25)  /* never take it */
 /* flags of p2w_sa_conv_h (0 = let the library choose the work-item shape by C2) */
 #define P2W_SA_ITEM_256 1        /* 4 targets x 256 output columns per work item */
 #define P2W_SA_ITEM_128 2        /* 8 targets x 128 output columns per work item */

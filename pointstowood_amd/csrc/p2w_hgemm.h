@@ -1059,6 +1059,15 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void gemm_hp_kernel(const _Float16
     gemm_hp_body<PREC, WR, WC, RT, CT, DOTK, false>(A, ldh_a, Wh, wscale, M, N, Kpad, nMt, nNt, nvb, ep, o, ef, tmode, stagger, nullptr);
 }
 
+// 64 x 128 tiles, three workgroups per CU (4 waves of 32 x 64): for the short-K layers (expand, hoists, the FP modules' skip GEMMs:
+// 1 - 8 slabs per tile) whose tiles are half epilogue - more independent workgroups per CU overlap one's stores with another's slabs
+template <int PREC>
+__global__ __launch_bounds__(256, 3) void gemm_hp64_kernel(const _Float16* __restrict__ A, int ldh_a, const _Float16* __restrict__ Wh,
+                                                        float wscale, int M, int N, int Kpad, int nMt, int nNt, int nvb, EpiArgs ep,
+                                                        OutArgs o, int ef, int tmode) {
+    gemm_hp_body<PREC, 2, 2, 1, 2, false, false>(A, ldh_a, Wh, wscale, M, N, Kpad, nMt, nNt, nvb, ep, o, ef, tmode, 0, nullptr);
+}
+
 // Split-K tail (see gemm_hp_body): A = first row of the tail range, M = its rows; tiles are numbered row-major (tile r: row
 // tile r / nNt, column tile r % nNt); grid = 8 * ceil(tiles * S / 8) workgroups.
 template <int PREC, int WR, int WC, int RT, int CT>
@@ -1133,7 +1142,22 @@ static int32_t launch_gemm_h(const _Float16* Ah, int32_t ldh_a, const _Float16* 
     // that run side by side (gemm_hp_sk_kernel: raw fp32 pieces in the workspace) + a fix-up launch (gemm_hp_skfix_kernel: pieces
     // added in a fixed order, the same epilogue code).  The choice is a cost model over measured slab times - a function of the
     // shape alone, so equal calls give equal bits.
-    if (sk_S == 0 && skws && !dotw && !(flags & P2W_GEMM_NO_STREAMK)) {
+    // The 64 x 128 tile (three workgroups per CU) where per-launch A/Bs over the network's layers say it wins (tools/gemm_launches.py):
+    // one or two column tiles (N <= 192: the hoists and the narrow project layer, -10 ... -18 %), and launches of at most two
+    // rounds of 128 x 128 tiles whose last round is mostly empty while the smaller tile's is not (the 17 506-row layers of the bench
+    // batch's level 3: -10 ... -17 %).  MFMA-heavy layers lose on it (W crosses L2 -> LDS twice as often per product).
+    bool t64 = false;
+    if (!dotw && sk_S == 0 && !ep.imeta && !(flags & (P2W_GEMM_TILE_128 | P2W_GEMM_TILE_256 | P2W_GEMM_NO_TILE_64))) {
+        if (flags & P2W_GEMM_TILE_64) t64 = true;
+        else if (K <= 1024 && N <= 192) t64 = true;
+        else if (K <= 1024 && !big) {
+            const long nNt1 = p2w_cdiv(N, 128), T128 = (long)p2w_cdiv(M, 128) * nNt1, T64 = (long)p2w_cdiv(M, 64) * nNt1;
+            const long S128 = 2L * n_cu, S64 = 3L * n_cu;
+            const double w128 = (double)((T128 + S128 - 1) / S128 * S128) / (double)T128, w64 = (double)((T64 + S64 - 1) / S64 * S64) / (double)T64;
+            t64 = T128 <= 2 * S128 && w128 >= 1.3 * w64;
+        }
+    }
+    if (sk_S == 0 && skws && !dotw && !t64 && !(flags & P2W_GEMM_NO_STREAMK)) {
         const int nslab = Kpad / HCfg<PREC>::kslab;
         // per-slab times (us) of a workgroup, measured (tools/gemm_sk_ab.py, tools/gemm_launches.py): 128 x 128 tile alone on its
         // CU / two per CU, 256 x 256 tile (one per CU)
@@ -1278,6 +1302,10 @@ static int32_t launch_gemm_h(const _Float16* Ah, int32_t ldh_a, const _Float16* 
         const int nslab = Kpad / HCfg<PREC>::kslab, nNt1 = p2w_cdiv(N, 128), T_t = p2w_cdiv(M, 128) * nNt1;
         gemm_hp_sk_kernel<PREC, 2, 2, 2, 2><<<8 * p2w_cdiv(T_t * sk_S, 8), 256, 0, stream>>>(Ah, ldh_a, Wp, M, Kpad, nNt1, T_t, sk_S, skws);
         gemm_hp_skfix_kernel<PREC, 2, 2, 2, 2><<<T_t * 4, 256, 0, stream>>>(skws, T_t, sk_S, nslab, nNt1, wscale, M, N, ep, o, ef);   // (RT16 = 4 row blocks per tile)
+    } else if (t64) {
+        const int nMt = p2w_cdiv(M, 64), nNt1 = p2w_cdiv(N, 128);
+        const int tm = pick_mode(nNt1, nMt, 3), nvb = tile_grid(nMt, nNt1, tm);
+        gemm_hp64_kernel<PREC><<<pgrid(nvb, 3), 256, 0, stream>>>(Ah, ldh_a, Wp, wscale, M, N, Kpad, nMt, nNt1, nvb, ep, o, ef, tm);
     } else if (big) {
         const int nMt = p2w_cdiv(M, 256), nNt2 = Npad / 256;
         const int tm = pick_mode(nNt2, nMt, 1), nvb = tile_grid(nMt, nNt2, tm);

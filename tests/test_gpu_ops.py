@@ -169,7 +169,10 @@ H_TOL = {0: 4e-5, 1: 3e-3, 2: 2.5e-2}
 
 @pytest.mark.parametrize("prec", [0, 1, 2])
 @pytest.mark.parametrize("M,N,K,flags", [(300, 200, 100, 0), (1000, 512, 516, 0), (700, 256, 64, 2), (257, 130, 36, 0),
-                                         (513, 512, 1024, 2), (513, 512, 1024, 1 | 16), (64, 3, 512, 0)])
+                                         (513, 512, 1024, 2), (513, 512, 1024, 1 | 16), (64, 3, 512, 0),
+                                         # P2W_GEMM_TILE_64 = 1 << 24: the 64 x 128 tile, three workgroups per CU
+                                         (300, 200, 100, 1 << 24), (1000, 512, 516, 1 << 24), (257, 130, 36, 1 << 24), (5, 128, 64, 1 << 24),
+                                         (150000, 512, 128, 1 << 24), (70001, 256, 32, 1 << 24)])
 def test_gemm_h_epilogue(prec, M, N, K, flags):
     """p2w_gemm_h2 (f16x3 / fp16 / bf16 MFMA, H operands, both tile sizes and tile orders) + fused epilogue vs fp64,
     fp32 and H outputs."""
@@ -389,7 +392,8 @@ def test_gemm_h_rowdot_head(prec, M, N, K, flags):
 
 
 @pytest.mark.parametrize("prec", [0, 1, 2])
-@pytest.mark.parametrize("M,N,K,flags", [(1000, 128, 512, 0), (515, 96, 100, 0), (2048, 256, 64, 2), (300, 32, 40, 0)])
+@pytest.mark.parametrize("M,N,K,flags", [(1000, 128, 512, 0), (515, 96, 100, 0), (2048, 256, 64, 2), (300, 32, 40, 0),
+                                         (90000, 512, 128, 1 << 24), (515, 96, 100, 1 << 24)])
 def test_gemm_h_writes_into_wider_rows_and_reads_an_h_residual(prec, M, N, K, flags):
     """The two boundary features the in-place skip concatenation uses (engine.py): (1) ldh_o is a row PITCH - the launch writes
     its N columns (+ zero pad to the K-slab boundary) at a column offset of wider rows and leaves every other column alone;
