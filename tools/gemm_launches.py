@@ -35,7 +35,9 @@ def spy(self, name, A, ldh_a, M, lin, *a, **kw):
 
 E._gemm_h2 = spy
 res = {}
-FLAGSETS = (0, 0, 0, 0) if VARIANT else (0, 1, 2, 1 << 24)   # library's choice, forced 128 x 128, forced 256 x 256 (a variant library: three times the library's choice)
+FLAGSETS = (0, 0, 0, 0) if VARIANT else (0, 1, 2, 1 << 24)
+if os.environ.get("FLAGSETS"):   # four flag sets of one's own, e.g. FLAGSETS=0,512,768,1024 (start stagger 0 / 4 / 6 / 8 us: bits 8..13)
+    FLAGSETS = tuple(int(v) for v in os.environ["FLAGSETS"].split(","))   # library's choice, forced 128 x 128, forced 256 x 256 (a variant library: three times the library's choice)
 for flags in FLAGSETS:
     net = Net(num_classes=1, C=32, k=32, gemm_flags=flags)
     net.load_state_dict(weights.synth_state_dict(1, 32, seed=0), strict=True)
