@@ -715,7 +715,7 @@ def main():
         saved = hoist_saved_macs(geo, net.engine_options) if dom == "gemm_kernel" else 0
         pts = world * args.steps * BATCH * NPTS
         h = args.precision != "fp32"
-        kname = {"gemm_kernel": (f"gemm_hp_kernel<{args.precision}> (persistent; 256x256 and 128x128 tile instantiations, all launches)"
+        kname = {"gemm_kernel": (f"gemm_hp_kernel<{args.precision}> (persistent; 256x256, 128x128 and 64x128 tile instantiations, split-K tails, all launches)"
                                  if h else "gemm_kernel"),
                  "sa_conv_kernel": (f"sa_conv16p_kernel<{args.precision}> (+ sa_edge_meta_kernel)" if h else "sa_conv_kernel")}
         traffic, traffic_src, traffic_step = None, None, None

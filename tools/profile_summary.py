@@ -27,11 +27,14 @@ def short(name):
         if m.group(1) in ("gemm_h2g_kernel", "gemm_hp_kernel"):
             return f"{m.group(1)}<prec{m.group(2)},{m.group(3)},{m.group(4)},{m.group(5)},{m.group(6)}" + (",rowdot>" if m.group(7) == "1" else ">")
         return f"sa_conv16p_kernel<prec{m.group(2)},{m.group(3)},{m.group(4)},G{m.group(5)}>"
+    m = re.match(r"_Z\d+(gemm_hp64_kernel|gemm_hp_sk_kernel)ILi(\d)E", n)
+    if m:
+        return f"{m.group(1)}<prec{m.group(2)}>" + (" (64x128 tile)" if m.group(1) == "gemm_hp64_kernel" else " (split-K pieces)")
     return n[:90]
 
 
 def klass(name):
-    if "gemm_h2g_kernel" in name or "gemm_hp_kernel" in name or name.startswith("gemm_kernel") or "rowdot_finish" in name:
+    if "gemm_h2g_kernel" in name or "gemm_hp" in name or name.startswith("gemm_kernel") or "rowdot_finish" in name:
         return "gemm_kernel"
     if "sa_conv16p_kernel" in name or "sa_conv16s_kernel" in name or "sa_edge_meta" in name or "sa_part_" in name or name.startswith("sa_conv_kernel"):
         return "sa_conv_kernel"
