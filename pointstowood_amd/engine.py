@@ -821,19 +821,20 @@ class Engine:
         # Row-chunked chains: interpolate -> MLP layer 0 -> MLP layer 1 (-> head for fp1) run chunk by chunk so the wide
         # intermediates of a chunk are consumed out of the Infinity Cache (same trick as the residual blocks).
         y, y_xyzr, y_h = g, zeros_c, None      # coarse features (fp32), their positions, their H form (where the next module hoists)
+        y_rows, y_cols = g.shape               # (a module whose successor takes the linearity route leaves no fp32 form)
         logits = torch.empty(N, dtype=torch.float32, device=dev) if w.num_classes == 1 else None
         o_multi = new(N, w.num_classes) if w.num_classes != 1 else None
         logits_out = logits
         for fl in (4, 3, 2, 1):
             fine = lv[fl - 1]
-            m, Fc, cf, ld = fine.n, y.shape[1], cat[fl - 1], pitch[fl - 1]
+            m, Fc, cf, ld = fine.n, y_cols, cat[fl - 1], pitch[fl - 1]
             nbr, deg, kw = (nbr4, deg4, 1) if fl == 4 else (*geo.fp_nbr[fl - 1], 2)
             fine_xyzr = geo.sorted0 if (fl == 1 and sorted0) else fine.xyzr   # FP1's rows (and fp_nbr[0]'s) are in cell order then
             l0, l1 = w.fp[fl]
             # layer 0's interpolated half on the coarse rows (PackedWeights.fp_split)?  This module: the previous one left the H
             # form of its output; the next one: this module's output must leave one
             hoists = lambda rows_c, rows_f: bool(self.fp_hoist and 0 < rows_c <= self.fp_hoist_ratio * rows_f)
-            Mx = y.shape[0]
+            Mx = y_rows
             hoist = hoists(Mx, m)
             next_hoist = fl >= 2 and hoists(m, lv[fl - 2].n)
             if hoist:
@@ -853,7 +854,7 @@ class Engine:
             chunk = max(256, min(m, pick_chunk(m, chunk * 512 // (Fc + Fs[fl - 1]), max(1, l0.N // 256)) if self.chunk_pick
                                  else (chunk * 512 // (Fc + Fs[fl - 1])) // 256 * 256))
             mc = min(m, chunk)
-            need_f32 = fl > 1 or keep is not None
+            need_f32 = (fl > 1 and not next_hoist) or keep is not None   # (the next module interpolates the fp32 rows unless it hoists)
             b = new(m, l1.N) if need_f32 else None
             # chunk chains alternate between two streams like the residual blocks' (each lane has its own intermediates)
             nst = max(1, min(self._chains(), -(-m // chunk)))
@@ -903,6 +904,7 @@ class Engine:
                 done.record(side)
                 cur.wait_event(done)
             y, y_xyzr, y_h = b, fine.xyzr, yh_full
+            y_rows, y_cols = m, l1.N
             if keep is not None:
                 if fl == 1 and sorted0 and b is not None:   # rows back in input order for whoever asked
                     bo = torch.empty_like(b)
