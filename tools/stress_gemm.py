@@ -20,7 +20,7 @@ for case in range(cases):
     M = rng.choice([1, 7, 63, 64, 255, 256, 257, 300, 511, 777, 1024, 2100, 4097, 9000])
     N = rng.choice([1, 2, 3, 30, 64, 65, 128, 130, 192, 256, 258, 384, 512, 640, 768])
     K = rng.choice([4, 32, 36, 64, 100, 128, 200, 256, 512, 516, 1024])
-    flags = rng.choice([0, 0, 0, 1, 2, 4, 8, 16, 1 | 16, 2 | 8])
+    flags = rng.choice([0, 0, 0, 1, 2, 4, 8, 16, 1 | 16, 2 | 8, 1 << 24, (1 << 24) | 4, (1 << 24) | 16, 1 << 25])   # (1 << 24: the 64 x 128 tile; 1 << 25: never)
     use = {k: rng.random() < 0.6 for k in ("bias", "s0", "s1", "res", "f32", "h")}
     if not (use["f32"] or use["h"]):
         use["f32"] = True
