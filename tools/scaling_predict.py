@@ -84,6 +84,9 @@ class FakeDist:
             out[r].copy_(src)
 
 
+REPEATS = 2
+
+
 def run_world(pc, net, world, gen):
     store, log, ranks = {}, [], []
     cls_stats = []
@@ -96,17 +99,28 @@ def run_world(pc, net, world, gen):
         cls_stats.append(st)
     if world == 1:
         st = cls_stats[0]
+        for _ in range(REPEATS - 1):
+            s1 = {}
+            pipeline.segment_plot(pc, net, generator=gen(), stats=s1)
+            torch.cuda.synchronize()
+            for key in ("voxelise_s", "classify_s", "backproject_s"):
+                st[key] = min(st[key], s1[key])
         return {"world": 1, "ranks": [{"rank": 0, "voxelise_s": st["voxelise_s"], "classify_s": st["classify_s"],
                                        "backproject_s": st["backproject_s"], "forwards": len(st["batch_points"]),
                                        "points": sum(st["batch_points"])}],
                 "exchange_bytes": [0, 0], "predicted_s": st["voxelise_s"] + st["classify_s"] + st["backproject_s"]}
-    for r in range(world):      # pass 2: everything, with the peers' recorded blocks
-        st = {}
-        d = FakeDist(r, world, store, [], stop=False)     # (the LAST exchange - the per-point results - is answered with the rank's own slice)
-        t0 = time.perf_counter()
-        pipeline.segment_plot(pc, net, generator=gen(), stats=st, dist=d)
-        torch.cuda.synchronize()
-        st["total_s"] = time.perf_counter() - t0
+    for r in range(world):      # pass 2: everything, with the peers' recorded blocks; REPEATS times, every stage's fastest run counts
+        st = None                # (a single run of a 0.05 - 0.3 s stage on a box that has just changed its clock is +-20 %)
+        for _ in range(REPEATS):
+            s1 = {}
+            d = FakeDist(r, world, store, [], stop=False)     # (the LAST exchange - the per-point results - is answered with the rank's own slice)
+            pipeline.segment_plot(pc, net, generator=gen(), stats=s1, dist=d)
+            torch.cuda.synchronize()
+            if st is None:
+                st = s1
+            else:
+                for key in ("voxelise_s", "classify_s", "backproject_s"):
+                    st[key] = min(st[key], s1[key])
         # (classify_s includes the stand-in gather: a device copy)
         ranks.append({"rank": r, "voxelise_s": round(st["voxelise_s"], 4), "classify_s": round(st["classify_s"], 4),
                       "backproject_s": round(st["backproject_s"], 4), "forwards": len(st["batch_points"]), "points": sum(st["batch_points"])})
@@ -131,7 +145,10 @@ def main():
     ap.add_argument("--points", type=int, default=10_000_000)
     ap.add_argument("--worlds", default="1,2,4,8")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--repeats", type=int, default=2, help="runs per rank; every stage's fastest one counts")
     args = ap.parse_args()
+    global REPEATS
+    REPEATS = max(1, args.repeats)
     dev = torch.device("cuda", 0)
     net = Net(num_classes=1, C=bench.C, k=bench.K_NBR)
     net.load_state_dict(weights.synth_state_dict(1, bench.C, seed=0), strict=True)
@@ -148,7 +165,7 @@ def main():
         r["plot_points_per_s"] = round(args.points / r["predicted_s"], 1)
     doc = {"what": "predicted strong-scaling curve of BASELINE configs[3] (one plot, all ranks together), every rank's share measured in "
                    "turn on ONE MI355X through pipeline.segment_plot with a recording stand-in for torch.distributed",
-           "points": args.points, "xgmi_ring_GBps_assumed": XGMI_LINK_GBPS,
+           "points": args.points, "xgmi_ring_GBps_assumed": XGMI_LINK_GBPS, "runs_per_rank": REPEATS,
            "replicated_per_rank": "voxelise, the search grid of ALL classified points (inside backproject_s)",
            "worlds": res}
     txt = json.dumps(doc, indent=1)
