@@ -333,6 +333,9 @@ def test_gemm_h_interpolated_residual(prec, M, Mx, N, K, kw, sk):
     assert (fused - plain).abs().max().item() <= (4e-6 if prec == 0 else 2e-3) * scale
     assert (fused - generic).abs().max().item() <= (4e-6 if prec == 0 else 2e-3) * scale
     assert float(fused[:, N:].abs().max() if ldh_o > N else 0.0) == 0.0
+    if sk:   # the split-K fix-up's epilogue interpolates too (P2W_GEMM_STREAMK = 64 forces a split tail)
+        forced = run(Epilogue(ptr(db), None, None, None, None, ptr(dZ), N, 0, 0, 0, 1, None, ptr(rec), Mx), flags=64)
+        assert (forced - fused).abs().max().item() <= (4e-6 * (K / 512) ** 0.5 + 1e-7 if prec == 0 else 2e-3) * scale
     # what the boundary refuses: an H residual, records without rows (a forced 256 x 256 tile is ignored)
     ep = Epilogue(ptr(db), None, None, None, None, ptr(dZ), N, 0, 0, 0, 1, None, ptr(rec), Mx)
     outh = torch.zeros((M, planes * ldh_o), dtype=Ah.dtype, device="cuda")
