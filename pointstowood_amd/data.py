@@ -11,7 +11,30 @@ Only the behaviour that path uses is provided:
 """
 from __future__ import annotations
 
+import contextlib
+
+import numpy as np
 import torch
+
+
+@contextlib.contextmanager
+def serial_host_ops():
+    """Runs the enclosed CPU tensor operations with ONE intra-op thread and restores the caller's count afterwards.
+
+    The feed side of the path (``TestingDataset.__getitem__``, collation: predicter.py:78-94,177) is a dozen tensor operations on a
+    few hundred to 16 384 points.  With the process-wide thread count torch picks on the GPU hosts (128 - 256) each of them that
+    enters a parallel region - MKL's vector sqrt, ``repeat_interleave``, reductions above the 32 768-element grain - wakes the
+    whole OpenMP team: measured on the MI355X host 2.0 ms per ``torch.sqrt`` of 600 values and 4.3 ms per ``repeat_interleave``
+    of 8, i.e. 25 ms per batch of 8 voxels (tools/loop_profile.py), and the spinning team slows the launching thread 4 x.  Results
+    do not depend on the thread count (element-wise operations; the reductions here keep one column / row per thread)."""
+    n = torch.get_num_threads()
+    if n > 1:
+        torch.set_num_threads(1)
+    try:
+        yield
+    finally:
+        if n > 1:
+            torch.set_num_threads(n)
 
 
 class Data:
@@ -50,13 +73,15 @@ class Batch(Data):
         if not data_list:
             raise ValueError("empty batch")
         out = cls()
-        for k in data_list[0].tensors():
-            parts = [getattr(d, k) for d in data_list]
-            parts = [p.reshape(1) if p.dim() == 0 else p for p in parts]
-            setattr(out, k, torch.cat(parts, dim=0))
-        n = torch.tensor([d.pos.shape[0] for d in data_list], dtype=torch.long)
-        out.batch = torch.repeat_interleave(torch.arange(len(data_list), dtype=torch.long), n)
-        out.ptr = torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(n, 0)])
+        with serial_host_ops():
+            for k in data_list[0].tensors():
+                parts = [getattr(d, k) for d in data_list]
+                parts = [p.reshape(1) if p.dim() == 0 else p for p in parts]
+                setattr(out, k, torch.cat(parts, dim=0))
+            n = np.array([d.pos.shape[0] for d in data_list], dtype=np.int64)
+            # (numpy: integer results, and torch.repeat_interleave runs a parallel region over the B counts)
+            out.batch = torch.from_numpy(np.repeat(np.arange(len(data_list), dtype=np.int64), n))
+            out.ptr = torch.from_numpy(np.concatenate([np.zeros(1, dtype=np.int64), np.cumsum(n)]))
         out.num_graphs = len(data_list)
         return out
 

@@ -20,7 +20,7 @@ from collections import OrderedDict
 import numpy as np
 import torch
 
-from .data import Batch, Data, DataLoader
+from .data import Batch, Data, DataLoader, serial_host_ops
 from .dist import batch_cost, partition_batches
 
 
@@ -52,15 +52,16 @@ class VoxelDataset(torch.utils.data.Dataset):
 
     def __getitem__(self, index):
         pc = torch.as_tensor(self.raw(index))
-        pos = pc[:, :3].to(torch.float32)
-        refl = pc[:, self.reflectance_index].to(torch.float32)
-        shift = pos.mean(dim=0)
-        pos = pos - shift
-        sf = torch.sqrt((pos ** 2).sum(dim=1)).max()
-        bad = torch.isnan(pos).any(dim=1) | torch.isnan(refl)
-        if bool(bad.any()):
-            print(f"Encountered NaN values in sample at index {index}")
-            pos, refl = pos[~bad], refl[~bad]
+        with serial_host_ops():   # a dozen small CPU operations: one intra-op thread (25 ms -> 1 ms per batch of 8 on the GPU hosts)
+            pos = pc[:, :3].to(torch.float32)
+            refl = pc[:, self.reflectance_index].to(torch.float32)
+            shift = pos.mean(dim=0)
+            pos = pos - shift
+            sf = torch.sqrt((pos ** 2).sum(dim=1)).max()
+            bad = torch.isnan(pos).any(dim=1) | torch.isnan(refl)
+            if bool(bad.any()):
+                print(f"Encountered NaN values in sample at index {index}")
+                pos, refl = pos[~bad], refl[~bad]
         return Data(pos=pos, reflectance=refl, local_shift=shift, sf=sf)
 
 
@@ -231,32 +232,38 @@ def classify_voxels(model, dataset, is_wood: float = 0.5, device="cuda", batch_s
     ``Net.stream`` - geometry of the next forward beside the features of the current ones, one device-to-host copy at the end.
     ``reference_sampler=True``: the reference's ``BalancedBatchSampler`` at ``batch_size`` voxels per forward (it draws from the
     global numpy RNG and drops the voxels of the last incomplete batch, as there), through the same pipeline."""
+    batches = plan_batches(dataset, batch_size, reference_sampler, max_points, max_voxels)
+    return classify(model, prefetch_batches(dataset, batches, pin=torch.device(device).type == "cuda"), is_wood, device)
+
+
+def plan_batches(dataset, batch_size: int = 8, reference_sampler: bool = False, max_points: int = 262144, max_voxels: int = 256):
+    """The forwards of a ``predict.py --voxels`` run as a list of voxel-index lists - ONE plan for one process and for every rank of a
+    sharded run (it is deterministic, so every rank computes the same list and ``classify_sharded`` deals it out): logits depend
+    on a batch's composition through the batch-global grid origin of ``voxel_grid``, so the same directory must give the same
+    rows on 1 and on N GPUs.  Default: ``PointBudgetSampler`` (``batch_size`` is not used: forwards are sized in points);
+    ``reference_sampler``: the reference's ``BalancedBatchSampler`` at ``batch_size`` voxels per forward (global numpy RNG - seed it
+    identically on every rank -, remainder dropped, as there)."""
     if reference_sampler:
-        sampler = BalancedBatchSampler(dataset, batch_size, reference=True)
-    else:
-        sampler = PointBudgetSampler(dataset.preload(), max_points, max_voxels)
-    return classify(model, prefetch_batches(dataset, list(sampler), pin=torch.device(device).type == "cuda"), is_wood, device)
+        return [list(b) for b in BalancedBatchSampler(dataset, batch_size, reference=True)]
+    return [list(b) for b in PointBudgetSampler(dataset.preload(), max_points, max_voxels)]
 
 
 def prefetch_batches(dataset, batches, pin: bool = True, workers: int = 1, ahead: int = 4):
     """The loader of ``classify_voxels``: yields ``Batch.from_data_list([dataset[i] for i in b])`` for every b of ``batches``, in
     order, built `ahead` batches ahead by a background thread and (``pin``) in pinned memory, so that the host-side feed - a dozen
     small tensor operations per voxel (predicter.py:78-94) - runs beside the forwards in flight instead of between them.  The
-    worker computes with ONE intra-op thread: the operations are a few thousand elements each, and with the process-wide thread
-    count the reference's CLI sets (all cores, predict.py:79-84) each of them costs a thread-team barrier (measured on a
-    256-thread host: 0.5 ms per voxel instead of 0.1).  More than one worker thread does not pay: the per-voxel operations
+    dataset and the collation compute with ONE intra-op thread (``data.serial_host_ops``, restored after every call: the
+    operations are a few thousand elements each, and with the process-wide thread count the reference's CLI sets - all cores,
+    predict.py:79-84 - each of them costs a thread-team wake-up).  More than one worker thread does not pay: the per-voxel operations
     are too small to release the interpreter lock for long (measured: 0.43 s with 1 worker, 0.97 with 2, 6.1 with 8)."""
     import collections
     from concurrent.futures import ThreadPoolExecutor
-
-    def init():
-        torch.set_num_threads(1)          # (per calling thread: the feed's workers only)
 
     def build(b):
         out = Batch.from_data_list([dataset[i] for i in b])
         return out.pin_memory() if pin else out
     batches = list(batches)
-    with ThreadPoolExecutor(max_workers=max(1, min(workers, len(batches))), initializer=init) as pool:
+    with ThreadPoolExecutor(max_workers=max(1, min(workers, len(batches)))) as pool:
         pending = collections.deque()
         it = iter(batches)
         for b in it:

@@ -124,7 +124,7 @@ def main(argv=None):
         raise SystemExit('predict.py needs an MI355X: the HIP path has no CPU fallback')
 
     from pointstowood_amd import DataLoader, Net
-    from pointstowood_amd.predicter import (BalancedBatchSampler, VoxelDataset, classify_sharded, classify_voxels, load_model)
+    from pointstowood_amd.predicter import VoxelDataset, classify_sharded, classify_voxels, load_model, plan_batches
     # one process per GPU under `python -m torch.distributed.run --nproc-per-node N predict.py --voxels ...`: the voxel
     # batches are sharded over the ranks (predicter.classify_sharded), rank 0 writes the result
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
@@ -147,10 +147,10 @@ def main(argv=None):
         raise SystemExit(f'no voxel_*.pt files in {args.voxels}')
     t0 = time.time()
     if world > 1:
-        sampler = BalancedBatchSampler(ds, args.batch_size, reference=args.reference_sampler)
+        # the SAME plan as one process (predicter.plan_batches: point-budget forwards, or the reference's sampler), dealt to the ranks
         if args.reference_sampler:
             np.random.seed(0)      # the reference's sampler draws from the global numpy RNG: every rank needs the same batches
-        out = classify_sharded(model, ds, [list(b) for b in sampler], args.is_wood, device, dist)
+        out = classify_sharded(model, ds, plan_batches(ds, args.batch_size, args.reference_sampler), args.is_wood, device, dist)
     else:
         # the reference's loop (predicter.py:193-215) through the stream pipeline: voxels read once, forwards packed by a point
         # budget (--reference-sampler: its BalancedBatchSampler at --batch_size voxels per forward), one D2H copy at the end

@@ -53,14 +53,42 @@ def _cases():
         ("dups_tiny_b3_c4", [dup, tiny, U(2.0, 128, 31, False)], 4, 32, 1),
         ("u4_3k_refl_c8", [U(4.0, 3000, 126, True)], 8, 32, 1),
         ("u2_16k_c32", [U(2.0, 16384, 123, False)], 32, 32, 0),             # canonical U2-16k
+        # BASELINE configs[1] at its own size - the bench workload's batch 0 (bench.py host_batch(0, 0)): B = 8 x U(2.0, 16 384,
+        # seeds 123..130), k = 32, xyz only.  Inputs are regenerated from the recipe by the tests (checksums + samples here);
+        # every logit is stored (0.5 MB), the level tensors as checksums + sampled rows.  ~1 min of reference forward on 8 vCPUs.
+        ("config1_b8_16k_c32", [U(2.0, 16384, 123 + i, False) for i in range(8)], 32, 32, 0,
+         {"full": ("logits",), "recipe": [("uniform", 2.0, 16384, 123 + i, 0) for i in range(8)]}),
+        # the plot regime (configs[3]): 8 voxels of 2 m cells cut out of the synthetic forest plot - stems, crowns and ground:
+        # far more level-2 / 3 points per input point than a uniform cube (M3 / N ~ 0.5)
+        ("forest_plot_b8_c32", plot_voxels(), 32, 32, 0, {"full": ("logits",)}),
     ]
 
 
-def _store(out, name, t):
+def plot_voxels(n=400_000, side=20.0, cell=2.0, count=8):
+    """`count` voxels of a `cell`-metre grid over synth.forest_plot(n, side) with 128..16384 points, spread over the size range
+    (plain floor binning - the voxeliser's own arithmetic is pinned elsewhere: tests/golden/make_golden_host.py), each centred and
+    scaled like TestingDataset.__getitem__ (synth._finish); reflectance squashed into (-1, 1)."""
+    pc = synth.forest_plot(n, seed=3, side=side)
+    key = torch.floor(pc[:, :3] / cell).to(torch.long)
+    key = (key[:, 0] * 4096 + key[:, 1]) * 4096 + key[:, 2]
+    order = torch.argsort(key, stable=True)
+    _, counts = torch.unique_consecutive(key[order], return_counts=True)
+    starts = torch.cumsum(counts, 0) - counts
+    ok = ((counts >= 128) & (counts <= 16384)).nonzero(as_tuple=True)[0]
+    ok = ok[torch.argsort(counts[ok], stable=True)]
+    pick = ok[torch.linspace(0, len(ok) - 1, count).round().long()]
+    out = []
+    for v in pick.tolist():
+        rows = order[starts[v]: starts[v] + counts[v]]
+        out.append(synth._finish(pc[rows, :3].contiguous(), torch.tanh(pc[rows, 3] / 10.0).contiguous()))
+    return out
+
+
+def _store(out, name, t, full=False):
     a = t.detach().cpu().numpy()
     if a.dtype == np.int64:
         a = a.astype(np.int32)
-    if a.size <= FULL_LIMIT:
+    if a.size <= FULL_LIMIT or full:
         out[name] = a
     else:
         rows = np.linspace(0, a.shape[0] - 1, SAMPLE_ROWS).astype(np.int64)
@@ -73,7 +101,8 @@ def _store(out, name, t):
             out[name + "__sum"] = np.array([a.astype(np.int64).sum(), (a.astype(np.int64) * (np.arange(a.size).reshape(a.shape) % 8191 + 1)).sum()])
 
 
-def run_case(name, voxels, C, k, wseed):
+def run_case(name, voxels, C, k, wseed, opts=None):
+    opts = opts or {}
     torch.manual_seed(0)
     net = ref_model.Net(num_classes=1, C=C).eval()
     tab = weights.key_table(1, C)
@@ -123,6 +152,8 @@ def run_case(name, voxels, C, k, wseed):
     for kname in ("pos", "batch", "reflectance", "sf", "local_shift", "ptr"):
         _store(out, "in." + kname, batch[kname])
     out["meta"] = np.array([C, k, wseed, len(voxels)], dtype=np.int64)
+    if "recipe" in opts:   # inputs too large to store: the generator call per voxel (kind, side, points, seed, reflectance)
+        out["in.recipe"] = np.array([[1 if r[0] == "uniform" else 2, r[1], r[2], r[3], r[4]] for r in opts["recipe"]], dtype=np.float64)
     for l in range(3):
         _store(out, f"idx{l+1}", rec["idx"][l])
         _store(out, f"edge{l+1}.q", rec["edges"][l][0])
@@ -131,7 +162,7 @@ def run_case(name, voxels, C, k, wseed):
     _store(out, "stem", d.x)
     for n, t in feats.items():
         _store(out, n, t)
-    _store(out, "logits", logits.reshape(-1))
+    _store(out, "logits", logits.reshape(-1), full="logits" in opts.get("full", ()))
     _store(out, "probs", torch.sigmoid(logits.reshape(-1)))
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **out)
@@ -150,10 +181,10 @@ def main():
     only = set(sys.argv[1:])
     man_path = os.path.join(HERE, "manifest.json")
     manifest = json.load(open(man_path)) if (only and os.path.exists(man_path)) else {}
-    for name, voxels, C, k, wseed in _cases():
+    for name, voxels, C, k, wseed, *rest in _cases():
         if only and name not in only:
             continue
-        manifest[name] = run_case(name, voxels, C, k, wseed)
+        manifest[name] = run_case(name, voxels, C, k, wseed, *rest)
     manifest["_generator"] = {"torch": torch.__version__, "numpy": np.__version__,
                               "reference": "harryjfowen/PointsToWood @ 2025-09-12 (/root/reference)",
                               "note": "reference src/model.py + src/pointnet.py imported over oracle/stubs"}

@@ -129,10 +129,20 @@ def test_config1_b8_x_16384_xyz_only():
     check_structure(geo, 8 * 16384)
     # known level sizes of voxel 0 alone are ~15366/10156/2185; in a batch they shift by << 1 %
     assert abs(geo.levels[1].n / 8 - 15366) < 200 and abs(geo.levels[2].n / 8 - 10156) < 200
-    sub = extreme_voxels(inp)
-    if len(sub) < 2:
-        sub = extreme_voxels(inp, extra=[(sub[0] + 1) % 8])
-    check_subbatch_parity(vox, inp, logits, geo, sub)
+    # the WHOLE batch against the reference's own forward of it (tests/golden/config1_b8_16k_c32.npz: every logit, the level
+    # indices / edges as checksums + sampled rows) - not a sub-batch
+    from tests import golden_util as G
+    g, ginp, meta = G.load(G.CONFIG1_CASE)
+    assert torch.equal(ginp["pos"], inp["pos"]) and meta["k"] == K
+    from pointstowood_amd.ops import _edges
+    for l in (1, 2, 3):
+        lv = geo.levels[l]
+        G.check(g, f"idx{l}", lv.idx[: lv.n].long(), what="geometry ")
+        e = _edges(lv.nbr[: lv.n], lv.deg[: lv.n])
+        G.check(g, f"edge{l}.q", e[0], what="geometry ")
+        G.check(g, f"edge{l}.c", e[1], what="geometry ")
+    G.check(g, "logits", logits, atol=4e-4)
+    assert (torch.sigmoid(logits.cpu()) - torch.sigmoid(torch.from_numpy(g["logits"]))).abs().max() <= 1e-4
 
 
 def test_config2_b64_x_16384_reflectance():

@@ -39,7 +39,7 @@ def _edges(lv, k):
 
 
 @pytest.mark.parametrize("precision", ["f16x3", "fp32"])
-@pytest.mark.parametrize("name", G.CASES)
+@pytest.mark.parametrize("name", G.ALL_CASES)
 def test_forward_matches_reference_vectors(name, precision):
     g, inp, meta = G.load(name)
     keep = {}

@@ -316,6 +316,47 @@ def test_classify_sharded_gloo_world2(tmp_path):
         assert np.array_equal(np.asarray(out, dtype=single.dtype), single)
 
 
+def _cli_plan_worker(rank, world, port, vdir, q):
+    import torch.distributed as dist
+    from pointstowood_amd.predicter import VoxelDataset, classify_sharded, plan_batches
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ds = VoxelDataset(vdir)
+    out = classify_sharded(_FakeModel(), ds, plan_batches(ds, 8, False, max_points=1500, max_voxels=3), 0.5, "cpu", dist)
+    q.put((rank, out.tolist()))
+    dist.destroy_process_group()
+
+
+def test_cli_plan_gives_the_same_rows_on_one_and_on_two_ranks(tmp_path):
+    """predict.py --voxels plans its forwards ONE way (predicter.plan_batches: point-budget batches) whether it runs as one process
+    (classify_voxels) or sharded (classify_sharded): the rows are equal, row for row (logits depend on a batch's composition -
+    here through _FakeModel's batch term, in the product through the batch-global grid origin)."""
+    import torch.multiprocessing as mp
+    from pointstowood_amd.predicter import VoxelDataset, classify_voxels
+    g = torch.Generator().manual_seed(6)
+    for i, n in enumerate((300, 900, 150, 700, 500, 1100, 250, 130)):
+        torch.save(torch.cat([torch.rand(n, 3, generator=g) * 2 + 10 * i, torch.rand(n, 1, generator=g)], 1), tmp_path / f"voxel_{i}.pt")
+    single = classify_voxels(_FakeModel(), VoxelDataset(str(tmp_path)), 0.5, "cpu", batch_size=8, max_points=1500, max_voxels=3)
+    assert single.shape == (4030, 5)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + 11) % 1000
+    ps = [ctx.Process(target=_cli_plan_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=180) for _ in range(2))
+    [p.join(30) for p in ps]
+    for _, out in res:
+        assert np.array_equal(np.asarray(out, dtype=single.dtype), single)
+
+
+def test_serial_host_ops_restores_the_thread_count():
+    from pointstowood_amd.data import serial_host_ops
+    n = torch.get_num_threads()
+    with serial_host_ops():
+        assert torch.get_num_threads() == 1
+    assert torch.get_num_threads() == n
+
+
 def test_predict_cli_keeps_the_reference_flag_surface():
     import importlib.util
     spec = importlib.util.spec_from_file_location("p2w_predict", os.path.join(ROOT, "predict.py"))

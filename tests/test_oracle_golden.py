@@ -13,7 +13,7 @@ from tests import golden_util as G
 
 def test_manifest_hashes():
     man = G.manifest()
-    for name in G.CASES:
+    for name in G.ALL_CASES:
         path = os.path.join(G.GOLDEN_DIR, man[name]["file"])
         assert hashlib.sha256(open(path, "rb").read()).hexdigest() == man[name]["sha256"]
 
@@ -34,7 +34,14 @@ def test_survey_known_answers():
     assert idx.numel() == 2034 and int(idx.sum()) == 2083618 and idx[:4].tolist() == [245, 1133, 855, 63]
 
 
-@pytest.mark.parametrize("name", G.CASES)
+def test_full_size_inputs_regenerate_bit_equal():
+    """The configs[1] fixture stores a recipe instead of 131 072 input rows: G.load regenerates them and checks them exactly."""
+    g, inp, meta = G.load(G.CONFIG1_CASE)
+    assert inp["pos"].shape == (8 * 16384, 3) and meta == dict(C=32, k=32, wseed=0, B=8)
+    assert g["logits"].shape == (8 * 16384,)           # every logit of the reference forward is stored
+
+
+@pytest.mark.parametrize("name", G.CASES + [G.PLOT_CASE])
 def test_oracle_matches_reference_vectors(name):
     g, inp, meta = G.load(name)
     sd = weights.synth_state_dict(1, meta["C"], seed=meta["wseed"])
