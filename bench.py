@@ -57,9 +57,9 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batches", type=int, default=8, help="distinct seeded voxel batches the steps rotate over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-full", action="store_true",
-                    help="BASELINE.md section 4 in full: the whole batch 0 (8 voxels) as one batch instead of voxel 0 (minutes of CPU "
-                         "time); either way thread counts {16, 64, all} are each timed once and the best re-timed (median of 5)")
+    ap.add_argument("--cpu-baseline-voxel0", action="store_true",
+                    help="time the CPU oracle on voxel 0 of batch 0 only (seconds) instead of the whole 8-voxel batch (~2 min)")
+    ap.add_argument("--cpu-baseline-sweep", action="store_true", help="thread counts {16, 64, all} timed once each, the best re-timed")
     ap.add_argument("--cpu-baseline-child", default=None, metavar="THREADS:VOXELS:PASSES", help=argparse.SUPPRESS)
     ap.add_argument("--gather", default="final", choices=["final", "per-step"],
                     help="--gpus N: 'final' (default) = the path's only collective, the RCCL all-gather of the per-point logits, runs ONCE "
@@ -284,18 +284,17 @@ def cpu_baseline_child(spec):
     print(json.dumps({"times": ts, "points": n, "threads": torch.get_num_threads()}), flush=True)
 
 
-def cpu_baseline(full=False):
-    """CPU oracle (oracle/net.py, a port pinned to the reference's own outputs) on a bounded sample of batch 0 of this
-    benchmark, as ONE batch like the GPU runs it (same batch definition, same k, C, weights) - BASELINE.md section 4.
-    Sample: voxel 0 of batch 0 (default; the whole 8-voxel batch takes ~30 s per pass on a 64-core EPYC - the oracle's [E, C]
-    edge tensors fall out of cache - and is what --cpu-baseline-full times).  Thread counts {16, 64, all host cores} are each
-    timed once (after a warm-up pass), the best is re-timed and its median of 5 reported (the pool's 256-core hosts are shared:
-    single passes of the same process were seen 2 x apart; `passes_s` lists them, `best_pass_points_per_s` is the fastest).  Every leg is a fresh child
-    process with its thread pools pinned before the first torch call, so the number does not depend on what the GPU part
-    of this run left behind on the host (round 3: 3.9 k vs 13.6 k points/s for the same code)."""
+def cpu_baseline(full=True, sweep_threads=False):
+    """CPU oracle (oracle/net.py, a port pinned to the reference's own outputs) on batch 0 of this benchmark as ONE batch, like
+    the GPU runs it (same batch definition, same k, C, weights) - BASELINE.md section 4.  Default: the WHOLE batch (8 voxels,
+    131 072 points: ~30 s per pass on a 64-core EPYC - the oracle's [E, C] edge tensors fall out of cache) at 64 threads (the
+    best count in every sweep of rounds 3 - 5), one warm-up pass + 3 timed ones in a fresh child process (~2 min); full=False:
+    voxel 0 only; sweep_threads: thread counts {16, 64, all host cores} timed once each first, the best re-timed.  The child's
+    thread pools are pinned before its first torch call, so the number does not depend on what the GPU part of this run left
+    behind on the host (round 3: 3.9 k vs 13.6 k points/s for the same code)."""
     nvox = BATCH if full else 1
     cores = os.cpu_count() or 1
-    sweep = sorted({min(cores, t) for t in (16, 64, cores)})
+    sweep = sorted({min(cores, t) for t in (16, 64, cores)}) if sweep_threads else [min(cores, 64)]
 
     def leg(threads, passes):
         env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), OMP_PROC_BIND="false",
@@ -307,19 +306,21 @@ def cpu_baseline(full=False):
         return json.loads(r.stdout.strip().splitlines()[-1])
 
     tried = {}
-    for threads in sweep:
-        out = leg(threads, 1)
-        tried[threads], n = out["times"][0], out["points"]
-    best = min(tried, key=lambda t: (tried[t], t))
-    final = leg(best, 5)
+    if len(sweep) > 1:
+        for threads in sweep:
+            out = leg(threads, 1)
+            tried[threads] = out["times"][0]
+    best = min(tried, key=lambda t: (tried[t], t)) if tried else sweep[0]
+    passes = 3 if full else 5
+    final = leg(best, passes)
+    n = final["points"]
     dt = statistics.median(final["times"])
     return {"value": n / dt, "unit": "points/s", "cores": best, "kind": "port", "cpu_model": cpu_model(), "host_cores": cores,
             "cores_used_of_present": f"{best}/{cores}", "ms_per_batch": dt * 1e3, "voxels": nvox,
             "threads_tried": {str(t): round(v, 3) for t, v in tried.items()},
             "passes_s": [round(t, 3) for t in final["times"]], "best_pass_points_per_s": round(n / min(final["times"]), 1),
             "sample": f"voxels 0..{nvox - 1} of batch 0 as one batch ({n} pts, U2-16k seeds 123..{122 + nvox}), k={K_NBR}, C={C}, fp32; "
-                      f"thread counts {sweep} timed once each in fresh processes, best ({best}) re-timed: median of 5 passes after 1 "
-                      f"warm-up, {dt:.2f} s per pass"}
+                      f"{best} threads in a fresh process: median of {passes} passes after 1 warm-up, {dt:.2f} s per pass"}
 
 
 def device_feed(vox, device):
@@ -327,7 +328,18 @@ def device_feed(vox, device):
     return Feed.to_device(synth.collate(vox), device)
 
 
-def measure_workload(net, data, reps=5):
+def hbm_kernels(per, geo, opts):
+    """SURVEY.md 8(d) algorithmic bytes / measured time / 8 TB/s for the memory-bound kernels of one profiled forward."""
+    out = {}
+    for name, nbytes in algorithmic_bytes(geo, opts).items():
+        if name in per and per[name][0] > 0:
+            gbps = nbytes / (per[name][0] * 1e-3) / 1e9
+            out[name] = {"algorithmic_bytes_per_step": nbytes, "ms_per_step": round(per[name][0], 4), "launches": per[name][1],
+                         "achieved_GBps": round(gbps, 1), "frac_of_8TBps": round(gbps / PEAK_HBM_GBPS, 4)}
+    return out
+
+
+def measure_workload(net, data, reps=5, hbm=False):
     """One extra workload: setup forward (sizes the allocator), `reps` pipelined steps over the same batch, then one
     sequential profiled step for the per-kernel times and the algorithmic FLOPs of the level sizes actually produced."""
     import torch
@@ -347,7 +359,9 @@ def measure_workload(net, data, reps=5):
     out = {"points": n, "voxels": int(data.sf.numel()), "steps": reps, "ms_per_batch": round(dt * 1e3, 3),
            "range_fallbacks": int(getattr(net._engine, "range_fallbacks", 0)),
            "points_per_s": round(n / dt, 1), "end_to_end_tflops_algorithmic": round(2.0 * total_macs / dt / 1e12, 2),
-           "level_sizes": sizes, "kernel_ms_top3": {k: round(v[0], 3) for k, v in top}}
+           "M_over_N": [round(m / max(n, 1), 3) for m in sizes["M"]], "kernel_ms_top3": {k: round(v[0], 3) for k, v in top}}
+    if hbm:   # the memory-bound kernels where they have work (B = 64: 1 M points per launch)
+        out["hbm_kernels"] = hbm_kernels(per, geo, net.engine_options)
     for kname, macs in kmacs.items():
         if kname in per and per[kname][0] > 0:
             out[kname + "_tflops_algorithmic"] = round(2.0 * macs / (per[kname][0] * 1e-3) / 1e12, 1)
@@ -488,7 +502,7 @@ def extra_workloads(net, args, device):
     ]
     for name, make in cases:
         d = device_feed(make(), device)
-        out[name] = dict(measure_workload(net, d), dtype=args.precision)
+        out[name] = dict(measure_workload(net, d, hbm=name.startswith("configs[2]")), dtype=args.precision)
         if name.startswith("configs[4]") and args.precision == "f16x3":
             net16 = Net(num_classes=1, C=C, k=K_NBR, precision="fp16", **engine_options(args.engine_opt))
             net16.load_state_dict(weights.synth_state_dict(1, C, seed=0), strict=True)
@@ -498,6 +512,28 @@ def extra_workloads(net, args, device):
             del net16
         del d
         torch.cuda.empty_cache()
+    # small batches: the reference's default --batch_size 8 on plot-sized voxels (~1355 points each): pipelined and one call at a time
+    sb = [device_feed([synth.uniform_voxel(2.0, 1355, 100 * j + i, False) for i in range(BATCH)], device) for j in range(4)]
+    for d in sb:
+        net(d)
+    for _ in net.stream(sb[i % 4] for i in range(8)):
+        pass
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in net.stream(sb[i % 4] for i in range(100)):
+        pass
+    torch.cuda.synchronize()
+    dt_p = (time.perf_counter() - t0) / 100
+    t0 = time.perf_counter()
+    for i in range(50):
+        net(sb[i % 4])
+        torch.cuda.synchronize()
+    dt_s = (time.perf_counter() - t0) / 50
+    out["small batches B=8 x 1355 xyz-only"] = {"points": BATCH * 1355, "pipelined_ms_per_batch": round(dt_p * 1e3, 3),
+                                                "pipelined_points_per_s": round(BATCH * 1355 / dt_p, 1),
+                                                "single_call_ms_per_batch": round(dt_s * 1e3, 3),
+                                                "single_call_points_per_s": round(BATCH * 1355 / dt_s, 1)}
+    del sb
     if not args.no_plot_workload:   # last, and on a Net of its own: its oversized voxels must not shape the other workloads' engine state
         out["configs[3] 10 M-point plot (voxelise + classify + back-project, 1 GPU)"] = plot_workload(args, device)
     return out
@@ -706,6 +742,23 @@ def main():
                 "what": "same steps with the inputs (pos, batch, reflectance, sf, ptr: 2.7 MB) copied from pinned host memory and "
                         "the logits (0.5 MB) copied back inside the timed region"}
 
+    # the call the reference makes (predicter.py:198: outputs = model(data)): ONE forward per step on the caller's stream, the host
+    # waits for every step's logits before it issues the next (no cross-batch pipeline; inside the forward the searches run beside
+    # the features - EngineOptions.overlap)
+    single_call = None
+    if world == 1:
+        for d in resident:
+            net(d)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            net(resident[i % nb])
+            torch.cuda.synchronize()
+        dt_sc = (time.perf_counter() - t0) / args.steps
+        single_call = {"ms_per_step": dt_sc * 1e3, "value": BATCH * NPTS / dt_sc, "unit": "points/s", "steps": args.steps,
+                       "what": "one net(data) per step + torch.cuda.synchronize() after each (the reference's loop shape, predicter.py:198): "
+                               "searches on a second stream beside the features inside the forward, no cross-batch pipeline"}
+
     if rank == 0:
         per, geo = profile_step(net, resident[0])
         total_macs, kmacs, sizes = algorithmic_macs(geo)
@@ -729,13 +782,7 @@ def main():
                 traffic_src = os.path.relpath(tfile, ROOT)
         except (OSError, ValueError, KeyError):
             pass
-        abytes = algorithmic_bytes(geo, net.engine_options)
-        hbm = {}
-        for name, nbytes in abytes.items():
-            if name in per and per[name][0] > 0:
-                gbps = nbytes / (per[name][0] * 1e-3) / 1e9
-                hbm[name] = {"algorithmic_bytes_per_step": nbytes, "ms_per_step": round(per[name][0], 4), "launches": per[name][1],
-                             "achieved_GBps": round(gbps, 1), "frac_of_8TBps": round(gbps / PEAK_HBM_GBPS, 4)}
+        hbm = hbm_kernels(per, geo, net.engine_options)
         pairs = search_pairs(geo)
         # The searches against the fp32 VALU peak: the roofline figure counts the distance evaluations the grid kernels PERFORM
         # (profiles/r5_search_evaluated.json: counted in a -DP2W_SLAB_PROFILE build on this workload's batch 0); the reference's
@@ -771,25 +818,36 @@ def main():
                               "little of the chip's arithmetic the exact searches need, not how well they use it")
         notes = {"f16x3": "f16x3 issues 3 fp16 MFMAs per algorithmic product: ceiling for algorithmic FLOPs is peak/3",
                  "fp16": "one fp16 MFMA per product", "bf16": "one bf16 MFMA per product", "fp32": "exact fp32 MFMA"}
-        line = {
+        # Order of the line: the diagnostics FIRST (workloads, per-kernel tables), the contract keys LAST - whoever keeps only the
+        # tail of the line keeps metric / value / roofline / cpu_baseline / single_call / pcie_inclusive.
+        line = {}
+        if world == 1 and not args.no_workloads:
+            line["workloads"] = extra_workloads(net, args, device)
+        line.update({
+            "search": search,
+            "hbm_kernels": hbm,
+            "kernel_ms_per_step": {kname: round(v[0], 4) for kname, v in sorted(per.items(), key=lambda kv: -kv[1][0])},
+            "timing_note": f"timed region {dt:.2f} s ({args.steps} steps) right after {args.warmup} warm-up steps: a cold-clock number; box-to-box spread of this "
+                           "line is +-3-5 % (DVFS), same-box A/Bs are in docs/LAB_NOTES.md",
+            # forwards the f16x3 range guard recomputed on the fp32 MFMA path (0 on this benchmark: a non-zero count would mean the
+            # timed steps were not f16x3 steps)
+            "range_fallbacks": int(getattr(net._engine, "range_fallbacks", 0)),
+            "end_to_end_tflops_algorithmic": 2.0 * total_macs * args.steps / dt / 1e12,
+        })
+        if rank_stats is not None:
+            line["ranks"] = rank_stats
+        line.update({
             "metric": "classified points/sec", "value": pts / dt, "unit": "points/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "ms_per_step_median": statistics.median(per_step),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: batch_size 8 x 16384-pt 2 m voxels, k=32, xyz-only, 1 batch per GPU per step, "
                                    f"{nb} distinct seeded batches in rotation, inputs resident in HBM",
-                       "setup": "one untimed pass over the distinct batches through the pipeline before the warmup steps (sizes the caching allocator's per-stream pools)",
                        "global_batch_voxels": world * BATCH, "points_per_step": world * BATCH * NPTS, "C": C,
                        "level_sizes_batch0": sizes, "parallelism": f"voxel-batch sharding x{world}, RCCL all-gather of logits "
-                                                                    + ("once after the last step (all steps' logits in one collective, inside the timed region)"
-                                                                       if args.gather == "final" else "after every step"),
-                       "gather": args.gather,
+                                                                    + ("once after the last step" if args.gather == "final" else "after every step"),
                        "pipeline": ("HIP streams: geometry(i+1) || features(i), features alternating over "
                                     f"{net.engine_options.feature_streams} high-priority streams") if args.pipeline else "sequential"},
-            "timing_note": f"timed region {dt:.2f} s ({args.steps} steps) right after {args.warmup} warm-up steps: a cold-clock number; box-to-box spread of this "
-                           "line is +-3-5 % (DVFS), same-box A/Bs are in docs/LAB_NOTES.md",
-            "end_to_end_tflops_algorithmic": 2.0 * total_macs * args.steps / dt / 1e12,
-            "pcie_inclusive": pcie,
             "roofline": {"bound": "mfma", "kernel": kname.get(dom, dom), "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)",
                          "traffic_bytes_per_step": traffic_step, "traffic_source": traffic_src, "note": notes[args.precision],
@@ -797,22 +855,15 @@ def main():
                          "algorithmic_gflop_per_step": 2.0 * kmacs[dom] / 1e9,
                          "executed_gflop_per_step": 2.0 * (kmacs[dom] - saved) / 1e9,
                          "executed_frac": 2.0 * (kmacs[dom] - saved) / (dom_ms * 1e-3) / 1e12 * MFMA_PER_PRODUCT[args.precision] / peak,
-                         "executed_note": "executed MFMA rate / peak: the products the kernels really issue (the FP modules' layer 0 "
-                                          "runs its interpolated half on the coarse rows: fewer than the reference formulation's) x MFMAs per product",
                          "mfma_busy": mfma_busy(args.precision)},
-            "hbm_kernels": hbm,
-            "search": search,
-            "kernel_ms_per_step": {kname: round(v[0], 4) for kname, v in sorted(per.items(), key=lambda kv: -kv[1][0])},
-            # forwards the f16x3 range guard recomputed on the fp32 MFMA path (0 on this benchmark: a non-zero count would mean the
-            # timed steps were not f16x3 steps)
-            "range_fallbacks": int(getattr(net._engine, "range_fallbacks", 0)),
-        }
-        if rank_stats is not None:
-            line["ranks"] = rank_stats
-        if world == 1 and not args.no_workloads:
-            line["workloads"] = extra_workloads(net, args, device)
+        })
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(full=args.cpu_baseline_full)
+            line["cpu_baseline"] = cpu_baseline(full=not args.cpu_baseline_voxel0, sweep_threads=args.cpu_baseline_sweep)
+        if world == 1:
+            line["single_call"] = single_call
+        # `value` is measured with the inputs resident in HBM, as the bench contract requires; SURVEY.md 8(d) words the metric "incl.
+        # H2D/D2H": the same steps fed from pinned host memory with the logits copied back inside the region are `pcie_inclusive`
+        line["pcie_inclusive"] = pcie
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

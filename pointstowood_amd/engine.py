@@ -17,6 +17,7 @@ folded into the neighbouring GEMM's weights or epilogue when the checkpoint is p
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import math
 from dataclasses import dataclass, field, fields
@@ -279,6 +280,9 @@ class EngineOptions:
                                   # run as a stream-K tail where the library's cost model says it pays (then a level is ONE chunk:
                                   # chunk_full_rounds does not apply)
     sa_flags: int = 0             # P2W_SA_ITEM_* bits passed to p2w_sa_conv_h (A/B runs)
+    overlap: bool = True          # ONE forward (model(data), the reference's call): the searches on a second stream beside the features
+                                  # (each feature kernel waits for the event of the search it reads); False: strictly one stream
+    search_priority: int = 0      # HIP priority of that stream (-1 = high)
 
     def __post_init__(self):
         if self.sampler not in ("table", "sort"):
@@ -442,16 +446,28 @@ class Engine:
         return self._ws
 
     # -- phase 1 ------------------------------------------------------------------------------
-    def _geometry_async(self, pos, reflectance, ptr0, sf, force_sort: bool = False) -> Geometry:
+    def _geometry_async(self, pos, reflectance, ptr0, sf, force_sort: bool = False, search_stream=None) -> Geometry:
+        """Enqueues the geometry phase: first the SAMPLING chain (record packing, the three grid sub-samplings and level
+        positions - everything the level sizes depend on - and the one device-to-host copy of those sizes), then the six
+        SEARCHES.  ``search_stream`` None: all on the current stream.  Otherwise (the single-call forward) the searches go to
+        that stream behind the sampling chain and every search records an event (``geo.ev_nbr[l]``, ``geo.ev_fp[f]``) that the
+        feature phase waits for where it first reads the result: the searches of level l + 1 then run BESIDE the features of
+        level l.  All buffers are allocated on the current stream either way."""
         L = lib()
         dev = pos.device
         N, B, k = pos.shape[0], sf.numel(), self.k
         i32 = dict(dtype=torch.int32, device=dev)
         f32 = dict(dtype=torch.float32, device=dev)
+        i64 = dict(dtype=torch.int64, device=dev)
         geo = Geometry(B=B, N=N, k=k, sf=sf)
         geo.args = (pos, reflectance, ptr0, sf)
         geo.stream = torch.cuda.current_stream()
-        status = torch.zeros(3, **i32)    # per level: 1 = the table sampler's grid did not fit (results undefined)
+        geo.search_stream = search_stream
+        # the three levels' CSR arrays and the table sampler's status words live in ONE buffer, so that the level sizes
+        # (ptr_l[B]) and the status reach the host in one copy without a gather kernel in front of it
+        pstride = (B + 1 + 3) // 4 * 4
+        meta = torch.empty(3 * pstride + 4, **i32)
+        status = meta[3 * pstride:]       # per level: 1 = the table sampler's grid did not fit (results undefined)
         geo.table_levels = []
         geo.table_probes = []      # levels whose table was handed out BELOW the remembered growth factor (see _table_cells)
         xyzr0, batch0 = torch.empty((N, 4), **f32), torch.empty(N, **i32)
@@ -470,13 +486,14 @@ class Engine:
                 bbox[level] = t
             return bbox[level]
         grid_search = self.search != "brute"   # brute: whole-voxel streaming kernels (A/B, tests)
-        i64 = dict(dtype=torch.int64, device=dev)
         sorted0 = skeys0 = None   # level 0 in cell order (the level-1 sampler's sort), each record carrying its own index
         ckeys, grids, ranks = {}, {}, {}     # level -> cell key of every record (ascending) / p2w_grid of the sampling call
         cstart, cstart0 = {}, None           # level -> cell -> position table of its records (table sampler only)
+        aux0 = []
+        # ---- sampling chain: sampler l -> level positions l -> sampler l + 1 ... (model.py:103-106,122-126)
         for l, res in enumerate(SA_RES):
             src = geo.levels[l]
-            lv = Level(xyzr=torch.empty((N, 4), **f32), ptr=torch.empty(B + 1, **i32), batch=torch.empty(N, **i32),
+            lv = Level(xyzr=torch.empty((N, 4), **f32), ptr=meta[l * pstride: l * pstride + B + 1], batch=torch.empty(N, **i32),
                        idx=torch.empty(N, **i32), nbr=torch.empty((N, k), **i32), deg=torch.empty(N, **i32))
             order = torch.empty(N, **i32) if l == 0 else None
             skeys = torch.empty(N, **i64) if l == 0 else None
@@ -503,8 +520,8 @@ class Engine:
                 self._call("voxel_sample", L.p2w_voxel_sample, ptr(src.xyzr), ptr(src.ptr), B, N, res, ptr(lv.idx),
                            ptr(lv.ptr), ptr(lv.batch), ptr(order), ptr(skeys), ptr(ckeys[l + 1]), ptr(grids[l + 1]),
                            ptr(ranks[l]) if l > 0 else None, ptr(ranks[l]) if l == 0 else None, ptr(ws), ws.numel())
-            if l == 0:   # model.py:117-118: the 0.04 level uses radius(r = 2*resolution)
-                # The input points arrive in arbitrary order; the searches that touch level 0 (this ball query as
+            if l == 0:
+                # The input points arrive in arbitrary order; the searches that touch level 0 (the ball query as
                 # candidates, the last interpolation as queries) run over the cell-sorted copy so that a workgroup's
                 # queries are neighbours in space and only the grid rows near them are visited.  Results are unchanged.
                 sorted0, skeys0 = torch.empty((N, 4), **f32), skeys
@@ -515,65 +532,89 @@ class Engine:
                     geo.order64 = order.long()
                     geo.inv0 = torch.empty(N, **i32)
                     geo.inv0[geo.order64] = torch.arange(N, **i32)
-                if grid_search:
-                    self._call("ball_query", L.p2w_ball_query_grid_indexed, ptr(sorted0), ptr(skeys0), ptr(src.ptr), ptr(grids[1]),
-                               ptr(cstart0), ptr(src.xyzr), ptr(lv.idx), ptr(lv.ptr), B, N, res * 2, k, ptr(lv.nbr), ptr(lv.deg),
-                               SEARCH_X_INDEX_IN_W | (SEARCH_BOX if self.search_box & 1 else 0))
-                    aux0 = [order, sorted0, skeys0]
-                else:
-                    box0 = torch.empty((nbox, 6), **f32)
-                    self._call("tile_bbox", L.p2w_tile_bbox, ptr(sorted0), ptr(src.ptr), B, N, ptr(box0))
-                    self._call("ball_query", L.p2w_ball_query, ptr(sorted0), ptr(src.ptr), ptr(src.xyzr), ptr(lv.idx),
-                               ptr(lv.ptr), B, N, res * 2, k, ptr(lv.nbr), ptr(lv.deg), ptr(box0), SEARCH_X_INDEX_IN_W)
-                    aux0 = [order, box0, sorted0]
-            elif grid_search:   # model.py:120
-                self._call("knn", L.p2w_knn_grid_indexed, ptr(src.xyzr), ptr(ckeys[l]), ptr(src.ptr), ptr(grids[l]), ptr(cstart.get(l)),
-                           ptr(src.xyzr),
-                           ptr(lv.idx), ptr(lv.ptr), B, N, k, ptr(lv.nbr), ptr(lv.deg), None,
-                           (SEARCH_BOX if self.search_box & 2 else 0))
-            else:
-                self._call("knn", L.p2w_knn, ptr(src.xyzr), ptr(src.ptr), ptr(src.xyzr), ptr(lv.idx), ptr(lv.ptr), B, N,
-                           k, ptr(lv.nbr), ptr(lv.deg), ptr(boxes(l)), 0)
+                aux0 += [order, sorted0, skeys0]
             self._call("level_gather", L.p2w_level_gather, ptr(src.xyzr), ptr(lv.idx), ptr(lv.batch), ptr(lv.ptr), B, N,
                        ptr(sf), ptr(lv.xyzr))
             geo.levels.append(lv)
-        # k=2 searches of knn_interpolate (model.py:149): fine level f queries coarse level f+1
-        for f in (2, 1, 0):
-            fine, coarse = geo.levels[f], geo.levels[f + 1]
-            nbr, deg = torch.empty((N, 2), **i32), torch.empty(N, **i32)
-            # level 0 queries run over the cell-sorted copy; their result rows go to the points' own rows (row in .w) - or stay in
-            # cell order when the feature phase keeps level 0 in that order (fp1_cell_order)
-            q, fl = (sorted0, 0 if getattr(geo, "rows0_sorted", False) else SEARCH_Q_ROW_IN_W) if f == 0 else (fine.xyzr, 0)
-            if grid_search:
-                hint = None
-                if ranks.get(f) is not None:   # both of a point's two nearest coarse points are within its cell
-                    hint = torch.empty(N, **f32)   # representative's / a storage neighbour's representative's distance
-                    self._call("knn_hint", L.p2w_knn_hint2, ptr(q), ptr(ranks[f]), ptr(fine.ptr), B, N, ptr(coarse.xyzr),
-                               ptr(hint))
-                    aux0.append(hint)
-                self._call("knn2", L.p2w_knn_grid_indexed, ptr(coarse.xyzr), ptr(ckeys[f + 1]), ptr(coarse.ptr), ptr(grids[f + 1]),
-                           ptr(cstart.get(f + 1)), ptr(q), None, ptr(fine.ptr), B, N, 2, ptr(nbr), ptr(deg), ptr(hint),
-                           fl | (SEARCH_BOX if self.search_box & 4 else 0))
-            else:
-                self._call("knn2", L.p2w_knn, ptr(coarse.xyzr), ptr(coarse.ptr), ptr(q), None, ptr(fine.ptr), B, N, 2,
-                           ptr(nbr), ptr(deg), ptr(boxes(f + 1)), fl)
-            geo.fp_nbr[f] = (nbr, deg)
+        # the level sizes (and the table sampler's status words) start their way to the host here, ahead of the searches
+        geo.counts_dev = meta
+        geo.counts_host = torch.empty(meta.numel(), dtype=torch.int32, pin_memory=True)
+        geo.counts_host.copy_(meta, non_blocking=True)
+        geo.pstride = pstride
+        geo.sizes_ready = torch.cuda.Event()
+        geo.sizes_ready.record()
+        # ---- searches
+        cur = geo.stream
+        geo.ev_nbr, geo.ev_fp = {}, {}
+        if search_stream is not None:
+            search_stream.wait_event(geo.sizes_ready)
+
+        def searching():
+            return torch.cuda.stream(search_stream) if search_stream is not None else contextlib.nullcontext()
+
+        def mark(table, key):
+            if search_stream is not None:
+                table[key] = torch.cuda.Event()
+                table[key].record()
+        with searching():
+            for l, res in enumerate(SA_RES):
+                src, lv = geo.levels[l], geo.levels[l + 1]
+                if l == 0:   # model.py:117-118: the 0.04 level uses radius(r = 2*resolution)
+                    if grid_search:
+                        self._call("ball_query", L.p2w_ball_query_grid_indexed, ptr(sorted0), ptr(skeys0), ptr(src.ptr), ptr(grids[1]),
+                                   ptr(cstart0), ptr(src.xyzr), ptr(lv.idx), ptr(lv.ptr), B, N, res * 2, k, ptr(lv.nbr), ptr(lv.deg),
+                                   SEARCH_X_INDEX_IN_W | (SEARCH_BOX if self.search_box & 1 else 0))
+                    else:
+                        box0 = torch.empty((nbox, 6), **f32)
+                        self._call("tile_bbox", L.p2w_tile_bbox, ptr(sorted0), ptr(src.ptr), B, N, ptr(box0))
+                        self._call("ball_query", L.p2w_ball_query, ptr(sorted0), ptr(src.ptr), ptr(src.xyzr), ptr(lv.idx),
+                                   ptr(lv.ptr), B, N, res * 2, k, ptr(lv.nbr), ptr(lv.deg), ptr(box0), SEARCH_X_INDEX_IN_W)
+                        aux0.append(box0)
+                elif grid_search:   # model.py:120
+                    self._call("knn", L.p2w_knn_grid_indexed, ptr(src.xyzr), ptr(ckeys[l]), ptr(src.ptr), ptr(grids[l]), ptr(cstart.get(l)),
+                               ptr(src.xyzr),
+                               ptr(lv.idx), ptr(lv.ptr), B, N, k, ptr(lv.nbr), ptr(lv.deg), None,
+                               (SEARCH_BOX if self.search_box & 2 else 0))
+                else:
+                    self._call("knn", L.p2w_knn, ptr(src.xyzr), ptr(src.ptr), ptr(src.xyzr), ptr(lv.idx), ptr(lv.ptr), B, N,
+                               k, ptr(lv.nbr), ptr(lv.deg), ptr(boxes(l)), 0)
+                mark(geo.ev_nbr, l + 1)
+            # k=2 searches of knn_interpolate (model.py:149): fine level f queries coarse level f+1
+            for f in (2, 1, 0):
+                fine, coarse = geo.levels[f], geo.levels[f + 1]
+                nbr, deg = torch.empty((N, 2), **i32), torch.empty(N, **i32)
+                # level 0 queries run over the cell-sorted copy; their result rows go to the points' own rows (row in .w) - or stay in
+                # cell order when the feature phase keeps level 0 in that order (fp1_cell_order)
+                q, fl = (sorted0, 0 if getattr(geo, "rows0_sorted", False) else SEARCH_Q_ROW_IN_W) if f == 0 else (fine.xyzr, 0)
+                if grid_search:
+                    hint = None
+                    if ranks.get(f) is not None:   # both of a point's two nearest coarse points are within its cell
+                        hint = torch.empty(N, **f32)   # representative's / a storage neighbour's representative's distance
+                        self._call("knn_hint", L.p2w_knn_hint2, ptr(q), ptr(ranks[f]), ptr(fine.ptr), B, N, ptr(coarse.xyzr),
+                                   ptr(hint))
+                        aux0.append(hint)
+                    self._call("knn2", L.p2w_knn_grid_indexed, ptr(coarse.xyzr), ptr(ckeys[f + 1]), ptr(coarse.ptr), ptr(grids[f + 1]),
+                               ptr(cstart.get(f + 1)), ptr(q), None, ptr(fine.ptr), B, N, 2, ptr(nbr), ptr(deg), ptr(hint),
+                               fl | (SEARCH_BOX if self.search_box & 4 else 0))
+                else:
+                    self._call("knn2", L.p2w_knn, ptr(coarse.xyzr), ptr(coarse.ptr), ptr(q), None, ptr(fine.ptr), B, N, 2,
+                               ptr(nbr), ptr(deg), ptr(boxes(f + 1)), fl)
+                geo.fp_nbr[f] = (nbr, deg)
+                mark(geo.ev_fp, f)
+            geo.done = torch.cuda.Event()
+            geo.done.record()
         aux0 += list(ckeys.values()) + list(grids.values()) + [t for t in ranks.values() if t is not None]
         aux0 += [t for t in list(cstart.values()) + [cstart0] if t is not None]
         if getattr(geo, "rows0_sorted", False):
             aux0 += [geo.inv0, geo.order64]
         geo.aux = list(bbox.values()) + aux0
-        geo.counts_dev = torch.cat([torch.stack([geo.levels[l].ptr[B] for l in (1, 2, 3)]), status])
-        geo.counts_host = torch.empty(6, dtype=torch.int32, pin_memory=True)
-        geo.counts_host.copy_(geo.counts_dev, non_blocking=True)
-        geo.done = torch.cuda.Event()
-        geo.done.record()
         return geo
 
     def _geometry_finish(self, geo):
-        """The only host sync of the forward: wait for the three level sizes."""
-        geo.done.synchronize()
-        overflow = [l for l in range(3) if int(geo.counts_host[3 + l])]
+        """The host's wait for the three level sizes (in flight since the end of the sampling chain, while the searches run)."""
+        geo.sizes_ready.synchronize()
+        ps = geo.pstride
+        overflow = [l for l in geo.table_levels if int(geo.counts_host[3 * ps + l])]
         if overflow:
             # the batch's cell grid did not fit the sampler's table at these levels (device-side knowledge): everything
             # downstream of the first of them is undefined.  Repeat the geometry with the sort (rare: voxels much larger than
@@ -585,12 +626,15 @@ class Engine:
                 if self._table_scale[l] >= self.TABLE_SCALE_MAX:
                     self._table_rest[l] = self.TABLE_REST     # no more room to give: the sort serves the next batches
                 self._table_scale[l] = min(self._table_scale[l] * 8, self.TABLE_SCALE_MAX)
+            search_stream = getattr(geo, "search_stream", None)
             with torch.cuda.stream(geo.stream):
-                redo = self._geometry_async(*geo.args, force_sort=True)
-            redo.done.synchronize()
+                if search_stream is not None:       # the discarded searches still read the buffers this Geometry is about to drop
+                    geo.stream.wait_event(geo.done)
+                redo = self._geometry_async(*geo.args, force_sort=True, search_stream=search_stream)
+            redo.sizes_ready.synchronize()
             geo.__dict__.update(redo.__dict__)
         for l in (1, 2, 3):
-            geo.levels[l].n = int(geo.counts_host[l - 1])
+            geo.levels[l].n = int(geo.counts_host[(l - 1) * geo.pstride + geo.B])
         return geo
 
     def geometry(self, pos, reflectance, ptr0, sf) -> Geometry:
@@ -601,11 +645,14 @@ class Engine:
         """Enqueues the feature phase on the current stream.  With the range guard on, ``geo.watch`` then holds the phase's range
         report (in flight on the same stream: ``checked`` evaluates it once the phase has finished)."""
         if self.prec is not None:
-            self._range_begin(geo.sf.device)
+            if getattr(geo, "early", None) is None:      # (an early part has opened the range watch already)
+                self._range_begin(geo.sf.device)
             logits = self._features_h2(geo, keep)
             geo.watch = self._range_end()
             return logits
         geo.watch = None
+        if getattr(geo, "search_stream", None) is not None:   # the fp32 parity mode runs behind the searches
+            torch.cuda.current_stream().wait_event(geo.done)
         return self._features_fp32(geo, keep)
 
     def checked(self, geo: Geometry, logits, keep: dict | None = None):
@@ -696,6 +743,46 @@ class Engine:
             ws = pool[key] = torch.empty(int(lib().p2w_gemm_h2_sk_ws_bytes()), dtype=torch.uint8, device=dev)
         return ws
 
+    def _hoist(self, xh_src, pitch_src, n_src, p, l):
+        """SA level l's hoisted layer-1 product P = x_src W1x^T + b1: n_src rows + one all-zero row (read by empty neighbour slots),
+        row pitch padded to whole K slabs with zero columns (p2w_sa_conv_h reads it with unconditional loads)."""
+        ka = 32 if self.prec == PREC_F16X3 else 64
+        C1 = p["C1"]
+        C1p = (C1 + ka - 1) // ka * ka
+        P = torch.empty((n_src + 1, C1p), dtype=torch.float32, device=xh_src.device)
+        P[n_src].zero_()
+        if C1p != C1:
+            P[:, C1:].zero_()
+        self._gemm_h2("gemm_hoist", xh_src, pitch_src, n_src, p["hoist"], out_f32=P, ldo=C1p, watch=f"hoist{l}")
+        return P
+
+    def _features_early(self, geo: Geometry):
+        """The part of the H feature phase that needs the input points only (stem, SA1's hoisted layer-1 product): the
+        single-call forward enqueues it BEFORE the host waits for the level sizes, so the GPU is never idle during that wait."""
+        L, w = lib(), self.w
+        dev = geo.sf.device
+        Cw, N, prec = w.C, geo.N, self.prec
+        ka, planes = (32, 2) if prec == PREC_F16X3 else (64, 1)
+        hdt = torch.bfloat16 if self.precision == "bf16" else torch.float16
+        F3 = 16 * Cw
+        pitch0 = (F3 + Cw + ka - 1) // ka * ka
+        cat0 = torch.empty((N, planes * pitch0), dtype=hdt, device=dev)      # rows of FP1: [interpolated (16 C) | stem features (C)]
+        xh0 = cat0[:, planes * F3:]
+        x0 = torch.empty((N, Cw), dtype=torch.float32, device=dev)
+        # Level 0 in the sampler's CELL ORDER (fp1_cell_order): the H rows of the input points' features - the skip columns of FP1's rows,
+        # the A operand of SA1's hoisted product - are row p = the p-th point of the cell-sorted order, so are FP1's rows, its MLP, the head;
+        # the logits are scattered back at the end.  Spatial neighbours are then memory neighbours: the last interpolation's two coarse
+        # rows per point and SA1's P rows come from L2.  The fp32 stem features (data.x, model.py:228) stay in input order.
+        if bool(getattr(geo, "rows0_sorted", False)):
+            self._call("stem", L.p2w_stem_h2_indexed, prec, ptr(geo.sorted0), N, ptr(w.stem_w), ptr(w.stem_b), Cw, ptr(x0), ptr(xh0),
+                       pitch0, self._watch("stem", N))
+        else:
+            self._call("stem", L.p2w_stem_h2, prec, ptr(geo.levels[0].xyzr), N, ptr(w.stem_w), ptr(w.stem_b), Cw, ptr(x0), ptr(xh0),
+                       pitch0, self._watch("stem", N))
+        self.stem_out = x0
+        P1 = self._hoist(xh0, pitch0, N, w.sa[0], 1)
+        return dict(lv0=geo.levels[0], cat0=cat0, x0=x0, P1=P1)
+
     def _features_h2(self, geo: Geometry, keep: dict | None = None):
         """H pipeline (f16x3 / fp16 / bf16): every GEMM operand is an H tensor (16-bit planes: fp16 hi/lo for f16x3, one
         fp16 / bf16 plane otherwise) written once by its producer.
@@ -722,22 +809,14 @@ class Engine:
         # concatenated rows of the four FP modules: fine level f = 0..3 gets [m_f, Fc + Fs_f], Fc = 16 C interpolated columns
         Fs = [Cw, 4 * Cw, 8 * Cw, 16 * Cw]
         rows = [N, lv[1].n, lv[2].n, lv[3].n]
-        cat = [newh(rows[f], F3 + Fs[f]) for f in range(4)]
         pitch = [pad8(F3 + Fs[f]) for f in range(4)]
+        early = getattr(geo, "early", None) or self._features_early(geo)
+        cat = [early["cat0"]] + [newh(rows[f], F3 + Fs[f]) for f in range(1, 4)]
         xh = [hcol(cat[f], F3) for f in range(4)]   # H features of level f = the skip columns of its FP module's rows
-        x0 = new(N, Cw)
-        # Level 0 in the sampler's CELL ORDER (fp1_cell_order): the H rows of the input points' features - the skip columns of FP1's rows,
-        # the A operand of SA1's hoisted product - are row p = the p-th point of the cell-sorted order, so are FP1's rows, its MLP, the head;
-        # the logits are scattered back at the end.  Spatial neighbours are then memory neighbours: the last interpolation's two coarse
-        # rows per point and SA1's P rows come from L2.  The fp32 stem features (data.x, model.py:228) stay in input order.
+        x0 = early["x0"]
         sorted0 = bool(getattr(geo, "rows0_sorted", False))
-        if sorted0:
-            self._call("stem", L.p2w_stem_h2_indexed, prec, ptr(geo.sorted0), N, ptr(w.stem_w), ptr(w.stem_b), Cw, ptr(x0), ptr(xh[0]),
-                       pitch[0], self._watch("stem", N))
-        else:
-            self._call("stem", L.p2w_stem_h2, prec, ptr(lv[0].xyzr), N, ptr(w.stem_w), ptr(w.stem_b), Cw, ptr(x0), ptr(xh[0]),
-                       pitch[0], self._watch("stem", N))
-        self.stem_out = x0
+        wait = lambda ev: torch.cuda.current_stream().wait_event(ev) if ev is not None else None   # a search result is about to be read
+        ev_nbr, ev_fp = getattr(geo, "ev_nbr", {}), getattr(geo, "ev_fp", {})
         if keep is not None:
             keep["stem"] = x0
         x3 = None
@@ -747,11 +826,8 @@ class Engine:
             # hoisted layer-1 product P = x_src W1x^T + b1: src.n rows + one all-zero row (read by empty neighbour slots), row
             # pitch padded to whole K slabs with zero columns (p2w_sa_conv_h reads it with unconditional loads)
             C1p = pad8(C1)
-            P = new(src.n + 1, C1p)
-            P[src.n].zero_()
-            if C1p != C1:
-                P[:, C1:].zero_()
-            self._gemm_h2("gemm_hoist", xh[l - 1], pitch[l - 1], src.n, p["hoist"], out_f32=P, ldo=C1p, watch=f"hoist{l}")
+            P = early["P1"] if l == 1 else self._hoist(xh[l - 1], pitch[l - 1], src.n, p, l)
+            wait(ev_nbr.get(l))
             conv = new(M, C2) if (keep is not None or not res_h) else None
             convh = newh(M, C2)
             # level 1 is the ball query: on sparse input most targets have few neighbours, and those with <= 8 share an MFMA
@@ -829,6 +905,8 @@ class Engine:
             fine = lv[fl - 1]
             m, Fc, cf, ld = fine.n, y_cols, cat[fl - 1], pitch[fl - 1]
             nbr, deg, kw = (nbr4, deg4, 1) if fl == 4 else (*geo.fp_nbr[fl - 1], 2)
+            if fl < 4:
+                wait(ev_fp.get(fl - 1))
             fine_xyzr = geo.sorted0 if (fl == 1 and sorted0) else fine.xyzr   # FP1's rows (and fp_nbr[0]'s) are in cell order then
             l0, l1 = w.fp[fl]
             # layer 0's interpolated half on the coarse rows (PackedWeights.fp_split)?  This module: the previous one left the H
@@ -998,16 +1076,41 @@ class Engine:
         return torch.squeeze(logits)
 
     def forward(self, pos, reflectance, ptr0, sf, keep=None):
-        geo = self.geometry(pos, reflectance, ptr0, sf)
+        """One forward = the call the reference makes (``outputs = model(data)``, predicter.py:198).  With ``overlap`` (default) the
+        six neighbour searches run on a second HIP stream beside the feature phase: the sampling chain (0.2 ms) comes first, the
+        level sizes start their way to the host, and while the host waits for them the GPU already runs the stem, SA1's hoisted
+        product and the first searches; every feature kernel that reads a search result waits for that search's event.  Results
+        are those of the sequential order, bit for bit."""
+        overlap = bool(self.overlap) and self.events is None
+        search_stream = self._search_stream() if overlap else None
+        geo = self._geometry_async(pos, reflectance, ptr0, sf, search_stream=search_stream)
+        early = None
+        if overlap and self.prec is not None:
+            self._range_begin(dev := sf.device)
+            early = self._features_early(geo)     # needs N only: enqueued BEFORE the host's wait for the level sizes
+        self._geometry_finish(geo)
+        if early is not None and early["lv0"] is not geo.levels[0]:   # (the table overflowed and the geometry was redone: level 0 is new)
+            early = None
         if keep is not None:
             keep["geometry"] = geo
             if keep.get("geometry_only"):   # profiling: the level sizes are wanted, the fp32 copies of the level features are not
                 keep = None
+        geo.early = early
         logits = self.features(geo, keep)
+        if geo.search_stream is not None:     # nothing of this forward is left on the side stream when the caller gets its logits
+            torch.cuda.current_stream().wait_event(geo.done)
         if geo.watch is not None:   # the range guard needs the finished phase: one more host wait per forward (Net.stream hides it)
             torch.cuda.current_stream().synchronize()
             logits = self.checked(geo, logits, keep)
         return logits
+
+    def _search_stream(self):
+        """The side stream of the single-call forward's searches (one per caller stream)."""
+        pool = self.__dict__.setdefault("_search_streams", {})
+        key = _lib.stream()
+        if key not in pool:
+            pool[key] = torch.cuda.Stream(priority=int(self.search_priority))
+        return pool[key]
 
     # -- two-stream software pipeline over a sequence of batches ---------------------------------------------
     def forward_stream(self, inputs):
