@@ -1478,8 +1478,15 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
     // c ^ ((row >> 1) & 7), A rows then B rows); single plane: rows of 64 B, chunk q stored at q ^ ((row >> 2) & 3).
     constexpr int RCH = 4 * NP;                                   // 16-byte chunks per image row
     auto img = [](int row, int chunk) { return (row * RCH + (NP == 2 ? (chunk ^ ((row >> 1) & 7)) : (chunk ^ ((row >> 2) & 3)))) * 16; };
+    // The A rows (written by the producer's ds_write_b128, not by the DMA) take one more swizzle bit in f16x3: odd rows swap their
+    // hi and lo halves.  A ds_write_b128 is served in groups of 8 lanes on 32 banks (one 128-byte image row = one bank row): the
+    // group's lanes 0-3 write the 4 hi chunks of row r, lanes 4-7 those of row r + 1 - with the B image's swizzle both land on the
+    // same half of the bank row (2-way conflict on every store: SQ_LDS_BANK_CONFLICT 12 - 20 % of the LDS cycles, r5 profiles);
+    // with the halves swapped on odd rows they fill one bank row.  The fragment reads (16-lane groups over 64 banks) stay
+    // conflict-free: rows {0-3, 12-15, 20-27} of a group still map to 16 distinct 16-byte slots.
+    auto imgA = [](int row, int chunk) { return (row * RCH + (NP == 2 ? (chunk ^ ((row >> 1) & 7) ^ ((row & 1) << 2)) : (chunk ^ ((row >> 2) & 3)))) * 16; };
     const int prow = tid >> 2, pq = tid & 3;   // rows prow + 128*u, u < NR (the swizzle term is the same for all of them)
-    const int a_dst = img(prow, pq);           // hi plane chunk; the lo chunk (f16x3) is at a_dst ^ 64
+    const int a_dst = imgA(prow, pq);          // hi plane chunk; the lo chunk (f16x3) is at a_dst ^ 64
     // per-lane pieces of the B DMA source that do not depend on the item
     size_t boff[NI];
     int dstc[NI];
@@ -1584,7 +1591,7 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
     const int r = lane & 31, h = lane >> 5;
     int offA[RT], offB[2];   // plane 0 (hi), k step 0; the lo plane is ^ 64, k step 1 is ^ 32
 #pragma unroll
-    for (int t = 0; t < RT; ++t) offA[t] = img(wr * 32 * RT + 32 * t + r, h);
+    for (int t = 0; t < RT; ++t) offA[t] = imgA(wr * 32 * RT + 32 * t + r, h);
 #pragma unroll
     for (int t = 0; t < 2; ++t) offB[t] = A_CH * 16 + img(wc * 64 + 32 * t + r, h);
     f32x16 acc[RT][2];

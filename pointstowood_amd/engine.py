@@ -283,6 +283,8 @@ class EngineOptions:
     overlap: bool = True          # ONE forward (model(data), the reference's call): the searches on a second stream beside the features
                                   # (each feature kernel waits for the event of the search it reads); False: strictly one stream
     search_priority: int = 0      # HIP priority of that stream (-1 = high)
+    single_res_streams: int = 2   # row-chunk chains in flight inside a LONE forward (see res_streams: there the pipeline's second phase
+                                  # fills the round tails; here nothing else does)
 
     def __post_init__(self):
         if self.sampler not in ("table", "sort"):
@@ -335,8 +337,9 @@ class Engine:
 
     # -- small helpers ------------------------------------------------------------------------
     def _chains(self):
-        """Chunk chains in flight inside one feature phase (EngineOptions.res_streams)."""
-        return max(1, int(self.res_streams))
+        """Chunk chains in flight inside one feature phase: EngineOptions.res_streams in the stream pipeline (which keeps two whole
+        phases in flight), EngineOptions.single_res_streams in a lone forward (nothing else fills its round tails)."""
+        return max(1, int(self.single_res_streams if getattr(self, "_lone", False) else self.res_streams))
 
     def _side_stream(self, cur):
         """The second chunk-chain stream of the feature phase running on `cur` (one per feature stream: phases in flight on
@@ -1096,7 +1099,11 @@ class Engine:
             if keep.get("geometry_only"):   # profiling: the level sizes are wanted, the fp32 copies of the level features are not
                 keep = None
         geo.early = early
-        logits = self.features(geo, keep)
+        self._lone = self.events is None
+        try:
+            logits = self.features(geo, keep)
+        finally:
+            self._lone = False
         if geo.search_stream is not None:     # nothing of this forward is left on the side stream when the caller gets its logits
             torch.cuda.current_stream().wait_event(geo.done)
         if geo.watch is not None:   # the range guard needs the finished phase: one more host wait per forward (Net.stream hides it)

@@ -14,11 +14,18 @@ import math
 import torch
 
 
-def uniform_voxel(side: float, n: int, seed: int, reflectance: bool = False, offset=(0.0, 0.0, 0.0)):
+def uniform_points(side: float, n: int, seed: int, reflectance: bool = False, offset=(0.0, 0.0, 0.0)):
+    """The raw points of ``uniform_voxel`` (before centring): seeded CPU generator, element-wise arithmetic - the same bits on
+    every host.  (The centring is not: ``mean`` and ``sqrt`` round differently on different CPUs' vector units, so fixtures at
+    sizes too large to store keep ``local_shift`` / ``sf`` and rebuild ``pos`` = these points - the stored shift.)"""
     g = torch.Generator().manual_seed(seed)
     p = torch.rand(n, 3, generator=g) * side + torch.tensor(offset, dtype=torch.float32)
     refl = (torch.rand(n, generator=g) * 2 - 1) if reflectance else torch.zeros(n)
-    return _finish(p, refl)
+    return p, refl
+
+
+def uniform_voxel(side: float, n: int, seed: int, reflectance: bool = False, offset=(0.0, 0.0, 0.0)):
+    return _finish(*uniform_points(side, n, seed, reflectance, offset))
 
 
 def surface_voxel(side: float, n: int, seed: int, reflectance: bool = True):

@@ -123,17 +123,16 @@ def _forward(net, inp):
 
 def test_config1_b8_x_16384_xyz_only():
     """BASELINE configs[1] = the bench workload: B=8 x 16384, k=32, xyz only."""
-    vox = [synth.uniform_voxel(2.0, 16384, 123 + i, False) for i in range(8)]
-    inp = synth.collate(vox)
+    # the WHOLE batch against the reference's own forward of it (tests/golden/config1_b8_16k_c32.npz: every logit, the level
+    # indices / edges as checksums + sampled rows) - not a sub-batch.  Inputs: the fixture's (the bench batch as the authoring
+    # host centred it; another CPU's mean / sqrt can differ in the last bit)
+    from tests import golden_util as G
+    g, inp, meta = G.load(G.CONFIG1_CASE)
+    assert meta["k"] == K and inp["pos"].shape[0] == 8 * 16384
     logits, geo = _forward(_net(), inp)
     check_structure(geo, 8 * 16384)
     # known level sizes of voxel 0 alone are ~15366/10156/2185; in a batch they shift by << 1 %
     assert abs(geo.levels[1].n / 8 - 15366) < 200 and abs(geo.levels[2].n / 8 - 10156) < 200
-    # the WHOLE batch against the reference's own forward of it (tests/golden/config1_b8_16k_c32.npz: every logit, the level
-    # indices / edges as checksums + sampled rows) - not a sub-batch
-    from tests import golden_util as G
-    g, ginp, meta = G.load(G.CONFIG1_CASE)
-    assert torch.equal(ginp["pos"], inp["pos"]) and meta["k"] == K
     from pointstowood_amd.ops import _edges
     for l in (1, 2, 3):
         lv = geo.levels[l]
