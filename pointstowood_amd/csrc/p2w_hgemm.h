@@ -1484,7 +1484,10 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
     // same half of the bank row (2-way conflict on every store: SQ_LDS_BANK_CONFLICT 12 - 20 % of the LDS cycles, r5 profiles);
     // with the halves swapped on odd rows they fill one bank row.  The fragment reads (16-lane groups over 64 banks) stay
     // conflict-free: rows {0-3, 12-15, 20-27} of a group still map to 16 distinct 16-byte slots.
-    auto imgA = [](int row, int chunk) { return (row * RCH + (NP == 2 ? (chunk ^ ((row >> 1) & 7) ^ ((row & 1) << 2)) : (chunk ^ ((row >> 2) & 3)))) * 16; };
+#ifndef P2W_SA_A_SWZ
+#define P2W_SA_A_SWZ 1   // 0: the B image's swizzle for A as well (A/B builds: tools/build_variant.sh)
+#endif
+    auto imgA = [](int row, int chunk) { return (row * RCH + (NP == 2 ? (chunk ^ ((row >> 1) & 7) ^ (P2W_SA_A_SWZ ? ((row & 1) << 2) : 0)) : (chunk ^ ((row >> 2) & 3)))) * 16; };
     const int prow = tid >> 2, pq = tid & 3;   // rows prow + 128*u, u < NR (the swizzle term is the same for all of them)
     const int a_dst = imgA(prow, pq);          // hi plane chunk; the lo chunk (f16x3) is at a_dst ^ 64
     // per-lane pieces of the B DMA source that do not depend on the item

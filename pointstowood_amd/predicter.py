@@ -40,14 +40,35 @@ class VoxelDataset(torch.utils.data.Dataset):
         return len(self.keys)
 
     def raw(self, index):
-        return self._mem[index] if self._mem is not None else torch.load(self.keys[index])
+        if self._mem is not None:
+            return self._mem[index]
+        kept = getattr(self, "_kept", None)
+        if kept is not None and kept[index] is not None:
+            return kept[index]
+        return torch.load(self.keys[index])
 
-    def preload(self):
-        """Reads every voxel file once and keeps it (the reference reads each file twice: its sampler loads every voxel for its
-        length, the loader loads it again - predicter.py:28-31,78-80); returns the voxel lengths, also kept as ``lengths``."""
-        if self._mem is None:
-            self._mem = [torch.load(k) for k in self.keys]
-        self.lengths = [int(len(v)) for v in self._mem]
+    PRELOAD_BYTES = 8 << 30   # host memory preload() may keep (a 10 M-point plot's voxels are ~0.4 GB; 100 M+ points would be tens of GB)
+
+    def preload(self, max_bytes: int | None = None):
+        """Reads every voxel file once for its length (the reference reads each file twice: its sampler loads every voxel for its
+        length, the loader loads it again - predicter.py:28-31,78-80) and KEEPS the tensors while they fit ``max_bytes`` of host
+        memory (default ``PRELOAD_BYTES``); voxels beyond the budget are read again from disk when their batch is built (the
+        reference's streaming behaviour).  Returns the voxel lengths, also kept as ``lengths``."""
+        if self._mem is not None:
+            self.lengths = [int(len(v)) for v in self._mem]
+            return self.lengths
+        budget = self.PRELOAD_BYTES if max_bytes is None else int(max_bytes)
+        kept, lengths, used = [], [], 0
+        for k in self.keys:
+            v = torch.load(k)
+            lengths.append(int(len(v)))
+            nbytes = v.numel() * v.element_size() if isinstance(v, torch.Tensor) else 0
+            if isinstance(v, torch.Tensor) and used + nbytes <= budget:
+                kept.append(v)
+                used += nbytes
+            else:
+                kept.append(None)
+        self._kept, self.lengths = kept, lengths
         return self.lengths
 
     def __getitem__(self, index):

@@ -11,13 +11,15 @@ dev = torch.device("cuda", 0)
 net = Net(num_classes=1, C=bench.C, k=bench.K_NBR, precision=os.environ.get("P2W_PRECISION", "f16x3")).to(dev).eval()
 net.load_state_dict(weights.synth_state_dict(1, bench.C, seed=0), strict=True)
 net = net.to(dev)
-# LT_WORKLOAD: uniform (the bench batch, default) | surface | config2 | config4
+# LT_WORKLOAD: uniform (the bench batch, default) | surface | config2 | config4 | small
 from pointstowood_amd import synthetic_voxels as synth
 wl = os.environ.get("LT_WORKLOAD", "uniform")
 if wl == "surface":
     data = bench.device_feed([synth.surface_voxel(2.0, bench.NPTS, 300 + i, False) for i in range(bench.BATCH)], dev)
 elif wl == "config2":
     data = bench.device_feed([synth.uniform_voxel(2.0, bench.NPTS, 200 + i, True) for i in range(64)], dev)
+elif wl == "small":    # the reference's default --batch_size 8 on plot-sized voxels
+    data = bench.device_feed([synth.uniform_voxel(2.0, 1355, 100 + i, False) for i in range(bench.BATCH)], dev)
 elif wl == "config4":
     data = bench.device_feed([synth.uniform_voxel(2.0, n, 400 + i, True) for i, n in enumerate(synth.mixed_sizes())], dev)
 else:
