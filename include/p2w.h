@@ -164,6 +164,17 @@ int32_t p2w_knn_hint2(const float* xyzr_q, const int32_t* rank, const int32_t* p
 int32_t p2w_ball_query_grid(const float* xyzr_x, const uint64_t* keys_x, const int32_t* ptr_x, const p2w_grid* grid,
                             const float* xyzr_q, const int32_t* qidx, const int32_t* ptr_q, int32_t B, int32_t m_bound,
                             double r, int32_t cap, int32_t* nbr, int32_t* deg, int32_t flags, p2w_stream_t stream);
+/* p2w_voxel_sample_table on a workspace whose between-calls state (24 bytes of bounding-box words at their atomics' identities, one
+ * counter at zero) is already in place: p2w_voxel_sample_table_prepare(ws) establishes it once on a fresh (or foreign-written)
+ * workspace, every p2w_voxel_sample_table[_prepared] call leaves it in place again - so the three sub-samplings of a forward
+ * (model.py:103-106, once per SA level) take 6 launches each instead of 8, none of them a memset.  Same arguments, same results. */
+int32_t p2w_voxel_sample_table_prepare(void* ws, size_t ws_bytes, p2w_stream_t stream);
+int32_t p2w_voxel_sample_table_prepared(const float* xyzr, const int32_t* ptr, int32_t B, int32_t n_bound, float res,
+                                        int32_t* idx_out, int32_t* ptr_out, int32_t* batch_out, int32_t* order_out,
+                                        uint64_t* sorted_keys_out, uint64_t* cell_keys_out, p2w_grid* grid_out, int32_t* inv_out,
+                                        int32_t* rank_sorted_out, int32_t* cell_start_out, int32_t* cell_start_sorted_out,
+                                        int32_t* status_out, int64_t table_cells, void* ws, size_t ws_bytes, p2w_stream_t stream);
+
 /* The same two searches with the sampler's cell -> position table of the candidates (p2w_voxel_sample_table's
  * cell_start_out when the candidates are the level it produced, cell_start_sorted_out when they are its input points in
  * cell-sorted order; NULL = bisect keys_x as p2w_knn_grid does): identical results, the run tables cost one load per run end. */

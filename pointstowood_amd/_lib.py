@@ -39,6 +39,9 @@ SIGNATURES = {
     "p2w_voxel_sample_table_ws_bytes": (_sz, [_i32, C.c_int64]),
     "p2w_voxel_sample_table": (_i32, [_vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64,
                                       _vp, _sz, _vp]),
+    "p2w_voxel_sample_table_prepare": (_i32, [_vp, _sz, _vp]),
+    "p2w_voxel_sample_table_prepared": (_i32, [_vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64,
+                                               _vp, _sz, _vp]),
     "p2w_knn_grid_indexed": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
     "p2w_ball_query_grid_indexed": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, C.c_double, _i32, _vp, _vp, _i32, _vp]),
     "p2w_knn_hint2": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),

@@ -52,9 +52,10 @@ __global__ void vs_init_kernel(VsHeader* h) {
 }
 
 __global__ __launch_bounds__(256) void vs_minmax_kernel(const float4* __restrict__ xyzr, const int* __restrict__ ptr, int B,
-                                                        VsHeader* h) {
+                                                        VsHeader* h, int* __restrict__ status_zero = nullptr) {
     __shared__ float red[4][6];
     const int n = ptr[B];
+    if (status_zero && blockIdx.x == 0 && threadIdx.x == 0) *status_zero = 0;   // (the table sampler's status word: set by tk_insert_kernel, behind this launch)
     float v[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};  // lo xyz, hi xyz
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const float4 p = xyzr[i];
@@ -371,14 +372,52 @@ __global__ __launch_bounds__(256) void tk_insert_kernel(const float4* __restrict
     if (cnt) atomicAdd(&cnt[t], 1);
 }
 
-// block-local exclusive scans of the occupancy flags (-> rank) and, optionally, of the counts (-> off); block totals
+// exclusive scan of `nblk` block totals (occupancy and counts), in place, by ONE workgroup of 1024 threads; *total_out = the
+// occupancy total.  The totals were written by other workgroups of the same launch: read at agent scope.
+__device__ __forceinline__ void tk_scan_totals(int* __restrict__ bs_occ, int* __restrict__ bs_cnt, int nblk, int* __restrict__ total_out) {
+    __shared__ int wsum2[2][16];
+    __shared__ int carry[2];
+    if (threadIdx.x == 0) { carry[0] = 0; carry[1] = 0; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int base = 0; base < nblk; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int vf = i < nblk ? __hip_atomic_load(&bs_occ[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        const int vc = i < nblk ? __hip_atomic_load(&bs_cnt[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        int xf = vf, xc = vc;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int of = __shfl_up(xf, d), oc = __shfl_up(xc, d);
+            if (lane >= d) { xf += of; xc += oc; }
+        }
+        if (lane == 63) { wsum2[0][wave] = xf; wsum2[1][wave] = xc; }
+        __syncthreads();
+        int bf = carry[0], bc = carry[1], tf = 0, tc = 0;
+        for (int w = 0; w < 16; ++w) {
+            if (w < wave) { bf += wsum2[0][w]; bc += wsum2[1][w]; }
+            tf += wsum2[0][w]; tc += wsum2[1][w];
+        }
+        if (i < nblk) { bs_occ[i] = bf + xf - vf; bs_cnt[i] = bc + xc - vc; }
+        __syncthreads();
+        if (threadIdx.x == 0) { carry[0] += tf; carry[1] += tc; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total_out = carry[0];
+}
+
+// block-local exclusive scans of the occupancy flags (-> rank) and, optionally, of the counts (-> off); block totals.  The LAST
+// workgroup to finish (a counter in the workspace: zero between calls, reset by that workgroup) scans the block totals in place -
+// what a second, one-workgroup launch used to do.
 __global__ __launch_bounds__(TK_BLOCK) void tk_scan1_kernel(const int* __restrict__ tab_max, const int* __restrict__ cnt, long long T_cap,
                                                            int* __restrict__ rank, int* __restrict__ off, int* __restrict__ bs_occ,
                                                            int* __restrict__ bs_cnt, const int* __restrict__ status,
-                                                           const int* __restrict__ ptr, int B, float res, const VsHeader* __restrict__ h) {
+                                                           const int* __restrict__ ptr, int B, float res, const VsHeader* __restrict__ h,
+                                                           int* __restrict__ done, int* __restrict__ total_out) {
     __shared__ int wsum[2][TK_BLOCK / 64];
+    __shared__ int is_last;
     if (*status || ptr[B] == 0) return;
-    if ((long long)blockIdx.x * TK_TILE >= tk_used(tk_geom(h, ptr, B, res), T_cap)) return;   // tiles the grid does not reach
+    const long long used = tk_used(tk_geom(h, ptr, B, res), T_cap);
+    if ((long long)blockIdx.x * TK_TILE >= used) return;   // tiles the grid does not reach
     const long long t0 = (long long)blockIdx.x * TK_TILE + (long long)threadIdx.x * TK_ITEMS;
     int f[TK_ITEMS], c[TK_ITEMS], sf = 0, sc = 0;
 #pragma unroll
@@ -409,46 +448,18 @@ __global__ __launch_bounds__(TK_BLOCK) void tk_scan1_kernel(const int* __restric
         if (t < T_cap) { rank[t] = rf; if (cnt) off[t] = rc; }
         rf += f[e]; rc += c[e];
     }
-    if (threadIdx.x == 0) { bs_occ[blockIdx.x] = tf; bs_cnt[blockIdx.x] = tc; }
-}
-
-// exclusive scan of the block totals, in place, by one workgroup
-__global__ __launch_bounds__(1024) void tk_scan2_kernel(int* __restrict__ bs_occ, int* __restrict__ bs_cnt, int nblk, int* __restrict__ total_out,
-                                                        const int* __restrict__ status, const int* __restrict__ ptr, int B, float res,
-                                                        const VsHeader* __restrict__ h, long long T_cap) {
-    __shared__ int wsum[2][16];
-    __shared__ int carry[2];
-    if (*status || ptr[B] == 0) return;
-    {   // only the tiles tk_scan1_kernel has written
-        const long long used = tk_used(tk_geom(h, ptr, B, res), T_cap);
-        const int nb = (int)((used + TK_TILE - 1) / TK_TILE);
-        nblk = nb < nblk ? nb : nblk;
+    const int nb = (int)((used + TK_TILE - 1) / TK_TILE);   // workgroups that take part
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&bs_occ[blockIdx.x], tf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&bs_cnt[blockIdx.x], tc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        is_last = (atomicAdd(done, 1) == nb - 1) ? 1 : 0;
     }
-    if (threadIdx.x == 0) { carry[0] = 0; carry[1] = 0; }
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int base = 0; base < nblk; base += 1024) {
-        const int i = base + threadIdx.x;
-        const int vf = i < nblk ? bs_occ[i] : 0, vc = i < nblk ? bs_cnt[i] : 0;
-        int xf = vf, xc = vc;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int of = __shfl_up(xf, d), oc = __shfl_up(xc, d);
-            if (lane >= d) { xf += of; xc += oc; }
-        }
-        if (lane == 63) { wsum[0][wave] = xf; wsum[1][wave] = xc; }
-        __syncthreads();
-        int bf = carry[0], bc = carry[1], tf = 0, tc = 0;
-        for (int w = 0; w < 16; ++w) {
-            if (w < wave) { bf += wsum[0][w]; bc += wsum[1][w]; }
-            tf += wsum[0][w]; tc += wsum[1][w];
-        }
-        if (i < nblk) { bs_occ[i] = bf + xf - vf; bs_cnt[i] = bc + xc - vc; }
-        __syncthreads();
-        if (threadIdx.x == 0) { carry[0] += tf; carry[1] += tc; }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *total_out = carry[0];
+    if (!is_last) return;
+    __threadfence();
+    tk_scan_totals(bs_occ, bs_cnt, nb, total_out);
+    if (threadIdx.x == 0) *done = 0;   // zero again for the next call on this workspace
 }
 
 __global__ __launch_bounds__(256) void tk_compact_kernel(const int* __restrict__ tab_max, const int* __restrict__ rank,
@@ -506,8 +517,11 @@ __global__ __launch_bounds__(256) void tk_points_kernel(const int* __restrict__ 
                                                         const int* __restrict__ off, const int* __restrict__ bs_cnt, int* __restrict__ fill,
                                                         const int* __restrict__ ptr, int B, int n_bound, int* __restrict__ inv_out,
                                                         int* __restrict__ order_out, unsigned long long* __restrict__ sorted_keys_out,
-                                                        int* __restrict__ rank_sorted_out, const int* __restrict__ status) {
+                                                        int* __restrict__ rank_sorted_out, const int* __restrict__ status, VsHeader* __restrict__ hdr_reset) {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    // the call's last kernel leaves the workspace as p2w_voxel_sample_table_prepare() does: the bounding box ready for the next
+    // call's atomics (nothing of this call reads it any more)
+    if (i < 3) { hdr_reset->lo[i] = 0xffffffffu; hdr_reset->hi[i] = 0u; }
     if (i >= ptr[B] || i >= n_bound) return;
     if (*status) {   // overflow: harmless per-point outputs (rank 0, identity order) for whatever is already queued behind us
         if (inv_out) inv_out[i] = 0;
@@ -553,25 +567,45 @@ extern "C" size_t p2w_voxel_sample_table_ws_bytes(int32_t n_bound, int64_t table
     return L.bytes;
 }
 
-extern "C" int32_t p2w_voxel_sample_table(const float* xyzr, const int32_t* ptr, int32_t B, int32_t n_bound, float res,
-                                          int32_t* idx_out, int32_t* ptr_out, int32_t* batch_out, int32_t* order_out,
-                                          uint64_t* sorted_keys_out, uint64_t* cell_keys_out, p2w_grid* grid_out,
-                                          int32_t* inv_out, int32_t* rank_sorted_out, int32_t* cell_start_out,
-                                          int32_t* cell_start_sorted_out, int32_t* status_out, int64_t table_cells,
-                                          void* ws, size_t ws_bytes, p2w_stream_t stream) {
+// Workspace state between calls (p2w_voxel_sample_table_prepared): bounding-box words at their atomics' identities, the scan's
+// completion counter at zero.  p2w_voxel_sample_table_prepare() establishes it on a fresh workspace, every call restores it.
+extern "C" int32_t p2w_voxel_sample_table_prepare(void* ws, size_t ws_bytes, p2w_stream_t stream) {
+    P2W_CHECK_PTR(ws); P2W_CHECK_ALIGN16(ws);
+    TkLayout L;
+    tk_layout(1, 1, &L);
+    if (ws_bytes < L.total + 256) return P2W_EWORKSPACE;
+    char* w = static_cast<char*>(ws);
+    hipError_t e = hipMemsetAsync(w + L.total, 0, 256, p2w_s(stream));
+    if (e != hipSuccess) return (int32_t)e;
+    vs_init_kernel<<<1, 64, 0, p2w_s(stream)>>>(reinterpret_cast<VsHeader*>(w + L.hdr));
+    return P2W_LAUNCH_STATUS();
+}
+
+static int32_t voxel_sample_table_impl(bool prepared, const float* xyzr, const int32_t* ptr, int32_t B, int32_t n_bound, float res,
+                                       int32_t* idx_out, int32_t* ptr_out, int32_t* batch_out, int32_t* order_out,
+                                       uint64_t* sorted_keys_out, uint64_t* cell_keys_out, p2w_grid* grid_out,
+                                       int32_t* inv_out, int32_t* rank_sorted_out, int32_t* cell_start_out,
+                                       int32_t* cell_start_sorted_out, int32_t* status_out, int64_t table_cells,
+                                       void* ws, size_t ws_bytes, p2w_stream_t stream) {
     P2W_CHECK_PTR(ptr); P2W_CHECK_PTR(ptr_out); P2W_CHECK_PTR(status_out);
     if (cell_start_sorted_out && !order_out) return P2W_ENULL;   // the sorted order's counts are only kept when it is asked for
     if (B <= 0 || n_bound < 0 || !(res > 0.0f) || table_cells <= 0 || table_cells > ((int64_t)1 << 30)) return P2W_EINVAL;
     hipStream_t s = p2w_s(stream);
-    hipError_t e = hipMemsetAsync(status_out, 0, sizeof(int), s);
-    if (e != hipSuccess) return (int32_t)e;
-    if (n_bound == 0) return (int32_t)hipMemsetAsync(ptr_out, 0, sizeof(int) * (B + 1), s);
+    if (n_bound == 0) {
+        hipError_t e = hipMemsetAsync(status_out, 0, sizeof(int), s);
+        if (e != hipSuccess) return (int32_t)e;
+        return (int32_t)hipMemsetAsync(ptr_out, 0, sizeof(int) * (B + 1), s);
+    }
     P2W_CHECK_PTR(xyzr); P2W_CHECK_PTR(idx_out); P2W_CHECK_PTR(batch_out); P2W_CHECK_PTR(ws);
     P2W_CHECK_ALIGN16(xyzr); P2W_CHECK_ALIGN16(ws);
     if ((sorted_keys_out || rank_sorted_out) && !order_out) return P2W_ENULL;
     TkLayout L;
     tk_layout(n_bound, table_cells, &L);
     if (ws_bytes < L.bytes) return P2W_EWORKSPACE;
+    if (!prepared) {
+        const int32_t rc = p2w_voxel_sample_table_prepare(ws, ws_bytes, stream);
+        if (rc != P2W_OK) return rc;
+    }
     char* w = static_cast<char*>(ws);
     auto* hdr = reinterpret_cast<VsHeader*>(w + L.hdr);
     int* tab_max = reinterpret_cast<int*>(w + L.tab_max);
@@ -583,23 +617,46 @@ extern "C" int32_t p2w_voxel_sample_table(const float* xyzr, const int32_t* ptr,
     int* bs_occ = reinterpret_cast<int*>(w + L.bs_occ);
     int* bs_cnt = reinterpret_cast<int*>(w + L.bs_cnt);
     int* total = reinterpret_cast<int*>(w + L.total);
+    int* done = total + 16;                                  // the scan's completion counter (zero between calls)
     const auto* x4 = reinterpret_cast<const float4*>(xyzr);
     const int nblk_pts = p2w_cdiv(n_bound, 256);
-    vs_init_kernel<<<1, 64, 0, s>>>(hdr);
-    vs_minmax_kernel<<<nblk_pts < 256 ? nblk_pts : 256, 256, 0, s>>>(x4, ptr, B, hdr);
+    // 6 launches: bounding box (+ status = 0) -> clear -> insert -> scan (the last workgroup scans the block totals) -> compact -> points
+    // (+ the workspace's between-calls state restored)
+    vs_minmax_kernel<<<nblk_pts < 256 ? nblk_pts : 256, 256, 0, s>>>(x4, ptr, B, hdr, status_out);
     // -1 = empty cell, zero counts: only over the part of the table this batch's grid uses (known on the device)
     tk_clear_kernel<<<p2w_cdiv(table_cells, 1024), 256, 0, s>>>(ptr, B, res, hdr, (long long)table_cells, tab_max, cnt, fill);
     tk_insert_kernel<<<nblk_pts, 256, 0, s>>>(x4, ptr, B, n_bound, res, hdr, (long long)table_cells, tab_max, cnt, key32, status_out);
-    tk_scan1_kernel<<<L.nblk, TK_BLOCK, 0, s>>>(tab_max, cnt, (long long)table_cells, rank, off, bs_occ, bs_cnt, status_out, ptr, B, res, hdr);
-    tk_scan2_kernel<<<1, 1024, 0, s>>>(bs_occ, bs_cnt, L.nblk, total, status_out, ptr, B, res, hdr, (long long)table_cells);
+    tk_scan1_kernel<<<L.nblk, TK_BLOCK, 0, s>>>(tab_max, cnt, (long long)table_cells, rank, off, bs_occ, bs_cnt, status_out, ptr, B, res, hdr,
+                                                 done, total);
     const long long cgrid = (table_cells + 1 > B + 1 ? table_cells + 1 : B + 1);
     tk_compact_kernel<<<p2w_cdiv(cgrid, 256), 256, 0, s>>>(tab_max, rank, bs_occ, total, (long long)table_cells, ptr, B, res, hdr, idx_out,
                                                             ptr_out, batch_out, reinterpret_cast<unsigned long long*>(cell_keys_out),
                                                             grid_out, status_out, off, bs_cnt, cell_start_out, cell_start_sorted_out);
-    if (inv_out || order_out)
-        tk_points_kernel<<<nblk_pts, 256, 0, s>>>(key32, rank, bs_occ, off, bs_cnt, fill, ptr, B, n_bound, inv_out, order_out,
-                                                  reinterpret_cast<unsigned long long*>(sorted_keys_out), rank_sorted_out, status_out);
+    tk_points_kernel<<<nblk_pts, 256, 0, s>>>(key32, rank, bs_occ, off, bs_cnt, fill, ptr, B, n_bound, inv_out, order_out,
+                                              reinterpret_cast<unsigned long long*>(sorted_keys_out), rank_sorted_out, status_out, hdr);
     return P2W_LAUNCH_STATUS();
+}
+
+extern "C" int32_t p2w_voxel_sample_table(const float* xyzr, const int32_t* ptr, int32_t B, int32_t n_bound, float res,
+                                          int32_t* idx_out, int32_t* ptr_out, int32_t* batch_out, int32_t* order_out,
+                                          uint64_t* sorted_keys_out, uint64_t* cell_keys_out, p2w_grid* grid_out,
+                                          int32_t* inv_out, int32_t* rank_sorted_out, int32_t* cell_start_out,
+                                          int32_t* cell_start_sorted_out, int32_t* status_out, int64_t table_cells,
+                                          void* ws, size_t ws_bytes, p2w_stream_t stream) {
+    return voxel_sample_table_impl(false, xyzr, ptr, B, n_bound, res, idx_out, ptr_out, batch_out, order_out, sorted_keys_out, cell_keys_out,
+                                   grid_out, inv_out, rank_sorted_out, cell_start_out, cell_start_sorted_out, status_out, table_cells, ws,
+                                   ws_bytes, stream);
+}
+
+extern "C" int32_t p2w_voxel_sample_table_prepared(const float* xyzr, const int32_t* ptr, int32_t B, int32_t n_bound, float res,
+                                                   int32_t* idx_out, int32_t* ptr_out, int32_t* batch_out, int32_t* order_out,
+                                                   uint64_t* sorted_keys_out, uint64_t* cell_keys_out, p2w_grid* grid_out,
+                                                   int32_t* inv_out, int32_t* rank_sorted_out, int32_t* cell_start_out,
+                                                   int32_t* cell_start_sorted_out, int32_t* status_out, int64_t table_cells,
+                                                   void* ws, size_t ws_bytes, p2w_stream_t stream) {
+    return voxel_sample_table_impl(true, xyzr, ptr, B, n_bound, res, idx_out, ptr_out, batch_out, order_out, sorted_keys_out, cell_keys_out,
+                                   grid_out, inv_out, rank_sorted_out, cell_start_out, cell_start_sorted_out, status_out, table_cells, ws,
+                                   ws_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -438,6 +438,8 @@ class Engine:
             raise RuntimeError("p2w_voxel_sample_table_ws_bytes failed")
         if self._ws_t is None or self._ws_t.numel() < need or self._ws_t.device != device:
             self._ws_t = torch.empty(need, dtype=torch.uint8, device=device)
+            # the sampler's between-calls state (p2w_voxel_sample_table_prepared): once per workspace, on the stream that will use it
+            check(lib().p2w_voxel_sample_table_prepare(ptr(self._ws_t), self._ws_t.numel(), _lib.stream()), "voxel_sample_table_prepare")
         return self._ws_t
 
     def _workspace(self, n, device):
@@ -449,13 +451,14 @@ class Engine:
         return self._ws
 
     # -- phase 1 ------------------------------------------------------------------------------
-    def _geometry_async(self, pos, reflectance, ptr0, sf, force_sort: bool = False, search_stream=None) -> Geometry:
+    def _geometry_async(self, pos, reflectance, ptr0, sf, force_sort: bool = False, search_stream=None, defer_searches: bool = False) -> Geometry:
         """Enqueues the geometry phase: first the SAMPLING chain (record packing, the three grid sub-samplings and level
         positions - everything the level sizes depend on - and the one device-to-host copy of those sizes), then the six
         SEARCHES.  ``search_stream`` None: all on the current stream.  Otherwise (the single-call forward) the searches go to
         that stream behind the sampling chain and every search records an event (``geo.ev_nbr[l]``, ``geo.ev_fp[f]``) that the
         feature phase waits for where it first reads the result: the searches of level l + 1 then run BESIDE the features of
-        level l.  All buffers are allocated on the current stream either way."""
+        level l.  All buffers are allocated on the current stream either way.  ``defer_searches``: the caller enqueues them
+        itself (``geo.launch_searches()``) - the lone forward puts its size-independent feature kernels in front of them."""
         L = lib()
         dev = pos.device
         N, B, k = pos.shape[0], sf.numel(), self.k
@@ -515,7 +518,7 @@ class Engine:
                 # searches INTO these candidates look their runs up instead of bisecting the keys
                 cstart[l + 1] = torch.empty(cells + 1, **i32) if self.search_index else None
                 cstart0 = torch.empty(cells + 1, **i32) if (self.search_index and l == 0) else None
-                self._call("voxel_sample", L.p2w_voxel_sample_table, ptr(src.xyzr), ptr(src.ptr), B, N, res, ptr(lv.idx),
+                self._call("voxel_sample", L.p2w_voxel_sample_table_prepared, ptr(src.xyzr), ptr(src.ptr), B, N, res, ptr(lv.idx),
                            ptr(lv.ptr), ptr(lv.batch), ptr(order), ptr(skeys), ptr(ckeys[l + 1]), ptr(grids[l + 1]),
                            ptr(ranks[l]) if l > 0 else None, ptr(ranks[l]) if l == 0 else None, ptr(cstart[l + 1]),
                            ptr(cstart0), ptr(status[l:]), cells, ptr(ws_t), ws_t.numel())
@@ -546,71 +549,77 @@ class Engine:
         geo.pstride = pstride
         geo.sizes_ready = torch.cuda.Event()
         geo.sizes_ready.record()
-        # ---- searches
-        cur = geo.stream
+        # ---- searches (as a closure: the lone forward enqueues its size-independent feature kernels between the two chains)
         geo.ev_nbr, geo.ev_fp = {}, {}
-        if search_stream is not None:
-            search_stream.wait_event(geo.sizes_ready)
 
-        def searching():
-            return torch.cuda.stream(search_stream) if search_stream is not None else contextlib.nullcontext()
-
-        def mark(table, key):
+        def launch_searches():
+            geo.launch_searches = None
             if search_stream is not None:
-                table[key] = torch.cuda.Event()
-                table[key].record()
-        with searching():
-            for l, res in enumerate(SA_RES):
-                src, lv = geo.levels[l], geo.levels[l + 1]
-                if l == 0:   # model.py:117-118: the 0.04 level uses radius(r = 2*resolution)
-                    if grid_search:
-                        self._call("ball_query", L.p2w_ball_query_grid_indexed, ptr(sorted0), ptr(skeys0), ptr(src.ptr), ptr(grids[1]),
-                                   ptr(cstart0), ptr(src.xyzr), ptr(lv.idx), ptr(lv.ptr), B, N, res * 2, k, ptr(lv.nbr), ptr(lv.deg),
-                                   SEARCH_X_INDEX_IN_W | (SEARCH_BOX if self.search_box & 1 else 0))
+                search_stream.wait_event(geo.sizes_ready)
+
+            def searching():
+                return torch.cuda.stream(search_stream) if search_stream is not None else contextlib.nullcontext()
+
+            def mark(table, key):
+                if search_stream is not None:
+                    table[key] = torch.cuda.Event()
+                    table[key].record()
+            with searching():
+                for l, res in enumerate(SA_RES):
+                    src, lv = geo.levels[l], geo.levels[l + 1]
+                    if l == 0:   # model.py:117-118: the 0.04 level uses radius(r = 2*resolution)
+                        if grid_search:
+                            self._call("ball_query", L.p2w_ball_query_grid_indexed, ptr(sorted0), ptr(skeys0), ptr(src.ptr), ptr(grids[1]),
+                                       ptr(cstart0), ptr(src.xyzr), ptr(lv.idx), ptr(lv.ptr), B, N, res * 2, k, ptr(lv.nbr), ptr(lv.deg),
+                                       SEARCH_X_INDEX_IN_W | (SEARCH_BOX if self.search_box & 1 else 0))
+                        else:
+                            box0 = torch.empty((nbox, 6), **f32)
+                            self._call("tile_bbox", L.p2w_tile_bbox, ptr(sorted0), ptr(src.ptr), B, N, ptr(box0))
+                            self._call("ball_query", L.p2w_ball_query, ptr(sorted0), ptr(src.ptr), ptr(src.xyzr), ptr(lv.idx),
+                                       ptr(lv.ptr), B, N, res * 2, k, ptr(lv.nbr), ptr(lv.deg), ptr(box0), SEARCH_X_INDEX_IN_W)
+                            geo.aux.append(box0)
+                    elif grid_search:   # model.py:120
+                        self._call("knn", L.p2w_knn_grid_indexed, ptr(src.xyzr), ptr(ckeys[l]), ptr(src.ptr), ptr(grids[l]), ptr(cstart.get(l)),
+                                   ptr(src.xyzr),
+                                   ptr(lv.idx), ptr(lv.ptr), B, N, k, ptr(lv.nbr), ptr(lv.deg), None,
+                                   (SEARCH_BOX if self.search_box & 2 else 0))
                     else:
-                        box0 = torch.empty((nbox, 6), **f32)
-                        self._call("tile_bbox", L.p2w_tile_bbox, ptr(sorted0), ptr(src.ptr), B, N, ptr(box0))
-                        self._call("ball_query", L.p2w_ball_query, ptr(sorted0), ptr(src.ptr), ptr(src.xyzr), ptr(lv.idx),
-                                   ptr(lv.ptr), B, N, res * 2, k, ptr(lv.nbr), ptr(lv.deg), ptr(box0), SEARCH_X_INDEX_IN_W)
-                        aux0.append(box0)
-                elif grid_search:   # model.py:120
-                    self._call("knn", L.p2w_knn_grid_indexed, ptr(src.xyzr), ptr(ckeys[l]), ptr(src.ptr), ptr(grids[l]), ptr(cstart.get(l)),
-                               ptr(src.xyzr),
-                               ptr(lv.idx), ptr(lv.ptr), B, N, k, ptr(lv.nbr), ptr(lv.deg), None,
-                               (SEARCH_BOX if self.search_box & 2 else 0))
-                else:
-                    self._call("knn", L.p2w_knn, ptr(src.xyzr), ptr(src.ptr), ptr(src.xyzr), ptr(lv.idx), ptr(lv.ptr), B, N,
-                               k, ptr(lv.nbr), ptr(lv.deg), ptr(boxes(l)), 0)
-                mark(geo.ev_nbr, l + 1)
-            # k=2 searches of knn_interpolate (model.py:149): fine level f queries coarse level f+1
-            for f in (2, 1, 0):
-                fine, coarse = geo.levels[f], geo.levels[f + 1]
-                nbr, deg = torch.empty((N, 2), **i32), torch.empty(N, **i32)
-                # level 0 queries run over the cell-sorted copy; their result rows go to the points' own rows (row in .w) - or stay in
-                # cell order when the feature phase keeps level 0 in that order (fp1_cell_order)
-                q, fl = (sorted0, 0 if getattr(geo, "rows0_sorted", False) else SEARCH_Q_ROW_IN_W) if f == 0 else (fine.xyzr, 0)
-                if grid_search:
-                    hint = None
-                    if ranks.get(f) is not None:   # both of a point's two nearest coarse points are within its cell
-                        hint = torch.empty(N, **f32)   # representative's / a storage neighbour's representative's distance
-                        self._call("knn_hint", L.p2w_knn_hint2, ptr(q), ptr(ranks[f]), ptr(fine.ptr), B, N, ptr(coarse.xyzr),
-                                   ptr(hint))
-                        aux0.append(hint)
-                    self._call("knn2", L.p2w_knn_grid_indexed, ptr(coarse.xyzr), ptr(ckeys[f + 1]), ptr(coarse.ptr), ptr(grids[f + 1]),
-                               ptr(cstart.get(f + 1)), ptr(q), None, ptr(fine.ptr), B, N, 2, ptr(nbr), ptr(deg), ptr(hint),
-                               fl | (SEARCH_BOX if self.search_box & 4 else 0))
-                else:
-                    self._call("knn2", L.p2w_knn, ptr(coarse.xyzr), ptr(coarse.ptr), ptr(q), None, ptr(fine.ptr), B, N, 2,
-                               ptr(nbr), ptr(deg), ptr(boxes(f + 1)), fl)
-                geo.fp_nbr[f] = (nbr, deg)
-                mark(geo.ev_fp, f)
-            geo.done = torch.cuda.Event()
-            geo.done.record()
+                        self._call("knn", L.p2w_knn, ptr(src.xyzr), ptr(src.ptr), ptr(src.xyzr), ptr(lv.idx), ptr(lv.ptr), B, N,
+                                   k, ptr(lv.nbr), ptr(lv.deg), ptr(boxes(l)), 0)
+                    mark(geo.ev_nbr, l + 1)
+                # k=2 searches of knn_interpolate (model.py:149): fine level f queries coarse level f+1
+                for f in (2, 1, 0):
+                    fine, coarse = geo.levels[f], geo.levels[f + 1]
+                    nbr, deg = torch.empty((N, 2), **i32), torch.empty(N, **i32)
+                    # level 0 queries run over the cell-sorted copy; their result rows go to the points' own rows (row in .w) - or stay in
+                    # cell order when the feature phase keeps level 0 in that order (fp1_cell_order)
+                    q, fl = (sorted0, 0 if getattr(geo, "rows0_sorted", False) else SEARCH_Q_ROW_IN_W) if f == 0 else (fine.xyzr, 0)
+                    if grid_search:
+                        hint = None
+                        if ranks.get(f) is not None:   # both of a point's two nearest coarse points are within its cell
+                            hint = torch.empty(N, **f32)   # representative's / a storage neighbour's representative's distance
+                            self._call("knn_hint", L.p2w_knn_hint2, ptr(q), ptr(ranks[f]), ptr(fine.ptr), B, N, ptr(coarse.xyzr),
+                                       ptr(hint))
+                            geo.aux.append(hint)
+                        self._call("knn2", L.p2w_knn_grid_indexed, ptr(coarse.xyzr), ptr(ckeys[f + 1]), ptr(coarse.ptr), ptr(grids[f + 1]),
+                                   ptr(cstart.get(f + 1)), ptr(q), None, ptr(fine.ptr), B, N, 2, ptr(nbr), ptr(deg), ptr(hint),
+                                   fl | (SEARCH_BOX if self.search_box & 4 else 0))
+                    else:
+                        self._call("knn2", L.p2w_knn, ptr(coarse.xyzr), ptr(coarse.ptr), ptr(q), None, ptr(fine.ptr), B, N, 2,
+                                   ptr(nbr), ptr(deg), ptr(boxes(f + 1)), fl)
+                    geo.fp_nbr[f] = (nbr, deg)
+                    mark(geo.ev_fp, f)
+                geo.done = torch.cuda.Event()
+                geo.done.record()
+            geo.aux += list(bbox.values())
         aux0 += list(ckeys.values()) + list(grids.values()) + [t for t in ranks.values() if t is not None]
         aux0 += [t for t in list(cstart.values()) + [cstart0] if t is not None]
         if getattr(geo, "rows0_sorted", False):
             aux0 += [geo.inv0, geo.order64]
-        geo.aux = list(bbox.values()) + aux0
+        geo.aux = aux0
+        geo.launch_searches = launch_searches
+        if not defer_searches:
+            launch_searches()
         return geo
 
     def _geometry_finish(self, geo):
@@ -1086,11 +1095,15 @@ class Engine:
         are those of the sequential order, bit for bit."""
         overlap = bool(self.overlap) and self.events is None
         search_stream = self._search_stream() if overlap else None
-        geo = self._geometry_async(pos, reflectance, ptr0, sf, search_stream=search_stream)
+        geo = self._geometry_async(pos, reflectance, ptr0, sf, search_stream=search_stream, defer_searches=overlap)
         early = None
         if overlap and self.prec is not None:
-            self._range_begin(dev := sf.device)
-            early = self._features_early(geo)     # needs N only: enqueued BEFORE the host's wait for the level sizes
+            # needs N only: enqueued BEFORE the searches (whose enqueue costs the host 0.15 ms) and before the host's wait for the
+            # level sizes - the caller's stream goes from the sampling chain straight into the stem
+            self._range_begin(sf.device)
+            early = self._features_early(geo)
+        if geo.launch_searches is not None:
+            geo.launch_searches()
         self._geometry_finish(geo)
         if early is not None and early["lv0"] is not geo.levels[0]:   # (the table overflowed and the geometry was redone: level 0 is new)
             early = None

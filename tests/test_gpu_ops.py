@@ -678,6 +678,62 @@ def test_table_sampler_equals_sort_sampler(sizes, res, surface):
                                     None, None, None, None, None, None, ptr(status), cells, ptr(wt), 1024, stream()) == -4      # workspace
 
 
+def test_prepared_table_sampler_keeps_its_workspace_state():
+    """p2w_voxel_sample_table_prepared (6 launches: the engine's call) on a workspace prepared ONCE gives the results of
+    p2w_voxel_sample_table call after call - two different batches alternating, an overflowing call (table too small) and an
+    empty batch in between: every call leaves the between-calls state (bounding-box words, scan counter) in place again."""
+    from pointstowood_amd._lib import lib, ptr, stream
+    L = lib()
+    i32, i64 = dict(dtype=torch.int32, device="cuda"), dict(dtype=torch.int64, device="cuda")
+    res = 0.08
+
+    def batch(sizes, seed):
+        b = synth.collate([synth.uniform_voxel(2.0, n, seed + i, True) for i, n in enumerate(sizes)])
+        xyzr = torch.zeros((b["pos"].shape[0], 4), device="cuda")
+        xyzr[:, :3] = b["pos"].cuda()
+        return xyzr, torch.tensor([0] + list(np.cumsum(sizes)), **i32), len(sizes)
+
+    def run(fn, xyzr, csr, B, cells, wt, status):
+        n = xyzr.shape[0]
+        o = dict(idx=torch.full((n,), -7, **i32), ptr=torch.full((B + 1,), -7, **i32), batch=torch.full((n,), -7, **i32),
+                 order=torch.full((n,), -7, **i32), skeys=torch.full((n,), -7, **i64), ckeys=torch.full((n,), -7, **i64),
+                 grid=torch.zeros(8, **i64), inv=torch.full((n,), -7, **i32), rsort=torch.full((n,), -7, **i32),
+                 cs=torch.full((cells + 1,), -7, **i32), css=torch.full((cells + 1,), -7, **i32))
+        assert fn(ptr(xyzr), ptr(csr), B, n, res, ptr(o["idx"]), ptr(o["ptr"]), ptr(o["batch"]), ptr(o["order"]), ptr(o["skeys"]),
+                  ptr(o["ckeys"]), ptr(o["grid"]), ptr(o["inv"]), ptr(o["rsort"]), ptr(o["cs"]), ptr(o["css"]), ptr(status), cells, ptr(wt),
+                  wt.numel(), stream()) == 0
+        torch.cuda.synchronize()
+        return o, int(status)
+    b1, b2 = batch([9000, 300, 4000], 11), batch([2500, 7000], 40)
+    cells = 3 * (int(2.3 / res) + 3) ** 3
+    nmax = max(b1[0].shape[0], b2[0].shape[0])
+    need = int(L.p2w_voxel_sample_table_ws_bytes(nmax, cells))
+    w_ref = torch.empty(need, dtype=torch.uint8, device="cuda")
+    wt = torch.randint(0, 255, (need,), dtype=torch.uint8, device="cuda")        # a workspace somebody else has written
+    assert L.p2w_voxel_sample_table_prepare(ptr(wt), wt.numel(), stream()) == 0
+    status = torch.full((1,), 9, **i32)
+    ref = {0: run(L.p2w_voxel_sample_table, *b1, cells, w_ref, status), 1: run(L.p2w_voxel_sample_table, *b2, cells, w_ref, status)}
+    for step, which in enumerate([0, 1, 1, 0, "small", 0, "empty", 1, 0]):
+        if which == "small":     # the grid does not fit: status 1, an empty level - and the state survives
+            o, st = run(L.p2w_voxel_sample_table_prepared, *b1, 1000, wt, status)
+            assert st == 1 and int(o["ptr"].abs().max()) == 0
+            continue
+        if which == "empty":     # no points at all (n_bound > 0 rows, every voxel empty)
+            xyzr, _, B = b2
+            o, st = run(L.p2w_voxel_sample_table_prepared, xyzr, torch.zeros(B + 1, **i32), B, cells, wt, status)
+            assert st == 0 and int(o["ptr"].abs().max()) == 0
+            continue
+        (r, rst), (o, st) = ref[which], run(L.p2w_voxel_sample_table_prepared, *(b1, b2)[which], cells, wt, status)
+        assert st == 0 and rst == 0
+        m = int(r["ptr"][-1])
+        assert torch.equal(o["ptr"], r["ptr"]) and torch.equal(o["grid"], r["grid"]) and torch.equal(o["inv"], r["inv"]), step
+        for k in ("idx", "batch", "ckeys"):
+            assert torch.equal(o[k][:m], r[k][:m]), (step, k)
+        assert torch.equal(o["skeys"], r["skeys"]) and torch.equal(o["rsort"], o["inv"][o["order"].long()]), step
+        T = int(r["grid"][4] * r["grid"][5] * r["grid"][6]) * (2 if which else 3)
+        assert torch.equal(o["cs"][: T + 1], r["cs"][: T + 1]) and torch.equal(o["css"][: T + 1], r["css"][: T + 1]), step
+
+
 @pytest.mark.parametrize("box", [0, 4])
 @pytest.mark.parametrize("sizes,surface", [([5000], False), ([1500, 40, 2600], True), ([16384, 3000], False), ([300, 0, 9000], True)])
 def test_indexed_grid_searches_equal_the_bisecting_ones(sizes, surface, box):
