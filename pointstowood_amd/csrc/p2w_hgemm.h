@@ -32,6 +32,10 @@ typedef const __attribute__((address_space(1))) void* glb_vp;
 constexpr int H_BK = 32;   // k per plane of a PointNetConv slab
 #ifndef P2W_SA_PREFETCH_FRAGS
 #define P2W_SA_PREFETCH_FRAGS 1   // 0: the previous form (A/B: fused PointNetConv class -2.9 %)
+#ifndef P2W_SA_PK_FMA
+#define P2W_SA_PK_FMA 0           // 1: the producer's layer-1 correction on packed fp32 FMAs (v_pk_fma_f32: same bits) - measured +3 % on the
+                                  // class (1.88 against 1.82 ms, alternating processes): the packed form issues no faster and co-executes worse with the MFMAs
+#endif
 #endif
 constexpr int SA_EPI_COLS = 1024;   // capacity of the fused PointNetConv's LDS table of per-column epilogue parameters (C2 limit)
 
@@ -1560,10 +1564,25 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
             const float4 p = src.v[u][half];
             const float gx = rg.x, gy = rg.y, gz = rg.z, gw = rg.w;
             float v[4];
+#if P2W_SA_PK_FMA
+            // the four FMAs of a column pair as two-wide packed ones (v_pk_fma_f32: the same IEEE fma per half, so the same bits; half
+            // the VALU issue slots of the producer's arithmetic)
+            const fpair gxx = {gx, gx}, gyy = {gy, gy}, gzz = {gz, gz}, gww = {gw, gw};
+            fpair a01 = __builtin_elementwise_fma(gxx, fpair{wx.x, wx.y}, fpair{p.x, p.y});
+            fpair a23 = __builtin_elementwise_fma(gxx, fpair{wx.z, wx.w}, fpair{p.z, p.w});
+            a01 = __builtin_elementwise_fma(gyy, fpair{wy.x, wy.y}, a01);
+            a23 = __builtin_elementwise_fma(gyy, fpair{wy.z, wy.w}, a23);
+            a01 = __builtin_elementwise_fma(gzz, fpair{wz.x, wz.y}, a01);
+            a23 = __builtin_elementwise_fma(gzz, fpair{wz.z, wz.w}, a23);
+            a01 = __builtin_elementwise_fma(gww, fpair{wf.x, wf.y}, a01);
+            a23 = __builtin_elementwise_fma(gww, fpair{wf.z, wf.w}, a23);
+            v[0] = fmaxf(a01[0], 0.f); v[1] = fmaxf(a01[1], 0.f); v[2] = fmaxf(a23[0], 0.f); v[3] = fmaxf(a23[1], 0.f);
+#else
             v[0] = fmaxf(fmaf(gw, wf.x, fmaf(gz, wz.x, fmaf(gy, wy.x, fmaf(gx, wx.x, p.x)))), 0.f);
             v[1] = fmaxf(fmaf(gw, wf.y, fmaf(gz, wz.y, fmaf(gy, wy.y, fmaf(gx, wx.y, p.y)))), 0.f);
             v[2] = fmaxf(fmaf(gw, wf.z, fmaf(gz, wz.z, fmaf(gy, wy.z, fmaf(gx, wx.z, p.z)))), 0.f);
             v[3] = fmaxf(fmaf(gw, wf.w, fmaf(gz, wz.w, fmaf(gy, wy.w, fmaf(gx, wx.w, p.w)))), 0.f);
+#endif
             if constexpr (PREC == 0) {
                 unsigned h01, l01, h23, l23;
                 split_pair(v[0], v[1], h01, l01);

@@ -283,6 +283,8 @@ class EngineOptions:
     overlap: bool = True          # ONE forward (model(data), the reference's call): the searches on a second stream beside the features
                                   # (each feature kernel waits for the event of the search it reads); False: strictly one stream
     search_priority: int = 0      # HIP priority of that stream (-1 = high)
+    early_first: bool = True      # ... and the size-independent feature kernels (stem, SA1's hoisted product) are enqueued BEFORE the searches
+    table_prepared: bool = True   # table sampler through p2w_voxel_sample_table_prepared (6 launches per level; False: the 8-launch entry point)
     single_res_streams: int = 2   # row-chunk chains in flight inside a LONE forward (see res_streams: there the pipeline's second phase
                                   # fills the round tails; here nothing else does)
 
@@ -518,7 +520,7 @@ class Engine:
                 # searches INTO these candidates look their runs up instead of bisecting the keys
                 cstart[l + 1] = torch.empty(cells + 1, **i32) if self.search_index else None
                 cstart0 = torch.empty(cells + 1, **i32) if (self.search_index and l == 0) else None
-                self._call("voxel_sample", L.p2w_voxel_sample_table_prepared, ptr(src.xyzr), ptr(src.ptr), B, N, res, ptr(lv.idx),
+                self._call("voxel_sample", L.p2w_voxel_sample_table_prepared if self.table_prepared else L.p2w_voxel_sample_table, ptr(src.xyzr), ptr(src.ptr), B, N, res, ptr(lv.idx),
                            ptr(lv.ptr), ptr(lv.batch), ptr(order), ptr(skeys), ptr(ckeys[l + 1]), ptr(grids[l + 1]),
                            ptr(ranks[l]) if l > 0 else None, ptr(ranks[l]) if l == 0 else None, ptr(cstart[l + 1]),
                            ptr(cstart0), ptr(status[l:]), cells, ptr(ws_t), ws_t.numel())
@@ -1097,6 +1099,8 @@ class Engine:
         search_stream = self._search_stream() if overlap else None
         geo = self._geometry_async(pos, reflectance, ptr0, sf, search_stream=search_stream, defer_searches=overlap)
         early = None
+        if not self.early_first and geo.launch_searches is not None:
+            geo.launch_searches()
         if overlap and self.prec is not None:
             # needs N only: enqueued BEFORE the searches (whose enqueue costs the host 0.15 ms) and before the host's wait for the
             # level sizes - the caller's stream goes from the sampling chain straight into the stem
