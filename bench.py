@@ -586,9 +586,10 @@ def plot_main(args, world, rank, device, dist):
             "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"BASELINE configs[3]: {n}-point synthetic forest plot ({side:.0f} m square), grid_size 2.0/4.0, min_pts 128, "
                                    "max_pts 16384, voxel batches of a fifth of a rank's share (262144 .. 2097152 points, 1 voxel per 1024 points) LPT-sharded over the ranks, one all-gather "
-                                   "of the classified points, back-projection (k=64 median vote) on contiguous plot slices, one all-gather",
+                                   "of the float32 probabilities (4 B per classified point), back-projection (k=64 median vote) owned by x-slabs of the plot "
+                                   "against the voxels within a halo, one all-gather of the results",
                        "voxels": stats.get("voxels"), "classified_points": stats.get("classified_points"), "C": C,
-                       "parallelism": f"voxel-batch sharding x{world} + plot-slice sharding x{world}, 2 RCCL all-gathers"},
+                       "parallelism": f"voxel-batch sharding x{world} + spatial (x-slab) sharding of the back-projection x{world}, 2 RCCL all-gathers"},
             "stages_s_rank0_last_step": {k: round(v, 4) for k, v in stats.items() if k.endswith("_s")},
             "classified_points_per_s": stats.get("classified_points", 0) / max(stats.get("classify_s", 1e-9), 1e-9),
         }), flush=True)

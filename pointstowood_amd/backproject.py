@@ -130,3 +130,34 @@ def collect_predictions(cls_xyz, cls_pred, cls_prob, query_xyz, any_wood: float 
         label[rows] = lab
         pwood[rows] = pw
     return label, pwood
+
+
+def collect_predictions_checked(cls_xyz, cls_pred, cls_prob, query_xyz, any_wood: float = 1.0, cell: float | None = None,
+                                chunk: int = 1 << 22):
+    """``collect_predictions`` plus, per query, the float64 distance to its k-th neighbour among ``cls_xyz`` (+inf where fewer
+    than k candidates exist): what a caller that searched a SUBSET of the classified points needs to prove the result exact
+    (pipeline._backproject_spatial: every candidate not in the subset lies farther than that distance)."""
+    L = lib()
+    k = 32 if any_wood != 1 else 64
+    nq, dev = query_xyz.shape[0], query_xyz.device
+    pred = cls_pred.to(torch.float32).contiguous()
+    prob = cls_prob.to(torch.float32).contiguous()
+    label = torch.zeros(nq, dtype=torch.float32, device=dev)
+    pwood = torch.zeros(nq, dtype=torch.float32, device=dev)
+    dk = torch.full((nq,), float("inf"), dtype=torch.float64, device=dev)
+    if cls_xyz.shape[0] == 0 or nq == 0:
+        return label, pwood, dk
+    c64, q64 = cls_xyz.to(torch.float64), query_xyz.to(torch.float64)
+    for rows, nbr, deg in neighbours(cls_xyz, query_xyz, k, cell, chunk):
+        m = rows.shape[0]
+        lab = torch.empty(m, dtype=torch.float32, device=dev)
+        pw = torch.empty(m, dtype=torch.float32, device=dev)
+        check(L.p2w_vote(ptr(nbr), ptr(deg), k, ptr(pred), ptr(prob), m, float(any_wood), ptr(lab), ptr(pw), _lib.stream()),
+              "vote")
+        label[rows] = lab
+        pwood[rows] = pw
+        full = deg >= k
+        last = nbr[:, k - 1].long().clamp(min=0)
+        d = (c64[last] - q64[rows]).pow(2).sum(dim=1).sqrt()
+        dk[rows] = torch.where(full, d, torch.full_like(d, float("inf")))
+    return label, pwood, dk

@@ -11,8 +11,8 @@ import time
 
 import torch
 
-from .backproject import collect_predictions
-from .dist import batch_cost, gather_rows, partition_batches, slice_for_rank
+from .backproject import collect_predictions, collect_predictions_checked
+from .dist import batch_cost, gather_logits, gather_rows, partition_batches, slice_for_rank
 from .predicter import PointBudgetSampler, collate_device
 from .preprocessing import voxelise
 
@@ -53,7 +53,7 @@ def default_budget(total_points: int, world: int, free, dist=None, device=None) 
 
 def segment_plot(pc, model, grid_sizes=(2.0, 4.0), min_pts: int = 128, max_pts: int = 16384, is_wood: float = 0.5,
                  any_wood: float = 1.0, max_points: int | None = None, mode: str = "compat", generator=None, stats=None,
-                 dist=None, max_voxels: int | None = None, ground: bool = True):
+                 dist=None, max_voxels: int | None = None, ground: bool = True, shard: str = "spatial", halo: float = 1.0):
     """pc: [N, >= 4] float tensor on the GPU (x, y, z, reflectance, ...), plot-local coordinates (fp32-safe).
     Returns (n_z [N], label [N], pwood [N]) float32 on the device: the three columns the reference appends
     (``predicter.py:233``).  ``stats`` (dict, optional) receives stage timings and counts.  ``max_points`` /
@@ -64,9 +64,14 @@ def segment_plot(pc, model, grid_sizes=(2.0, 4.0), min_pts: int = 128, max_pts: 
 
     ``dist`` (an initialised ``torch.distributed``, one process per GPU, every rank holding the same ``pc`` and the same
     ``generator`` state): every rank voxelises (cheap, and it makes the voxel list identical everywhere without an
-    exchange), classifies its LPT share of the voxel batches, the classified points are all-gathered once, each rank
-    back-projects a contiguous slice of the plot and the slices are all-gathered: two data exchanges (plus, with the default
-    budget, one all-reduce of a scalar: the ranks' least free memory)."""
+    exchange) and classifies its LPT share of the voxel batches.  ``shard="spatial"`` (default): the per-point probabilities
+    - 4 bytes per classified point, the ONLY thing a rank cannot compute itself - are all-gathered once; the back-projection
+    is owned spatially (rank r takes the r-th share of the plot points in ascending x and builds its search grid over the
+    classified points of the voxels within ``halo`` metres of its slab only; a query whose k-th neighbour could lie beyond
+    the slab's covered range is repeated against a 4 x wider set, at most against everything - no further exchange); the
+    per-point results are all-gathered once.  ``shard="slices"``: round 5's flow (all classified points to every rank, plot
+    slices in input order).  Both give the single-process result bit for bit; with the default budget one all-reduce of a
+    scalar (the ranks' least free memory) precedes them."""
     dev = pc.device
     t0 = time.perf_counter()
     vox, n_z = voxelise(pc, tuple(grid_sizes), min_pts, max_pts, mode=mode, generator=generator, ground=ground)
@@ -84,6 +89,7 @@ def segment_plot(pc, model, grid_sizes=(2.0, 4.0), min_pts: int = 128, max_pts: 
     if max_voxels is None:
         max_voxels = max(1, max_points // 1024)
     batches = list(PointBudgetSampler(lengths, max_points, max_voxels))
+    all_batches = batches
     plan, batch_rows = None, [sum(lengths[i] for i in b) for b in batches]
     if world > 1:
         plan = partition_batches([sum(batch_cost(lengths[i]) for i in b) for b in batches], world)   # LPT on est. FLOPs
@@ -99,12 +105,16 @@ def segment_plot(pc, model, grid_sizes=(2.0, 4.0), min_pts: int = 128, max_pts: 
             pending.append(d)
             yield d
 
+    spatial = world > 1 and shard == "spatial"
     xyz, prob = [], []
     for logits in model.stream(feed()):
         d = pending.popleft()
         prob.append(torch.sigmoid(torch.nan_to_num(logits)).reshape(-1))                 # predicter.py:197-199
-        # predicter.py:203-211: the un-shifted coordinates are float64 sums of the float32 position and shift
-        xyz.append(d.pos.to(torch.float64) + d.local_shift.view(-1, 3)[d.batch].to(torch.float64))
+        if not spatial:
+            # predicter.py:203-211: the un-shifted coordinates are float64 sums of the float32 position and shift
+            xyz.append(d.pos.to(torch.float64) + d.local_shift.view(-1, 3)[d.batch].to(torch.float64))
+    if spatial:
+        return _backproject_spatial(pc, vox, lengths, all_batches, plan, batch_rows, prob, n_z, is_wood, any_wood, halo, dist, stats, t0)
     if xyz:
         cls = torch.cat([torch.cat(xyz), torch.cat(prob)[:, None].to(torch.float64)], 1)
     else:
@@ -135,3 +145,98 @@ def segment_plot(pc, model, grid_sizes=(2.0, 4.0), min_pts: int = 128, max_pts: 
         _sync(dev)
         stats["backproject_s"] = time.perf_counter() - t0
     return n_z, label, pwood
+
+
+def _classified_xyz(voxels):
+    """Un-shifted float64 coordinates of the classified points of `voxels` (a list of voxel tensors), as the classify loop
+    forms them (predicter.py:203-211: float32 centred position + float32 shift, added in float64).  Per-voxel arithmetic
+    (collate_device: sequential per-segment mean), so the bits do not depend on which voxels are collated together - any rank
+    can compute any voxel's classified coordinates from the voxel list it holds anyway."""
+    d = collate_device(voxels)
+    return d.pos.to(torch.float64) + d.local_shift.view(-1, 3)[d.batch].to(torch.float64)
+
+
+def _backproject_spatial(pc, vox, lengths, batches, plan, batch_rows, prob_parts, n_z, is_wood, any_wood, halo, dist, stats, t0):
+    """The sharded back-projection with spatial ownership (see segment_plot).  Exchanges: ONE all-gather of the float32
+    probabilities (sizes known to everyone from the plan), ONE all-gather of (label, pwood) (sizes known from the plot size)."""
+    dev, n = pc.device, pc.shape[0]
+    world, rank = dist.get_world_size(), dist.get_rank()
+    # -- exchange 1: every classified point's probability, in the order ONE process classifies in (batch by batch) ----------
+    mine = torch.cat(prob_parts) if prob_parts else torch.zeros(0, dtype=torch.float32, device=dev)
+    counts = [sum(batch_rows[b] for b in plan[r]) for r in range(world)]
+    if mine.numel() != counts[rank]:
+        raise RuntimeError(f"rank {rank} classified {mine.numel()} points, the batch plan holds {counts[rank]}")
+    gathered = gather_logits(mine.to(torch.float32), dist, counts)
+    start, off = {}, 0
+    for r in range(world):
+        for b in plan[r]:
+            start[b], off = off, off + batch_rows[b]
+    prob_all = torch.cat([gathered[start[b]: start[b] + batch_rows[b]] for b in range(len(batch_rows))]) if batch_rows else gathered
+    if stats is not None:
+        _sync(dev)
+        stats["classify_s"], t0 = time.perf_counter() - t0, time.perf_counter()
+        stats["classified_points"] = int(prob_all.numel())
+        stats["exchange_bytes"] = [4 * max(counts) * world]
+    # -- who owns what: plot points in ascending x, rank r the r-th share; voxels by their extent in x -----------------------
+    x = pc[:, 0].to(torch.float32)
+    order_x = torch.argsort(x, stable=True)
+    q0, q1 = slice_for_rank(n, rank, world)
+    own = order_x[q0:q1]
+    # row of every voxel's first classified point in the single-process order, voxel ids in that order
+    vox_order = [v for b in batches for v in b]
+    vstart, acc = [0] * len(lengths), 0
+    for v in vox_order:
+        vstart[v], acc = acc, acc + lengths[v]
+    vlen = torch.tensor(lengths, dtype=torch.int64, device=dev)
+    allx = torch.cat([v[:, 0] for v in vox]).to(torch.float32) if vox else torch.zeros(0, device=dev)
+    vx_lo = torch.segment_reduce(allx, "min", lengths=vlen).cpu().tolist()
+    vx_hi = torch.segment_reduce(allx, "max", lengths=vlen).cpu().tolist()
+    del allx
+    k = 32 if any_wood != 1 else 64
+    label = torch.zeros(own.numel(), dtype=torch.float32, device=dev)
+    pwood = torch.zeros(own.numel(), dtype=torch.float32, device=dev)
+    if own.numel() and prob_all.numel():
+        qxyz = pc[own, :3]
+        qx = qxyz[:, 0].to(torch.float64)
+        xlo, xhi = float(qx.min()), float(qx.max())
+        todo = torch.arange(own.numel(), device=dev)       # own queries not settled yet
+        h, tiers = float(halo), []
+        while todo.numel():
+            lo, hi = (xlo - h if rank > 0 else -float("inf")), (xhi + h if rank < world - 1 else float("inf"))
+            # (1 mm of slack: a classified coordinate is the voxel's raw one up to float32 rounding of the centring)
+            sel = [v for v in vox_order if vx_hi[v] >= lo - 1e-3 and vx_lo[v] <= hi + 1e-3]
+            everything = len(sel) == len(vox_order)
+            if sel:
+                cxyz = _classified_xyz([vox[v] for v in sel])
+                ls = torch.tensor([lengths[v] for v in sel], dtype=torch.int64, device=dev)
+                st = torch.tensor([vstart[v] for v in sel], dtype=torch.int64, device=dev)
+                first = torch.cumsum(ls, 0) - ls
+                rows = torch.repeat_interleave(st - first, ls) + torch.arange(int(ls.sum()), device=dev)
+                cprob = prob_all[rows].contiguous()
+                cpred = (cprob >= is_wood).to(torch.float32)                                   # predicter.py:200
+                lab, pw, dk = collect_predictions_checked(cxyz, cpred, cprob, qxyz[todo], any_wood=any_wood)
+                del cxyz, rows
+            else:
+                lab = pw = torch.zeros(todo.numel(), dtype=torch.float32, device=dev)
+                dk = torch.full((todo.numel(),), float("inf"), dtype=torch.float64, device=dev)
+            # exact where the k-th neighbour is closer than the nearest end of the range this candidate set covers completely
+            # (strictly: a tie at the range's end could involve a point outside it); a set that holds everything is exact anyway
+            margin = torch.minimum(qx[todo] - lo, hi - qx[todo])
+            ok = torch.ones_like(dk, dtype=torch.bool) if everything else (dk < margin)
+            label[todo[ok]], pwood[todo[ok]] = lab[ok], pw[ok]
+            tiers.append((len(sel), int(todo.numel()), int((~ok).sum())))
+            todo = todo[~ok]
+            h *= 4.0
+        if stats is not None:
+            stats["backproject_tiers"] = tiers      # (voxels in the candidate set, queries asked, queries left) per halo tier
+    # -- exchange 2: the per-point results, rank-major = ascending x; back to input order ----------------------------------
+    sizes = [slice_for_rank(n, r, world) for r in range(world)]
+    both = gather_logits(torch.stack([label, pwood], 1).reshape(-1), dist, [2 * (b - a) for a, b in sizes]).view(-1, 2)
+    out_label = torch.empty(n, dtype=torch.float32, device=dev)
+    out_pwood = torch.empty(n, dtype=torch.float32, device=dev)
+    out_label[order_x], out_pwood[order_x] = both[:, 0], both[:, 1]
+    if stats is not None:
+        _sync(dev)
+        stats["backproject_s"] = time.perf_counter() - t0
+        stats["exchange_bytes"].append(8 * max(b - a for a, b in sizes) * world)
+    return n_z, out_label, out_pwood

@@ -660,42 +660,65 @@ def _cpu_collect(cls_xyz, cls_pred, cls_prob, query_xyz, any_wood=1.0, k=1):
     return cls_pred[j].clone(), cls_prob[j].clone()
 
 
+def _cpu_collect_checked(cls_xyz, cls_pred, cls_prob, query_xyz, any_wood=1.0, k=1):
+    """Stand-in for backproject.collect_predictions_checked: the same nearest-point rule + the distance to that point (the "k-th"
+    neighbour at k = 1), which the spatially sharded flow needs to prove a subset search exact.  Ties -> lowest index, like the product."""
+    nq = query_xyz.shape[0]
+    if cls_xyz.shape[0] == 0 or nq == 0:
+        z = torch.zeros(nq)
+        return z, z.clone(), torch.full((nq,), float("inf"), dtype=torch.float64)
+    d = torch.cat([torch.cdist(q.to(torch.float64), cls_xyz.to(torch.float64)) for q in query_xyz.split(4096)])
+    dk, j = d.min(dim=1)
+    return cls_pred[j].clone(), cls_prob[j].clone(), dk
+
+
 def _cpu_stand_ins():
     """In a spawned worker: the CPU stand-ins of the two GPU stages around the host-side logic under test."""
     from oracle import preprocess as OP
     from pointstowood_amd import pipeline, preprocessing
     pipeline.collect_predictions = _cpu_collect
+    pipeline.collect_predictions_checked = _cpu_collect_checked
     preprocessing.backend = OP.TensorBackend
     return pipeline
 
 
-def _plot_worker(rank, world, port, max_points, q):
+def _plot_worker(rank, world, port, max_points, shard, q):
     import torch.distributed as dist
     pipeline = _cpu_stand_ins()
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(1)
-    pipeline.collect_predictions = _cpu_collect
+    calls = []
+    orig_gather = dist.all_gather
+
+    def counting_gather(out, t, *a, **kw):
+        calls.append(int(t.numel()))
+        return orig_gather(out, t, *a, **kw)
+    dist.all_gather = counting_gather
     pc = _plot(n=12000, seed=3)
     stats = {}
     n_z, label, pwood = pipeline.segment_plot(pc, _FakeStreamModel(), (4.0,), min_pts=64, max_pts=100000, max_points=max_points,
-                                              generator=torch.Generator().manual_seed(0), stats=stats, dist=dist)
-    q.put((rank, float(label.sum()), float(pwood.double().sum()), float(n_z.double().sum()), stats.get("voxels")))
+                                              generator=torch.Generator().manual_seed(0), stats=stats, dist=dist, shard=shard, halo=0.5)
+    dist.all_gather = orig_gather
+    q.put((rank, label.tolist(), pwood.tolist(), float(n_z.double().sum()), stats.get("voxels"), len(calls), stats.get("backproject_tiers")))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,max_points", [(4, 3000), (8, 100000)])
-def test_segment_plot_sharded_gloo_world4_and_8(world, max_points, monkeypatch, tensor_backend):
-    """The sharded plot flow (pipeline.segment_plot: LPT-partitioned voxel batches -> all-gather of the classified points ->
-    plot slices -> all-gather of the per-point results) at world sizes 4 and 8, including ranks that get NO batch (world 8
-    with one large-budget batch: seven idle ranks) and ranks whose share is one small batch: every rank must end with the
-    single-process result."""
+@pytest.mark.parametrize("world,max_points,shard", [(4, 3000, "spatial"), (8, 100000, "spatial"), (4, 3000, "slices"), (8, 3000, "spatial")])
+def test_segment_plot_sharded_gloo_world4_and_8(world, max_points, shard, monkeypatch, tensor_backend):
+    """The sharded plot flow (pipeline.segment_plot) at world sizes 4 and 8, including ranks that get NO batch (world 8 with one
+    large-budget batch: seven idle ranks) and ranks whose share is one small batch: every rank must end with the single-process
+    result, point for point.  shard="spatial" (default): LPT-partitioned voxel batches -> ONE all-gather of the float32
+    probabilities -> back-projection owned by x-slabs against the voxels within a halo (0.5 m here, so that the wider tiers are
+    exercised: a query whose nearest classified point is farther than its distance to the covered range's end is repeated against
+    a 4 x wider set) -> ONE all-gather of the results: exactly two collectives.  shard="slices": round 5's flow."""
     import torch.multiprocessing as mp
     from pointstowood_amd import pipeline
     from pointstowood_amd.dist import batch_cost, partition_batches
     from pointstowood_amd.predicter import PointBudgetSampler
     from pointstowood_amd.preprocessing import voxelise
     monkeypatch.setattr(pipeline, "collect_predictions", _cpu_collect)
+    monkeypatch.setattr(pipeline, "collect_predictions_checked", _cpu_collect_checked)
     pc = _plot(n=12000, seed=3)
     n_z, label, pwood = pipeline.segment_plot(pc, _FakeStreamModel(), (4.0,), min_pts=64, max_pts=100000, max_points=max_points,
                                               generator=torch.Generator().manual_seed(0))
@@ -704,20 +727,24 @@ def test_segment_plot_sharded_gloo_world4_and_8(world, max_points, monkeypatch, 
     batches = list(PointBudgetSampler(lengths, max_points, max(1, max_points // 1024)))   # segment_plot's default voxel cap
     plan = partition_batches([sum(batch_cost(lengths[i]) for i in b) for b in batches], world)
     assert sorted(i for p in plan for i in p) == list(range(len(batches)))
-    if world == 8:
+    if world == 8 and max_points == 100000:
         assert sum(1 for p in plan if not p) >= 1            # the case under test: idle ranks
-    else:
+    elif world == 4:
         assert len(batches) >= world and all(plan)            # every rank busy, shares of one or two batches
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + (os.getpid() + 13 * world) % 1000
-    ps = [ctx.Process(target=_plot_worker, args=(r, world, port, max_points, q)) for r in range(world)]
+    port = 31500 + (os.getpid() + 13 * world + 7 * len(shard) + max_points // 1000) % 1000
+    ps = [ctx.Process(target=_plot_worker, args=(r, world, port, max_points, shard, q)) for r in range(world)]
     [p.start() for p in ps]
-    res = sorted(q.get(timeout=120) for _ in range(world))
+    res = sorted(q.get(timeout=180) for _ in range(world))
     [p.join(60) for p in ps]
-    expect = (float(label.sum()), float(pwood.double().sum()), float(n_z.double().sum()))
     for r in res:
-        assert r[1:4] == pytest.approx(expect, rel=1e-6, abs=1e-6), (r, expect)
+        assert r[1] == label.tolist() and r[2] == pwood.tolist(), f"rank {r[0]} differs from the single-process result"
+        assert r[3] == pytest.approx(float(n_z.double().sum()), rel=1e-6)
+        assert r[5] == (2 if shard == "spatial" else 4)      # collectives of the data path (slices: two lengths + two blocks)
+    if shard == "spatial":
+        tiers = [r[6] for r in res if r[6]]
+        assert tiers and any(len(t) > 1 for t in tiers), tiers      # the 0.5 m halo did leave queries for a wider tier somewhere
 
 
 def _budget_worker(rank, world, port, q):

@@ -44,8 +44,9 @@ class FakeDist:
     collective call index and rank); a rank whose peers have not been recorded yet stops at its first data exchange."""
     ReduceOp = ReduceOp
 
-    def __init__(self, rank, world, store, log, stop=True):
+    def __init__(self, rank, world, store, log, stop=True, lengths_first=False):
         self.rank, self.world, self.store, self.log, self.calls, self.stop = rank, world, store, log, 0, stop
+        self.lengths_first = lengths_first      # shard="slices": gather_rows = a lengths all-gather + the padded blocks
 
     def get_world_size(self, group=None):
         return self.world
@@ -68,7 +69,8 @@ class FakeDist:
         slot[self.rank] = t.detach().clone()
         self.log.append({"call": c, "rank": self.rank, "bytes_contributed": t.numel() * t.element_size()})
         if len(slot) < self.world:
-            if c % 2 == 1 and self.stop:   # a data block whose peers are not known yet: pass 1 ends here (the lengths call before it is
+            data = (c % 2 == 1) if self.lengths_first else True   # round 5's flow sends a lengths call in front of every data block
+            if data and self.stop:         # a data block whose peers are not known yet: pass 1 ends here (a lengths call before it is
                 raise _Stop()              # answered with this rank's own length for everybody: its buffer holds exactly its own rows)
             for o in out:
                 o.copy_(t)
@@ -85,15 +87,18 @@ class FakeDist:
 
 
 REPEATS = 2
+SHARD = "spatial"
 
 
 def run_world(pc, net, world, gen):
+    old = SHARD == "slices"
     store, log, ranks = {}, [], []
     cls_stats = []
     for r in range(world):      # pass 1: classify shares
         st = {}
         try:
-            pipeline.segment_plot(pc, net, generator=gen(), stats=st, dist=FakeDist(r, world, store, log) if world > 1 else None)
+            pipeline.segment_plot(pc, net, generator=gen(), stats=st, shard=SHARD,
+                                  dist=FakeDist(r, world, store, log, lengths_first=old) if world > 1 else None)
         except _Stop:
             torch.cuda.synchronize()
         cls_stats.append(st)
@@ -113,8 +118,8 @@ def run_world(pc, net, world, gen):
         st = None                # (a single run of a 0.05 - 0.3 s stage on a box that has just changed its clock is +-20 %)
         for _ in range(REPEATS):
             s1 = {}
-            d = FakeDist(r, world, store, [], stop=False)     # (the LAST exchange - the per-point results - is answered with the rank's own slice)
-            pipeline.segment_plot(pc, net, generator=gen(), stats=s1, dist=d)
+            d = FakeDist(r, world, store, [], stop=False, lengths_first=old)     # (the LAST exchange - the per-point results - is answered with the rank's own slice)
+            pipeline.segment_plot(pc, net, generator=gen(), stats=s1, dist=d, shard=SHARD)
             torch.cuda.synchronize()
             if st is None:
                 st = s1
@@ -123,14 +128,19 @@ def run_world(pc, net, world, gen):
                     st[key] = min(st[key], s1[key])
         # (classify_s includes the stand-in gather: a device copy)
         ranks.append({"rank": r, "voxelise_s": round(st["voxelise_s"], 4), "classify_s": round(st["classify_s"], 4),
-                      "backproject_s": round(st["backproject_s"], 4), "forwards": len(st["batch_points"]), "points": sum(st["batch_points"])})
-    blocks = store[1]
-    max_rows = max(int(b.shape[0]) for b in blocks.values())
-    ex1 = world * max_rows * blocks[0].shape[1] * blocks[0].element_size()            # padded all-gather of the classified points
-    ex2 = 0
-    if 3 in store:
-        b2 = store[3]
-        ex2 = world * max(int(b.shape[0]) for b in b2.values()) * b2[0].shape[1] * b2[0].element_size()
+                      "backproject_s": round(st["backproject_s"], 4), "forwards": len(st["batch_points"]), "points": sum(st["batch_points"]),
+                      "backproject_tiers": st.get("backproject_tiers")})
+    if old:
+        blocks = store[1]
+        max_rows = max(int(b.shape[0]) for b in blocks.values())
+        ex1 = world * max_rows * blocks[0].shape[1] * blocks[0].element_size()            # padded all-gather of the classified points
+        ex2 = 0
+        if 3 in store:
+            b2 = store[3]
+            ex2 = world * max(int(b.shape[0]) for b in b2.values()) * b2[0].shape[1] * b2[0].element_size()
+    else:   # two all-gathers of known sizes: the float32 probabilities, the (label, pwood) pairs
+        ex1 = world * max(int(b.numel()) for b in store[0].values()) * 4
+        ex2 = world * max(int(b.numel()) for b in store[1].values()) * 4 if 1 in store else 0
     ring = lambda nbytes: nbytes * (world - 1) / world / (XGMI_LINK_GBPS * 1e9)
     crit = max(x["voxelise_s"] + x["classify_s"] + x["backproject_s"] for x in ranks)
     cls = [x["classify_s"] for x in ranks]
@@ -146,9 +156,11 @@ def main():
     ap.add_argument("--worlds", default="1,2,4,8")
     ap.add_argument("--out", default=None)
     ap.add_argument("--repeats", type=int, default=2, help="runs per rank; every stage's fastest one counts")
+    ap.add_argument("--shard", default="spatial", choices=["spatial", "slices"], help="segment_plot's sharding of the back-projection")
     args = ap.parse_args()
-    global REPEATS
+    global REPEATS, SHARD
     REPEATS = max(1, args.repeats)
+    SHARD = args.shard
     dev = torch.device("cuda", 0)
     net = Net(num_classes=1, C=bench.C, k=bench.K_NBR)
     net.load_state_dict(weights.synth_state_dict(1, bench.C, seed=0), strict=True)
@@ -166,7 +178,9 @@ def main():
     doc = {"what": "predicted strong-scaling curve of BASELINE configs[3] (one plot, all ranks together), every rank's share measured in "
                    "turn on ONE MI355X through pipeline.segment_plot with a recording stand-in for torch.distributed",
            "points": args.points, "xgmi_ring_GBps_assumed": XGMI_LINK_GBPS, "runs_per_rank": REPEATS,
-           "replicated_per_rank": "voxelise, the search grid of ALL classified points (inside backproject_s)",
+           "shard": SHARD,
+           "replicated_per_rank": ("voxelise, the search grid of ALL classified points (inside backproject_s)" if SHARD == "slices" else
+                                   "voxelise, the x-order of the plot points and the voxels' x-ranges (inside backproject_s)"),
            "worlds": res}
     txt = json.dumps(doc, indent=1)
     print(txt)
