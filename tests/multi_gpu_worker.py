@@ -3,8 +3,8 @@
 Runs the two sharded entry points of the product over the real collective backend (``nccl`` = RCCL on ROCm) and compares
 them, bit for bit, with the single-process result computed on rank 0's GPU:
 
-* ``pipeline.segment_plot(dist=...)``  - LPT-sharded voxel batches, all-gather of the classified points, plot slices,
-                                          all-gather of labels / pwood;
+* ``pipeline.segment_plot(dist=...)``  - LPT-sharded voxel batches, all-gather of the probabilities, back-projection owned
+                                          by x-slabs of the plot, all-gather of labels / pwood;
 * ``predicter.classify_sharded``        - the sharded form of the reference's inference loop (predicter.py:193-213).
 
 ``--dry`` (CPU suite): gloo backend, a stand-in model and vote on the CPU - exercises this script's own logic where no
@@ -39,6 +39,18 @@ def _fake_collect(cls_xyz, cls_pred, cls_prob, query_xyz, any_wood=1.0, k=1):
     return cls_pred[j].clone(), cls_prob[j].clone()
 
 
+def _fake_collect_checked(cls_xyz, cls_pred, cls_prob, query_xyz, any_wood=1.0, k=1):
+    """... and the distance to that nearest point (the spatially sharded flow's exactness test at k = 1)."""
+    nq = query_xyz.shape[0]
+    if cls_xyz.shape[0] == 0 or nq == 0:
+        z = torch.zeros(nq)
+        return z, z.clone(), torch.full((nq,), float("inf"), dtype=torch.float64)
+    c64 = cls_xyz.to(torch.float64)
+    parts = [torch.cdist(q.to(torch.float64), c64).min(dim=1) for q in query_xyz.split(4096)]     # (chunk by chunk: never the full matrix)
+    dk, j = torch.cat([p.values for p in parts]), torch.cat([p.indices for p in parts])
+    return cls_pred[j].clone(), cls_prob[j].clone(), dk
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--dry", action="store_true")
@@ -53,6 +65,7 @@ def main():
         torch.set_num_threads(1)
         net = _FakeNet()
         pipeline.collect_predictions = _fake_collect
+        pipeline.collect_predictions_checked = _fake_collect_checked
         from oracle import preprocess as OP                    # the CPU stand-in of the voxeliser's HIP grid step
         from pointstowood_amd import preprocessing
         preprocessing.backend = OP.TensorBackend

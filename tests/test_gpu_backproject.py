@@ -219,3 +219,60 @@ def test_cell_start_table_and_search_through_it():
         a = [(r.clone(), n.clone(), d.clone()) for r, n, d in neighbours(c, qq, 64, cell)]
         b = [(r.clone(), n.clone(), d.clone()) for r, n, d in neighbours(c, qq, 64, cell, table_cells=0)]
         assert len(a) == len(b) and all(torch.equal(x, y) for ta, tb in zip(a, b) for x, y in zip(ta, tb))
+
+
+class _ReplayDist:
+    """torch.distributed for ONE rank of a pretended world on one GPU: all_gather records this rank's block per call index and
+    plays back the blocks the other ranks recorded in an earlier pass (a rank whose peers are unknown gets its own block back)."""
+    def __init__(self, rank, world, store):
+        self.rank, self.world, self.store, self.calls = rank, world, store, 0
+
+    def get_world_size(self, group=None):
+        return self.world
+
+    def get_rank(self, group=None):
+        return self.rank
+
+    def all_gather(self, out, t, group=None):
+        c, self.calls = self.calls, self.calls + 1
+        slot = self.store.setdefault(c, {})
+        slot[self.rank] = t.detach().clone()
+        for r in range(self.world):
+            out[r].copy_(slot.get(r, t))
+
+
+@pytest.mark.parametrize("world,halo", [(4, 1.0), (3, 0.05)])
+def test_spatially_sharded_backprojection_equals_one_process(world, halo):
+    """pipeline.segment_plot(shard="spatial") with the REAL stages (voxeliser, Net, grid kNN + float64 refinement + vote), every
+    rank's share run in turn on this GPU through a replaying stand-in for torch.distributed: pass 1 records every rank's
+    probabilities, pass 2 back-projects each rank's x-slab against its halo's voxels (wider tiers where the k-th neighbour could lie
+    outside), the assembled result equals the single-process labels and pwood BIT FOR BIT (k = 64 neighbour sets, ties by the
+    global index)."""
+    from pointstowood_amd import Net, pipeline
+    dev = torch.device("cuda")
+    net = Net(num_classes=1, C=8, k=16)
+    net.load_state_dict(weights.synth_state_dict(1, 8, seed=0), strict=True)
+    net = net.to(dev).eval()
+    pc = synth.forest_plot(400_000, seed=4, side=22.0).to(dev)
+    gen = lambda: torch.Generator(device=dev).manual_seed(0)
+    kw = dict(grid_sizes=(2.0, 4.0), min_pts=128, max_pts=16384, max_points=65536, max_voxels=64)
+    n_z1, label1, pwood1 = pipeline.segment_plot(pc, net, generator=gen(), **kw)
+    store = {}
+    for r in range(world):      # pass 1: the ranks' probabilities
+        pipeline.segment_plot(pc, net, generator=gen(), dist=_ReplayDist(r, world, store), halo=halo, **kw)
+    parts, tiers = [], []
+    for r in range(world):      # pass 2: with everybody's probabilities; the second exchange records the rank's results
+        st = {}
+        pipeline.segment_plot(pc, net, generator=gen(), dist=_ReplayDist(r, world, store), halo=halo, stats=st, **kw)
+        tiers.append(st["backproject_tiers"])
+    order_x = torch.argsort(pc[:, 0].to(torch.float32), stable=True)
+    from pointstowood_amd.dist import slice_for_rank
+    label, pwood = torch.empty_like(label1), torch.empty_like(pwood1)
+    for r in range(world):
+        q0, q1 = slice_for_rank(pc.shape[0], r, world)
+        both = store[1][r][: 2 * (q1 - q0)].view(-1, 2)
+        label[order_x[q0:q1]], pwood[order_x[q0:q1]] = both[:, 0], both[:, 1]
+    assert torch.equal(label, label1) and torch.equal(pwood, pwood1)
+    assert all(t[0][0] < t[-1][0] or len(t) == 1 for t in tiers)          # a wider tier holds more voxels
+    if halo < 0.1:
+        assert any(len(t) > 1 for t in tiers), tiers                        # a 5 cm halo cannot settle every query in the first tier

@@ -667,8 +667,9 @@ def _cpu_collect_checked(cls_xyz, cls_pred, cls_prob, query_xyz, any_wood=1.0, k
     if cls_xyz.shape[0] == 0 or nq == 0:
         z = torch.zeros(nq)
         return z, z.clone(), torch.full((nq,), float("inf"), dtype=torch.float64)
-    d = torch.cat([torch.cdist(q.to(torch.float64), cls_xyz.to(torch.float64)) for q in query_xyz.split(4096)])
-    dk, j = d.min(dim=1)
+    c64 = cls_xyz.to(torch.float64)
+    parts = [torch.cdist(q.to(torch.float64), c64).min(dim=1) for q in query_xyz.split(4096)]     # (chunk by chunk: never the full matrix)
+    dk, j = torch.cat([p.values for p in parts]), torch.cat([p.indices for p in parts])
     return cls_pred[j].clone(), cls_prob[j].clone(), dk
 
 
