@@ -177,7 +177,16 @@ def _backproject_spatial(pc, vox, lengths, batches, plan, batch_rows, prob_parts
         stats["classify_s"], t0 = time.perf_counter() - t0, time.perf_counter()
         stats["classified_points"] = int(prob_all.numel())
         stats["exchange_bytes"] = [4 * max(counts) * world]
-    # -- who owns what: plot points in ascending x, rank r the r-th share; voxels by their extent in x -----------------------
+    # -- who owns what: plot points in ascending x, rank r the r-th share; voxels by their bounding boxes ---------------------
+    tick = time.perf_counter()
+
+    def lap(key):
+        nonlocal tick
+        if stats is not None:
+            _sync(dev)
+            now = time.perf_counter()
+            stats.setdefault("backproject_parts_s", {})[key] = round(stats.get("backproject_parts_s", {}).get(key, 0.0) + now - tick, 4)
+            tick = now
     x = pc[:, 0].to(torch.float32)
     order_x = torch.argsort(x, stable=True)
     q0, q1 = slice_for_rank(n, rank, world)
@@ -188,47 +197,75 @@ def _backproject_spatial(pc, vox, lengths, batches, plan, batch_rows, prob_parts
     for v in vox_order:
         vstart[v], acc = acc, acc + lengths[v]
     vlen = torch.tensor(lengths, dtype=torch.int64, device=dev)
-    allx = torch.cat([v[:, 0] for v in vox]).to(torch.float32) if vox else torch.zeros(0, device=dev)
-    vx_lo = torch.segment_reduce(allx, "min", lengths=vlen).cpu().tolist()
-    vx_hi = torch.segment_reduce(allx, "max", lengths=vlen).cpu().tolist()
-    del allx
+    allp = torch.cat([v[:, :3] for v in vox]).to(torch.float32) if vox else torch.zeros((0, 3), device=dev)
+    box_lo = torch.segment_reduce(allp, "min", lengths=vlen)          # [V, 3] raw extent of every voxel
+    box_hi = torch.segment_reduce(allp, "max", lengths=vlen)
+    del allp
+    vx_lo, vx_hi = box_lo[:, 0].cpu().tolist(), box_hi[:, 0].cpu().tolist()
+    order_t = torch.tensor(vox_order, dtype=torch.int64, device=dev)
+    vstart_t = torch.tensor(vstart, dtype=torch.int64, device=dev)
+    lap("ownership")
     k = 32 if any_wood != 1 else 64
     label = torch.zeros(own.numel(), dtype=torch.float32, device=dev)
     pwood = torch.zeros(own.numel(), dtype=torch.float32, device=dev)
+    SLACK = 1e-3      # a classified coordinate is the voxel's raw one up to float32 rounding of the centring: 1 mm covers it
+
+    def search(sel, queries):
+        """Exact (label, pwood, k-th distance) of `queries` among the classified points of the voxels `sel` (ids in the
+        single-process order, so that distance ties break as they do there)."""
+        cxyz = _classified_xyz([vox[v] for v in sel])
+        ls = vlen[torch.tensor(sel, dtype=torch.int64, device=dev)]
+        first = torch.cumsum(ls, 0) - ls
+        rows = torch.repeat_interleave(vstart_t[torch.tensor(sel, dtype=torch.int64, device=dev)] - first, ls) + torch.arange(int(ls.sum()), device=dev)
+        cprob = prob_all[rows].contiguous()
+        cpred = (cprob >= is_wood).to(torch.float32)                                   # predicter.py:200
+        return collect_predictions_checked(cxyz, cpred, cprob, queries, any_wood=any_wood)
     if own.numel() and prob_all.numel():
         qxyz = pc[own, :3]
         qx = qxyz[:, 0].to(torch.float64)
         xlo, xhi = float(qx.min()), float(qx.max())
-        todo = torch.arange(own.numel(), device=dev)       # own queries not settled yet
-        h, tiers = float(halo), []
+        tiers = []
+        # tier 1: the slab.  Candidates = every voxel that reaches into [xlo - halo, xhi + halo] (all classified points inside that
+        # range are among them); a query is settled when its k-th neighbour is STRICTLY closer than the nearer end of the range
+        lo, hi = (xlo - halo if rank > 0 else -float("inf")), (xhi + halo if rank < world - 1 else float("inf"))
+        sel = [v for v in vox_order if vx_hi[v] >= lo - SLACK and vx_lo[v] <= hi + SLACK]
+        if sel:
+            lab, pw, dk = search(sel, qxyz)
+            ok = (dk < torch.minimum(qx - lo, hi - qx)) if len(sel) < len(vox_order) else torch.ones_like(dk, dtype=torch.bool)
+            label[ok], pwood[ok] = lab[ok], pw[ok]
+            todo = (~ok).nonzero(as_tuple=True)[0]
+        else:
+            todo = torch.arange(own.numel(), device=dev)
+        tiers.append((len(sel), int(own.numel()), int(todo.numel())))
+        lap("tier1")
+        # further tiers: the few queries left (isolated points whose k-th classified neighbour is metres away) against the voxels
+        # within R of THEM - every classified point within R of such a query is in one of those voxels, so a k-th distance < R
+        # settles it; R grows 4 x per tier until a tier holds every voxel (exact by definition)
+        R = max(4.0 * halo, 1.0)
         while todo.numel():
-            lo, hi = (xlo - h if rank > 0 else -float("inf")), (xhi + h if rank < world - 1 else float("inf"))
-            # (1 mm of slack: a classified coordinate is the voxel's raw one up to float32 rounding of the centring)
-            sel = [v for v in vox_order if vx_hi[v] >= lo - 1e-3 and vx_lo[v] <= hi + 1e-3]
+            qq = qxyz[todo].to(torch.float32)
+            near = torch.zeros(len(lengths), dtype=torch.bool, device=dev)
+            for part in qq.split(4096):      # [m, V] box-in-range tests
+                hit = ((box_lo[None, :, :] <= part[:, None, :] + (R + SLACK)) & (box_hi[None, :, :] >= part[:, None, :] - (R + SLACK))).all(dim=2)
+                near |= hit.any(dim=0)
+            sel_t = order_t[near[order_t]]
+            sel = sel_t.cpu().tolist()
             everything = len(sel) == len(vox_order)
             if sel:
-                cxyz = _classified_xyz([vox[v] for v in sel])
-                ls = torch.tensor([lengths[v] for v in sel], dtype=torch.int64, device=dev)
-                st = torch.tensor([vstart[v] for v in sel], dtype=torch.int64, device=dev)
-                first = torch.cumsum(ls, 0) - ls
-                rows = torch.repeat_interleave(st - first, ls) + torch.arange(int(ls.sum()), device=dev)
-                cprob = prob_all[rows].contiguous()
-                cpred = (cprob >= is_wood).to(torch.float32)                                   # predicter.py:200
-                lab, pw, dk = collect_predictions_checked(cxyz, cpred, cprob, qxyz[todo], any_wood=any_wood)
-                del cxyz, rows
+                lab, pw, dk = search(sel, qxyz[todo])
+                ok = torch.ones_like(dk, dtype=torch.bool) if everything else (dk < R)
+                label[todo[ok]], pwood[todo[ok]] = lab[ok], pw[ok]
+                left = todo[~ok]
             else:
-                lab = pw = torch.zeros(todo.numel(), dtype=torch.float32, device=dev)
-                dk = torch.full((todo.numel(),), float("inf"), dtype=torch.float64, device=dev)
-            # exact where the k-th neighbour is closer than the nearest end of the range this candidate set covers completely
-            # (strictly: a tie at the range's end could involve a point outside it); a set that holds everything is exact anyway
-            margin = torch.minimum(qx[todo] - lo, hi - qx[todo])
-            ok = torch.ones_like(dk, dtype=torch.bool) if everything else (dk < margin)
-            label[todo[ok]], pwood[todo[ok]] = lab[ok], pw[ok]
-            tiers.append((len(sel), int(todo.numel()), int((~ok).sum())))
-            todo = todo[~ok]
-            h *= 4.0
+                left = todo
+            tiers.append((len(sel), int(todo.numel()), int(left.numel())))
+            todo = left
+            R *= 4.0
+            if everything:
+                break
+        lap("further_tiers")
         if stats is not None:
-            stats["backproject_tiers"] = tiers      # (voxels in the candidate set, queries asked, queries left) per halo tier
+            stats["backproject_tiers"] = tiers      # (voxels in the candidate set, queries asked, queries left) per tier
     # -- exchange 2: the per-point results, rank-major = ascending x; back to input order ----------------------------------
     sizes = [slice_for_rank(n, r, world) for r in range(world)]
     both = gather_logits(torch.stack([label, pwood], 1).reshape(-1), dist, [2 * (b - a) for a, b in sizes]).view(-1, 2)

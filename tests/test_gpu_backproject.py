@@ -249,6 +249,7 @@ def test_spatially_sharded_backprojection_equals_one_process(world, halo):
     outside), the assembled result equals the single-process labels and pwood BIT FOR BIT (k = 64 neighbour sets, ties by the
     global index)."""
     from pointstowood_amd import Net, pipeline
+    from pointstowood_amd import synthetic_voxels as synth, synthetic_weights as weights
     dev = torch.device("cuda")
     net = Net(num_classes=1, C=8, k=16)
     net.load_state_dict(weights.synth_state_dict(1, 8, seed=0), strict=True)
