@@ -147,6 +147,25 @@ def segment_plot(pc, model, grid_sizes=(2.0, 4.0), min_pts: int = 128, max_pts: 
     return n_z, label, pwood
 
 
+def _x_slab_owners(x, world: int, bins: int = 4096):
+    """Ownership of the plot points by slabs in x with (nearly) equal point counts: slab boundaries at the bin edges of a
+    `bins`-bin histogram of x where the running count passes r / world (no sort of the plot), owner = the slab a point's x falls
+    into.  Returns (owner [n] uint8-like tensor, the per-rank index lists in input order).  Every rank computes the same thing."""
+    x = x.to(torch.float32)
+    n = x.numel()
+    lo, hi = float(x.min()), float(x.max())
+    if not (hi > lo) or world == 1:
+        owner = torch.zeros(n, dtype=torch.int64, device=x.device)
+    else:
+        width = (hi - lo) / bins
+        b = ((x - lo) / width).to(torch.int64).clamp_(0, bins - 1)
+        cum = torch.cumsum(torch.bincount(b, minlength=bins), 0)
+        targets = torch.tensor([n * r // world for r in range(1, world)], device=x.device)
+        edges = torch.searchsorted(cum, targets)            # slab r ends behind bin edges[r]
+        owner = torch.searchsorted(edges, b, right=False)   # bins <= edges[0] -> 0, ...
+    return owner, [(owner == r).nonzero(as_tuple=True)[0] for r in range(world)]
+
+
 def _classified_xyz(voxels):
     """Un-shifted float64 coordinates of the classified points of `voxels` (a list of voxel tensors), as the classify loop
     forms them (predicter.py:203-211: float32 centred position + float32 shift, added in float64).  Per-voxel arithmetic
@@ -187,20 +206,20 @@ def _backproject_spatial(pc, vox, lengths, batches, plan, batch_rows, prob_parts
             now = time.perf_counter()
             stats.setdefault("backproject_parts_s", {})[key] = round(stats.get("backproject_parts_s", {}).get(key, 0.0) + now - tick, 4)
             tick = now
-    x = pc[:, 0].to(torch.float32)
-    order_x = torch.argsort(x, stable=True)
-    q0, q1 = slice_for_rank(n, rank, world)
-    own = order_x[q0:q1]
+    owner, own_lists = _x_slab_owners(pc[:, 0], world)
+    own = own_lists[rank]
     # row of every voxel's first classified point in the single-process order, voxel ids in that order
     vox_order = [v for b in batches for v in b]
     vstart, acc = [0] * len(lengths), 0
     for v in vox_order:
         vstart[v], acc = acc, acc + lengths[v]
     vlen = torch.tensor(lengths, dtype=torch.int64, device=dev)
+    # raw bounding box of every voxel: one parallel min / max reduction over all voxels' rows (atomics, not a per-segment loop)
     allp = torch.cat([v[:, :3] for v in vox]).to(torch.float32) if vox else torch.zeros((0, 3), device=dev)
-    box_lo = torch.segment_reduce(allp, "min", lengths=vlen)          # [V, 3] raw extent of every voxel
-    box_hi = torch.segment_reduce(allp, "max", lengths=vlen)
-    del allp
+    seg = torch.repeat_interleave(torch.arange(len(lengths), device=dev), vlen, output_size=int(allp.shape[0]))
+    box_lo = torch.full((len(lengths), 3), float("inf"), device=dev).index_reduce_(0, seg, allp, "amin")
+    box_hi = torch.full((len(lengths), 3), -float("inf"), device=dev).index_reduce_(0, seg, allp, "amax")
+    del allp, seg
     vx_lo, vx_hi = box_lo[:, 0].cpu().tolist(), box_hi[:, 0].cpu().tolist()
     order_t = torch.tensor(vox_order, dtype=torch.int64, device=dev)
     vstart_t = torch.tensor(vstart, dtype=torch.int64, device=dev)
@@ -238,42 +257,45 @@ def _backproject_spatial(pc, vox, lengths, batches, plan, batch_rows, prob_parts
             todo = torch.arange(own.numel(), device=dev)
         tiers.append((len(sel), int(own.numel()), int(todo.numel())))
         lap("tier1")
-        # further tiers: the few queries left (isolated points whose k-th classified neighbour is metres away) against the voxels
-        # within R of THEM - every classified point within R of such a query is in one of those voxels, so a k-th distance < R
-        # settles it; R grows 4 x per tier until a tier holds every voxel (exact by definition)
-        R = max(4.0 * halo, 1.0)
+        # second tier: the few queries left (isolated points whose k-th classified neighbour is metres away).  Their k-th distance
+        # among the slab's candidates BOUNDS the true one from above (a subset's k-th neighbour is never closer), so the voxels that
+        # reach into the ball of that radius around the query hold its true k nearest: one more search settles them exactly.  A
+        # query that found fewer than k candidates at all has no bound: its radius grows 4 x per round, at most to everything.
+        R = dk[todo].clone() if sel else torch.full((todo.numel(),), float("inf"), dtype=torch.float64, device=dev)
+        grow = max(4.0 * halo, 1.0)
         while todo.numel():
+            Rq = torch.where(torch.isfinite(R), R * (1.0 + 1e-9), torch.full_like(R, grow)).to(torch.float32) + SLACK
             qq = qxyz[todo].to(torch.float32)
             near = torch.zeros(len(lengths), dtype=torch.bool, device=dev)
-            for part in qq.split(4096):      # [m, V] box-in-range tests
-                hit = ((box_lo[None, :, :] <= part[:, None, :] + (R + SLACK)) & (box_hi[None, :, :] >= part[:, None, :] - (R + SLACK))).all(dim=2)
+            for part, rad in zip(qq.split(4096), Rq.split(4096)):      # [m, V] box-reaches-ball tests (by the ball's bounding cube)
+                hit = ((box_lo[None, :, :] <= part[:, None, :] + rad[:, None, None]) & (box_hi[None, :, :] >= part[:, None, :] - rad[:, None, None])).all(dim=2)
                 near |= hit.any(dim=0)
-            sel_t = order_t[near[order_t]]
-            sel = sel_t.cpu().tolist()
+            sel = order_t[near[order_t]].cpu().tolist()
             everything = len(sel) == len(vox_order)
             if sel:
-                lab, pw, dk = search(sel, qxyz[todo])
-                ok = torch.ones_like(dk, dtype=torch.bool) if everything else (dk < R)
+                lab, pw, dk2 = search(sel, qxyz[todo])
+                ok = torch.ones_like(dk2, dtype=torch.bool) if everything else (torch.isfinite(R) | (dk2 < grow))
                 label[todo[ok]], pwood[todo[ok]] = lab[ok], pw[ok]
-                left = todo[~ok]
+                left, R = todo[~ok], torch.where(torch.isfinite(dk2), dk2, R)[~ok]
             else:
                 left = todo
             tiers.append((len(sel), int(todo.numel()), int(left.numel())))
             todo = left
-            R *= 4.0
+            grow *= 4.0
             if everything:
                 break
         lap("further_tiers")
         if stats is not None:
             stats["backproject_tiers"] = tiers      # (voxels in the candidate set, queries asked, queries left) per tier
-    # -- exchange 2: the per-point results, rank-major = ascending x; back to input order ----------------------------------
-    sizes = [slice_for_rank(n, r, world) for r in range(world)]
-    both = gather_logits(torch.stack([label, pwood], 1).reshape(-1), dist, [2 * (b - a) for a, b in sizes]).view(-1, 2)
+    # -- exchange 2: the per-point results, rank-major; back to input order ----------------------------------------------------
+    sizes = [int(o.numel()) for o in own_lists]
+    both = gather_logits(torch.stack([label, pwood], 1).reshape(-1), dist, [2 * c for c in sizes]).view(-1, 2)
+    where = torch.cat(own_lists)
     out_label = torch.empty(n, dtype=torch.float32, device=dev)
     out_pwood = torch.empty(n, dtype=torch.float32, device=dev)
-    out_label[order_x], out_pwood[order_x] = both[:, 0], both[:, 1]
+    out_label[where], out_pwood[where] = both[:, 0], both[:, 1]
     if stats is not None:
         _sync(dev)
         stats["backproject_s"] = time.perf_counter() - t0
-        stats["exchange_bytes"].append(8 * max(b - a for a, b in sizes) * world)
+        stats["exchange_bytes"].append(8 * max(sizes) * world)
     return n_z, out_label, out_pwood
