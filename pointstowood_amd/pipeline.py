@@ -74,7 +74,8 @@ def segment_plot(pc, model, grid_sizes=(2.0, 4.0), min_pts: int = 128, max_pts: 
     scalar (the ranks' least free memory) precedes them."""
     dev = pc.device
     t0 = time.perf_counter()
-    vox, n_z = voxelise(pc, tuple(grid_sizes), min_pts, max_pts, mode=mode, generator=generator, ground=ground)
+    cells = []
+    vox, n_z = voxelise(pc, tuple(grid_sizes), min_pts, max_pts, mode=mode, generator=generator, ground=ground, cells=cells)
     if stats is not None:
         _sync(dev)
         stats["voxelise_s"], t0 = time.perf_counter() - t0, time.perf_counter()
@@ -114,7 +115,7 @@ def segment_plot(pc, model, grid_sizes=(2.0, 4.0), min_pts: int = 128, max_pts: 
             # predicter.py:203-211: the un-shifted coordinates are float64 sums of the float32 position and shift
             xyz.append(d.pos.to(torch.float64) + d.local_shift.view(-1, 3)[d.batch].to(torch.float64))
     if spatial:
-        return _backproject_spatial(pc, vox, lengths, all_batches, plan, batch_rows, prob, n_z, is_wood, any_wood, halo, dist, stats, t0)
+        return _backproject_spatial(pc, vox, cells, lengths, all_batches, plan, batch_rows, prob, n_z, is_wood, any_wood, halo, dist, stats, t0)
     if xyz:
         cls = torch.cat([torch.cat(xyz), torch.cat(prob)[:, None].to(torch.float64)], 1)
     else:
@@ -153,7 +154,7 @@ def _x_slab_owners(x, world: int, bins: int = 4096):
     into.  Returns (owner [n] uint8-like tensor, the per-rank index lists in input order).  Every rank computes the same thing."""
     x = x.to(torch.float32)
     n = x.numel()
-    lo, hi = float(x.min()), float(x.max())
+    lo, hi = (float(v) for v in torch.aminmax(x)) if n else (0.0, 0.0)
     if not (hi > lo) or world == 1:
         owner = torch.zeros(n, dtype=torch.int64, device=x.device)
     else:
@@ -163,7 +164,9 @@ def _x_slab_owners(x, world: int, bins: int = 4096):
         targets = torch.tensor([n * r // world for r in range(1, world)], device=x.device)
         edges = torch.searchsorted(cum, targets)            # slab r ends behind bin edges[r]
         owner = torch.searchsorted(edges, b, right=False)   # bins <= edges[0] -> 0, ...
-    return owner, [(owner == r).nonzero(as_tuple=True)[0] for r in range(world)]
+    order = torch.argsort(owner.to(torch.uint8) if world <= 256 else owner, stable=True)      # one pass instead of `world` masks
+    counts = torch.bincount(owner, minlength=world).cpu().tolist()
+    return owner, list(order.split(counts))
 
 
 def _classified_xyz(voxels):
@@ -175,7 +178,7 @@ def _classified_xyz(voxels):
     return d.pos.to(torch.float64) + d.local_shift.view(-1, 3)[d.batch].to(torch.float64)
 
 
-def _backproject_spatial(pc, vox, lengths, batches, plan, batch_rows, prob_parts, n_z, is_wood, any_wood, halo, dist, stats, t0):
+def _backproject_spatial(pc, vox, cells, lengths, batches, plan, batch_rows, prob_parts, n_z, is_wood, any_wood, halo, dist, stats, t0):
     """The sharded back-projection with spatial ownership (see segment_plot).  Exchanges: ONE all-gather of the float32
     probabilities (sizes known to everyone from the plan), ONE all-gather of (label, pwood) (sizes known from the plot size)."""
     dev, n = pc.device, pc.shape[0]
@@ -214,12 +217,13 @@ def _backproject_spatial(pc, vox, lengths, batches, plan, batch_rows, prob_parts
     for v in vox_order:
         vstart[v], acc = acc, acc + lengths[v]
     vlen = torch.tensor(lengths, dtype=torch.int64, device=dev)
-    # raw bounding box of every voxel: one parallel min / max reduction over all voxels' rows (atomics, not a per-segment loop)
-    allp = torch.cat([v[:, :3] for v in vox]).to(torch.float32) if vox else torch.zeros((0, 3), device=dev)
-    seg = torch.repeat_interleave(torch.arange(len(lengths), device=dev), vlen, output_size=int(allp.shape[0]))
-    box_lo = torch.full((len(lengths), 3), float("inf"), device=dev).index_reduce_(0, seg, allp, "amin")
-    box_hi = torch.full((len(lengths), 3), -float("inf"), device=dev).index_reduce_(0, seg, allp, "amax")
-    del allp, seg
+    # a box that holds every voxel: all of a voxel's points share one xyz cell of its grid, so they lie within the grid's cell size
+    # of any one of them (preprocessing.voxelise hands out the first row of every voxel and the size of its grid)
+    first = torch.cat([f for f, _ in cells]).to(torch.float32)
+    size = torch.cat([torch.full((f.shape[0], 1), sz, dtype=torch.float32, device=dev) for f, sz in cells])
+    if first.shape[0] != len(lengths):
+        raise RuntimeError("voxeliser cells and voxel list disagree")
+    box_lo, box_hi = first - size, first + size
     vx_lo, vx_hi = box_lo[:, 0].cpu().tolist(), box_hi[:, 0].cpu().tolist()
     order_t = torch.tensor(vox_order, dtype=torch.int64, device=dev)
     vstart_t = torch.tensor(vstart, dtype=torch.int64, device=dev)

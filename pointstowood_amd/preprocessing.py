@@ -104,13 +104,17 @@ backend = HipBackend   # (tests of the host-side logic on the CPU put oracle.pre
 
 
 def voxelise(pc, grid_sizes=(2.0, 4.0), min_pts: int = 128, max_pts: int = 16384, mode: str = "compat", generator=None,
-             ground: bool = True):
+             ground: bool = True, cells: list | None = None):
     """pc: [N, >=4] (x, y, z, reflectance, ...).  Returns (voxels, n_z): ``voxels`` is a list of ``[n, cols+1]`` float32
     tensors on ``pc.device`` in the reference's order (grid size major, ascending cell id).
 
     ``ground=False`` is the reference's branch for input that already carries an ``n_z`` column (any ``*_ours.ply``
     written by this tool or the reference does): ``gpu_ground`` is skipped, the columns are binned as they come and the
-    LAST column is returned as n_z (preprocessing.py:81-86,127) - no second height column is appended."""
+    LAST column is returned as n_z (preprocessing.py:81-86,127) - no second height column is appended.
+
+    ``cells`` (a list, optional) receives one ``(first_xyz [v, 3], size)`` pair per grid size: a point of every voxel of that
+    grid (all of a voxel's points share its xyz cell, so the voxel lies within ``size`` of that point on every axis) - what
+    the spatially sharded back-projection selects voxels by."""
     if mode not in ("compat", "xyz"):
         raise ValueError("mode must be 'compat' or 'xyz'")
     pos = ground_normalise(pc.to(torch.float32)) if ground else pc.to(torch.float32).clone()
@@ -130,6 +134,11 @@ def voxelise(pc, grid_sizes=(2.0, 4.0), min_pts: int = 128, max_pts: int = 16384
             continue
         ends = starts + counts - 1
         nan_cnt = nan_before[ends] + nan_row[ends].to(torch.int64) - nan_before[starts]
+        if cells is not None:     # (a NaN first row would poison the box: take the voxel's row-wise nanmin-free choice = its first finite row)
+            first = gathered[starts, :3]
+            if bool(torch.isnan(first).any()):
+                first = torch.stack([gathered[s:s + c, :3][~torch.isnan(gathered[s:s + c, :3]).any(dim=1)][0] for s, c in zip(starts.tolist(), counts.tolist())])
+            cells.append((first, float(size)))
         for s, c, bad in zip(starts.tolist(), counts.tolist(), nan_cnt.tolist()):
             if c <= max_pts and bad == 0:
                 voxels.append(gathered[s:s + c])
