@@ -217,13 +217,11 @@ def _backproject_spatial(pc, vox, cells, lengths, batches, plan, batch_rows, pro
     for v in vox_order:
         vstart[v], acc = acc, acc + lengths[v]
     vlen = torch.tensor(lengths, dtype=torch.int64, device=dev)
-    # a box that holds every voxel: all of a voxel's points share one xyz cell of its grid, so they lie within the grid's cell size
-    # of any one of them (preprocessing.voxelise hands out the first row of every voxel and the size of its grid)
-    first = torch.cat([f for f, _ in cells]).to(torch.float32)
-    size = torch.cat([torch.full((f.shape[0], 1), sz, dtype=torch.float32, device=dev) for f, sz in cells])
-    if first.shape[0] != len(lengths):
+    # a box that holds every voxel: its xyz grid cell (preprocessing.voxelise hands the cells out with the voxels)
+    box_lo = torch.cat([a for a, _ in cells]).to(torch.float32)
+    box_hi = torch.cat([b for _, b in cells]).to(torch.float32)
+    if box_lo.shape[0] != len(lengths):
         raise RuntimeError("voxeliser cells and voxel list disagree")
-    box_lo, box_hi = first - size, first + size
     vx_lo, vx_hi = box_lo[:, 0].cpu().tolist(), box_hi[:, 0].cpu().tolist()
     order_t = torch.tensor(vox_order, dtype=torch.int64, device=dev)
     vstart_t = torch.tensor(vstart, dtype=torch.int64, device=dev)

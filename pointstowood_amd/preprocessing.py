@@ -112,9 +112,10 @@ def voxelise(pc, grid_sizes=(2.0, 4.0), min_pts: int = 128, max_pts: int = 16384
     written by this tool or the reference does): ``gpu_ground`` is skipped, the columns are binned as they come and the
     LAST column is returned as n_z (preprocessing.py:81-86,127) - no second height column is appended.
 
-    ``cells`` (a list, optional) receives one ``(first_xyz [v, 3], size)`` pair per grid size: a point of every voxel of that
-    grid (all of a voxel's points share its xyz cell, so the voxel lies within ``size`` of that point on every axis) - what
-    the spatially sharded back-projection selects voxels by."""
+    ``cells`` (a list, optional) receives one ``(box_lo [v, 3], box_hi [v, 3])`` pair per grid size: the xyz cell of every
+    voxel of that grid (all of a voxel's points share it: the grid's own arithmetic - column minimum, fp32 subtract / divide /
+    truncate - on the voxel's first row, widened by a thousandth of the cell size) - what the spatially sharded
+    back-projection selects voxels by."""
     if mode not in ("compat", "xyz"):
         raise ValueError("mode must be 'compat' or 'xyz'")
     pos = ground_normalise(pc.to(torch.float32)) if ground else pc.to(torch.float32).clone()
@@ -134,11 +135,13 @@ def voxelise(pc, grid_sizes=(2.0, 4.0), min_pts: int = 128, max_pts: int = 16384
             continue
         ends = starts + counts - 1
         nan_cnt = nan_before[ends] + nan_row[ends].to(torch.int64) - nan_before[starts]
-        if cells is not None:     # (a NaN first row would poison the box: take the voxel's row-wise nanmin-free choice = its first finite row)
-            first = gathered[starts, :3]
-            if bool(torch.isnan(first).any()):
-                first = torch.stack([gathered[s:s + c, :3][~torch.isnan(gathered[s:s + c, :3]).any(dim=1)][0] for s, c in zip(starts.tolist(), counts.tolist())])
-            cells.append((first, float(size)))
+        if cells is not None:
+            table = pos if mode == "compat" else pos[:, :3]
+            finite = torch.isfinite(table).all(dim=1)                       # rows with a non-finite value take no part in the grid's minima
+            lo3 = torch.where(finite[:, None], table[:, :3], torch.full_like(table[:, :3], float("inf"))).amin(dim=0)
+            first = gathered[starts, :3]          # (a kept run never starts with a non-finite row: those share the key that sorts last)
+            c = ((first - lo3) / float(size)).to(torch.int64).to(torch.float32)
+            cells.append((lo3 + c * float(size) - 1e-3 * float(size), lo3 + (c + 1.0) * float(size) + 1e-3 * float(size)))
         for s, c, bad in zip(starts.tolist(), counts.tolist(), nan_cnt.tolist()):
             if c <= max_pts and bad == 0:
                 voxels.append(gathered[s:s + c])

@@ -258,6 +258,15 @@ def test_spatially_sharded_backprojection_equals_one_process(world, halo):
     gen = lambda: torch.Generator(device=dev).manual_seed(0)
     kw = dict(grid_sizes=(2.0, 4.0), min_pts=128, max_pts=16384, max_points=65536, max_voxels=64)
     n_z1, label1, pwood1 = pipeline.segment_plot(pc, net, generator=gen(), **kw)
+    # the voxel cells the flow selects candidates by hold every point of their voxel
+    from pointstowood_amd.preprocessing import voxelise
+    cells = []
+    vox, _ = voxelise(pc, (2.0, 4.0), 128, 16384, generator=gen(), cells=cells)
+    lo, hi = torch.cat([a for a, _ in cells]), torch.cat([b for _, b in cells])
+    seg = torch.repeat_interleave(torch.arange(len(vox), device=dev), torch.tensor([v.shape[0] for v in vox], device=dev))
+    allp = torch.cat([v[:, :3] for v in vox])
+    assert lo.shape[0] == len(vox) and bool(((allp >= lo[seg]) & (allp <= hi[seg])).all())
+    assert float((hi - lo).max()) < 4.02 and float((hi - lo).min()) > 2.0
     store = {}
     for r in range(world):      # pass 1: the ranks' probabilities
         pipeline.segment_plot(pc, net, generator=gen(), dist=_ReplayDist(r, world, store), halo=halo, **kw)
