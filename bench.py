@@ -24,7 +24,7 @@ inside the timed region either way.  Rank 0 prints ONE JSON line.
 ``roofline`` is measured live: after the timed regions one extra, sequential step is run with HIP
 events around every run of consecutive launches of one kernel class (on the launch stream) and the
 dominant kernel's algorithmic FLOPs are divided by its measured time; ``traffic`` comes from the
-committed rocprofv3 PMC summary of the same command (``profiles/r5_<precision>_hbm_traffic.json``).
+committed rocprofv3 PMC summary of the same command (``profiles/r6_<precision>_hbm_traffic.json``).
 ``hbm_kernels`` gives the memory-bound kernels' algorithmic bytes / measured time
 against the 8 TB/s HBM peak.  ``cpu_baseline`` times the CPU oracle (``oracle/net.py``, a port of
 the reference forward pinned to the reference's own outputs) on a bounded sample of batch 0.
@@ -47,7 +47,7 @@ sys.path.insert(0, ROOT)
 PEAK_TFLOPS = {"fp32": 157.3, "f16x3": 2500.0, "fp16": 2500.0, "bf16": 2500.0}
 PEAK_HBM_GBPS = 8000.0
 C, K_NBR, BATCH, NPTS = 32, 32, 8, 16384
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r5_{precision}_hbm_traffic.json")   # written by tools/profile_round.sh
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r6_{precision}_hbm_traffic.json")   # written by tools/profile_round.sh
 
 
 def parse_args(argv=None):
@@ -193,10 +193,16 @@ def search_pairs(geo):
 # 2 adds per pair (oracle/ops.py's ((dx*dx)+(dy*dy))+(dz*dz), no FMA) = 8 FLOP; the compare / insertion is not counted
 PEAK_PAIRS_PER_S = 157.3e12 / 8.0
 
-SEARCH_EVAL_FILE = os.path.join(ROOT, "profiles", "r5_search_evaluated.json")
-MFMA_BUSY_FILE = os.path.join(ROOT, "profiles", "r5_{precision}_mfma_busy.csv")
+SEARCH_EVAL_FILE = os.path.join(ROOT, "profiles", "r6_search_evaluated.json")
+MFMA_BUSY_FILE = os.path.join(ROOT, "profiles", "r6_{precision}_mfma_busy.csv")
 
 KERNEL_OF = {"gemm_hoist": "gemm_kernel", "gemm_res": "gemm_kernel", "gemm_mlp": "gemm_kernel", "sa_conv": "sa_conv_kernel"}
+
+
+def _geom_hash():
+    """sha256 of the geometry kernels' source (the file the search kernels live in)."""
+    import hashlib
+    return hashlib.sha256(open(os.path.join(ROOT, "pointstowood_amd", "csrc", "p2w_geom.hip"), "rb").read()).hexdigest()[:16]
 
 
 def profile_step(net, data, reps=3):
@@ -786,12 +792,15 @@ def main():
         hbm = hbm_kernels(per, geo, net.engine_options)
         pairs = search_pairs(geo)
         # The searches against the fp32 VALU peak: the roofline figure counts the distance evaluations the grid kernels PERFORM
-        # (profiles/r5_search_evaluated.json: counted in a -DP2W_SLAB_PROFILE build on this workload's batch 0); the reference's
+        # (profiles/r6_search_evaluated.json: counted in a -DP2W_SLAB_PROFILE build on this workload's batch 0); the reference's
         # brute-force definition (queries x candidates per voxel) is what the kernels save, reported as a ratio, not as a fraction.
         evaluated, ev_src = {}, None
         try:
             ev = json.load(open(SEARCH_EVAL_FILE))
-            evaluated, ev_src = ev.get("evaluated_pairs_per_step", {}), os.path.relpath(SEARCH_EVAL_FILE, ROOT)
+            from pointstowood_amd import build as _build
+            # counted on one diagnostic build of the geometry kernels: only valid for the sources it was counted on
+            if ev.get("geom_srchash") in (None, _geom_hash()):
+                evaluated, ev_src = ev.get("evaluated_pairs_per_step", {}), os.path.relpath(SEARCH_EVAL_FILE, ROOT)
         except (OSError, ValueError):
             pass
         search = {"unit": "candidate-distance evaluations/s", "peak": PEAK_PAIRS_PER_S,

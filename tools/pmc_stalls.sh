@@ -4,7 +4,7 @@
 #   wait_pct = SQ_WAIT_ANY / SQ_WAVE_CYCLES, wait_inst = SQ_WAIT_INST_ANY / .., wait_lds = SQ_WAIT_INST_LDS / ..,
 #   active: LDS / VMEM / VALU / scalar instruction-active shares, MFMA busy and MFMA-VALU co-execution, VMEM level per instruction
 set -u
-TAG=${TAG:-r5}
+TAG=${TAG:-r6}
 export TMPDIR=/tmp
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/pmc_stalls

@@ -5,13 +5,13 @@
 #                                             FETCH_SIZE / WRITE_SIZE, MFMA busy, VALU issue counters
 #   tools/profile_round.sh config2|config4|surface   the named workload, 3 sequential forwards: kernel stats, FETCH / WRITE, MFMA busy
 set -u
-TAG=${TAG:-r5}
+TAG=${TAG:-r6}
 WHAT=${1:-bench}
 PREC=${2:-f16x3}
 export TMPDIR=/tmp
 ROOT=$(pwd)
 if [ "$WHAT" = "bench" ]; then
-  NAME=$PREC; FWD=24   # forwards per sequential process: 8 allocator-sizing + 2 warmup + 10 steps + 4 of the profiled step (1 untimed + 3)
+  NAME=$PREC; FWD=42   # forwards per sequential process: 8 allocator-sizing + 2 warmup + 10 steps + 18 of the single_call region (8 + 10) + 4 of the profiled step (1 untimed + 3)
   CMD="$ROOT/bench.py --no-cpu-baseline --no-pcie --no-workloads --steps 10 --warmup 2 --precision $PREC"
   SEQ="--pipeline 0"
 else

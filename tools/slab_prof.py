@@ -12,7 +12,7 @@ from pointstowood_amd import _lib as _libmod
 from pointstowood_amd._lib import lib
 import json
 JSON_OUT = None
-if "--json" in sys.argv:   # also write {kernel class: distance evaluations per forward} (bench.py reads profiles/r5_search_evaluated.json)
+if "--json" in sys.argv:   # also write {kernel class: distance evaluations per forward} (bench.py reads profiles/r6_search_evaluated.json)
     i = sys.argv.index("--json")
     JSON_OUT = sys.argv[i + 1]
     del sys.argv[i:i + 2]
@@ -49,7 +49,7 @@ def call(self, name, fn, *args):
 E.Engine._call = call
 net(data)
 if JSON_OUT:
-    json.dump({"workload": "BASELINE configs[1] batch 0 (B = 8 x 16384, k = 32)", "what": "candidate-distance evaluations the grid searches "
+    json.dump({"geom_srchash": bench._geom_hash(), "workload": "BASELINE configs[1] batch 0 (B = 8 x 16384, k = 32)", "what": "candidate-distance evaluations the grid searches "
                "actually perform per forward (sum over passes of staged candidates x active queries of the workgroup: wave 0's count x 4 waves), counted in a "
                "-DP2W_SLAB_PROFILE build", "evaluated_pairs_per_step": evaluated}, open(JSON_OUT, "w"), indent=1)
     print("wrote", JSON_OUT)
