@@ -73,6 +73,9 @@ def parse_args(argv=None):
                          "configs[3], ONE synthetic plot voxelised, classified and back-projected by all ranks together (strong scaling)")
     ap.add_argument("--plot-points", type=int, default=10_000_000, help="--workload plot: points of the synthetic plot")
     ap.add_argument("--no-pcie", action="store_true", help="skip the second (H2D/D2H-inclusive) timed region")
+    ap.add_argument("--no-single-call", action="store_true",
+                    help="skip the `single_call` region (lone forwards, searches beside the features): profiling runs whose per-kernel "
+                         "durations must be those of one kernel at a time")
     ap.add_argument("--pipeline", type=int, default=1,
                     help="1: two-stream pipeline over the step sequence (default); 0: strictly sequential forwards")
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "fp16", "bf16", "fp32"],
@@ -753,7 +756,7 @@ def main():
     # waits for every step's logits before it issues the next (no cross-batch pipeline; inside the forward the searches run beside
     # the features - EngineOptions.overlap)
     single_call = None
-    if world == 1:
+    if world == 1 and not args.no_single_call:
         for d in resident:
             net(d)
         torch.cuda.synchronize()
@@ -869,7 +872,7 @@ def main():
         })
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(full=not args.cpu_baseline_voxel0, sweep_threads=args.cpu_baseline_sweep)
-        if world == 1:
+        if single_call is not None:
             line["single_call"] = single_call
         # `value` is measured with the inputs resident in HBM, as the bench contract requires; SURVEY.md 8(d) words the metric "incl.
         # H2D/D2H": the same steps fed from pinned host memory with the logits copied back inside the region are `pcie_inclusive`

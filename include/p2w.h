@@ -388,8 +388,9 @@ int32_t p2w_gemm_h2_rowdot(int32_t prec, const void* A_h, int32_t ldh_a, const v
                            int32_t K, const p2w_epilogue* epi, const float* dot_w, float dot_b, float* out, void* ws,
                            size_t ws_bytes, int32_t flags, p2w_stream_t stream);
 /* p2w_sa_conv with H weights W2h and fp32 and/or H outputs.  P (the hoisted layer-1 product, fp32) has n_src + 1 rows of
- * ldp >= round_up(C1, K granularity) floats: rows 0..n_src-1 = x_src * W1x^T + b1 with ZERO pad columns, row n_src all
- * zero (the row empty neighbour slots read; the kernel's loads are unconditional).
+ * ldp >= round_up(C1, K granularity) floats: rows 0..n_src-1 = x_src * W1x^T + b1 with ZERO pad columns; row n_src is the row
+ * empty neighbour slots read (the kernel's loads are unconditional): it must EXIST, the call fills it with zeros itself (the only
+ * write through P).
  * ws: 16-byte aligned scratch of >= p2w_sa_conv_h_ws_bytes(M, flags) bytes for the per-edge metadata (P2W_EWORKSPACE otherwise);
  * kw <= 32 (one 32-row MFMA tile per target); round_up(C1, K granularity) <= 512, C2 <= 1024 (LDS tables), M < 2^25 and
  * (n_src + 1) * ldp < 2^33 (32-bit offsets) - P2W_EUNSUPPORTED otherwise. */

@@ -442,8 +442,10 @@ __global__ __launch_bounds__(256) void sa_edge_meta_kernel(const float4* __restr
                                                            const int* __restrict__ nbr, const int* __restrict__ deg, int kw,
                                                            int M, int n_src, int ldp4, int G, const int* __restrict__ list,
                                                            const int* __restrict__ n_list_dev, const int* __restrict__ src_row,
-                                                           int* __restrict__ meta_j, float4* __restrict__ meta_g, int* __restrict__ desc) {
+                                                           int* __restrict__ meta_j, float4* __restrict__ meta_g, int* __restrict__ desc,
+                                                           float4* __restrict__ zero_row) {
     const long g = (long)blockIdx.x * 256 + threadIdx.x;
+    if (zero_row && g < ldp4) zero_row[g] = make_float4(0.f, 0.f, 0.f, 0.f);   // P's row n_src: what empty neighbour slots gather (ldp4 <= 128 < 256)
     const int n_groups = list ? *n_list_dev : M;                 // slot groups that have a target
     const int gpt = 32 / G;
     const long n_tiles = ((long)n_groups + gpt - 1) / gpt;

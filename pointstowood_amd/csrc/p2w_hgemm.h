@@ -1847,7 +1847,8 @@ __global__ __launch_bounds__(512, 2) void sa_conv16p_kernel(const float* __restr
 __global__ __launch_bounds__(256) void sa_edge_meta_kernel(const float4* __restrict__ xyzr, const int* __restrict__ idx, const int* __restrict__ batch_dst,
                                     const float* __restrict__ sf, const int* __restrict__ nbr, const int* __restrict__ deg, int kw,
                                     int M, int n_src, int ldp4, int G, const int* __restrict__ list, const int* __restrict__ n_list_dev,
-                                    const int* __restrict__ src_row, int* __restrict__ meta_j, float4* __restrict__ meta_g, int* __restrict__ desc);
+                                    const int* __restrict__ src_row, int* __restrict__ meta_j, float4* __restrict__ meta_g, int* __restrict__ desc,
+                                    float4* __restrict__ zero_row);
 constexpr int SA_PART_BLOCK = 1024;
 __global__ __launch_bounds__(SA_PART_BLOCK) void sa_part_count_kernel(const int* __restrict__ deg, int kw, int M, int* __restrict__ blk_small);
 __global__ __launch_bounds__(1024) void sa_part_scan_kernel(int* __restrict__ blk_small, int nblk, int M, int* __restrict__ counts);
@@ -1889,8 +1890,10 @@ static int32_t launch_sa_conv_h(const float* P, int32_t ldp, int32_t n_src, cons
                    int* desc) {
         constexpr int G = decltype(g_c)::value;
         const long rows_max = tiles_max * 32;
+        // (the pre-pass also zeroes P's row n_src - the row empty neighbour slots gather: the caller need not)
         sa_edge_meta_kernel<<<p2w_cdiv(rows_max, 256), 256, 0, stream>>>(x4, idx, batch_dst, sf, nbr, deg, kw, M, n_src, ldp / 4, G,
-                                                                       list, n_list_dev, src_row, meta_j, meta_g, desc);
+                                                                       list, n_list_dev, src_row, meta_j, meta_g, desc,
+                                                                       reinterpret_cast<float4*>(const_cast<float*>(P) + (size_t)n_src * ldp));
         const long items = p2w_cdiv(tiles_max, tpi) * nNt3;
         int grid = (int)(items < n_cu ? items : n_cu);
         if (grid >= 8) grid &= ~7;   // whole XCD rounds (see the kernel's work assignment)

@@ -763,8 +763,7 @@ class Engine:
         ka = 32 if self.prec == PREC_F16X3 else 64
         C1 = p["C1"]
         C1p = (C1 + ka - 1) // ka * ka
-        P = torch.empty((n_src + 1, C1p), dtype=torch.float32, device=xh_src.device)
-        P[n_src].zero_()
+        P = torch.empty((n_src + 1, C1p), dtype=torch.float32, device=xh_src.device)     # (row n_src: zeroed by p2w_sa_conv_h's pre-pass)
         if C1p != C1:
             P[:, C1:].zero_()
         self._gemm_h2("gemm_hoist", xh_src, pitch_src, n_src, p["hoist"], out_f32=P, ldo=C1p, watch=f"hoist{l}")
@@ -907,7 +906,11 @@ class Engine:
         nbr4 = torch.empty(M3, dtype=torch.int32, device=dev)
         deg4 = torch.empty(M3, dtype=torch.int32, device=dev)
         self._call("fill_batch_nbr", L.p2w_fill_batch_nbr, ptr(lv[3].batch), M3, ptr(nbr4), ptr(deg4))
-        zeros_c = torch.zeros((B, 4), dtype=torch.float32, device=dev)
+        zc = self.__dict__.setdefault("_zeros_c", {})      # the pooled level's positions (model.py:138: zeros): one constant per batch size
+        if (B, dev) not in zc:
+            zc[(B, dev)] = torch.zeros((B, 4), dtype=torch.float32, device=dev)
+            torch.cuda.current_stream().synchronize()      # (once per batch size: later phases on other streams read it without an event)
+        zeros_c = zc[(B, dev)]
         # Row-chunked chains: interpolate -> MLP layer 0 -> MLP layer 1 (-> head for fp1) run chunk by chunk so the wide
         # intermediates of a chunk are consumed out of the Infinity Cache (same trick as the residual blocks).
         y, y_xyzr, y_h = g, zeros_c, None      # coarse features (fp32), their positions, their H form (where the next module hoists)

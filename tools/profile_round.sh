@@ -11,8 +11,8 @@ PREC=${2:-f16x3}
 export TMPDIR=/tmp
 ROOT=$(pwd)
 if [ "$WHAT" = "bench" ]; then
-  NAME=$PREC; FWD=42   # forwards per sequential process: 8 allocator-sizing + 2 warmup + 10 steps + 18 of the single_call region (8 + 10) + 4 of the profiled step (1 untimed + 3)
-  CMD="$ROOT/bench.py --no-cpu-baseline --no-pcie --no-workloads --steps 10 --warmup 2 --precision $PREC"
+  NAME=$PREC; FWD=24   # forwards per sequential process: 8 allocator-sizing + 2 warmup + 10 steps + 4 of the profiled step (1 untimed + 3)
+  CMD="$ROOT/bench.py --no-cpu-baseline --no-pcie --no-single-call --no-workloads --steps 10 --warmup 2 --precision $PREC"
   SEQ="--pipeline 0"
 else
   NAME=$WHAT; FWD=3
