@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/lds_pass
 rm -rf $OUT; mkdir -p $OUT
-CMD="$ROOT/bench.py --no-cpu-baseline --no-pcie --no-single-call --no-workloads --steps 6 --warmup 2 --pipeline 0 --engine-opt overlap=0 ${BENCH_EXTRA:-}"
+CMD="$ROOT/bench.py --no-cpu-baseline --no-pcie --no-single-call --no-workloads --steps 6 --warmup 2 --pipeline 0 --engine-opt overlap=0 --engine-opt single_res_streams=1 ${BENCH_EXTRA:-}"
 cd /tmp
 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d $OUT/c -- python3 $CMD > $OUT/c.json 2> $OUT/c.err
 cd $ROOT

@@ -13,7 +13,7 @@ ROOT=$(pwd)
 if [ "$WHAT" = "bench" ]; then
   NAME=$PREC; FWD=24   # forwards per sequential process: 8 allocator-sizing + 2 warmup + 10 steps + 4 of the profiled step (1 untimed + 3)
   CMD="$ROOT/bench.py --no-cpu-baseline --no-pcie --no-single-call --no-workloads --steps 10 --warmup 2 --precision $PREC"
-  SEQ="--pipeline 0 --engine-opt overlap=0"
+  SEQ="--pipeline 0 --engine-opt overlap=0 --engine-opt single_res_streams=1"
 else
   NAME=$WHAT; FWD=3
   CMD="$ROOT/tools/run_workload.py $WHAT 3 $PREC"

@@ -55,8 +55,8 @@ for mode in ("pipe", "seq"):
     fwd_mode = forwards + (1 if (mode == "pipe" and "bench.py" in command) else 0)
     with open(os.path.join(root, f"{tag}_{prec}_{mode}_kernel_stats.csv"), "w", newline="") as f:
         w = csv.writer(f)
-        cmd = re.sub(r"\S*/(bench\.py|tools/run_workload\.py)", r"\1", command).replace(" --pipeline 0", "").replace(" --engine-opt overlap=0", "") or "bench.py"
-        w.writerow([f"# rocprofv3 --kernel-trace --stats of: python3 {cmd}" + (" --pipeline 0 --engine-opt overlap=0" if (mode == "seq" and "bench.py" in cmd) else "")
+        cmd = re.sub(r"\S*/(bench\.py|tools/run_workload\.py)", r"\1", command).replace(" --pipeline 0", "").replace(" --engine-opt overlap=0 --engine-opt single_res_streams=1", "") or "bench.py"
+        w.writerow([f"# rocprofv3 --kernel-trace --stats of: python3 {cmd}" + (" --pipeline 0 --engine-opt overlap=0 --engine-opt single_res_streams=1" if (mode == "seq" and "bench.py" in cmd) else "")
                     + f" ({int(fwd_mode)} forwards per process)"])
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "per_forward_us"])
         for r in rows:
