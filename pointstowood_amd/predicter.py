@@ -281,8 +281,9 @@ def prefetch_batches(dataset, batches, pin: bool = True, workers: int = 1, ahead
     from concurrent.futures import ThreadPoolExecutor
 
     def build(b):
-        out = Batch.from_data_list([dataset[i] for i in b])
-        return out.pin_memory() if pin else out
+        with serial_host_ops():      # ... the pinned copies too: a parallel memcpy of a few MB wakes the whole OpenMP team
+            out = Batch.from_data_list([dataset[i] for i in b])
+            return out.pin_memory() if pin else out
     batches = list(batches)
     with ThreadPoolExecutor(max_workers=max(1, min(workers, len(batches)))) as pool:
         pending = collections.deque()
