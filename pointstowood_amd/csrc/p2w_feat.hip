@@ -917,7 +917,7 @@ extern "C" int32_t p2w_rowdot(const float* x, int32_t ldx, int32_t F, const floa
 }
 
 // ------------------------------------------------------------------------------------------------
-extern "C" int32_t p2w_version(void) { return 500; }
+extern "C" int32_t p2w_version(void) { return 600; }
 
 extern "C" const char* p2w_strerror(int32_t code) {
     switch (code) {

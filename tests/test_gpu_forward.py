@@ -242,6 +242,40 @@ def test_stream_pipeline_equals_sequential_forward():
         assert all((a - seq[i % 4]).abs().max() <= 2e-4 for i, a in enumerate(got)), kw
 
 
+def test_lone_forward_with_searches_beside_the_features_is_bit_identical():
+    """EngineOptions.overlap (default): inside ONE forward the six searches run on a second stream beside the feature phase
+    (per-search events, the stem and SA1's hoisted product enqueued before the host waits for the level sizes).  Same logits,
+    bit for bit, as the strictly sequential order - also with the 8-launch sampler entry point, the searches enqueued first,
+    one chunk chain, a high-priority search stream - on ragged batches, a batch whose table sampler overflows (4 m voxels:
+    the geometry is redone with the sort while the discarded searches are still in flight) and repeated calls."""
+    from pointstowood_amd import Net
+    vox = [synth.uniform_voxel(2.0, n, 170 + i, i % 2 == 0) for i, n in enumerate((3000, 800, 5000, 256, 2048, 4096))]
+    big = [synth.uniform_voxel(4.0, 6000, 190 + i, True) for i in range(3)]
+    batches = [synth.collate(vox[0:2]), synth.collate(big), synth.collate(vox[2:3]), synth.collate(vox[3:6]), synth.collate(big[:1] + vox[:1])]
+
+    def mk(b):
+        d = _D()
+        d.pos, d.batch, d.reflectance, d.sf = b["pos"].cuda(), b["batch"].cuda(), b["reflectance"].cuda(), b["sf"].cuda()
+        return d
+
+    def run(**kw):
+        net = Net(num_classes=1, C=8, k=32, **kw)
+        net.load_state_dict(weights.synth_state_dict(1, 8, seed=5), strict=True)
+        net = net.cuda().eval()
+        outs = [net(mk(b)).clone() for b in batches] + [net(mk(b)).clone() for b in batches[:2]]
+        torch.cuda.synchronize()
+        assert net._engine.range_fallbacks == 0
+        return outs
+    ref = run(overlap=False, single_res_streams=1)
+    for kw in (dict(), dict(table_prepared=False), dict(early_first=False), dict(single_res_streams=1), dict(search_priority=-1),
+               dict(overlap=False)):
+        got = run(**kw)
+        if kw.get("single_res_streams", 2) == 1 or "overlap" in kw:
+            assert all(torch.equal(a, b) for a, b in zip(got, ref)), kw
+        else:   # (two chunk chains plan the same GEMMs: these small batches have one chunk per level, so the bits agree too)
+            assert all(torch.equal(a, b) for a, b in zip(got, ref)), kw
+
+
 def test_table_sampler_recovers_after_oversized_voxels():
     """one batch of 4 m voxels grows the table sampler's remembered extent (x 8); a later batch of MANY nominal 2 m voxels,
     for which a table of that extent no longer fits, must not fall to the sort sampler for the life of the engine: it probes the
