@@ -677,6 +677,16 @@ class Engine:
         if not bad:
             return logits
         what = "; ".join(f"{n}: {v}" for n, v in bad[:4])
+        # "no value above 2^-5" is SAMPLED (wave 0 of every persistent workgroup's first tile): on a small or sparse layer the
+        # sample can miss.  It is acted on where a recomputation is available; it never raises by itself.
+        sampled_only = all(v.startswith("no value above") for _, v in bad)
+        if sampled_only and (self.fallback is None or getattr(geo, "rows0_sorted", False)):
+            if not getattr(self, "_seen_warned", False):
+                import warnings
+                self._seen_warned = True
+                warnings.warn(f"pointstowood_amd: precision {self.precision!r}: the range watch saw no value above {self.RANGE_LO:g} in its "
+                              f"sample of {what} and no fp32 recomputation is available in this configuration: logits returned as computed")
+            return logits
         if self.fallback is None:
             raise RuntimeError(f"precision {self.precision!r}: activations outside the range of the 16-bit planes ({what}); "
                                "use precision='fp32'")
