@@ -283,6 +283,7 @@ class EngineOptions:
     overlap: bool = True          # ONE forward (model(data), the reference's call): the searches on a second stream beside the features
                                   # (each feature kernel waits for the event of the search it reads); False: strictly one stream
     search_priority: int = 0      # HIP priority of that stream (-1 = high)
+    search_stagger: bool = False  # ... the later searches held back until the feature kernels they should run beside (A/B)
     early_first: bool = True      # ... and the size-independent feature kernels (stem, SA1's hoisted product) are enqueued BEFORE the searches
     table_prepared: bool = True   # table sampler through p2w_voxel_sample_table_prepared (6 launches per level; False: the 8-launch entry point)
     single_res_streams: int = 2   # row-chunk chains in flight inside a LONE forward (see res_streams: there the pipeline's second phase
@@ -554,66 +555,82 @@ class Engine:
         # ---- searches (as a closure: the lone forward enqueues its size-independent feature kernels between the two chains)
         geo.ev_nbr, geo.ev_fp = {}, {}
 
-        def launch_searches():
-            geo.launch_searches = None
+        def searching():
+            return torch.cuda.stream(search_stream) if search_stream is not None else contextlib.nullcontext()
+
+        def mark(table, key):
             if search_stream is not None:
+                table[key] = torch.cuda.Event()
+                table[key].record()
+
+        def sa_search(l):
+            res = SA_RES[l]
+            src, lv = geo.levels[l], geo.levels[l + 1]
+            if l == 0:   # model.py:117-118: the 0.04 level uses radius(r = 2*resolution)
+                if grid_search:
+                    self._call("ball_query", L.p2w_ball_query_grid_indexed, ptr(sorted0), ptr(skeys0), ptr(src.ptr), ptr(grids[1]),
+                               ptr(cstart0), ptr(src.xyzr), ptr(lv.idx), ptr(lv.ptr), B, N, res * 2, k, ptr(lv.nbr), ptr(lv.deg),
+                               SEARCH_X_INDEX_IN_W | (SEARCH_BOX if self.search_box & 1 else 0))
+                else:
+                    box0 = torch.empty((nbox, 6), **f32)
+                    self._call("tile_bbox", L.p2w_tile_bbox, ptr(sorted0), ptr(src.ptr), B, N, ptr(box0))
+                    self._call("ball_query", L.p2w_ball_query, ptr(sorted0), ptr(src.ptr), ptr(src.xyzr), ptr(lv.idx),
+                               ptr(lv.ptr), B, N, res * 2, k, ptr(lv.nbr), ptr(lv.deg), ptr(box0), SEARCH_X_INDEX_IN_W)
+                    geo.aux.append(box0)
+            elif grid_search:   # model.py:120
+                self._call("knn", L.p2w_knn_grid_indexed, ptr(src.xyzr), ptr(ckeys[l]), ptr(src.ptr), ptr(grids[l]), ptr(cstart.get(l)),
+                           ptr(src.xyzr),
+                           ptr(lv.idx), ptr(lv.ptr), B, N, k, ptr(lv.nbr), ptr(lv.deg), None,
+                           (SEARCH_BOX if self.search_box & 2 else 0))
+            else:
+                self._call("knn", L.p2w_knn, ptr(src.xyzr), ptr(src.ptr), ptr(src.xyzr), ptr(lv.idx), ptr(lv.ptr), B, N,
+                           k, ptr(lv.nbr), ptr(lv.deg), ptr(boxes(l)), 0)
+            mark(geo.ev_nbr, l + 1)
+
+        def fp_search(f):
+            # k=2 searches of knn_interpolate (model.py:149): fine level f queries coarse level f+1
+            fine, coarse = geo.levels[f], geo.levels[f + 1]
+            nbr, deg = torch.empty((N, 2), **i32), torch.empty(N, **i32)
+            # level 0 queries run over the cell-sorted copy; their result rows go to the points' own rows (row in .w) - or stay in
+            # cell order when the feature phase keeps level 0 in that order (fp1_cell_order)
+            q, fl = (sorted0, 0 if getattr(geo, "rows0_sorted", False) else SEARCH_Q_ROW_IN_W) if f == 0 else (fine.xyzr, 0)
+            if grid_search:
+                hint = None
+                if ranks.get(f) is not None:   # both of a point's two nearest coarse points are within its cell
+                    hint = torch.empty(N, **f32)   # representative's / a storage neighbour's representative's distance
+                    self._call("knn_hint", L.p2w_knn_hint2, ptr(q), ptr(ranks[f]), ptr(fine.ptr), B, N, ptr(coarse.xyzr),
+                               ptr(hint))
+                    geo.aux.append(hint)
+                self._call("knn2", L.p2w_knn_grid_indexed, ptr(coarse.xyzr), ptr(ckeys[f + 1]), ptr(coarse.ptr), ptr(grids[f + 1]),
+                           ptr(cstart.get(f + 1)), ptr(q), None, ptr(fine.ptr), B, N, 2, ptr(nbr), ptr(deg), ptr(hint),
+                           fl | (SEARCH_BOX if self.search_box & 4 else 0))
+            else:
+                self._call("knn2", L.p2w_knn, ptr(coarse.xyzr), ptr(coarse.ptr), ptr(q), None, ptr(fine.ptr), B, N, 2,
+                           ptr(nbr), ptr(deg), ptr(boxes(f + 1)), fl)
+            geo.fp_nbr[f] = (nbr, deg)
+            mark(geo.ev_fp, f)
+        jobs = [lambda l=l: sa_search(l) for l in range(3)] + [lambda f=f: fp_search(f) for f in (2, 1, 0)]
+
+        def launch_searches(count=None, after=None):
+            """Enqueues the next `count` searches (all that are left: None) in the order ball query, kNN level 2, kNN level 3, the
+            interpolation searches of levels 2, 1, 0; `after`: an event the search stream waits for first (the staggered lone
+            forward holds a search back until the feature kernel it should run beside has started)."""
+            first = len(jobs) == 6
+            todo = jobs[: (len(jobs) if count is None else count)]
+            del jobs[: len(todo)]
+            if first and search_stream is not None:
                 search_stream.wait_event(geo.sizes_ready)
-
-            def searching():
-                return torch.cuda.stream(search_stream) if search_stream is not None else contextlib.nullcontext()
-
-            def mark(table, key):
-                if search_stream is not None:
-                    table[key] = torch.cuda.Event()
-                    table[key].record()
+            if after is not None and search_stream is not None:
+                search_stream.wait_event(after)
             with searching():
-                for l, res in enumerate(SA_RES):
-                    src, lv = geo.levels[l], geo.levels[l + 1]
-                    if l == 0:   # model.py:117-118: the 0.04 level uses radius(r = 2*resolution)
-                        if grid_search:
-                            self._call("ball_query", L.p2w_ball_query_grid_indexed, ptr(sorted0), ptr(skeys0), ptr(src.ptr), ptr(grids[1]),
-                                       ptr(cstart0), ptr(src.xyzr), ptr(lv.idx), ptr(lv.ptr), B, N, res * 2, k, ptr(lv.nbr), ptr(lv.deg),
-                                       SEARCH_X_INDEX_IN_W | (SEARCH_BOX if self.search_box & 1 else 0))
-                        else:
-                            box0 = torch.empty((nbox, 6), **f32)
-                            self._call("tile_bbox", L.p2w_tile_bbox, ptr(sorted0), ptr(src.ptr), B, N, ptr(box0))
-                            self._call("ball_query", L.p2w_ball_query, ptr(sorted0), ptr(src.ptr), ptr(src.xyzr), ptr(lv.idx),
-                                       ptr(lv.ptr), B, N, res * 2, k, ptr(lv.nbr), ptr(lv.deg), ptr(box0), SEARCH_X_INDEX_IN_W)
-                            geo.aux.append(box0)
-                    elif grid_search:   # model.py:120
-                        self._call("knn", L.p2w_knn_grid_indexed, ptr(src.xyzr), ptr(ckeys[l]), ptr(src.ptr), ptr(grids[l]), ptr(cstart.get(l)),
-                                   ptr(src.xyzr),
-                                   ptr(lv.idx), ptr(lv.ptr), B, N, k, ptr(lv.nbr), ptr(lv.deg), None,
-                                   (SEARCH_BOX if self.search_box & 2 else 0))
-                    else:
-                        self._call("knn", L.p2w_knn, ptr(src.xyzr), ptr(src.ptr), ptr(src.xyzr), ptr(lv.idx), ptr(lv.ptr), B, N,
-                                   k, ptr(lv.nbr), ptr(lv.deg), ptr(boxes(l)), 0)
-                    mark(geo.ev_nbr, l + 1)
-                # k=2 searches of knn_interpolate (model.py:149): fine level f queries coarse level f+1
-                for f in (2, 1, 0):
-                    fine, coarse = geo.levels[f], geo.levels[f + 1]
-                    nbr, deg = torch.empty((N, 2), **i32), torch.empty(N, **i32)
-                    # level 0 queries run over the cell-sorted copy; their result rows go to the points' own rows (row in .w) - or stay in
-                    # cell order when the feature phase keeps level 0 in that order (fp1_cell_order)
-                    q, fl = (sorted0, 0 if getattr(geo, "rows0_sorted", False) else SEARCH_Q_ROW_IN_W) if f == 0 else (fine.xyzr, 0)
-                    if grid_search:
-                        hint = None
-                        if ranks.get(f) is not None:   # both of a point's two nearest coarse points are within its cell
-                            hint = torch.empty(N, **f32)   # representative's / a storage neighbour's representative's distance
-                            self._call("knn_hint", L.p2w_knn_hint2, ptr(q), ptr(ranks[f]), ptr(fine.ptr), B, N, ptr(coarse.xyzr),
-                                       ptr(hint))
-                            geo.aux.append(hint)
-                        self._call("knn2", L.p2w_knn_grid_indexed, ptr(coarse.xyzr), ptr(ckeys[f + 1]), ptr(coarse.ptr), ptr(grids[f + 1]),
-                                   ptr(cstart.get(f + 1)), ptr(q), None, ptr(fine.ptr), B, N, 2, ptr(nbr), ptr(deg), ptr(hint),
-                                   fl | (SEARCH_BOX if self.search_box & 4 else 0))
-                    else:
-                        self._call("knn2", L.p2w_knn, ptr(coarse.xyzr), ptr(coarse.ptr), ptr(q), None, ptr(fine.ptr), B, N, 2,
-                                   ptr(nbr), ptr(deg), ptr(boxes(f + 1)), fl)
-                    geo.fp_nbr[f] = (nbr, deg)
-                    mark(geo.ev_fp, f)
-                geo.done = torch.cuda.Event()
-                geo.done.record()
-            geo.aux += list(bbox.values())
+                for job in todo:
+                    job()
+                if not jobs:
+                    geo.done = torch.cuda.Event()
+                    geo.done.record()
+            if not jobs:
+                geo.launch_searches = None
+                geo.aux += list(bbox.values())
         aux0 += list(ckeys.values()) + list(grids.values()) + [t for t in ranks.values() if t is not None]
         aux0 += [t for t in list(cstart.values()) + [cstart0] if t is not None]
         if getattr(geo, "rows0_sorted", False):
@@ -643,6 +660,8 @@ class Engine:
             search_stream = getattr(geo, "search_stream", None)
             with torch.cuda.stream(geo.stream):
                 if search_stream is not None:       # the discarded searches still read the buffers this Geometry is about to drop
+                    if geo.launch_searches is not None:
+                        geo.launch_searches()
                     geo.stream.wait_event(geo.done)
                 redo = self._geometry_async(*geo.args, force_sort=True, search_stream=search_stream)
             redo.sizes_ready.synchronize()
@@ -666,6 +685,8 @@ class Engine:
             return logits
         geo.watch = None
         if getattr(geo, "search_stream", None) is not None:   # the fp32 parity mode runs behind the searches
+            if geo.launch_searches is not None:
+                geo.launch_searches()
             torch.cuda.current_stream().wait_event(geo.done)
         return self._features_fp32(geo, keep)
 
@@ -840,6 +861,20 @@ class Engine:
         sorted0 = bool(getattr(geo, "rows0_sorted", False))
         wait = lambda ev: torch.cuda.current_stream().wait_event(ev) if ev is not None else None   # a search result is about to be read
         ev_nbr, ev_fp = getattr(geo, "ev_nbr", {}), getattr(geo, "ev_fp", {})
+
+        def need(table, key):
+            """The search result (table, key) is about to be read: if the staggered forward has not enqueued that search yet, it
+            goes out now; then the caller's stream waits for its event."""
+            while table.get(key) is None and getattr(geo, "launch_searches", None) is not None:
+                geo.launch_searches(1)
+            wait(table.get(key))
+
+        def stage(count):
+            """Staggered lone forward: enqueue the next `count` searches behind the feature kernel just launched."""
+            if getattr(geo, "launch_searches", None) is not None and getattr(geo, "search_stream", None) is not None:
+                ev = torch.cuda.Event()
+                ev.record()
+                geo.launch_searches(count, after=ev)
         if keep is not None:
             keep["stem"] = x0
         x3 = None
@@ -850,7 +885,7 @@ class Engine:
             # pitch padded to whole K slabs with zero columns (p2w_sa_conv_h reads it with unconditional loads)
             C1p = pad8(C1)
             P = early["P1"] if l == 1 else self._hoist(xh[l - 1], pitch[l - 1], src.n, p, l)
-            wait(ev_nbr.get(l))
+            need(ev_nbr, l)
             conv = new(M, C2) if (keep is not None or not res_h) else None
             convh = newh(M, C2)
             # level 1 is the ball query: on sparse input most targets have few neighbours, and those with <= 8 share an MFMA
@@ -863,6 +898,7 @@ class Engine:
                        ptr(geo.sf), ptr(dst.nbr), ptr(dst.deg), geo.k, M, ptr(p["w1r4"]), ptr(p["W2"].w16),
                        p["W2"].wscale, C1, C2, ptr(p["b2"]), ptr(p["bn_s"]), ptr(p["bn_t"]), ptr(conv), C2, ptr(convh),
                        pad8(C2), ptr(meta), meta.numel(), sa_flags, ptr(geo.inv0) if (l == 1 and sorted0) else None, self._watch(f"sa{l}", M))
+            stage(1 if l < 3 else 2)     # (no-op unless staggered: kNN level 3 behind SA1, interpolation search 2 behind SA2, 1 and 0 behind SA3)
             # fp32 form of the level's output: level 3 feeds cat(x, pos) of the global module; otherwise only on request
             out = new(M, C2) if (keep is not None or l == 3) else None
             # residual block in row chunks: the two 4F-wide intermediates of a chunk (2 x chunk x 4F x 4 B) are written
@@ -933,7 +969,7 @@ class Engine:
             m, Fc, cf, ld = fine.n, y_cols, cat[fl - 1], pitch[fl - 1]
             nbr, deg, kw = (nbr4, deg4, 1) if fl == 4 else (*geo.fp_nbr[fl - 1], 2)
             if fl < 4:
-                wait(ev_fp.get(fl - 1))
+                need(ev_fp, fl - 1)
             fine_xyzr = geo.sorted0 if (fl == 1 and sorted0) else fine.xyzr   # FP1's rows (and fp_nbr[0]'s) are in cell order then
             l0, l1 = w.fp[fl]
             # layer 0's interpolated half on the coarse rows (PackedWeights.fp_split)?  This module: the previous one left the H
@@ -1120,7 +1156,9 @@ class Engine:
             self._range_begin(sf.device)
             early = self._features_early(geo)
         if geo.launch_searches is not None:
-            geo.launch_searches()
+            # search_stagger: the ball query and the level-2 kNN now; the level-3 kNN and the interpolation searches are enqueued by
+            # the feature phase where it wants them to start (each behind the PointNetConv of the level before)
+            geo.launch_searches(2 if (overlap and self.search_stagger and self.prec is not None) else None)
         self._geometry_finish(geo)
         if early is not None and early["lv0"] is not geo.levels[0]:   # (the table overflowed and the geometry was redone: level 0 is new)
             early = None

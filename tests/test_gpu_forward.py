@@ -268,7 +268,7 @@ def test_lone_forward_with_searches_beside_the_features_is_bit_identical():
         return outs
     ref = run(overlap=False, single_res_streams=1)
     for kw in (dict(), dict(table_prepared=False), dict(early_first=False), dict(single_res_streams=1), dict(search_priority=-1),
-               dict(overlap=False)):
+               dict(search_stagger=True), dict(overlap=False)):
         got = run(**kw)
         if kw.get("single_res_streams", 2) == 1 or "overlap" in kw:
             assert all(torch.equal(a, b) for a, b in zip(got, ref)), kw
