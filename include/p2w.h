@@ -167,7 +167,7 @@ int32_t p2w_ball_query_grid(const float* xyzr_x, const uint64_t* keys_x, const i
 /* p2w_voxel_sample_table on a workspace whose between-calls state (24 bytes of bounding-box words at their atomics' identities, one
  * counter at zero) is already in place: p2w_voxel_sample_table_prepare(ws) establishes it once on a fresh (or foreign-written)
  * workspace, every p2w_voxel_sample_table[_prepared] call leaves it in place again - so the three sub-samplings of a forward
- * (model.py:103-106, once per SA level) take 6 launches each instead of 8, none of them a memset.  Same arguments, same results. */
+ * (model.py:103-106, once per SA level) take 5 launches each instead of 7, none of them a memset.  Same arguments, same results. */
 int32_t p2w_voxel_sample_table_prepare(void* ws, size_t ws_bytes, p2w_stream_t stream);
 int32_t p2w_voxel_sample_table_prepared(const float* xyzr, const int32_t* ptr, int32_t B, int32_t n_bound, float res,
                                         int32_t* idx_out, int32_t* ptr_out, int32_t* batch_out, int32_t* order_out,

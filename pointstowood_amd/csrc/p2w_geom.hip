@@ -462,15 +462,14 @@ __global__ __launch_bounds__(TK_BLOCK) void tk_scan1_kernel(const int* __restric
     if (threadIdx.x == 0) *done = 0;   // zero again for the next call on this workspace
 }
 
-__global__ __launch_bounds__(256) void tk_compact_kernel(const int* __restrict__ tab_max, const int* __restrict__ rank,
-                                                         const int* __restrict__ bs_occ, const int* __restrict__ total, long long T_cap,
-                                                         const int* __restrict__ ptr, int B, float res, const VsHeader* __restrict__ h,
-                                                         int* __restrict__ idx_out, int* __restrict__ ptr_out, int* __restrict__ batch_out,
-                                                         unsigned long long* __restrict__ cell_keys_out, p2w_grid* __restrict__ grid_out,
-                                                         const int* __restrict__ status, const int* __restrict__ off,
-                                                         const int* __restrict__ bs_cnt, int* __restrict__ cell_start_out,
-                                                         int* __restrict__ cell_start_sorted_out) {
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void tk_compact_body(long long t, const int* __restrict__ tab_max, const int* __restrict__ rank,
+                                                const int* __restrict__ bs_occ, const int* __restrict__ total, long long T_cap,
+                                                const int* __restrict__ ptr, int B, float res, const VsHeader* __restrict__ h,
+                                                int* __restrict__ idx_out, int* __restrict__ ptr_out, int* __restrict__ batch_out,
+                                                unsigned long long* __restrict__ cell_keys_out, p2w_grid* __restrict__ grid_out,
+                                                const int* __restrict__ status, const int* __restrict__ off,
+                                                const int* __restrict__ bs_cnt, int* __restrict__ cell_start_out,
+                                                int* __restrict__ cell_start_sorted_out) {
     const int n = ptr[B];
     if (*status || n == 0) {   // overflow: hand out an EMPTY level, so that whatever the caller has already queued behind this
         if (t <= B) ptr_out[t] = 0;   // call (searches, the next level's sampling) sees zero points instead of undefined sizes
@@ -513,15 +512,11 @@ __global__ __launch_bounds__(256) void tk_compact_kernel(const int* __restrict__
     if (cell_keys_out) cell_keys_out[o] = (unsigned long long)t;
 }
 
-__global__ __launch_bounds__(256) void tk_points_kernel(const int* __restrict__ key32, const int* __restrict__ rank, const int* __restrict__ bs_occ,
-                                                        const int* __restrict__ off, const int* __restrict__ bs_cnt, int* __restrict__ fill,
-                                                        const int* __restrict__ ptr, int B, int n_bound, int* __restrict__ inv_out,
-                                                        int* __restrict__ order_out, unsigned long long* __restrict__ sorted_keys_out,
-                                                        int* __restrict__ rank_sorted_out, const int* __restrict__ status, VsHeader* __restrict__ hdr_reset) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    // the call's last kernel leaves the workspace as p2w_voxel_sample_table_prepare() does: the bounding box ready for the next
-    // call's atomics (nothing of this call reads it any more)
-    if (i < 3) { hdr_reset->lo[i] = 0xffffffffu; hdr_reset->hi[i] = 0u; }
+__device__ __forceinline__ void tk_points_body(int i, const int* __restrict__ key32, const int* __restrict__ rank, const int* __restrict__ bs_occ,
+                                               const int* __restrict__ off, const int* __restrict__ bs_cnt, int* __restrict__ fill,
+                                               const int* __restrict__ ptr, int B, int n_bound, int* __restrict__ inv_out,
+                                               int* __restrict__ order_out, unsigned long long* __restrict__ sorted_keys_out,
+                                               int* __restrict__ rank_sorted_out, const int* __restrict__ status) {
     if (i >= ptr[B] || i >= n_bound) return;
     if (*status) {   // overflow: harmless per-point outputs (rank 0, identity order) for whatever is already queued behind us
         if (inv_out) inv_out[i] = 0;
@@ -538,6 +533,37 @@ __global__ __launch_bounds__(256) void tk_points_kernel(const int* __restrict__ 
         order_out[pos] = i;
         if (sorted_keys_out) sorted_keys_out[pos] = (unsigned long long)t;
         if (rank_sorted_out) rank_sorted_out[pos] = r;
+    }
+}
+
+// compaction (one thread per table cell) and the per-point outputs (one thread per input point) only READ the scan's results:
+// one launch does both.  Its successor in the stream is the next call's bounding-box pass, whose atomics need the header's
+// identities back - but every workgroup of THIS kernel still reads the header (tk_geom), so it cannot restore it itself;
+// the LAST workgroup to finish does (ticket in the workspace, zero between calls, reset by that workgroup).
+__global__ __launch_bounds__(256) void tk_finish_kernel(const int* __restrict__ tab_max, const int* __restrict__ rank,
+                                                        const int* __restrict__ bs_occ, const int* __restrict__ total, long long T_cap,
+                                                        const int* __restrict__ ptr, int B, float res, VsHeader* __restrict__ h,
+                                                        int* __restrict__ idx_out, int* __restrict__ ptr_out, int* __restrict__ batch_out,
+                                                        unsigned long long* __restrict__ cell_keys_out, p2w_grid* __restrict__ grid_out,
+                                                        const int* __restrict__ status, const int* __restrict__ off,
+                                                        const int* __restrict__ bs_cnt, int* __restrict__ cell_start_out,
+                                                        int* __restrict__ cell_start_sorted_out, const int* __restrict__ key32,
+                                                        int* __restrict__ fill, int n_bound, int* __restrict__ inv_out,
+                                                        int* __restrict__ order_out, unsigned long long* __restrict__ sorted_keys_out,
+                                                        int* __restrict__ rank_sorted_out, long long cgrid, int* __restrict__ ticket) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t < cgrid)
+        tk_compact_body(t, tab_max, rank, bs_occ, total, T_cap, ptr, B, res, h, idx_out, ptr_out, batch_out, cell_keys_out, grid_out, status, off,
+                        bs_cnt, cell_start_out, cell_start_sorted_out);
+    if (t < n_bound && (inv_out || order_out))
+        tk_points_body((int)t, key32, rank, bs_occ, off, bs_cnt, fill, ptr, B, n_bound, inv_out, order_out, sorted_keys_out, rank_sorted_out, status);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(ticket, 1) == (int)gridDim.x - 1) {      // every other workgroup has finished reading the header
+            for (int d = 0; d < 3; ++d) { h->lo[d] = 0xffffffffu; h->hi[d] = 0u; }
+            *ticket = 0;
+        }
     }
 }
 
@@ -620,8 +646,8 @@ static int32_t voxel_sample_table_impl(bool prepared, const float* xyzr, const i
     int* done = total + 16;                                  // the scan's completion counter (zero between calls)
     const auto* x4 = reinterpret_cast<const float4*>(xyzr);
     const int nblk_pts = p2w_cdiv(n_bound, 256);
-    // 6 launches: bounding box (+ status = 0) -> clear -> insert -> scan (the last workgroup scans the block totals) -> compact -> points
-    // (+ the workspace's between-calls state restored)
+    // 5 launches: bounding box (+ status = 0) -> clear -> insert -> scan (the last workgroup scans the block totals) -> compact + points
+    // (whose last workgroup restores the workspace's between-calls state)
     vs_minmax_kernel<<<nblk_pts < 256 ? nblk_pts : 256, 256, 0, s>>>(x4, ptr, B, hdr, status_out);
     // -1 = empty cell, zero counts: only over the part of the table this batch's grid uses (known on the device)
     tk_clear_kernel<<<p2w_cdiv(table_cells, 1024), 256, 0, s>>>(ptr, B, res, hdr, (long long)table_cells, tab_max, cnt, fill);
@@ -629,11 +655,11 @@ static int32_t voxel_sample_table_impl(bool prepared, const float* xyzr, const i
     tk_scan1_kernel<<<L.nblk, TK_BLOCK, 0, s>>>(tab_max, cnt, (long long)table_cells, rank, off, bs_occ, bs_cnt, status_out, ptr, B, res, hdr,
                                                  done, total);
     const long long cgrid = (table_cells + 1 > B + 1 ? table_cells + 1 : B + 1);
-    tk_compact_kernel<<<p2w_cdiv(cgrid, 256), 256, 0, s>>>(tab_max, rank, bs_occ, total, (long long)table_cells, ptr, B, res, hdr, idx_out,
-                                                            ptr_out, batch_out, reinterpret_cast<unsigned long long*>(cell_keys_out),
-                                                            grid_out, status_out, off, bs_cnt, cell_start_out, cell_start_sorted_out);
-    tk_points_kernel<<<nblk_pts, 256, 0, s>>>(key32, rank, bs_occ, off, bs_cnt, fill, ptr, B, n_bound, inv_out, order_out,
-                                              reinterpret_cast<unsigned long long*>(sorted_keys_out), rank_sorted_out, status_out, hdr);
+    const long long fgrid = cgrid > n_bound ? cgrid : n_bound;
+    tk_finish_kernel<<<p2w_cdiv(fgrid, 256), 256, 0, s>>>(tab_max, rank, bs_occ, total, (long long)table_cells, ptr, B, res, hdr, idx_out, ptr_out,
+                                                           batch_out, reinterpret_cast<unsigned long long*>(cell_keys_out), grid_out, status_out, off,
+                                                           bs_cnt, cell_start_out, cell_start_sorted_out, key32, fill, n_bound, inv_out, order_out,
+                                                           reinterpret_cast<unsigned long long*>(sorted_keys_out), rank_sorted_out, cgrid, done + 1);
     return P2W_LAUNCH_STATUS();
 }
 
