@@ -411,8 +411,8 @@ __device__ __forceinline__ void tk_scan_totals(int* __restrict__ bs_occ, int* __
 __global__ __launch_bounds__(TK_BLOCK) void tk_scan1_kernel(const int* __restrict__ tab_max, const int* __restrict__ cnt, long long T_cap,
                                                            int* __restrict__ rank, int* __restrict__ off, int* __restrict__ bs_occ,
                                                            int* __restrict__ bs_cnt, const int* __restrict__ status,
-                                                           const int* __restrict__ ptr, int B, float res, const VsHeader* __restrict__ h,
-                                                           int* __restrict__ done, int* __restrict__ total_out) {
+                                                           const int* __restrict__ ptr, int B, float res, VsHeader* __restrict__ h,
+                                                           int* __restrict__ done, int* __restrict__ total_out, VsHeader* __restrict__ h2) {
     __shared__ int wsum[2][TK_BLOCK / 64];
     __shared__ int is_last;
     if (*status || ptr[B] == 0) return;
@@ -459,7 +459,13 @@ __global__ __launch_bounds__(TK_BLOCK) void tk_scan1_kernel(const int* __restric
     if (!is_last) return;
     __threadfence();
     tk_scan_totals(bs_occ, bs_cnt, nb, total_out);
-    if (threadIdx.x == 0) *done = 0;   // zero again for the next call on this workspace
+    if (threadIdx.x == 0) {
+        *done = 0;   // zero again for the next call on this workspace
+        // every workgroup of this launch has read the bounding box: hand the call's last kernel a copy and give the next call's
+        // bounding-box pass its atomics' identities back (the workspace's between-calls state)
+        *h2 = *h;
+        for (int d = 0; d < 3; ++d) { h->lo[d] = 0xffffffffu; h->hi[d] = 0u; }
+    }
 }
 
 __device__ __forceinline__ void tk_compact_body(long long t, const int* __restrict__ tab_max, const int* __restrict__ rank,
@@ -537,12 +543,12 @@ __device__ __forceinline__ void tk_points_body(int i, const int* __restrict__ ke
 }
 
 // compaction (one thread per table cell) and the per-point outputs (one thread per input point) only READ the scan's results:
-// one launch does both.  Its successor in the stream is the next call's bounding-box pass, whose atomics need the header's
-// identities back - but every workgroup of THIS kernel still reads the header (tk_geom), so it cannot restore it itself;
-// the LAST workgroup to finish does (ticket in the workspace, zero between calls, reset by that workgroup).
+// one launch does both.  The grid geometry comes from the COPY of the bounding box the scan's last workgroup left (`h2`): the
+// primary one already carries the next call's identities.  Where the scan did not run (status set, empty batch) nothing here
+// reads a bounding box, and thread 0 restores the primary one.
 __global__ __launch_bounds__(256) void tk_finish_kernel(const int* __restrict__ tab_max, const int* __restrict__ rank,
                                                         const int* __restrict__ bs_occ, const int* __restrict__ total, long long T_cap,
-                                                        const int* __restrict__ ptr, int B, float res, VsHeader* __restrict__ h,
+                                                        const int* __restrict__ ptr, int B, float res, const VsHeader* __restrict__ h2,
                                                         int* __restrict__ idx_out, int* __restrict__ ptr_out, int* __restrict__ batch_out,
                                                         unsigned long long* __restrict__ cell_keys_out, p2w_grid* __restrict__ grid_out,
                                                         const int* __restrict__ status, const int* __restrict__ off,
@@ -550,21 +556,16 @@ __global__ __launch_bounds__(256) void tk_finish_kernel(const int* __restrict__ 
                                                         int* __restrict__ cell_start_sorted_out, const int* __restrict__ key32,
                                                         int* __restrict__ fill, int n_bound, int* __restrict__ inv_out,
                                                         int* __restrict__ order_out, unsigned long long* __restrict__ sorted_keys_out,
-                                                        int* __restrict__ rank_sorted_out, long long cgrid, int* __restrict__ ticket) {
+                                                        int* __restrict__ rank_sorted_out, long long cgrid, VsHeader* __restrict__ h) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t == 0 && (*status || ptr[B] == 0)) {
+        for (int d = 0; d < 3; ++d) { h->lo[d] = 0xffffffffu; h->hi[d] = 0u; }
+    }
     if (t < cgrid)
-        tk_compact_body(t, tab_max, rank, bs_occ, total, T_cap, ptr, B, res, h, idx_out, ptr_out, batch_out, cell_keys_out, grid_out, status, off,
+        tk_compact_body(t, tab_max, rank, bs_occ, total, T_cap, ptr, B, res, h2, idx_out, ptr_out, batch_out, cell_keys_out, grid_out, status, off,
                         bs_cnt, cell_start_out, cell_start_sorted_out);
     if (t < n_bound && (inv_out || order_out))
         tk_points_body((int)t, key32, rank, bs_occ, off, bs_cnt, fill, ptr, B, n_bound, inv_out, order_out, sorted_keys_out, rank_sorted_out, status);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        if (atomicAdd(ticket, 1) == (int)gridDim.x - 1) {      // every other workgroup has finished reading the header
-            for (int d = 0; d < 3; ++d) { h->lo[d] = 0xffffffffu; h->hi[d] = 0u; }
-            *ticket = 0;
-        }
-    }
 }
 
 struct TkLayout { size_t hdr, key32, bs_occ, bs_cnt, total, tab_max, rank, cnt, off, fill, bytes; long long T_cap; int nblk; };
@@ -646,20 +647,21 @@ static int32_t voxel_sample_table_impl(bool prepared, const float* xyzr, const i
     int* done = total + 16;                                  // the scan's completion counter (zero between calls)
     const auto* x4 = reinterpret_cast<const float4*>(xyzr);
     const int nblk_pts = p2w_cdiv(n_bound, 256);
-    // 5 launches: bounding box (+ status = 0) -> clear -> insert -> scan (the last workgroup scans the block totals) -> compact + points
-    // (whose last workgroup restores the workspace's between-calls state)
+    // 5 launches: bounding box (+ status = 0) -> clear -> insert -> scan (its last workgroup scans the block totals and restores the
+    // workspace's between-calls state) -> compact + points
     vs_minmax_kernel<<<nblk_pts < 256 ? nblk_pts : 256, 256, 0, s>>>(x4, ptr, B, hdr, status_out);
     // -1 = empty cell, zero counts: only over the part of the table this batch's grid uses (known on the device)
     tk_clear_kernel<<<p2w_cdiv(table_cells, 1024), 256, 0, s>>>(ptr, B, res, hdr, (long long)table_cells, tab_max, cnt, fill);
     tk_insert_kernel<<<nblk_pts, 256, 0, s>>>(x4, ptr, B, n_bound, res, hdr, (long long)table_cells, tab_max, cnt, key32, status_out);
+    auto* hdr2 = reinterpret_cast<VsHeader*>(total + 32);    // the bounding box as this call measured it (the primary is reset by the scan)
     tk_scan1_kernel<<<L.nblk, TK_BLOCK, 0, s>>>(tab_max, cnt, (long long)table_cells, rank, off, bs_occ, bs_cnt, status_out, ptr, B, res, hdr,
-                                                 done, total);
+                                                 done, total, hdr2);
     const long long cgrid = (table_cells + 1 > B + 1 ? table_cells + 1 : B + 1);
     const long long fgrid = cgrid > n_bound ? cgrid : n_bound;
-    tk_finish_kernel<<<p2w_cdiv(fgrid, 256), 256, 0, s>>>(tab_max, rank, bs_occ, total, (long long)table_cells, ptr, B, res, hdr, idx_out, ptr_out,
+    tk_finish_kernel<<<p2w_cdiv(fgrid, 256), 256, 0, s>>>(tab_max, rank, bs_occ, total, (long long)table_cells, ptr, B, res, hdr2, idx_out, ptr_out,
                                                            batch_out, reinterpret_cast<unsigned long long*>(cell_keys_out), grid_out, status_out, off,
                                                            bs_cnt, cell_start_out, cell_start_sorted_out, key32, fill, n_bound, inv_out, order_out,
-                                                           reinterpret_cast<unsigned long long*>(sorted_keys_out), rank_sorted_out, cgrid, done + 1);
+                                                           reinterpret_cast<unsigned long long*>(sorted_keys_out), rank_sorted_out, cgrid, hdr);
     return P2W_LAUNCH_STATUS();
 }
 
