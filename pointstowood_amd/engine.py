@@ -285,7 +285,7 @@ class EngineOptions:
     search_priority: int = 0      # HIP priority of that stream (-1 = high)
     search_stagger: bool = False  # ... the later searches held back until the feature kernels they should run beside (A/B)
     early_first: bool = True      # ... and the size-independent feature kernels (stem, SA1's hoisted product) are enqueued BEFORE the searches
-    table_prepared: bool = True   # table sampler through p2w_voxel_sample_table_prepared (6 launches per level; False: the 8-launch entry point)
+    table_prepared: bool = True   # table sampler through p2w_voxel_sample_table_prepared (5 launches per level; False: the 7-launch entry point)
     single_res_streams: int = 2   # row-chunk chains in flight inside a LONE forward (see res_streams: there the pipeline's second phase
                                   # fills the round tails; here nothing else does)
 
