@@ -30,15 +30,21 @@ for net in nets:
     else:
         assert all(torch.equal(a, b) for a, b in zip(ref, outs)), "variants disagree"
 ROUNDS, STEPS = int(os.environ.get("ROUNDS", "7")), int(os.environ.get("STEPS", "24"))
+# CALLER_PRIORITY=-1: the caller's stream (= the feature phase's) is a high-priority one, the searches' stays at search_priority
+caller = torch.cuda.Stream(priority=int(os.environ["CALLER_PRIORITY"])) if os.environ.get("CALLER_PRIORITY") else torch.cuda.current_stream()
 t = [[] for _ in nets]
-for r in range(ROUNDS):
-    for i, net in enumerate(nets):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for s in range(STEPS):
-            net(data[s % len(data)])
+with torch.cuda.stream(caller):
+    for net in nets:
+        for d in data:
+            net(d)
+    for r in range(ROUNDS):
+        for i, net in enumerate(nets):
             torch.cuda.synchronize()
-        t[i].append((time.perf_counter() - t0) / STEPS * 1e3)
+            t0 = time.perf_counter()
+            for s in range(STEPS):
+                net(data[s % len(data)])
+                torch.cuda.synchronize()
+            t[i].append((time.perf_counter() - t0) / STEPS * 1e3)
 for v, ts in zip(variants, t):
     print(f"{v or '(defaults)':40s} {statistics.median(ts):7.3f} ms per forward   (rounds: {' '.join(f'{x:.3f}' for x in ts)})")
 print("logits bit-identical across the variants")
