@@ -309,7 +309,7 @@ def cpu_baseline(full=True, sweep_threads=False):
         env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), OMP_PROC_BIND="false",
                    OMP_WAIT_POLICY="PASSIVE", HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", f"{threads}:{nvox}:{passes}"],
-                           env=env, capture_output=True, text=True, timeout=1800)
+                           env=env, capture_output=True, text=True, timeout=600 if nvox > 1 else 300)
         if r.returncode != 0:
             raise RuntimeError("cpu baseline child failed: " + r.stderr[-2000:])
         return json.loads(r.stdout.strip().splitlines()[-1])
@@ -835,7 +835,10 @@ def main():
         # tail of the line keeps metric / value / roofline / cpu_baseline / single_call / pcie_inclusive.
         line = {}
         if world == 1 and not args.no_workloads:
-            line["workloads"] = extra_workloads(net, args, device)
+            try:      # the headline line must not die on an auxiliary workload
+                line["workloads"] = extra_workloads(net, args, device)
+            except Exception as e:
+                line["workloads"] = {"error": repr(e)[:400]}
         line.update({
             "search": search,
             "hbm_kernels": hbm,
@@ -871,7 +874,13 @@ def main():
                          "mfma_busy": mfma_busy(args.precision)},
         })
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(full=not args.cpu_baseline_voxel0, sweep_threads=args.cpu_baseline_sweep)
+            try:      # (a host without the memory or the time for the whole batch: fall back to voxel 0, then to an error entry)
+                line["cpu_baseline"] = cpu_baseline(full=not args.cpu_baseline_voxel0, sweep_threads=args.cpu_baseline_sweep)
+            except Exception as e:
+                try:
+                    line["cpu_baseline"] = dict(cpu_baseline(full=False), note="whole-batch run failed: " + repr(e)[:200])
+                except Exception as e2:
+                    line["cpu_baseline"] = {"error": repr(e2)[:400]}
         if single_call is not None:
             line["single_call"] = single_call
         # `value` is measured with the inputs resident in HBM, as the bench contract requires; SURVEY.md 8(d) words the metric "incl.
