@@ -461,6 +461,12 @@ def test_bench_contract_line():
         assert key in rf, key
     assert rf["bound"] in ("hbm", "mfma") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     assert abs(d["value"] - 8 * 16384 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    # the diagnostics come first, the contract keys last (a reader that keeps the line's tail keeps them); the lone-forward and the
+    # PCIe-inclusive figures close the line
+    keys = list(d)
+    assert keys.index("workloads") < keys.index("metric") < keys.index("roofline") < keys.index("single_call") < keys.index("pcie_inclusive")
+    assert keys[-1] == "pcie_inclusive" and d["single_call"]["ms_per_step"] > 0 and d["pcie_inclusive"]["ms_per_step"] > 0
+    assert "error" not in d["workloads"]
 
 
 # ---- INTEGRATION.md route B as a composition: the reference forward's statements over pointstowood_amd.ops -----------------
