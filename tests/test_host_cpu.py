@@ -748,6 +748,29 @@ def test_segment_plot_sharded_gloo_world4_and_8(world, max_points, shard, monkey
         assert tiers and any(len(t) > 1 for t in tiers), tiers      # the 0.5 m halo did leave queries for a wider tier somewhere
 
 
+def test_x_slab_owners_are_balanced_contiguous_and_complete():
+    """pipeline._x_slab_owners: every plot point has exactly one owner, slabs are contiguous in x (a slab's largest x is below the
+    next one's smallest), sizes within a few histogram bins of n / world - also for clustered x (most points in 2 % of the range),
+    constant x and an empty plot."""
+    from pointstowood_amd.pipeline import _x_slab_owners
+    g = torch.Generator().manual_seed(0)
+    for name, x in (("uniform", torch.rand(50000, generator=g) * 100 - 50),
+                    ("clustered", torch.cat([torch.rand(45000, generator=g) * 2 + 10, torch.rand(5000, generator=g) * 100 - 50])),
+                    ("constant", torch.full((1000,), 3.0)), ("empty", torch.zeros(0))):
+        for world in (1, 2, 8):
+            owner, lists = _x_slab_owners(x, world)
+            assert len(lists) == world and sum(o.numel() for o in lists) == x.numel(), (name, world)
+            assert torch.equal(torch.sort(torch.cat(lists)).values, torch.arange(x.numel())), (name, world)
+            mine = [x[o] for o in lists if o.numel()]
+            assert all(float(a.max()) <= float(b.min()) for a, b in zip(mine[:-1], mine[1:])), (name, world)
+            if name == "uniform":
+                assert max(o.numel() for o in lists) <= 1.02 * x.numel() / world + 50, (name, world)
+            if name == "clustered" and world == 8:     # a 4096-bin histogram still splits the dense 2 % of the range over several ranks
+                assert max(o.numel() for o in lists) <= 0.2 * x.numel(), [o.numel() for o in lists]
+            for o in lists:                            # every rank's list keeps the input order (the final scatter relies on the lists alone)
+                assert torch.equal(o, torch.sort(o).values)
+
+
 def _budget_worker(rank, world, port, q):
     import torch.distributed as dist
     pipeline = _cpu_stand_ins()
