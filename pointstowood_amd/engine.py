@@ -275,7 +275,11 @@ class EngineOptions:
                                   # saturates at 65504) and whether any lay above 2^-5 (a tensor without one has its lo plane on fp16's
                                   # subnormal floor); a forward with such a layer is recomputed on the fp32 MFMA path (Engine.fallback, set
                                   # by Net) instead of returning silently degraded logits.  (fp16 / bf16 are throughput modes whose
-                                  # error is reported, not bounded: no watch.)
+                                  # error is reported, not bounded: no watch.)  The watch costs one host wait per forward for the finished
+                                  # phase's report: Net.stream hides it behind the NEXT batch's feature phase only with feature_streams >= 2
+                                  # (with one feature stream the GPU idles while the host looks at the report and enqueues the next batch);
+                                  # "no value above 2^-5" is a SAMPLE (first tile of every persistent workgroup): it triggers the fp32
+                                  # recomputation where one is available and never raises by itself
     gemm_stream_k: bool = True    # GEMMs run through p2w_gemm_h2_sk with a per-stream workspace: rows that do not fill a whole chip round
                                   # run as a stream-K tail where the library's cost model says it pays (then a level is ONE chunk:
                                   # chunk_full_rounds does not apply)
